@@ -1,0 +1,193 @@
+/* l2q.h -- C ABI of libl2q.so: hand-written gfx950 (MI355X / CDNA4) kernels for the L2HMC /
+ * HMC leapfrog integrator over 2D U(1) and 4D SU(3) lattice gauge fields.
+ *
+ * The reference (saforem2/l2hmc-qcd) is 100 % Python and has no FFI boundary; its hot path
+ * is a sequence of ATen calls behind the Python classes `Dynamics`, `LatticeSU3`, `LatticeU1`,
+ * `SU3`, `U1Phase`, `LeapfrogLayer`.  Each entry point below replaces one such ATen sequence;
+ * the reference lines it replaces are cited (paths relative to src/l2hmc/ of the reference).
+ * The Python classes of the same names in `l2hmc-qcd_amd/l2hmc/` call these through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain C types.  All pointers are DEVICE pointers owned by the caller
+ *     (normally PyTorch's allocator).  Nothing is allocated and nothing synchronises inside;
+ *     work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - return 0 on success, negative L2Q_E* on failure; l2q_last_error() gives the text.
+ *   - "native" SU(3) field layout (what every lattice kernel consumes and produces):
+ *         xn[chain][mu][e][site]   complex128 (re, im interleaved, 16 B)
+ *     with e = 3*row + col of the 3x3 link matrix and site = ((t*X + x)*Y + y)*Z + z.
+ *     One wavefront reading entry e of 64 consecutive sites is a single coalesced 1 KiB load.
+ *     The reference's public layout x[chain][mu][t][x][y][z][3][3] is converted at the API
+ *     edge by l2q_su3_pack / l2q_su3_unpack; a trajectory stays in native layout throughout.
+ *   - native flat index of a real per-entry quantity (masks, s/t/q network heads):
+ *         j_n = (mu*9 + e)*V + site        (reference: j = (mu*V + site)*9 + e)
+ *     native index of the 8-component algebra vector (vnet input):
+ *         k_n = (mu*8 + a)*V + site        (reference: k = (mu*V + site)*8 + a)
+ *   - U(1) fields keep the reference layout x[chain][2][T][X] (already site-contiguous).
+ *   - per-chain reductions are order-stable (fixed tree, no atomics) so that dH and the
+ *     accept/reject mask are reproducible run to run.
+ */
+#ifndef L2Q_H_
+#define L2Q_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2Q_OK 0
+#define L2Q_EINVAL (-1) /* bad argument (null pointer, non-positive size, bad enum) */
+#define L2Q_ESHAPE (-2) /* inconsistent shapes / workspace too small */
+#define L2Q_EHIP (-3)   /* HIP runtime error at launch */
+
+/* activation enum for the network kernels (network/pytorch/network.py:40-46) */
+#define L2Q_ACT_NONE 0
+#define L2Q_ACT_TANH 1
+#define L2Q_ACT_RELU 2
+#define L2Q_ACT_LEAKY_RELU 3
+#define L2Q_ACT_ELU 4
+#define L2Q_ACT_SWISH 5
+
+const char* l2q_last_error(void);
+int l2q_version(void);
+/* performance knobs (results never depend on them): "plaq_occ" / "force_occ" in {2,3,4} pick
+ * the register-allocation variant (min waves per SIMD) of the stencil kernels; "xcd_swizzle"
+ * in {0,1}.  Returns the previous value, or L2Q_EINVAL for an unknown key/value. */
+int l2q_set_tuning(const char* key, int value);
+/* bytes of scratch the reductions need for `nb` chains of `n_per_chain` work items */
+size_t l2q_reduce_ws_bytes(int nb, long n_per_chain);
+
+/* ---------------------------------------------------------------- layout conversion */
+/* batched transpose in[batch][rows][cols] -> out[batch][cols][rows], elem_bytes in {4,8,16}.
+ * pack:   reference [.., site, e] -> native [.., e, site]  (rows = V, cols = 9 or 8)
+ * unpack: the same call with rows/cols swapped. */
+int l2q_transpose(const void* in, void* out, long batch, int rows, int cols, int elem_bytes,
+                  void* stream);
+/* x[nb][4][V][3][3] c128 <-> xn[nb][4][9][V] c128 */
+int l2q_su3_pack(const void* x_ref, void* x_nat, int nb, long V, void* stream);
+int l2q_su3_unpack(const void* x_nat, void* x_ref, int nb, long V, void* stream);
+
+/* ---------------------------------------------------------------- SU(3) lattice kernels */
+/* Per-chain plaquette sums: out[c][0] = sum_{sites, 6 planes} Re tr P, out[c][1] = Im.
+ * Replaces LatticeSU3._wilson_loops + the reductions in action/_plaquettes/_sin_charges/
+ * _int_charges (lattice/su3/pytorch/lattice.py:157-269):
+ *   action = -(beta/3) out[c][0];  plaqs = out[c][0]/(18 V);  sinQ = out[c][1]/(18 V);
+ *   intQ = out[c][1]/(32 pi^2).   Algorithmic traffic: 576 B per (chain, site). */
+int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, double* out,
+                        void* ws, size_t ws_bytes, void* stream);
+/* F = (beta/3) TAH(U_mu(x) * sum of 6 staples), written in native layout.
+ * Replaces LatticeSU3.grad_action (autograd + projectTAH, lattice.py:299-308).
+ * Algorithmic traffic: 1152 B per (chain, site). */
+int l2q_su3_force(const void* xn, double beta, void* fn, int nb, int T, int X, int Y, int Z,
+                  void* stream);
+/* fused plain-HMC half-kick: v += coef * F(x)   (dynamics/pytorch/dynamics.py:903-911,
+ * coef = -eps/2); F is never materialised. */
+int l2q_su3_force_kick(const void* xn, double beta, double coef, void* vn, int nb, int T,
+                       int X, int Y, int Z, void* stream);
+/* out = keep (.) x + expm(eps * v) @ ((1 - keep) (.) x), element-wise 0/1 mask on matrix
+ * entries.  mask_n: float32 [36 V] in native order or NULL (keep = 0 everywhere: the plain
+ * `update_gauge`, group/su3/pytorch/group.py:45-50).  keep = mask if !complement else 1-mask.
+ * Replaces Dynamics._update_x_fwd/_bwd SU3 branch (dynamics.py:1420-1425, 1468-1474).
+ * `out` may alias xn. */
+int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* mask_n,
+                     int complement, void* out, int nb, long V, void* stream);
+/* projectSU on every link (group/su3/pytorch/utils.py:341-346); out may alias in. */
+int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* stream);
+/* su3_to_vec(projectSU(.)) -> vec[nfields][8][V] double (group.py:138-147); the vnet
+ * GEMM A-operand (dynamics.py:1154-1156). */
+int l2q_su3_projsu_vec8(const void* in, double* vec, long nfields, long V, void* stream);
+/* projectTAH on every link (group.py:92-103); out may alias in. */
+int l2q_su3_project_tah(const void* in, void* out, long nfields, long V, void* stream);
+/* out[c] = 0.5 * sum_links (|p|_F^2 - 8)   (group.py:125-126) */
+int l2q_su3_kinetic_reduce(const void* vn, int nb, long V, double* out, void* ws,
+                           size_t ws_bytes, void* stream);
+/* momenta from 8 standard-normal fields normals[8][nfields*V] in the reference's draw order
+ * r3, r8, r01, r02, r12, i01, i02, i12 (group/su3/pytorch/utils.py:171-195). */
+int l2q_su3_assemble_tah(const double* normals, void* vn, long nfields, long V, void* stream);
+/* max over links of |x^H x - 1|_F^2 + |det x - 1|^2 and its mean, per chain
+ * (checkSU, utils.py:376-391): out[c][0] = sqrt(mean/20), out[c][1] = sqrt(max/20). */
+int l2q_su3_check_su(const void* xn, int nb, long V, double* out, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* ---------------------------------------------------------------- L2HMC momentum update */
+/* Generalised v-update with real network heads s, t, q [nb][n] applied entry-wise:
+ *   forward : v' = exp(eps s/2) v - (eps/2) (F exp(eps q) + t),  logdet[c] =  sum eps s/2
+ *   backward: v' = exp(-eps s/2) (v + (eps/2) (F exp(eps q) + t)), logdet[c] = -sum eps s/2
+ * (dynamics.py:1266-1297).  is_complex=1: v, F are complex128 [nb][n] (SU3, heads multiply
+ * both parts, t adds to the real part); 0: real.  elem_bytes 8 (f64) or 4 (f32, U1).
+ * v is updated in place. */
+int l2q_v_update(void* v, const void* force, const void* s, const void* t, const void* q,
+                 double eps, int forward, int is_complex, int elem_bytes, int nb, long n,
+                 void* logdet, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- accept / reject */
+/* acc = exp(min(0, h_init - h_prop + sumlogdet)); mask = (acc > u) as float32 0/1
+ * (dynamics.py:1065-1087).  elem_bytes of h/sumlogdet/acc/u: 8 or 4. */
+int l2q_accept(const void* h_init, const void* h_prop, const void* sumlogdet, const void* u,
+               void* acc, float* mask, int nb, int elem_bytes, void* stream);
+/* out[c][:] = mask[c] ? a[c][:] : b[c][:]   (dynamics.py:677-682), row_bytes per chain */
+int l2q_select_rows(const void* a, const void* b, const float* mask, void* out, int nb,
+                    long row_bytes, void* stream);
+/* y = alpha * x over n doubles (momentum flip, dynamics.py:1001); y may alias x */
+int l2q_scale_f64(const double* x, double alpha, double* y, long n, void* stream);
+
+/* ---------------------------------------------------------------- dense network layers */
+/* C[M][N] = epilogue( A[M][K] . W[N][K]^T (+ A2[M][K2] . W2[N][K2]^T) + bias[N] (+ bias2[N]) )
+ * fp64 on v_mfma_f64_16x16x4_f64.  Replaces nn.Linear + activation / ScaledTanh in
+ * LeapfrogLayer.forward (network/pytorch/network.py:430-451, 522-551):
+ *   epilogue: y = act(z);  if (coeff) y = scale * exp(coeff[n]) * y  else y = scale * y.
+ * A2/W2/bias2 may be NULL (K2 = 0).  ws: split-K scratch (l2q_gemm_ws_bytes). */
+int l2q_gemm_f64(const double* A, const double* W, int M, int N, long K, const double* A2,
+                 const double* W2, long K2, const double* bias, const double* bias2,
+                 const double* coeff, double scale, int act, double* C, void* ws,
+                 size_t ws_bytes, void* stream);
+size_t l2q_gemm_ws_bytes(int M, int N, long K, long K2);
+/* fp32 variant on v_mfma_f32_16x16x4_f32 (U(1) networks). */
+int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const float* A2,
+                 const float* W2, long K2, const float* bias, const float* bias2,
+                 const float* coeff, float scale, int act, float* C, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- U(1) lattice kernels */
+/* x[nb][2][T][X] angles, elem_bytes 4 or 8.
+ * out[c][0] = sum cos(theta), [1] = sum sin(theta), [2] = sum project_angle(theta)
+ * (lattice/u1/pytorch/lattice.py:154-159, 80-86, 188-228):
+ *   action = beta (V - out0); plaqs = out0/V; sinQ = out1/2pi; intQ = out2/2pi. */
+int l2q_u1_plaq_reduce(const void* x, int nb, int T, int X, int elem_bytes, void* out,
+                       void* stream);
+/* F0 = beta [sin th - sin th(t,x-1)], F1 = beta [-sin th + sin th(t-1,x)]
+ * (autograd of the action, lattice.py:102-117).  If v != NULL: v += coef * F (fused kick)
+ * and `force` may be NULL. */
+int l2q_u1_force(const void* x, double beta, void* force, void* v, double coef, int nb, int T,
+                 int X, int elem_bytes, void* stream);
+/* NCP position update (dynamics.py:1386-1477, use_ncp branch) followed by compat_proj:
+ *   forward : x' = m x + (1-m) [2 atan(tan(x/2) e^{eps s}) + eps (v e^{eps q} + t)]
+ *   backward: x' = m x + (1-m) [2 atan(tan(x/2) e^{-eps s}) - e^{-eps s} eps (v e^{eps q} + t)]
+ *   logdet[c] = sum (1-m) log(e^{+-eps s} / (cos^2(x/2) + e^{+-2 eps s} sin^2(x/2)))
+ * mask: float32 [n] (the kept entries; complement flips it).  x updated in place. */
+int l2q_u1_x_update(void* x, const void* v, const void* s, const void* t, const void* q,
+                    const float* mask, int complement, double eps, int forward, int use_ncp,
+                    int elem_bytes, int nb, long n, void* logdet, void* stream);
+/* ((x + pi) mod 2 pi) - pi   (group/u1/pytorch/group.py:137-138); y may alias x */
+int l2q_u1_wrap(const void* x, void* y, long n, int elem_bytes, void* stream);
+/* out[c] = 0.5 sum v^2 (group/u1/pytorch/group.py:164-165) */
+int l2q_u1_kinetic_reduce(const void* v, int nb, long n, int elem_bytes, void* out,
+                          void* stream);
+/* y = x + alpha * p  (U1Phase.update_gauge, group.py:102-103) */
+int l2q_axpy(const void* p, double alpha, void* x, long n, int elem_bytes, void* stream);
+/* [cos(m x), sin(m x)] channels for the U(1) xnet input (group.py:86-89 applied to the
+ * masked field, dynamics.py:1398,1174): out[nb][4][T*X] from x[nb][2][T*X] */
+int l2q_u1_masked_cos_sin(const void* x, const float* mask, int complement, void* out, int nb,
+                          long n, int elem_bytes, void* stream);
+/* periodic-padded conv2d (+ optional max-pool p, + activation), NCHW fp32:
+ * PeriodicPadding(k-1) -> Conv2d(k) -> [MaxPool2d(p)] -> [act]
+ * (network/pytorch/network.py:151-172, 283-326). */
+int l2q_conv2d_periodic_f32(const float* in, const float* w, const float* bias, float* out,
+                            int nb, int cin, int H, int W, int cout, int k, int pool, int act,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2Q_H_ */

@@ -1,0 +1,90 @@
+// l2q_common.hpp -- error plumbing, launch helpers and order-stable block reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/l2q.h"
+
+namespace l2q {
+
+void set_error(const char* fmt, ...);
+
+struct Tuning {
+  int plaq_occ = 2;
+  int force_occ = 2;
+  int xcd_swizzle = 1;
+};
+Tuning& tuning();
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return L2Q_EHIP;
+  }
+  return L2Q_OK;
+}
+
+#define L2Q_REQUIRE(cond, code, msg)          \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::l2q::set_error("%s: %s", __func__, msg); \
+      return code;                            \
+    }                                         \
+  } while (0)
+
+constexpr int kBlock = 256;          // 4 wavefronts of 64
+constexpr int kXcds = 8;             // MI355X: 8 XCDs, block b is observed on XCD b % 8
+
+// XCD-aware remap of a 1-D grid: hardware block `b` runs on XCD b % 8, so give each XCD a
+// contiguous range of logical work (neighbouring site blocks of the same chains share the
+// XCD-private L2).  Speed only -- any placement is correct.
+__device__ __forceinline__ long xcd_swizzle(long b, long total, int enable = 1) {
+  if (!enable || total % kXcds != 0) return b;
+  const long per = total / kXcds;
+  return (b % kXcds) * per + b / kXcds;
+}
+
+// Sum of `v` over the 256 threads of a block, returned on thread 0.  Fixed tree: wave
+// butterfly via DPP/shuffles, then 4 wave partials through LDS -- same order every run.
+__device__ __forceinline__ double block_sum(double v, double* lds /* >= 4 doubles */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) r += lds[w];
+  }
+  return r;
+}
+
+__device__ __forceinline__ double block_max(double v, double* lds) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    r = lds[0];
+    for (int w = 1; w < nw; ++w) r = fmax(r, lds[w]);
+  }
+  return r;
+}
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// second stage of the per-chain reductions: partial[c][nblk][ncomp] -> out[c][ncomp],
+// one block per chain, sequential fixed order over blocks inside each lane, then block_sum.
+// out[c][k] = scale * sum_b partial[c][b][k] + offset
+void launch_finalize(const double* partial, double* out, int nb, long nblk, int ncomp,
+                     double scale, double offset, hipStream_t st);
+
+}  // namespace l2q

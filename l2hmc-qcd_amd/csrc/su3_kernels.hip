@@ -1,0 +1,471 @@
+// su3_kernels.hip -- 4D SU(3) lattice kernels for gfx950 (MI355X).
+//
+// Native field layout xn[chain][mu][e][site] complex128: lane <-> site, so every load of a
+// matrix entry is one coalesced 16 B/lane wavefront load; the 3x3 algebra lives in
+// registers (su3_math.hpp).  Stencil neighbours are re-read through L1/L2; the 1-D grids
+// are XCD-swizzled so the blocks that share a chain's links share an XCD's L2.
+#include "l2q_common.hpp"
+#include "su3_math.hpp"
+
+namespace l2q {
+
+struct Dims {
+  int T, X, Y, Z;
+  int V;          // sites per chain (36 V complex entries per chain must fit an int)
+};
+
+__device__ __forceinline__ void load_link(M3& m, const double2* __restrict__ f, int V, int s) {
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double2 d = f[e * V + s];
+    m.re[e] = d.x; m.im[e] = d.y;
+  }
+}
+
+__device__ __forceinline__ void store_link(double2* __restrict__ f, int V, int s, const M3& m) {
+#pragma unroll
+  for (int e = 0; e < 9; ++e) f[e * V + s] = make_double2(m.re[e], m.im[e]);
+}
+
+struct Site {
+  int t, x, y, z;
+};
+
+__device__ __forceinline__ Site site_coords(int s, const Dims& d) {
+  Site r;
+  r.z = s % d.Z; s /= d.Z;
+  r.y = s % d.Y; s /= d.Y;
+  r.x = s % d.X; s /= d.X;
+  r.t = s;
+  return r;
+}
+
+// mu is wave-uniform everywhere below (loop counters / blockIdx), so these selects are
+// scalar and nothing is indexed dynamically in VGPR arrays.
+__device__ __forceinline__ int coord_of(const Site& p, int mu) {
+  return mu == 0 ? p.t : mu == 1 ? p.x : mu == 2 ? p.y : p.z;
+}
+__device__ __forceinline__ int stride_of(const Dims& d, int mu) {
+  return mu == 0 ? d.X * d.Y * d.Z : mu == 1 ? d.Y * d.Z : mu == 2 ? d.Z : 1;
+}
+__device__ __forceinline__ int extent_of(const Dims& d, int mu) {
+  return mu == 0 ? d.T : mu == 1 ? d.X : mu == 2 ? d.Y : d.Z;
+}
+// site index of the periodic forward / backward neighbour of s (coordinate cm in direction mu)
+__device__ __forceinline__ int fwd(int s, int cm, const Dims& d, int mu) {
+  const int st = stride_of(d, mu), n = extent_of(d, mu);
+  return (cm + 1 == n) ? s - (n - 1) * st : s + st;
+}
+__device__ __forceinline__ int bwd(int s, int cm, const Dims& d, int mu) {
+  const int st = stride_of(d, mu), n = extent_of(d, mu);
+  return (cm == 0) ? s + (n - 1) * st : s - st;
+}
+
+// ------------------------------------------------------------------ plaquette reduce
+// sum over the 6 planes u > v of tr[ U_u(s) U_v(s+u) (U_v(s) U_u(s+v))^H ]
+// (lattice/su3/pytorch/lattice.py:164-174).  The plane loop is deliberately NOT unrolled:
+// it bounds the live ranges (<= 3 matrices) instead of letting the scheduler hoist 144 loads.
+template <int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void su3_plaq_kernel(const double2* __restrict__ xn,
+                                                               Dims d, long nblk, int swz,
+                                                               double* __restrict__ partial) {
+  __shared__ double lds[8];
+  const long total = (long)gridDim.x;
+  const long w = xcd_swizzle(blockIdx.x, total, swz);
+  const long c = w / nblk, blk = w % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  double sr = 0.0, si = 0.0;
+  if (s < d.V) {
+    const double2* xc = xn + c * 36L * d.V;
+    const Site p = site_coords(s, d);
+    const int V = d.V;
+#pragma unroll 1
+    for (int u = 1; u < 4; ++u) {
+      const int s_pu = fwd(s, coord_of(p, u), d, u);
+#pragma unroll 1
+      for (int v = 0; v < u; ++v) {
+        const int s_pv = fwd(s, coord_of(p, v), d, v);
+        M3 a, b, yuv;
+        load_link(a, xc + u * 9 * V, V, s);
+        load_link(b, xc + v * 9 * V, V, s_pu);
+        m3_mul_nn(yuv, a, b);
+        load_link(a, xc + v * 9 * V, V, s);
+        load_link(b, xc + u * 9 * V, V, s_pv);
+        m3_trace_y_abh(sr, si, yuv, a, b);
+      }
+    }
+  }
+  const double br = block_sum(sr, lds);
+  const double bi = block_sum(si, lds + 4);
+  if (threadIdx.x == 0) {
+    partial[(c * nblk + blk) * 2 + 0] = br;
+    partial[(c * nblk + blk) * 2 + 1] = bi;
+  }
+}
+
+// ------------------------------------------------------------------ staple force
+// KICK = false: fn[c][mu] = coef * TAH(U A);  KICK = true: vn[c][mu] += coef * TAH(U A)
+// A_mu(s) = sum_{nu != mu} [ U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H
+//                           + U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu) ]
+template <bool KICK, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void su3_force_kernel(const double2* __restrict__ xn,
+                                                                Dims d, long nblk, int swz, double coef,
+                                                                double2* __restrict__ out) {
+  const long total = (long)gridDim.x;
+  const long w = xcd_swizzle(blockIdx.x, total, swz);
+  // logical order: chain-major, then site block, then mu (4 consecutive blocks share sites)
+  const int mu = (int)(w & 3);
+  const long cb = w >> 2;
+  const long c = cb / nblk, blk = cb % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  if (s >= d.V) return;
+  const int V = d.V;
+  const double2* xc = xn + c * 36L * V;
+  const double2* fm = xc + mu * 9 * V;
+  const Site p = site_coords(s, d);
+  const int cmu = coord_of(p, mu);
+  const int s_pmu = fwd(s, cmu, d, mu);
+  M3 acc;
+  m3_zero(acc);
+#pragma unroll 1
+  for (int nu = 0; nu < 4; ++nu) {
+    if (nu == mu) continue;
+    const double2* fn = xc + nu * 9 * V;
+    const int cnu = coord_of(p, nu);
+    const int s_pnu = fwd(s, cnu, d, nu);
+    const int s_mnu = bwd(s, cnu, d, nu);
+    const int s_pmu_mnu = bwd(s_pmu, cnu, d, nu);     // nu-coordinate unchanged by the mu hop
+    M3 a, b, t;
+    // up:   U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H
+    load_link(a, fn, V, s_pmu);
+    load_link(b, fm, V, s_pnu);
+    m3_mul_na(t, a, b);
+    load_link(a, fn, V, s);
+    m3_mac_na(acc, t, a);
+    // down: U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu)
+    load_link(a, fn, V, s_pmu_mnu);
+    load_link(b, fm, V, s_mnu);
+    m3_mul_aa(t, a, b);
+    load_link(a, fn, V, s_mnu);
+    m3_mac_nn(acc, t, a);
+  }
+  M3 u, ua, f;
+  load_link(u, fm, V, s);
+  m3_mul_nn(ua, u, acc);
+  m3_tah(f, ua);
+  double2* o = out + (c * 4 + mu) * 9L * V;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    double2 r = make_double2(coef * f.re[e], coef * f.im[e]);
+    if (KICK) {
+      const double2 v = o[e * V + s];
+      r.x += v.x; r.y += v.y;
+    }
+    o[e * V + s] = r;
+  }
+}
+
+// ------------------------------------------------------------------ per-link kernels
+// out = keep (.) x + expm(eps v) @ ((1-keep) (.) x)
+__global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
+                                                              const double2* __restrict__ vn,
+                                                              double eps,
+                                                              const float* __restrict__ mask,
+                                                              int complement, double2* out,
+                                                              int V, long nblk) {
+  const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;     // f = chain*4 + mu
+  const int s = (int)blk * kBlock + threadIdx.x;
+  if (s >= V) return;
+  const int mu = (int)(f & 3);
+  M3 x, a, e;
+  load_link(x, xn + f * 9L * V, V, s);
+  load_link(a, vn + f * 9L * V, V, s);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { a.re[i] *= eps; a.im[i] *= eps; }
+  m3_expm(e, a);
+  M3 kept, moved, r;
+  if (mask != nullptr) {
+    const float* mk = mask + mu * 9 * V;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      double k = (double)mk[i * V + s];
+      if (complement) k = 1.0 - k;
+      kept.re[i] = k * x.re[i]; kept.im[i] = k * x.im[i];
+      moved.re[i] = (1.0 - k) * x.re[i]; moved.im[i] = (1.0 - k) * x.im[i];
+    }
+    m3_mul_nn(r, e, moved);
+    m3_add(r, kept);
+  } else {
+    m3_mul_nn(r, e, x);
+  }
+  store_link(out + f * 9L * V, V, s, r);
+}
+
+// MODE 0: projectSU -> links;  1: projectSU -> vec8;  2: projectTAH -> links
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void su3_project_kernel(const double2* in,
+                                                             double2* out_links,
+                                                             double* __restrict__ out_vec, int V,
+                                                             long nblk) {
+  const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  if (s >= V) return;
+  M3 x, r;
+  load_link(x, in + f * 9L * V, V, s);
+  if (MODE == 2) {
+    m3_tah(r, x);
+  } else {
+    m3_project_su(r, x);
+  }
+  if (MODE == 1) {
+    double v[8];
+    m3_to_vec8(v, r);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) out_vec[(f * 8 + a) * (long)V + s] = v[a];
+  } else {
+    store_link(out_links + f * 9L * V, V, s, r);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void su3_assemble_tah_kernel(const double* __restrict__ nrm,
+                                                                  double2* __restrict__ vn, long V,
+                                                                  long nblk, long nlinks) {
+  const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const long s = blk * kBlock + threadIdx.x;
+  if (s >= V) return;
+  const long l = f * V + s;
+  const double h = 0.70710678118654757;          // sqrt(1/2)
+  const double r3 = h * nrm[0 * nlinks + l];
+  const double r8 = h * 0.57735026918962573 * nrm[1 * nlinks + l];
+  const double r01 = h * nrm[2 * nlinks + l], r02 = h * nrm[3 * nlinks + l];
+  const double r12 = h * nrm[4 * nlinks + l], i01 = h * nrm[5 * nlinks + l];
+  const double i02 = h * nrm[6 * nlinks + l], i12 = h * nrm[7 * nlinks + l];
+  double2* o = vn + f * 9 * V;
+  o[0 * V + s] = make_double2(0.0, r8 + r3);
+  o[1 * V + s] = make_double2(r01, i01);
+  o[2 * V + s] = make_double2(r02, i02);
+  o[3 * V + s] = make_double2(-r01, i01);
+  o[4 * V + s] = make_double2(0.0, r8 - r3);
+  o[5 * V + s] = make_double2(r12, i12);
+  o[6 * V + s] = make_double2(-r02, i02);
+  o[7 * V + s] = make_double2(-r12, i12);
+  o[8 * V + s] = make_double2(0.0, -2.0 * r8);
+}
+
+// per-chain sum over all 36 V complex entries of |p|^2; the -8 per link and the 1/2 are
+// applied in the finalize stage through `scale` and an offset there.
+__global__ __launch_bounds__(kBlock) void su3_norm2_kernel(const double2* __restrict__ vn,
+                                                           long n_per_chain, long nblk,
+                                                           double* __restrict__ partial) {
+  __shared__ double lds[4];
+  const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const double2* v = vn + c * n_per_chain;
+  double acc = 0.0;
+  // each block owns a contiguous run of 4 * kBlock entries
+  const long base = blk * (4L * kBlock);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long j = base + (long)k * kBlock + threadIdx.x;
+    if (j < n_per_chain) {
+      const double2 d = v[j];
+      acc = fma(d.x, d.x, acc);
+      acc = fma(d.y, d.y, acc);
+    }
+  }
+  const double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partial[c * nblk + blk] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void su3_check_kernel(const double2* __restrict__ xn, long V,
+                                                           long nblk, double* __restrict__ psum,
+                                                           double* __restrict__ pmax) {
+  __shared__ double lds[8];
+  const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;   // blk over 4 V links
+  const long l = blk * kBlock + threadIdx.x;
+  double dv = 0.0;
+  const bool on = l < 4 * V;
+  if (on) {
+    const long mu = l / V, s = l % V;
+    M3 x, t;
+    load_link(x, xn + (c * 4 + mu) * 9L * V, (int)V, (int)s);
+    m3_mul_an(t, x, x);
+    t.re[0] -= 1.0; t.re[4] -= 1.0; t.re[8] -= 1.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dv += t.re[i] * t.re[i] + t.im[i] * t.im[i];
+    double dr, di;
+    m3_det(dr, di, x);
+    dv += (dr - 1.0) * (dr - 1.0) + di * di;
+  }
+  const double bs = block_sum(dv, lds);
+  const double bm = block_max(dv, lds + 4);
+  if (threadIdx.x == 0) { psum[c * nblk + blk] = bs; pmax[c * nblk + blk] = bm; }
+}
+
+__global__ void check_finalize_kernel(const double* __restrict__ psum,
+                                      const double* __restrict__ pmax, long nblk, double nlinks,
+                                      double* __restrict__ out) {
+  __shared__ double lds[8];
+  const long c = blockIdx.x;
+  double s = 0.0, m = 0.0;
+  for (long b = threadIdx.x; b < nblk; b += blockDim.x) {
+    s += psum[c * nblk + b];
+    m = fmax(m, pmax[c * nblk + b]);
+  }
+  const double ts = block_sum(s, lds);
+  const double tm = block_max(m, lds + 4);
+  if (threadIdx.x == 0) {
+    out[c * 2 + 0] = sqrt(ts / nlinks / 20.0);
+    out[c * 2 + 1] = sqrt(tm / 20.0);
+  }
+}
+
+}  // namespace l2q
+
+using namespace l2q;
+
+template <bool KICK>
+static void launch_force(const double2* xn, Dims d, int nb, long nblk, double coef, double2* out,
+                         hipStream_t st) {
+  const dim3 grid((unsigned)(nb * nblk * 4)), block(kBlock);
+  const int swz = tuning().xcd_swizzle;
+  switch (tuning().force_occ) {
+    case 4: hipLaunchKernelGGL((su3_force_kernel<KICK, 4>), grid, block, 0, st, xn, d, nblk, swz, coef, out); break;
+    case 3: hipLaunchKernelGGL((su3_force_kernel<KICK, 3>), grid, block, 0, st, xn, d, nblk, swz, coef, out); break;
+    default: hipLaunchKernelGGL((su3_force_kernel<KICK, 2>), grid, block, 0, st, xn, d, nblk, swz, coef, out); break;
+  }
+}
+
+static bool dims_ok(int nb, int T, int X, int Y, int Z) {
+  return nb > 0 && T > 0 && X > 0 && Y > 0 && Z > 0 && (double)T * X * Y * Z * 36.0 < 2.0e9;
+}
+
+extern "C" {
+
+size_t l2q_reduce_ws_bytes(int nb, long n_per_chain) {
+  if (nb <= 0 || n_per_chain <= 0) return 0;
+  // two partial arrays of up to 2 doubles per 256-item block
+  return (size_t)nb * (size_t)cdiv(n_per_chain, kBlock) * 4 * sizeof(double) + 256;
+}
+
+int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, double* out, void* ws,
+                        size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(xn && out && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * 2 * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+  const dim3 grid((unsigned)(nb * nblk)), block(kBlock);
+  const int swz = tuning().xcd_swizzle;
+  switch (tuning().plaq_occ) {
+    case 4: hipLaunchKernelGGL(su3_plaq_kernel<4>, grid, block, 0, st, (const double2*)xn, d, nblk, swz, partial); break;
+    case 3: hipLaunchKernelGGL(su3_plaq_kernel<3>, grid, block, 0, st, (const double2*)xn, d, nblk, swz, partial); break;
+    default: hipLaunchKernelGGL(su3_plaq_kernel<2>, grid, block, 0, st, (const double2*)xn, d, nblk, swz, partial); break;
+  }
+  launch_finalize(partial, out, nb, nblk, 2, 1.0, 0.0, st);
+  return check_launch("l2q_su3_plaq_reduce");
+}
+
+int l2q_su3_force(const void* xn, double beta, void* fn, int nb, int T, int X, int Y, int Z,
+                  void* stream) {
+  L2Q_REQUIRE(xn && fn, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(xn != fn, L2Q_EINVAL, "force output must not alias the gauge field");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  launch_force<false>((const double2*)xn, d, nb, nblk, beta / 3.0, (double2*)fn, (hipStream_t)stream);
+  return check_launch("l2q_su3_force");
+}
+
+int l2q_su3_force_kick(const void* xn, double beta, double coef, void* vn, int nb, int T, int X,
+                       int Y, int Z, void* stream) {
+  L2Q_REQUIRE(xn && vn, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  launch_force<true>((const double2*)xn, d, nb, nblk, coef * beta / 3.0, (double2*)vn, (hipStream_t)stream);
+  return check_launch("l2q_su3_force_kick");
+}
+
+int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* mask_n,
+                     int complement, void* out, int nb, long V, void* stream) {
+  L2Q_REQUIRE(xn && vn && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_expm_mul_kernel, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
+                     complement, (double2*)out, (int)V, nblk);
+  return check_launch("l2q_su3_expm_mul");
+}
+
+int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* stream) {
+  L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_project_kernel<0>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)in, (double2*)out, (double*)nullptr, (int)V,
+                     nblk);
+  return check_launch("l2q_su3_project_su");
+}
+
+int l2q_su3_projsu_vec8(const void* in, double* vec, long nfields, long V, void* stream) {
+  L2Q_REQUIRE(in && vec, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_project_kernel<1>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)in, (double2*)nullptr, vec, (int)V, nblk);
+  return check_launch("l2q_su3_projsu_vec8");
+}
+
+int l2q_su3_project_tah(const void* in, void* out, long nfields, long V, void* stream) {
+  L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_project_kernel<2>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)in, (double2*)out, (double*)nullptr, (int)V,
+                     nblk);
+  return check_launch("l2q_su3_project_tah");
+}
+
+int l2q_su3_kinetic_reduce(const void* vn, int nb, long V, double* out, void* ws, size_t ws_bytes,
+                           void* stream) {
+  L2Q_REQUIRE(vn && out && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long n = 36 * V;
+  const long nblk = cdiv(n, 4L * kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(su3_norm2_kernel, dim3((unsigned)(nb * nblk)), dim3(kBlock), 0, st,
+                     (const double2*)vn, n, nblk, (double*)ws);
+  // 0.5 * (sum |p|^2 - 8 * 4V)
+  launch_finalize((const double*)ws, out, nb, nblk, 1, 0.5, -0.5 * 8.0 * 4.0 * (double)V, st);
+  return check_launch("l2q_su3_kinetic_reduce");
+}
+
+int l2q_su3_assemble_tah(const double* normals, void* vn, long nfields, long V, void* stream) {
+  L2Q_REQUIRE(normals && vn, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_assemble_tah_kernel, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, normals, (double2*)vn, V, nblk, nfields * V);
+  return check_launch("l2q_su3_assemble_tah");
+}
+
+int l2q_su3_check_su(const void* xn, int nb, long V, double* out, void* ws, size_t ws_bytes,
+                     void* stream) {
+  L2Q_REQUIRE(xn && out && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(4 * V, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * 2 * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  double* psum = (double*)ws;
+  double* pmax = psum + (size_t)nb * nblk;
+  hipLaunchKernelGGL(su3_check_kernel, dim3((unsigned)(nb * nblk)), dim3(kBlock), 0, st,
+                     (const double2*)xn, V, nblk, psum, pmax);
+  hipLaunchKernelGGL(check_finalize_kernel, dim3(nb), dim3(kBlock), 0, st, psum, pmax, nblk,
+                     4.0 * (double)V, out);
+  return check_launch("l2q_su3_check_su");
+}
+
+}  // extern "C"

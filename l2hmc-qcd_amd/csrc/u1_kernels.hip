@@ -1,0 +1,310 @@
+// u1_kernels.hip -- 2D U(1) lattice kernels (angles) for gfx950.
+//
+// Fields keep the reference layout x[chain][2][T][X] (site-contiguous already).  A 2D lattice
+// of one chain is tiny (8x8 ... 64x64), so one workgroup owns one chain: the whole lattice
+// is read once, per-chain reductions finish inside the block in a fixed order (no atomics,
+// no second pass) and 2048-8192 chains fill the 256 CUs.
+#include "l2q_common.hpp"
+
+namespace l2q {
+
+template <typename T> struct Math;
+template <> struct Math<float> {
+  static __device__ __forceinline__ float sin(float x) { return sinf(x); }
+  static __device__ __forceinline__ float cos(float x) { return cosf(x); }
+  static __device__ __forceinline__ float tan(float x) { return tanf(x); }
+  static __device__ __forceinline__ float atan(float x) { return atanf(x); }
+  static __device__ __forceinline__ float exp(float x) { return expf(x); }
+  static __device__ __forceinline__ float log(float x) { return logf(x); }
+  static __device__ __forceinline__ float floor(float x) { return floorf(x); }
+  static __device__ __forceinline__ float fmod(float x, float y) { return fmodf(x, y); }
+};
+template <> struct Math<double> {
+  static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+  static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+  static __device__ __forceinline__ double tan(double x) { return ::tan(x); }
+  static __device__ __forceinline__ double atan(double x) { return ::atan(x); }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double floor(double x) { return ::floor(x); }
+  static __device__ __forceinline__ double fmod(double x, double y) { return ::fmod(x, y); }
+};
+
+// theta(t,x) = U0(t,x) + U1(t+1,x) - U0(t,x+1) - U1(t,x)      (lattice.py:154-159)
+template <typename T>
+__device__ __forceinline__ T plaq_angle(const T* __restrict__ xc, int t, int x, int Tn, int Xn) {
+  const int V = Tn * Xn;
+  const int tp = (t + 1 == Tn) ? 0 : t + 1;
+  const int xp = (x + 1 == Xn) ? 0 : x + 1;
+  return xc[t * Xn + x] + xc[V + tp * Xn + x] - xc[t * Xn + xp] - xc[V + t * Xn + x];
+}
+
+// python-style modulo wrap: ((x + pi) mod 2pi) - pi with the sign of the divisor
+template <typename T>
+__device__ __forceinline__ T wrap_angle(T x) {
+  const T pi = (T)3.14159265358979323846, two_pi = (T)6.28318530717958647692;
+  T r = Math<T>::fmod(x + pi, two_pi);
+  if (r < (T)0) r += two_pi;
+  return r - pi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void u1_plaq_kernel(const T* __restrict__ x, int Tn, int Xn,
+                                                         T* __restrict__ out) {
+  __shared__ double lds[4];
+  const int c = blockIdx.x, V = Tn * Xn;
+  const T* xc = x + (long)c * 2 * V;
+  const T pi = (T)3.14159265358979323846, two_pi = (T)6.28318530717958647692;
+  double sc = 0.0, ss = 0.0, sp = 0.0;
+  for (int s = threadIdx.x; s < V; s += kBlock) {
+    const T th = plaq_angle(xc, s / Xn, s % Xn, Tn, Xn);
+    sc += (double)Math<T>::cos(th);
+    ss += (double)Math<T>::sin(th);
+    sp += (double)(th - two_pi * Math<T>::floor((th + pi) / two_pi));   // project_angle
+  }
+  const double a = block_sum(sc, lds);
+  const double b = block_sum(ss, lds);
+  const double p = block_sum(sp, lds);
+  if (threadIdx.x == 0) { out[c * 3 + 0] = (T)a; out[c * 3 + 1] = (T)b; out[c * 3 + 2] = (T)p; }
+}
+
+// force written and/or fused kick v += coef * F
+template <typename T>
+__global__ __launch_bounds__(kBlock) void u1_force_kernel(const T* __restrict__ x, T beta,
+                                                          T* __restrict__ force, T* v, T coef,
+                                                          int Tn, int Xn) {
+  const int c = blockIdx.x, V = Tn * Xn;
+  const T* xc = x + (long)c * 2 * V;
+  for (int s = threadIdx.x; s < V; s += kBlock) {
+    const int t = s / Xn, xx = s % Xn;
+    const int tm = (t == 0) ? Tn - 1 : t - 1;
+    const int xm = (xx == 0) ? Xn - 1 : xx - 1;
+    const T s0 = Math<T>::sin(plaq_angle(xc, t, xx, Tn, Xn));
+    const T sxm = Math<T>::sin(plaq_angle(xc, t, xm, Tn, Xn));
+    const T stm = Math<T>::sin(plaq_angle(xc, tm, xx, Tn, Xn));
+    const T f0 = beta * (s0 - sxm);
+    const T f1 = beta * (-s0 + stm);
+    const long o = (long)c * 2 * V;
+    if (force) { force[o + s] = f0; force[o + V + s] = f1; }
+    if (v) { v[o + s] += coef * f0; v[o + V + s] += coef * f1; }
+  }
+}
+
+template <typename T, bool FWD, bool NCP>
+__global__ __launch_bounds__(kBlock) void u1_x_update_kernel(T* x, const T* __restrict__ v,
+                                                             const T* __restrict__ s,
+                                                             const T* __restrict__ t,
+                                                             const T* __restrict__ q,
+                                                             const float* __restrict__ mask,
+                                                             int complement, T eps, long n,
+                                                             T* __restrict__ logdet) {
+  __shared__ double lds[4];
+  const long c = blockIdx.x;
+  double ld = 0.0;
+  for (long j = threadIdx.x; j < n; j += kBlock) {
+    const long o = c * n + j;
+    T keep = (T)mask[j];
+    if (complement) keep = (T)1 - keep;
+    const T mb = (T)1 - keep;
+    const T xj = x[o];
+    const T sj = FWD ? eps * s[o] : -eps * s[o];
+    const T es = Math<T>::exp(sj);
+    const T eq = Math<T>::exp(eps * q[o]);
+    const T tr = v[o] * eq + t[o];
+    T xp, l;
+    if (NCP) {
+      const T hx = xj / (T)2;
+      const T x1 = (T)2 * Math<T>::atan(Math<T>::tan(hx) * es);
+      xp = FWD ? (x1 + eps * tr) : (x1 - es * eps * tr);
+      const T ch = Math<T>::cos(hx), sh = es * Math<T>::sin(hx);
+      l = Math<T>::log(es / (ch * ch + sh * sh));
+    } else {
+      xp = FWD ? (xj * es + eps * tr) : (es * (xj - eps * tr));
+      l = sj;
+    }
+    ld += (double)(mb * l);
+    x[o] = wrap_angle<T>(keep * xj + mb * xp);
+  }
+  const double r = block_sum(ld, lds);
+  if (threadIdx.x == 0) logdet[c] = (T)r;
+}
+
+template <typename T>
+__global__ void u1_wrap_kernel(const T* x, T* y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = wrap_angle<T>(x[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void u1_kinetic_kernel(const T* __restrict__ v, long n,
+                                                            T* __restrict__ out) {
+  __shared__ double lds[4];
+  const long c = blockIdx.x;
+  double acc = 0.0;
+  for (long j = threadIdx.x; j < n; j += kBlock) {
+    const double p = (double)v[c * n + j];
+    acc = fma(p, p, acc);
+  }
+  const double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) out[c] = (T)(0.5 * r);
+}
+
+// out[c][0:2][site] = cos(keep * x), out[c][2:4][site] = sin(keep * x)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void u1_masked_cos_sin_kernel(const T* __restrict__ x,
+                                                                   const float* __restrict__ mask,
+                                                                   int complement,
+                                                                   T* __restrict__ out, long n) {
+  const long c = blockIdx.y;
+  const long j = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n) return;
+  T keep = (T)mask[j];
+  if (complement) keep = (T)1 - keep;
+  const T a = keep * x[c * n + j];
+  out[c * 2 * n + j] = Math<T>::cos(a);
+  out[c * 2 * n + n + j] = Math<T>::sin(a);
+}
+
+__device__ __forceinline__ float act_f32(float z, int act) {
+  switch (act) {
+    case L2Q_ACT_TANH: return tanhf(z);
+    case L2Q_ACT_RELU: return fmaxf(z, 0.0f);
+    case L2Q_ACT_LEAKY_RELU: return z > 0.0f ? z : 0.01f * z;
+    case L2Q_ACT_ELU: return z > 0.0f ? z : expm1f(z);
+    case L2Q_ACT_SWISH: return z / (1.0f + expf(-z));
+    default: return z;
+  }
+}
+
+// PeriodicPadding(k-1) -> Conv2d(k) (cross-correlation, stride 1) -> MaxPool(pool) -> act.
+// Padded index i of an (H + 2(k-1)) image maps to source (i - (k-1)) mod H, so the conv
+// output has H + k - 1 rows (network.py:158-172 + nn.Conv2d).  One thread per pooled output.
+__global__ __launch_bounds__(kBlock) void conv2d_periodic_kernel(
+    const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int cin, int H, int W, int cout, int k, int pool, int act, int Ho,
+    int Wo, long total) {
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= total) return;
+  const int wo = (int)(idx % Wo);
+  const int ho = (int)((idx / Wo) % Ho);
+  const int f = (int)((idx / ((long)Wo * Ho)) % cout);
+  const long b = idx / ((long)Wo * Ho * cout);
+  const float* inb = in + b * (long)cin * H * W;
+  const int pad = k - 1;
+  float best = -3.402823466e38f;
+  for (int ph = 0; ph < pool; ++ph)
+    for (int pw = 0; pw < pool; ++pw) {
+      const int r0 = ho * pool + ph, c0 = wo * pool + pw;     // conv output coordinates
+      float acc = bias[f];
+      for (int ci = 0; ci < cin; ++ci)
+        for (int i = 0; i < k; ++i) {
+          int r = (r0 + i - pad) % H; if (r < 0) r += H;
+          for (int j = 0; j < k; ++j) {
+            int cc = (c0 + j - pad) % W; if (cc < 0) cc += W;
+            acc = fmaf(inb[(ci * H + r) * W + cc], w[((f * cin + ci) * k + i) * k + j], acc);
+          }
+        }
+      best = fmaxf(best, acc);
+    }
+  out[idx] = act_f32(best, act);
+}
+
+}  // namespace l2q
+
+using namespace l2q;
+
+#define L2Q_DISPATCH_T(elem_bytes, CALL)                                  \
+  if ((elem_bytes) == 4) { using T = float; CALL; }                       \
+  else if ((elem_bytes) == 8) { using T = double; CALL; }                 \
+  else { set_error("%s: elem_bytes must be 4 or 8", __func__); return L2Q_EINVAL; }
+
+extern "C" {
+
+int l2q_u1_plaq_reduce(const void* x, int nb, int T_, int X_, int elem_bytes, void* out,
+                       void* stream) {
+  L2Q_REQUIRE(x && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && T_ > 0 && X_ > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  L2Q_DISPATCH_T(elem_bytes, hipLaunchKernelGGL(u1_plaq_kernel<T>, dim3(nb), dim3(kBlock), 0, st,
+                                                (const T*)x, T_, X_, (T*)out));
+  return check_launch("l2q_u1_plaq_reduce");
+}
+
+int l2q_u1_force(const void* x, double beta, void* force, void* v, double coef, int nb, int T_,
+                 int X_, int elem_bytes, void* stream) {
+  L2Q_REQUIRE(x && (force || v), L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && T_ > 0 && X_ > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  L2Q_DISPATCH_T(elem_bytes,
+                 hipLaunchKernelGGL(u1_force_kernel<T>, dim3(nb), dim3(kBlock), 0, st, (const T*)x,
+                                    (T)beta, (T*)force, (T*)v, (T)coef, T_, X_));
+  return check_launch("l2q_u1_force");
+}
+
+int l2q_u1_x_update(void* x, const void* v, const void* s, const void* t, const void* q,
+                    const float* mask, int complement, double eps, int forward, int use_ncp,
+                    int elem_bytes, int nb, long n, void* logdet, void* stream) {
+  L2Q_REQUIRE(x && v && s && t && q && mask && logdet, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+#define L2Q_XUPD(F, N)                                                                        \
+  hipLaunchKernelGGL((u1_x_update_kernel<T, F, N>), dim3(nb), dim3(kBlock), 0, st, (T*)x,     \
+                     (const T*)v, (const T*)s, (const T*)t, (const T*)q, mask, complement,    \
+                     (T)eps, n, (T*)logdet)
+  L2Q_DISPATCH_T(elem_bytes, {
+    if (forward) { if (use_ncp) L2Q_XUPD(true, true); else L2Q_XUPD(true, false); }
+    else { if (use_ncp) L2Q_XUPD(false, true); else L2Q_XUPD(false, false); }
+  });
+#undef L2Q_XUPD
+  return check_launch("l2q_u1_x_update");
+}
+
+int l2q_u1_wrap(const void* x, void* y, long n, int elem_bytes, void* stream) {
+  L2Q_REQUIRE(x && y, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(n > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  L2Q_DISPATCH_T(elem_bytes,
+                 hipLaunchKernelGGL(u1_wrap_kernel<T>, dim3((unsigned)cdiv(n, kBlock)),
+                                    dim3(kBlock), 0, st, (const T*)x, (T*)y, n));
+  return check_launch("l2q_u1_wrap");
+}
+
+int l2q_u1_kinetic_reduce(const void* v, int nb, long n, int elem_bytes, void* out, void* stream) {
+  L2Q_REQUIRE(v && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  L2Q_DISPATCH_T(elem_bytes, hipLaunchKernelGGL(u1_kinetic_kernel<T>, dim3(nb), dim3(kBlock), 0, st,
+                                                (const T*)v, n, (T*)out));
+  return check_launch("l2q_u1_kinetic_reduce");
+}
+
+int l2q_u1_masked_cos_sin(const void* x, const float* mask, int complement, void* out, int nb,
+                          long n, int elem_bytes, void* stream) {
+  L2Q_REQUIRE(x && mask && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  L2Q_DISPATCH_T(elem_bytes,
+                 hipLaunchKernelGGL(u1_masked_cos_sin_kernel<T>,
+                                    dim3((unsigned)cdiv(n, kBlock), (unsigned)nb), dim3(kBlock), 0,
+                                    st, (const T*)x, mask, complement, (T*)out, n));
+  return check_launch("l2q_u1_masked_cos_sin");
+}
+
+int l2q_conv2d_periodic_f32(const float* in, const float* w, const float* bias, float* out, int nb,
+                            int cin, int H, int W, int cout, int k, int pool, int act,
+                            void* stream) {
+  L2Q_REQUIRE(in && w && bias && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && cin > 0 && H > 0 && W > 0 && cout > 0 && k > 0, L2Q_EINVAL,
+              "non-positive size");
+  if (pool < 1) pool = 1;
+  const int Hc = H + k - 1, Wc = W + k - 1;         // conv output extent
+  const int Ho = Hc / pool, Wo = Wc / pool;
+  L2Q_REQUIRE(Ho > 0 && Wo > 0, L2Q_ESHAPE, "pooling window larger than the image");
+  const long total = (long)nb * cout * Ho * Wo;
+  hipLaunchKernelGGL(conv2d_periodic_kernel, dim3((unsigned)cdiv(total, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, in, w, bias, out, cin, H, W, cout, k, pool, act, Ho, Wo,
+                     total);
+  return check_launch("l2q_conv2d_periodic_f32");
+}
+
+}  // extern "C"

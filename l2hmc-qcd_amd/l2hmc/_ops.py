@@ -1,0 +1,299 @@
+"""Functional wrappers over the C ABI (``include/l2q.h``): tensors in, tensors out.
+
+SU(3) functions ending in ``_n`` take / return fields in the *native* layout
+``xn[nb, 4, 9, V]`` complex128 (see l2q.h); ``su3_pack`` / ``su3_unpack`` convert from / to the
+reference's public layout ``x[nb, 4, T, X, Y, Z, 3, 3]``.  Nothing here falls back to PyTorch
+arithmetic: every function launches HIP kernels from libl2q.so or raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import native as N
+
+C128 = torch.complex128
+
+
+def _vol(lat: Sequence[int]) -> int:
+    v = 1
+    for n in lat:
+        v *= int(n)
+    return v
+
+
+def _ws(nb: int, n_per_chain: int, device) -> torch.Tensor:
+    return N.workspace(N.reduce_ws_bytes(nb, n_per_chain), device)
+
+
+# ---------------------------------------------------------------------------- layout
+def transpose(a: torch.Tensor, batch: int, rows: int, cols: int) -> torch.Tensor:
+    """[batch, rows, cols] -> [batch, cols, rows] for 4/8/16-byte elements."""
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    N.call('l2q_transpose', a, out, batch, rows, cols, a.element_size())
+    return out
+
+
+def su3_pack(x: torch.Tensor) -> torch.Tensor:
+    """x[nb,4,T,X,Y,Z,3,3] (or any [nb, 4*V*9]-reshapeable) c128 -> xn[nb,4,9,V]."""
+    nb = x.shape[0]
+    x = x.to(C128).contiguous()
+    V = x.numel() // (nb * 36)
+    out = torch.empty((nb, 4, 9, V), dtype=C128, device=x.device)
+    N.call('l2q_su3_pack', x, out, nb, V)
+    return out
+
+
+def su3_unpack(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    nb, _, _, V = xn.shape
+    out = torch.empty((nb, 4, *[int(i) for i in lat], 3, 3), dtype=C128, device=xn.device)
+    N.call('l2q_su3_unpack', xn.contiguous(), out, nb, V)
+    return out
+
+
+def pack_entries(a: torch.Tensor, V: int, ncomp: int = 9) -> torch.Tensor:
+    """per-entry quantity [nb, 4*V*ncomp] in reference order -> native order [nb, 4*ncomp*V]."""
+    nb = a.shape[0]
+    return transpose(a.reshape(nb * 4, V, ncomp), nb * 4, V, ncomp).reshape(nb, -1)
+
+
+def unpack_entries(a: torch.Tensor, V: int, ncomp: int = 9) -> torch.Tensor:
+    nb = a.shape[0]
+    return transpose(a.reshape(nb * 4, ncomp, V), nb * 4, ncomp, V).reshape(nb, -1)
+
+
+def native_index(V: int, ncomp: int, device) -> torch.Tensor:
+    """idx[j_native] = j_reference for per-entry (ncomp=9) or vec8 (ncomp=8) quantities."""
+    return (torch.arange(4 * V * ncomp, device=device).reshape(4, V, ncomp)
+            .permute(0, 2, 1).reshape(-1).contiguous())
+
+
+# ---------------------------------------------------------------------------- SU(3)
+def su3_plaq_sums_n(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    """[nb, 2]: (sum Re tr P, sum Im tr P) over sites and the 6 planes."""
+    nb = xn.shape[0]
+    T, X, Y, Z = (int(i) for i in lat)
+    out = torch.empty((nb, 2), dtype=torch.float64, device=xn.device)
+    ws = _ws(nb, T * X * Y * Z * 36, xn.device)
+    N.call('l2q_su3_plaq_reduce', xn, nb, T, X, Y, Z, out, ws, ws.numel())
+    return out
+
+
+def su3_force_n(xn: torch.Tensor, beta: float, lat: Sequence[int]) -> torch.Tensor:
+    nb = xn.shape[0]
+    T, X, Y, Z = (int(i) for i in lat)
+    f = torch.empty_like(xn)
+    N.call('l2q_su3_force', xn, float(beta), f, nb, T, X, Y, Z)
+    return f
+
+
+def su3_force_kick_n(xn: torch.Tensor, beta: float, coef: float, vn: torch.Tensor,
+                     lat: Sequence[int]) -> torch.Tensor:
+    """vn += coef * F(xn) in place."""
+    T, X, Y, Z = (int(i) for i in lat)
+    N.call('l2q_su3_force_kick', xn, float(beta), float(coef), vn, xn.shape[0], T, X, Y, Z)
+    return vn
+
+
+def su3_expm_mul_n(xn: torch.Tensor, vn: torch.Tensor, eps: float,
+                   mask_n: Optional[torch.Tensor] = None, complement: bool = False,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    nb, _, _, V = xn.shape
+    out = torch.empty_like(xn) if out is None else out
+    N.call('l2q_su3_expm_mul', xn, vn, float(eps), mask_n, int(complement), out, nb, V)
+    return out
+
+
+def su3_project_su_n(xn: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(xn)
+    nf, V = xn.numel() // (9 * xn.shape[-1]), xn.shape[-1]
+    N.call('l2q_su3_project_su', xn, out, nf, V)
+    return out
+
+
+def su3_project_tah_n(xn: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(xn)
+    nf, V = xn.numel() // (9 * xn.shape[-1]), xn.shape[-1]
+    N.call('l2q_su3_project_tah', xn, out, nf, V)
+    return out
+
+
+def su3_projsu_vec8_n(xn: torch.Tensor) -> torch.Tensor:
+    """-> [nb, 4, 8, V] float64 (native vec8 order)."""
+    nb, _, _, V = xn.shape
+    out = torch.empty((nb, 4, 8, V), dtype=torch.float64, device=xn.device)
+    N.call('l2q_su3_projsu_vec8', xn, out, nb * 4, V)
+    return out
+
+
+def su3_kinetic_n(vn: torch.Tensor) -> torch.Tensor:
+    nb, _, _, V = vn.shape
+    out = torch.empty(nb, dtype=torch.float64, device=vn.device)
+    ws = _ws(nb, 36 * V, vn.device)
+    N.call('l2q_su3_kinetic_reduce', vn, nb, V, out, ws, ws.numel())
+    return out
+
+
+def su3_assemble_tah_n(normals: torch.Tensor) -> torch.Tensor:
+    """normals [8, nb, 4, V] float64 -> vn [nb, 4, 9, V]."""
+    _, nb, _, V = normals.shape
+    out = torch.empty((nb, 4, 9, V), dtype=C128, device=normals.device)
+    N.call('l2q_su3_assemble_tah', normals.contiguous(), out, nb * 4, V)
+    return out
+
+
+def su3_check_su_n(xn: torch.Tensor) -> torch.Tensor:
+    nb, _, _, V = xn.shape
+    out = torch.empty((nb, 2), dtype=torch.float64, device=xn.device)
+    ws = _ws(nb, 36 * V, xn.device)
+    N.call('l2q_su3_check_su', xn, nb, V, out, ws, ws.numel())
+    return out
+
+
+# ---------------------------------------------------------------------------- shared
+def v_update_(v: torch.Tensor, force: torch.Tensor, s: torch.Tensor, t: torch.Tensor,
+              q: torch.Tensor, eps: float, forward: bool) -> torch.Tensor:
+    """In-place generalised momentum update; returns logdet [nb]."""
+    nb = v.shape[0]
+    cplx = v.is_complex()
+    n = v.numel() // nb
+    real_dtype = s.dtype
+    logdet = torch.empty(nb, dtype=real_dtype, device=v.device)
+    ws = _ws(nb, n, v.device)
+    N.call('l2q_v_update', v, force, s, t, q, float(eps), int(forward), int(cplx),
+           s.element_size(), nb, n, logdet, ws, ws.numel())
+    return logdet
+
+
+def accept(h_init: torch.Tensor, h_prop: torch.Tensor, sumlogdet: torch.Tensor,
+           u: torch.Tensor):
+    nb = h_init.shape[0]
+    dt = h_init.dtype
+    acc = torch.empty(nb, dtype=dt, device=h_init.device)
+    mask = torch.empty(nb, dtype=torch.float32, device=h_init.device)
+    N.call('l2q_accept', h_init.contiguous(), h_prop.to(dt).contiguous(),
+           sumlogdet.to(dt).contiguous(), u.to(dt).contiguous(), acc, mask, nb,
+           h_init.element_size())
+    return acc, mask
+
+
+def select_rows(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """out[c] = a[c] if mask[c] else b[c]."""
+    nb = a.shape[0]
+    a, b = a.contiguous(), b.contiguous()
+    row_bytes = a.numel() // nb * a.element_size()
+    if row_bytes % 16:
+        raise N.L2QError('select_rows: row size must be a multiple of 16 bytes')
+    out = torch.empty_like(a)
+    N.call('l2q_select_rows', a, b, mask, out, nb, row_bytes)
+    return out
+
+
+def scale(x: torch.Tensor, alpha: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """alpha * x for float64 / complex128 tensors."""
+    out = torch.empty_like(x) if out is None else out
+    n = x.numel() * (2 if x.is_complex() else 1)
+    N.call('l2q_scale_f64', x, float(alpha), out, n)
+    return out
+
+
+def axpy_(x: torch.Tensor, p: torch.Tensor, alpha: float) -> torch.Tensor:
+    N.call('l2q_axpy', p, float(alpha), x, x.numel(), x.element_size())
+    return x
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+         a2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
+         bias2: Optional[torch.Tensor] = None, coeff: Optional[torch.Tensor] = None,
+         scale: float = 1.0, act: Optional[str] = None) -> torch.Tensor:
+    """epi(a @ w.T (+ a2 @ w2.T) + bias (+ bias2)) on the MFMA GEMM (fp64 or fp32)."""
+    m, k = a.shape
+    n = w.shape[0]
+    k2 = 0 if a2 is None else a2.shape[1]
+    if w.shape[1] != k or (a2 is not None and (w2 is None or w2.shape != (n, k2))):
+        raise N.L2QError(f'gemm: shape mismatch a{tuple(a.shape)} w{tuple(w.shape)}')
+    for other in (w, bias, a2, w2, bias2, coeff):
+        if other is not None and other.dtype != a.dtype:
+            raise N.L2QError(f'gemm: dtype mismatch {other.dtype} vs {a.dtype}')
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    ws = N.workspace(N.gemm_ws_bytes(m, n, k, k2), a.device)
+    name = {torch.float64: 'l2q_gemm_f64', torch.float32: 'l2q_gemm_f32'}.get(a.dtype)
+    if name is None:
+        raise N.L2QError(f'gemm: unsupported dtype {a.dtype}')
+    N.call(name, a, w, m, n, k, a2, w2, k2, bias, bias2, coeff, float(scale), N.ACT[act], out,
+           ws, ws.numel())
+    return out
+
+
+# ---------------------------------------------------------------------------- U(1)
+def u1_plaq_sums(x: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    """[nb, 3]: sum cos(theta), sum sin(theta), sum project_angle(theta)."""
+    nb = x.shape[0]
+    T, X = (int(i) for i in lat)
+    out = torch.empty((nb, 3), dtype=x.dtype, device=x.device)
+    N.call('l2q_u1_plaq_reduce', x, nb, T, X, x.element_size(), out)
+    return out
+
+
+def u1_force(x: torch.Tensor, beta: float, lat: Sequence[int]) -> torch.Tensor:
+    T, X = (int(i) for i in lat)
+    f = torch.empty_like(x)
+    N.call('l2q_u1_force', x, float(beta), f, None, 0.0, x.shape[0], T, X, x.element_size())
+    return f
+
+
+def u1_force_kick_(x: torch.Tensor, beta: float, coef: float, v: torch.Tensor,
+                   lat: Sequence[int]) -> torch.Tensor:
+    T, X = (int(i) for i in lat)
+    N.call('l2q_u1_force', x, float(beta), None, v, float(coef), x.shape[0], T, X,
+           x.element_size())
+    return v
+
+
+def u1_x_update_(x: torch.Tensor, v: torch.Tensor, s: torch.Tensor, t: torch.Tensor,
+                 q: torch.Tensor, mask: torch.Tensor, complement: bool, eps: float,
+                 forward: bool, use_ncp: bool = True) -> torch.Tensor:
+    nb = x.shape[0]
+    n = x.numel() // nb
+    logdet = torch.empty(nb, dtype=x.dtype, device=x.device)
+    N.call('l2q_u1_x_update', x, v, s, t, q, mask, int(complement), float(eps), int(forward),
+           int(use_ncp), x.element_size(), nb, n, logdet)
+    return logdet
+
+
+def u1_wrap(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    N.call('l2q_u1_wrap', x, out, x.numel(), x.element_size())
+    return out
+
+
+def u1_kinetic(v: torch.Tensor) -> torch.Tensor:
+    nb = v.shape[0]
+    out = torch.empty(nb, dtype=v.dtype, device=v.device)
+    N.call('l2q_u1_kinetic_reduce', v, nb, v.numel() // nb, v.element_size(), out)
+    return out
+
+
+def u1_masked_cos_sin(x: torch.Tensor, mask: torch.Tensor, complement: bool,
+                      lat: Sequence[int]) -> torch.Tensor:
+    """[nb, 4, T, X]: cat([cos(m x), sin(m x)], dim=1)."""
+    nb = x.shape[0]
+    n = x.numel() // nb
+    out = torch.empty((nb, 4, *[int(i) for i in lat]), dtype=x.dtype, device=x.device)
+    N.call('l2q_u1_masked_cos_sin', x, mask, int(complement), out, nb, n, x.element_size())
+    return out
+
+
+def conv2d_periodic(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, pool: int = 1,
+                    act: Optional[str] = None) -> torch.Tensor:
+    nb, cin, H, W = x.shape
+    cout, _, k, _ = w.shape
+    pool = max(int(pool), 1)
+    Ho, Wo = (H + k - 1) // pool, (W + k - 1) // pool
+    out = torch.empty((nb, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    N.call('l2q_conv2d_periodic_f32', x.float().contiguous(), w.float().contiguous(),
+           b.float().contiguous(), out, nb, cin, H, W, cout, k, pool, N.ACT[act])
+    return out

@@ -1,0 +1,137 @@
+"""ctypes binding of ``libl2q.so`` (C ABI: ``include/l2q.h``).
+
+The product path has NO fallback: if the library is missing, or a tensor is not a contiguous
+CUDA/HIP tensor, the call raises.  All launches go on PyTorch's current stream so that
+``torch.cuda.Event`` timing and stream ordering with the rest of the program hold.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lib', 'libl2q.so')
+
+ACT = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'leaky_relu': 3, 'elu': 4, 'swish': 5}
+
+P, I, L, D, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/l2q.h one to one
+SIGNATURES = {
+    'l2q_last_error': (C.c_char_p, []),
+    'l2q_version': (I, []),
+    'l2q_set_tuning': (I, [C.c_char_p, I]),
+    'l2q_reduce_ws_bytes': (Z, [I, L]),
+    'l2q_transpose': (I, [P, P, L, I, I, I, P]),
+    'l2q_su3_pack': (I, [P, P, I, L, P]),
+    'l2q_su3_unpack': (I, [P, P, I, L, P]),
+    'l2q_su3_plaq_reduce': (I, [P, I, I, I, I, I, P, P, Z, P]),
+    'l2q_su3_force': (I, [P, D, P, I, I, I, I, I, P]),
+    'l2q_su3_force_kick': (I, [P, D, D, P, I, I, I, I, I, P]),
+    'l2q_su3_expm_mul': (I, [P, P, D, P, I, P, I, L, P]),
+    'l2q_su3_project_su': (I, [P, P, L, L, P]),
+    'l2q_su3_projsu_vec8': (I, [P, P, L, L, P]),
+    'l2q_su3_project_tah': (I, [P, P, L, L, P]),
+    'l2q_su3_kinetic_reduce': (I, [P, I, L, P, P, Z, P]),
+    'l2q_su3_assemble_tah': (I, [P, P, L, L, P]),
+    'l2q_su3_check_su': (I, [P, I, L, P, P, Z, P]),
+    'l2q_v_update': (I, [P, P, P, P, P, D, I, I, I, I, L, P, P, Z, P]),
+    'l2q_accept': (I, [P, P, P, P, P, P, I, I, P]),
+    'l2q_select_rows': (I, [P, P, P, P, I, L, P]),
+    'l2q_scale_f64': (I, [P, D, P, L, P]),
+    'l2q_gemm_f64': (I, [P, P, I, I, L, P, P, L, P, P, P, D, I, P, P, Z, P]),
+    'l2q_gemm_ws_bytes': (Z, [I, I, L, L]),
+    'l2q_gemm_f32': (I, [P, P, I, I, L, P, P, L, P, P, P, F, I, P, P, Z, P]),
+    'l2q_u1_plaq_reduce': (I, [P, I, I, I, I, P, P]),
+    'l2q_u1_force': (I, [P, D, P, P, D, I, I, I, I, P]),
+    'l2q_u1_x_update': (I, [P, P, P, P, P, P, I, D, I, I, I, I, L, P, P]),
+    'l2q_u1_wrap': (I, [P, P, L, I, P]),
+    'l2q_u1_kinetic_reduce': (I, [P, I, L, I, P, P]),
+    'l2q_axpy': (I, [P, D, P, L, I, P]),
+    'l2q_u1_masked_cos_sin': (I, [P, P, I, P, I, L, I, P]),
+    'l2q_conv2d_periodic_f32': (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class L2QError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libl2q.so (once).  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise L2QError(
+                f'{LIB_PATH} not found: build it with `python __graft_entry__.py` '
+                '(hipcc --offload-arch=gfx950).  The l2hmc hot path has no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L2QError('l2q kernels need tensors on the GPU (got a CPU tensor); '
+                       'the hot path has no CPU fallback')
+    if not t.is_contiguous():
+        raise L2QError('l2q kernels need contiguous tensors')
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; tensors are passed as device pointers and the
+    current stream is appended.  Raises L2QError with l2q_last_error() on failure."""
+    lib = load()
+    conv = [ptr(a) if isinstance(a, torch.Tensor) else a for a in args]
+    rc = getattr(lib, name)(*conv, stream_ptr())
+    if rc != 0:
+        raise L2QError(f'{name} failed ({rc}): {lib.l2q_last_error().decode()}')
+
+
+def set_tuning(key: str, value: int) -> int:
+    return load().l2q_set_tuning(key.encode(), int(value))
+
+
+class Workspace:
+    """Grow-only scratch buffer for the order-stable reductions and split-K partials."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_WS = Workspace()
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return _WS.get(nbytes, device)
+
+
+def reduce_ws_bytes(nb: int, n_per_chain: int) -> int:
+    return int(load().l2q_reduce_ws_bytes(int(nb), int(n_per_chain)))
+
+
+def gemm_ws_bytes(m: int, n: int, k: int, k2: int = 0) -> int:
+    return int(load().l2q_gemm_ws_bytes(int(m), int(n), int(k), int(k2)))

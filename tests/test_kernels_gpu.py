@@ -1,0 +1,243 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the numpy
+oracle and the golden vectors generated from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import su3 as osu3, u1 as ou1, network as onet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from l2hmc import _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def err(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max())
+
+
+def test_pack_roundtrip(ops):
+    rng = np.random.default_rng(1)
+    L = (3, 2, 5, 4)
+    x = rng.normal(size=(2, 4, *L, 3, 3)) + 1j * rng.normal(size=(2, 4, *L, 3, 3))
+    xn = ops.su3_pack(dev(x))
+    ref = np.moveaxis(x.reshape(2, 4, -1, 9), 2, 3)
+    assert err(host(xn), ref) == 0.0
+    assert err(host(ops.su3_unpack(xn, L)), x) == 0.0
+    a = rng.normal(size=(2, 4 * 120 * 9))
+    an = ops.pack_entries(dev(a), 120)
+    idx = host(ops.native_index(120, 9, 'cuda'))
+    assert err(host(an), a[:, idx]) == 0.0
+    assert err(host(ops.unpack_entries(an, 120)), a) == 0.0
+    m = rng.integers(0, 2, size=(1, 4 * 120 * 9)).astype(np.float32)
+    assert err(host(ops.pack_entries(dev(m), 120)), m[:, idx]) == 0.0
+
+
+def test_su3_ops_golden(ops, golden):
+    g = golden('su3_ops')
+    L = tuple(int(i) for i in g['latvolume'])
+    V = int(np.prod(L))
+    beta = float(g['beta'])
+    xn = ops.su3_pack(dev(g['x']))
+    vn = ops.su3_pack(dev(g['v']))
+    s = host(ops.su3_plaq_sums_n(xn, L))
+    assert err(-(beta / 3) * s[:, 0], g['action']) < 1e-10
+    assert err(s[:, 0] / (18 * V), g['plaqs']) < 1e-14
+    assert err(s[:, 1] / (18 * V), g['sinQ']) < 1e-14
+    assert err(s[:, 1] / (32 * np.pi ** 2), g['intQ']) < 1e-13
+    fn = ops.su3_force_n(xn, beta, L)
+    assert err(host(ops.su3_unpack(fn, L)), g['force']) < 1e-13
+    assert err(host(ops.su3_kinetic_n(vn)), g['kinetic']) < 1e-10
+    nrm = dev(g['normals'].reshape(8, 2, 4, V))
+    assert err(host(ops.su3_unpack(ops.su3_assemble_tah_n(nrm), L)), g['v']) < 1e-15
+    e = ops.su3_expm_mul_n(xn, vn, float(g['eps_expm']))
+    assert err(host(ops.su3_unpack(e, L)), g['expm_v_x']) < 1e-13
+    # general (non anti-Hermitian) matrices: expm, projectSU, projectTAH, su3_to_vec
+    gen = g['general']                                # [4, 7, 3, 3]
+    nlinks = gen.shape[0] * gen.shape[1]
+    pad = np.zeros((1, 4, nlinks, 3, 3), complex)
+    pad[0, :] = gen.reshape(1, nlinks, 3, 3)
+    gn = ops.su3_pack(dev(pad))
+    eye = np.zeros_like(pad); eye[..., range(3), range(3)] = 1
+    eg = ops.su3_expm_mul_n(ops.su3_pack(dev(eye)), gn, 1.0)
+    got = host(eg).reshape(4, 3, 3, nlinks)[0].transpose(2, 0, 1).reshape(gen.shape)
+    assert err(got, g['expm_general']) < 1e-11
+    ps = host(ops.su3_project_su_n(gn)).reshape(4, 3, 3, nlinks)[0].transpose(2, 0, 1)
+    assert err(ps.reshape(gen.shape), g['projsu_general']) < 1e-12
+    pt = host(ops.su3_project_tah_n(gn)).reshape(4, 3, 3, nlinks)[0].transpose(2, 0, 1)
+    assert err(pt.reshape(gen.shape), g['tah_general']) < 1e-15
+    vx = host(ops.su3_projsu_vec8_n(xn))              # [nb, 4, 8, V]
+    assert err(np.moveaxis(vx, 2, 3).reshape(g['vec_x'].shape), g['vec_x']) < 1e-12
+    vf = host(ops.su3_projsu_vec8_n(fn))
+    # ill-conditioned in the reference itself (see tests/test_oracle_golden.py)
+    assert err(np.moveaxis(vf, 2, 3).reshape(g['vec_force'].shape), g['vec_force']) < 1e-7
+    chk = host(ops.su3_check_su_n(xn))
+    assert err(chk.T, g['checksu_x']) < 1e-14
+    # one HMC leapfrog step with the fused kick
+    v1 = vn.clone()
+    ops.su3_force_kick_n(xn, beta, -0.5 * 0.05, v1, L)
+    x1 = ops.su3_expm_mul_n(xn, v1, 0.05)
+    ops.su3_force_kick_n(x1, beta, -0.5 * 0.05, v1, L)
+    assert err(host(ops.su3_unpack(x1, L)), g['hmc_x1']) < 1e-13
+    assert err(host(ops.su3_unpack(v1, L)), g['hmc_v1']) < 1e-12
+
+
+@pytest.mark.parametrize('L', [(2, 2, 2, 2), (1, 3, 2, 5), (4, 4, 4, 4), (3, 5, 2, 7)])
+def test_su3_stencils_vs_oracle(ops, L):
+    """edge shapes: extent 1 and 2 (forward == backward neighbour), odd sizes, V not a
+    multiple of the block size."""
+    rng = np.random.default_rng(7)
+    nb = 3
+    x = osu3.project_su(rng.normal(size=(nb, 4, *L, 3, 3)) + 1j * rng.normal(size=(nb, 4, *L, 3, 3)))
+    xn = ops.su3_pack(dev(x))
+    re, im = osu3.plaq_sums(x)
+    s = host(ops.su3_plaq_sums_n(xn, L))
+    assert err(s, np.stack([re, im], 1)) < 1e-10
+    f = host(ops.su3_unpack(ops.su3_force_n(xn, 5.7, L), L))
+    assert err(f, osu3.grad_action(x, 5.7)) < 1e-12
+    from l2hmc import native
+    for occ in (2, 3, 4):
+        native.set_tuning('force_occ', occ); native.set_tuning('plaq_occ', occ)
+        assert err(host(ops.su3_plaq_sums_n(xn, L)), s) < 1e-10
+        assert err(host(ops.su3_unpack(ops.su3_force_n(xn, 5.7, L), L)), f) < 1e-13
+    native.set_tuning('force_occ', 2); native.set_tuning('plaq_occ', 2)
+
+
+def test_su3_cold_start(ops):
+    L = (4, 2, 6, 2)
+    x = np.zeros((2, 4, *L, 3, 3), complex); x[..., range(3), range(3)] = 1
+    V = int(np.prod(L))
+    xn = ops.su3_pack(dev(x))
+    s = host(ops.su3_plaq_sums_n(xn, L))
+    assert np.allclose(s[:, 0], 18 * V) and np.allclose(s[:, 1], 0)
+    assert float(ops.su3_force_n(xn, 6.0, L).abs().max()) == 0.0
+    assert np.allclose(host(ops.su3_kinetic_n(torch.zeros_like(xn))), -0.5 * 8 * 4 * V)
+
+
+def test_expm_mul_masked(ops, golden):
+    g = golden('su3_l2hmc')
+    L = tuple(int(i) for i in g['latvolume'])
+    V = int(np.prod(L))
+    xn = ops.su3_pack(dev(g['x']))
+    vn = ops.su3_pack(dev(g['v_fwd']))
+    eps = float(g['xeps'][0]); eps = eps / (1 + eps)
+    m = ops.pack_entries(dev(g['masks'][0:1]), V).reshape(-1)
+    got = ops.su3_expm_mul_n(xn, vn, eps, m, False)
+    assert err(host(ops.su3_unpack(got, L)), g['x_fwd']) < 1e-13
+    eps1 = float(g['xeps'][1]); eps1 = eps1 / (1 + eps1)
+    got = ops.su3_expm_mul_n(xn, vn, -eps1, m, True)     # keeps (1 - m)
+    assert err(host(ops.su3_unpack(got, L)), g['x_bwd']) < 1e-13
+
+
+def test_v_update_su3(ops, golden):
+    g = golden('su3_l2hmc')
+    L = tuple(int(i) for i in g['latvolume'])
+    V = int(np.prod(L))
+    vn = ops.su3_pack(dev(g['v0']))
+    fn = ops.su3_pack(dev(g['force0']))
+    s, t, q = (ops.pack_entries(dev(g[k]), V) for k in ('s', 't', 'q'))
+    eps = float(g['veps'][0]); eps = eps / (1 + eps)
+    v = vn.clone()
+    ld = ops.v_update_(v, fn, s, t, q, eps, True)
+    assert err(host(ops.su3_unpack(v, L)), g['v_fwd']) < 1e-13
+    assert err(host(ld), g['logdet_v_fwd']) < 1e-12
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('shape', [(3, 5, 40, 0), (128, 96, 700, 36), (257, 130, 4100, 0),
+                                   (2, 300, 16, 16), (130, 1000, 6, 0)])
+def test_gemm(ops, dtype, shape):
+    m, n, k, k2 = shape
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(m, k)).astype(dtype); w = (rng.normal(size=(n, k)) / np.sqrt(k)).astype(dtype)
+    b = rng.normal(size=n).astype(dtype); co = (0.3 * rng.normal(size=n)).astype(dtype)
+    a2 = w2 = b2 = None
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+    if k2:
+        a2 = rng.normal(size=(m, k2)).astype(dtype); w2 = rng.normal(size=(n, k2)).astype(dtype)
+        b2 = rng.normal(size=n).astype(dtype)
+        ref = ref + a2.astype(np.float64) @ w2.astype(np.float64).T + b2
+    tol = 1e-12 if dtype == np.float64 else 2e-4
+    for act in (None, 'tanh', 'leaky_relu', 'elu', 'swish', 'relu'):
+        want = 0.7 * np.exp(co) * onet.act(act, ref) if act else 0.7 * np.exp(co) * ref
+        got = ops.gemm(dev(a), dev(w), dev(b), a2=None if a2 is None else dev(a2),
+                       w2=None if w2 is None else dev(w2), bias2=None if b2 is None else dev(b2),
+                       coeff=dev(co), scale=0.7, act=act)
+        assert err(host(got), want) < tol * max(1.0, np.abs(want).max()), (act, shape)
+    got = ops.gemm(dev(a), dev(w))
+    assert err(host(got), a.astype(np.float64) @ w.astype(np.float64).T) < tol * 10
+
+
+@pytest.mark.parametrize('name', ['u1_conv', 'u1_c1'])
+def test_u1_ops_golden(ops, golden, name):
+    g = golden(name)
+    L = tuple(int(i) for i in g['latvolume'])
+    V = int(np.prod(L))
+    beta = float(g['beta'])
+    x = dev(g['x'])
+    nb = x.shape[0]
+    s = host(ops.u1_plaq_sums(x, L))
+    assert err(beta * (V - s[:, 0]), g['action']) < 2e-4
+    assert err(s[:, 0] / V, g['plaqs']) < 1e-6
+    assert err(s[:, 1] / (2 * np.pi), g['sinQ']) < 1e-5
+    assert err(s[:, 2] / (2 * np.pi), g['intQ']) < 1e-5
+    assert err(host(ops.u1_force(x, beta, L)), g['force']) < 1e-5
+    v = dev(g['normals'].reshape(nb, -1))
+    assert err(host(ops.u1_kinetic(v)), g['kinetic']) < 1e-4
+    # v update with the golden network heads
+    f = ops.u1_force(x, beta, L).reshape(nb, -1)
+    sd_eps = float(g['sd.veps.0']); eps = sd_eps / (1 + sd_eps)
+    v1 = v.clone()
+    ld = ops.v_update_(v1, f, dev(g['vnet_s']), dev(g['vnet_t']), dev(g['vnet_q']), eps, True)
+    assert err(host(v1), g['v_fwd']) < 1e-5
+    assert err(host(ld), g['logdet_v_fwd']) < 1e-4
+    # x update (NCP) forward with mask m, backward with the complement
+    xe = float(g['sd.xeps.0']); xeps = xe / (1 + xe)
+    m0 = dev(g['masks'][0])
+    x1 = x.clone().reshape(nb, -1)
+    ld = ops.u1_x_update_(x1, v, dev(g['xnet_s']), dev(g['xnet_t']), dev(g['xnet_q']), m0, False,
+                          xeps, True)
+    d = np.abs(np.angle(np.exp(1j * (host(x1).reshape(g['x_fwd'].shape) - g['x_fwd']))))
+    assert d.max() < 2e-5 and err(host(ld), g['logdet_x_fwd']) < 1e-4
+    xm = ops.u1_masked_cos_sin(x, m0, False, L)
+    want = ou1.group_to_vec(g['masks'][0].reshape(1, 2, *L) * g['x'])
+    assert err(host(xm), want) < 1e-6
+    assert err(host(ops.u1_wrap(x * 3)), ou1.compat_proj(g['x'] * np.float32(3))) < 1e-5
+
+
+def test_conv2d_periodic(ops):
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(3, 4, 5, 6)).astype(np.float32)
+    for k, pool, act in [(3, 1, None), (2, 2, 'leaky_relu'), (5, 1, 'tanh'), (2, 3, 'relu')]:
+        w = rng.normal(size=(7, 4, k, k)).astype(np.float32)
+        b = rng.normal(size=7).astype(np.float32)
+        want = onet.conv2d_valid(onet.periodic_pad(x, k - 1), w, b)
+        if pool > 1:
+            want = onet.maxpool2d(want, pool)
+        if act:
+            want = onet.act(act, want)
+        got = host(ops.conv2d_periodic(dev(x), dev(w), dev(b), pool, act))
+        assert got.shape == want.shape and err(got, want) < 1e-4
+
+
+def test_accept_select(ops):
+    h0 = dev(np.array([1.0, 2.0, 3.0, -1.0])); h1 = dev(np.array([1.5, 1.0, 3.0, 0.0]))
+    sld = dev(np.array([0.1, 0.0, -0.2, 0.0])); u = dev(np.array([0.5, 0.9, 0.9, 0.3]))
+    acc, mask = ops.accept(h0, h1, sld, u)
+    want = np.exp(np.minimum(0, host(h0) - host(h1) + host(sld)))
+    assert err(host(acc), want) < 1e-15
+    assert np.array_equal(host(mask), (want > host(u)).astype(np.float32))
+    a = dev(np.arange(4 * 6, dtype=np.float64).reshape(4, 6)); b = -a
+    out = host(ops.select_rows(a, b, mask))
+    assert np.array_equal(out, np.where(host(mask)[:, None] > 0, host(a), host(b)))
