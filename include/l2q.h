@@ -97,6 +97,11 @@ int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* st
 /* su3_to_vec(projectSU(.)) -> vec[nfields][8][V] double (group.py:138-147); the vnet
  * GEMM A-operand (dynamics.py:1154-1156). */
 int l2q_su3_projsu_vec8(const void* in, double* vec, long nfields, long V, void* stream);
+/* projectU: x (x^H x)^(-1/2) without the determinant phase (utils.py:332-338). */
+int l2q_su3_project_u(const void* in, void* out, long nfields, long V, void* stream);
+/* out = op(a) op(b) per link, op = adjoint if flagged (SU3.mul, group.py:56-69). */
+int l2q_su3_mul(const void* a, const void* b, int adjoint_a, int adjoint_b, void* out,
+                long nfields, long V, void* stream);
 /* projectTAH on every link (group.py:92-103); out may alias in. */
 int l2q_su3_project_tah(const void* in, void* out, long nfields, long V, void* stream);
 /* out[c] = 0.5 * sum_links (|p|_F^2 - 8)   (group.py:125-126) */
@@ -126,7 +131,8 @@ int l2q_v_update(void* v, const void* force, const void* s, const void* t, const
  * (dynamics.py:1065-1087).  elem_bytes of h/sumlogdet/acc/u: 8 or 4. */
 int l2q_accept(const void* h_init, const void* h_prop, const void* sumlogdet, const void* u,
                void* acc, float* mask, int nb, int elem_bytes, void* stream);
-/* out[c][:] = mask[c] ? a[c][:] : b[c][:]   (dynamics.py:677-682), row_bytes per chain */
+/* out[c][:] = mask[c] ? a[c][:] : b[c][:]   (dynamics.py:677-682), row_bytes (multiple of 4)
+ * per chain */
 int l2q_select_rows(const void* a, const void* b, const float* mask, void* out, int nb,
                     long row_bytes, void* stream);
 /* y = alpha * x over n doubles (momentum flip, dynamics.py:1001); y may alias x */

@@ -134,16 +134,17 @@ __global__ void accept_kernel(const T* h0, const T* h1, const T* sld, const T* u
   mask[i] = (a > u[i]) ? 1.0f : 0.0f;
 }
 
-__global__ __launch_bounds__(kBlock) void select_rows_kernel(const uint4* __restrict__ a,
-                                                             const uint4* __restrict__ b,
+template <typename W>
+__global__ __launch_bounds__(kBlock) void select_rows_kernel(const W* __restrict__ a,
+                                                             const W* __restrict__ b,
                                                              const float* __restrict__ mask,
-                                                             uint4* __restrict__ out, long row16,
+                                                             W* __restrict__ out, long roww,
                                                              long nblk) {
   const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const long j = blk * kBlock + threadIdx.x;
-  if (j >= row16) return;
+  if (j >= roww) return;
   const bool acc = mask[c] != 0.0f;
-  out[c * row16 + j] = acc ? a[c * row16 + j] : b[c * row16 + j];
+  out[c * roww + j] = acc ? a[c * roww + j] : b[c * roww + j];
 }
 
 __global__ void scale_kernel(const double* x, double alpha, double* y, long n) {
@@ -260,12 +261,19 @@ int l2q_select_rows(const void* a, const void* b, const float* mask, void* out, 
                     long row_bytes, void* stream) {
   L2Q_REQUIRE(a && b && mask && out, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && row_bytes > 0, L2Q_EINVAL, "non-positive size");
-  L2Q_REQUIRE(row_bytes % 16 == 0, L2Q_ESHAPE, "row_bytes must be a multiple of 16");
-  const long row16 = row_bytes / 16;
-  const long nblk = cdiv(row16, kBlock);
-  hipLaunchKernelGGL(select_rows_kernel, dim3((unsigned)(nb * nblk)), dim3(kBlock), 0,
-                     (hipStream_t)stream, (const uint4*)a, (const uint4*)b, mask, (uint4*)out, row16,
-                     nblk);
+  L2Q_REQUIRE(row_bytes % 4 == 0, L2Q_ESHAPE, "row_bytes must be a multiple of 4");
+  hipStream_t st = (hipStream_t)stream;
+#define L2Q_SEL(W)                                                                          \
+  do {                                                                                      \
+    const long roww = row_bytes / (long)sizeof(W);                                          \
+    const long nblk = cdiv(roww, kBlock);                                                   \
+    hipLaunchKernelGGL(select_rows_kernel<W>, dim3((unsigned)(nb * nblk)), dim3(kBlock), 0, \
+                       st, (const W*)a, (const W*)b, mask, (W*)out, roww, nblk);            \
+  } while (0)
+  if (row_bytes % 16 == 0) L2Q_SEL(uint4);
+  else if (row_bytes % 8 == 0) L2Q_SEL(uint2);
+  else L2Q_SEL(unsigned);
+#undef L2Q_SEL
   return check_launch("l2q_select_rows");
 }
 

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
   store_link(out + f * 9L * V, V, s, r);
 }
 
-// MODE 0: projectSU -> links;  1: projectSU -> vec8;  2: projectTAH -> links
+// MODE 0: projectSU -> links;  1: projectSU -> vec8;  2: projectTAH -> links;  3: projectU
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void su3_project_kernel(const double2* in,
                                                              double2* out_links,
@@ -214,6 +214,8 @@ __global__ __launch_bounds__(kBlock) void su3_project_kernel(const double2* in,
   load_link(x, in + f * 9L * V, V, s);
   if (MODE == 2) {
     m3_tah(r, x);
+  } else if (MODE == 3) {
+    m3_project_u(r, x);
   } else {
     m3_project_su(r, x);
   }
@@ -225,6 +227,23 @@ __global__ __launch_bounds__(kBlock) void su3_project_kernel(const double2* in,
   } else {
     store_link(out_links + f * 9L * V, V, s, r);
   }
+}
+
+// out = op(a) * op(b) per link, op = identity or adjoint   (SU3.mul, group.py:56-69)
+__global__ __launch_bounds__(kBlock) void su3_mul_kernel(const double2* a, const double2* b,
+                                                         int adj_a, int adj_b, double2* out, int V,
+                                                         long nblk) {
+  const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  if (s >= V) return;
+  M3 x, y, r;
+  load_link(x, a + f * 9L * V, V, s);
+  load_link(y, b + f * 9L * V, V, s);
+  if (adj_a && adj_b) m3_mul_aa(r, x, y);
+  else if (adj_a) m3_mul_an(r, x, y);
+  else if (adj_b) m3_mul_na(r, x, y);
+  else m3_mul_nn(r, x, y);
+  store_link(out + f * 9L * V, V, s, r);
 }
 
 __global__ __launch_bounds__(kBlock) void su3_assemble_tah_kernel(const double* __restrict__ nrm,
@@ -426,6 +445,27 @@ int l2q_su3_project_tah(const void* in, void* out, long nfields, long V, void* s
                      (hipStream_t)stream, (const double2*)in, (double2*)out, (double*)nullptr, (int)V,
                      nblk);
   return check_launch("l2q_su3_project_tah");
+}
+
+int l2q_su3_project_u(const void* in, void* out, long nfields, long V, void* stream) {
+  L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_project_kernel<3>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)in, (double2*)out, (double*)nullptr, (int)V,
+                     nblk);
+  return check_launch("l2q_su3_project_u");
+}
+
+int l2q_su3_mul(const void* a, const void* b, int adjoint_a, int adjoint_b, void* out,
+                long nfields, long V, void* stream) {
+  L2Q_REQUIRE(a && b && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_mul_kernel, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)a, (const double2*)b, adjoint_a, adjoint_b,
+                     (double2*)out, (int)V, nblk);
+  return check_launch("l2q_su3_mul");
 }
 
 int l2q_su3_kinetic_reduce(const void* vn, int nb, long V, double* out, void* ws, size_t ws_bytes,

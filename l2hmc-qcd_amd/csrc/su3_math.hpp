@@ -302,8 +302,8 @@ __device__ __forceinline__ void eigs3x3(double& e0, double& e1, double& e2, doub
   e2 = ll - sqs;
 }
 
-// out = x (x^H x)^(-1/2) * exp(-i arg(det)/3)         utils.py:286-346
-__device__ __forceinline__ void m3_project_su(M3& out, const M3& x) {
+// m = x (x^H x)^(-1/2)                                 utils.py:286-338
+__device__ __forceinline__ void m3_project_u(M3& m, const M3& x) {
   M3 t, t2;
   m3_mul_an(t, x, x);
   m3_mul_nn(t2, t, t);
@@ -329,8 +329,14 @@ __device__ __forceinline__ void m3_project_su(M3& out, const M3& x) {
     r.im[i] = c1 * t.im[i] + c2 * t2.im[i];
   }
   r.re[0] += c0; r.re[4] += c0; r.re[8] += c0;
-  M3 m;
   m3_mul_nn(m, x, r);
+}
+
+// out = projectU(x) * exp(-i arg(det)/3)                utils.py:341-346
+__device__ __forceinline__ void m3_project_su(M3& out, const M3& x) {
+  M3 m;
+  m3_project_u(m, x);
+  double detr, deti;
   m3_det(detr, deti, m);
   const double p = (-1.0 / 3.0) * atan2(deti, detr);
   double sp, cp;

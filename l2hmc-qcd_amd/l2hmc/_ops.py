@@ -121,11 +121,27 @@ def su3_project_tah_n(xn: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def su3_project_u_n(xn: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(xn)
+    nf, V = xn.numel() // (9 * xn.shape[-1]), xn.shape[-1]
+    N.call('l2q_su3_project_u', xn, out, nf, V)
+    return out
+
+
+def su3_mul_n(an: torch.Tensor, bn: torch.Tensor, adjoint_a: bool = False,
+              adjoint_b: bool = False) -> torch.Tensor:
+    out = torch.empty_like(an)
+    nf, V = an.numel() // (9 * an.shape[-1]), an.shape[-1]
+    N.call('l2q_su3_mul', an, bn, int(adjoint_a), int(adjoint_b), out, nf, V)
+    return out
+
+
 def su3_projsu_vec8_n(xn: torch.Tensor) -> torch.Tensor:
-    """-> [nb, 4, 8, V] float64 (native vec8 order)."""
-    nb, _, _, V = xn.shape
-    out = torch.empty((nb, 4, 8, V), dtype=torch.float64, device=xn.device)
-    N.call('l2q_su3_projsu_vec8', xn, out, nb * 4, V)
+    """[..., 9, V] c128 -> [..., 8, V] float64 (native vec8 order)."""
+    V = xn.shape[-1]
+    nf = xn.numel() // (9 * V)
+    out = torch.empty((*xn.shape[:-2], 8, V), dtype=torch.float64, device=xn.device)
+    N.call('l2q_su3_projsu_vec8', xn, out, nf, V)
     return out
 
 
@@ -138,10 +154,14 @@ def su3_kinetic_n(vn: torch.Tensor) -> torch.Tensor:
 
 
 def su3_assemble_tah_n(normals: torch.Tensor) -> torch.Tensor:
-    """normals [8, nb, 4, V] float64 -> vn [nb, 4, 9, V]."""
-    _, nb, _, V = normals.shape
-    out = torch.empty((nb, 4, 9, V), dtype=C128, device=normals.device)
-    N.call('l2q_su3_assemble_tah', normals.contiguous(), out, nb * 4, V)
+    """normals [8, ..., V] float64 -> vn [..., 9, V] (e.g. [8, nb, 4, V] -> [nb, 4, 9, V])."""
+    V = normals.shape[-1]
+    lead = tuple(normals.shape[1:-1])
+    nf = 1
+    for i in lead:
+        nf *= int(i)
+    out = torch.empty((*lead, 9, V), dtype=C128, device=normals.device)
+    N.call('l2q_su3_assemble_tah', normals.contiguous(), out, nf, V)
     return out
 
 
@@ -185,8 +205,6 @@ def select_rows(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor) -> torch.T
     nb = a.shape[0]
     a, b = a.contiguous(), b.contiguous()
     row_bytes = a.numel() // nb * a.element_size()
-    if row_bytes % 16:
-        raise N.L2QError('select_rows: row size must be a multiple of 16 bytes')
     out = torch.empty_like(a)
     N.call('l2q_select_rows', a, b, mask, out, nb, row_bytes)
     return out

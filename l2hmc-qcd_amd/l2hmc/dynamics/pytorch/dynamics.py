@@ -1,0 +1,814 @@
+"""``Dynamics`` -- the L2HMC / HMC leapfrog integrator, API of the reference's
+``src/l2hmc/dynamics/pytorch/dynamics.py`` (State :45-67, MonteCarloStates :70-74,
+Dynamics :113-1535) driven by the gfx950 kernels of ``libl2q.so``.
+
+How it differs from the reference *inside* (results are the same):
+
+* A trajectory runs on device-resident state in the kernels' native layout (SU(3):
+  ``xn[nb, 4, 9, V]`` complex planes, see include/l2q.h).  ``x`` is packed once on entry and
+  the proposal / output unpacked once on exit; nothing in between touches the host or the
+  reference layout.  Masks and network weights are permuted to native order once.
+* force = explicit staples (no autograd), action/plaquette/charges = one reduction pass,
+  ``expm(eps v) @ x`` with element masks = one kernel, ``su3_to_vec(projectSU(.))`` = one
+  kernel, the generalised v-update (+ logdet reduction) = one kernel, the vnet layers =
+  MFMA GEMMs with fused bias / activation / ScaledTanh epilogues.
+* Plain HMC fuses ``v -= eps/2 F`` into the force kernel (F is never written).
+
+The public sub-update methods (``_update_v_fwd`` ...) accept / return reference-layout
+``State`` objects like the reference and are what the parity tests call.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from dataclasses import dataclass
+from math import pi as PI
+from pathlib import Path
+from typing import Callable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+import l2hmc.configs as cfgs
+from l2hmc import DEVICE
+from l2hmc import _ops as ops
+from l2hmc.group.su3.pytorch.group import SU3
+from l2hmc.group.u1.pytorch.group import U1Phase
+from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+from l2hmc.network.pytorch.network import ConvStack, NetworkFactory, dummy_network
+
+log = logging.getLogger(__name__)
+
+TWO_PI = 2. * PI
+Shape = Union[tuple, list]
+Tensor = torch.Tensor
+Array = np.ndarray
+
+DynamicsInput = Tuple[Tensor, Tensor]
+DynamicsOutput = Tuple[Tensor, dict]
+
+
+@dataclass
+class State:
+    x: Tensor               # gauge links
+    v: Tensor               # conj. momenta
+    beta: Tensor            # inv. coupling const.
+
+    def __post_init__(self):
+        self.nb = self.x.shape[0]
+        self.xshape = self.x.shape
+
+    def flatten(self) -> State:
+        return State(x=self.x.flatten(1), v=self.v.flatten(1), beta=self.beta)
+
+    def to_numpy(self):
+        return {'x': self.x.detach().cpu().numpy(), 'v': self.v.detach().cpu().numpy(),
+                'beta': torch.as_tensor(self.beta).detach().cpu().numpy()}
+
+
+@dataclass
+class MonteCarloStates:
+    init: State             # Input state
+    proposed: State         # Proposal state
+    out: State              # Output state (after acc/rej)
+
+
+def sigmoid(x: torch.Tensor) -> torch.Tensor:
+    return 1. / (1. + torch.exp(-x))
+
+
+def _beta(beta) -> float:
+    return float(beta.item()) if isinstance(beta, torch.Tensor) else float(beta)
+
+
+class Dynamics(nn.Module):
+    def __init__(self, potential_fn: Callable, config: cfgs.DynamicsConfig,
+                 network_factory: Optional[NetworkFactory] = None):
+        super().__init__()
+        self.config = config
+        self.xdim = self.config.xdim
+        self.xshape = self.config.xshape
+        self.potential_fn = potential_fn
+        self.nlf = self.config.nleapfrog
+        self._device = DEVICE
+        self.device = DEVICE
+        self.group = self.config.group.upper()
+        if self.group == 'U1':
+            self.g = U1Phase()
+            self.lattice = LatticeU1(self.config.nchains, self.config.latvolume)
+        else:
+            self.g = SU3()
+            self.lattice = LatticeSU3(self.config.nchains, self.config.latvolume)
+        self.latvolume = tuple(int(i) for i in self.config.latvolume)
+        self.volume = int(np.prod(self.latvolume))
+        self.network_factory = network_factory
+        if network_factory is not None:
+            self._networks_built = True
+            self.networks = self._build_networks(network_factory)
+            self.xnet = self.networks['xnet']
+            self.vnet = self.networks['vnet']
+            self.register_module('xnet', self.networks['xnet'])
+            self.register_module('vnet', self.networks['vnet'])
+        else:
+            self._networks_built = False
+            self.xnet = dummy_network
+            self.vnet = dummy_network
+            self.networks = {'xnet': self.xnet, 'vnet': self.vnet}
+        self.masks = self._build_masks()
+        self._dtype: torch.dtype = torch.get_default_dtype()
+        if self._networks_built:
+            self._dtype = self._get_vnet(0).input_layer.xlayer.weight.dtype
+        rg = (not self.config.eps_fixed)
+        self.xeps = nn.ParameterList([
+            nn.parameter.Parameter(torch.tensor(self.config.eps, device=DEVICE),
+                                   requires_grad=rg)
+            for _ in range(self.config.nleapfrog)])
+        self.veps = nn.ParameterList([
+            nn.parameter.Parameter(torch.tensor(self.config.eps, device=DEVICE),
+                                   requires_grad=rg)
+            for _ in range(self.config.nleapfrog)])
+        # draw momenta / accept uniforms on this device's generator.  The reference draws on
+        # l2hmc.DEVICE (utils.py:173-189, dynamics.py:1083-1085); parity against its CPU path
+        # uses rng_device = 'cpu' (same generator stream) or injected draws.
+        self.rng_device = DEVICE
+        self._inject: Optional[dict] = None
+        self._eps_cache: dict = {}
+        self._masks_native: Optional[list] = None
+        self._perm: dict = {}
+
+    # ------------------------------------------------------------------ construction
+    def get_models(self) -> dict:
+        if self.config.use_separate_networks:
+            xnet, vnet = {}, {}
+            for lf in range(self.config.nleapfrog):
+                vnet[str(lf)] = self._get_vnet(lf)
+                if self.config.use_split_xnets:
+                    xnet[str(lf)] = {'0': self._get_xnet(lf, first=True),
+                                     '1': self._get_xnet(lf, first=False)}
+                else:
+                    xnet[str(lf)] = self._get_xnet(lf, first=True)
+        else:
+            vnet = self._get_vnet(0)
+            if self.config.use_split_xnets:
+                xnet = {'0': self._get_xnet(0, first=True), '1': self._get_xnet(0, first=False)}
+            else:
+                xnet = self._get_xnet(0, first=True)
+        return {'xnet': xnet, 'vnet': vnet}
+
+    def _build_networks(self, network_factory: NetworkFactory) -> nn.ModuleDict:
+        split = self.config.use_split_xnets
+        n = self.nlf if self.config.use_separate_networks else 1
+        return network_factory.build_networks(n, split, group=self.g)
+
+    def _build_masks(self):
+        """nlf binary masks [1, xdim] float32 with xdim // 2 ones (dynamics.py:1101-1110)."""
+        masks = []
+        for _ in range(self.config.nleapfrog):
+            _idx = np.arange(self.xdim)
+            idx = np.random.permutation(_idx)[:self.xdim // 2]
+            mask = np.zeros((self.xdim,), dtype=np.float32)
+            mask[idx] = 1.
+            masks.append(torch.from_numpy(mask[None, :]))
+        return masks
+
+    def set_masks(self, masks: Sequence) -> None:
+        self.masks = [torch.as_tensor(np.asarray(m), dtype=torch.float32).reshape(1, -1)
+                      for m in masks]
+        self._masks_native = None
+
+    def init_weights(self, method: str = 'xavier_uniform', **kw) -> None:
+        """(dynamics.py:372-535) re-initialise every Linear of the networks."""
+        fn = getattr(nn.init, method + '_' if not method.endswith('_') else method, None)
+        if method in ('zero', 'zeros'):
+            fn = nn.init.zeros_
+        if fn is None:
+            raise ValueError(f'unknown init method {method}')
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    fn(m.weight)
+
+    # ------------------------------------------------------------------ save / load
+    def save(self, outdir: os.PathLike) -> None:
+        netdir = Path(outdir).joinpath('networks')
+        netdir.mkdir(exist_ok=True, parents=True)
+        self.save_eps(outdir=netdir)
+        torch.save(self.state_dict(), netdir.joinpath('dynamics.pt').as_posix())
+
+    def save_eps(self, outdir: os.PathLike) -> None:
+        netdir = Path(outdir).joinpath('networks')
+        netdir.mkdir(exist_ok=True, parents=True)
+        xeps = np.array([i.detach().cpu().numpy() for i in self.xeps])
+        veps = np.array([i.detach().cpu().numpy() for i in self.veps])
+        np.save(netdir.joinpath('xeps.npy'), xeps)
+        np.save(netdir.joinpath('veps.npy'), veps)
+        np.savetxt(netdir.joinpath('xeps.txt').as_posix(), xeps)
+        np.savetxt(netdir.joinpath('veps.txt').as_posix(), veps)
+
+    def load(self, outdir: os.PathLike) -> None:
+        netdir = Path(outdir).joinpath('networks')
+        self.load_state_dict(torch.load(netdir.joinpath('dynamics.pt')))
+        self.assign_eps(self.load_eps(outdir))
+
+    def load_eps(self, outdir: os.PathLike) -> dict[str, dict[str, Tensor]]:
+        netdir = Path(outdir).joinpath('networks')
+        xe = torch.from_numpy(np.load(netdir.joinpath('xeps.npy')))
+        ve = torch.from_numpy(np.load(netdir.joinpath('veps.npy')))
+        return {'xeps': {str(lf): xe[lf] for lf in range(self.config.nleapfrog)},
+                'veps': {str(lf): ve[lf] for lf in range(self.config.nleapfrog)}}
+
+    def restore_eps(self, outdir: os.PathLike) -> None:
+        self.assign_eps(self.load_eps(Path(outdir).joinpath('networks')))
+
+    def assign_eps(self, eps) -> None:
+        if isinstance(eps, dict):
+            xe, ve = eps['xeps'], eps['veps']
+        elif isinstance(eps, tuple):
+            xe = {str(n): eps[0] for n in range(self.config.nleapfrog)}
+            ve = {str(n): eps[1] for n in range(self.config.nleapfrog)}
+        elif isinstance(eps, float):
+            xe = {str(n): eps for n in range(self.config.nleapfrog)}
+            ve = {str(n): eps for n in range(self.config.nleapfrog)}
+        else:
+            raise TypeError
+        rg = (not self.config.eps_fixed)
+        self.xeps = nn.ParameterList()
+        self.veps = nn.ParameterList()
+        for lf in range(self.config.nleapfrog):
+            self.xeps.append(nn.parameter.Parameter(
+                torch.as_tensor(xe[str(lf)]).clone().to(DEVICE), requires_grad=rg))
+            self.veps.append(nn.parameter.Parameter(
+                torch.as_tensor(ve[str(lf)]).clone().to(DEVICE), requires_grad=rg))
+        self._eps_cache = {}
+
+    # ------------------------------------------------------------------ helpers
+    def flatten(self, x: Tensor) -> Tensor:
+        return x.reshape(x.shape[0], -1)
+
+    def unflatten(self, x: Tensor) -> Tensor:
+        return x.reshape(x.shape[0], *self.xshape[1:])
+
+    def _eps(self, which: str, step: int) -> float:
+        """sigmoid(log(p)) of the step-size parameter, evaluated in the parameter's dtype
+        (dynamics.py:82-83, 1270, 1394); cached per parameter version (no per-step sync)."""
+        p = (self.xeps if which == 'x' else self.veps)[step]
+        key = (which, step)
+        hit = self._eps_cache.get(key)
+        if hit is not None and hit[0] == p._version and hit[2] is p:
+            return hit[1]
+        val = float(sigmoid(p.detach().cpu().log()))
+        self._eps_cache[key] = (p._version, val, p)
+        return val
+
+    def _get_vnet(self, step: int):
+        if not self._networks_built:
+            return self.vnet
+        if self.config.use_separate_networks:
+            return self.vnet.get_submodule(str(step))
+        return self.vnet
+
+    def _get_xnet(self, step: int, first: bool = False):
+        if not self._networks_built:
+            return self.xnet
+        if self.config.use_separate_networks:
+            xnet = self.xnet.get_submodule(str(step))
+            if self.config.use_split_xnets:
+                return xnet.get_submodule('first') if first else xnet.get_submodule('second')
+            return xnet
+        return self.xnet
+
+    def _get_mask(self, step: int) -> tuple[Tensor, Tensor]:
+        m = self.masks[step]
+        return m, torch.ones_like(m) - m
+
+    def _native_masks(self) -> list:
+        """float32 masks on the device in kernel order (SU3: native entry order)."""
+        if self._masks_native is None:
+            out = []
+            for m in self.masks:
+                m = m.to(DEVICE).reshape(1, -1).contiguous()
+                if self.group == 'SU3':
+                    m = ops.pack_entries(m, self.volume)
+                out.append(m.reshape(-1).contiguous())
+            self._masks_native = out
+        return self._masks_native
+
+    def _perms(self):
+        if not self._perm:
+            self._perm = {'in': ops.native_index(self.volume, 8, DEVICE),
+                          'out': ops.native_index(self.volume, 9, DEVICE)}
+        return self._perm
+
+    # ---- layout conversion (SU3: reference <-> native planes; U1: identity reshape)
+    def _pack(self, a: Tensor) -> Tensor:
+        a = a.to(DEVICE)
+        if self.group == 'SU3':
+            return ops.su3_pack(a.reshape(a.shape[0], -1))
+        return a.reshape(a.shape[0], 2, *self.latvolume).contiguous().clone()
+
+    def _unpack(self, an: Tensor) -> Tensor:
+        if self.group == 'SU3':
+            return ops.su3_unpack(an, self.latvolume)
+        return an.reshape(an.shape[0], 2, *self.latvolume)
+
+    # ------------------------------------------------------------------ native physics
+    def _force_n(self, xn: Tensor, beta) -> Tensor:
+        if self.group == 'SU3':
+            return ops.su3_force_n(xn, _beta(beta), self.latvolume)
+        return ops.u1_force(xn, _beta(beta), self.latvolume)
+
+    def _kick_n(self, xn: Tensor, vn: Tensor, beta, coef: float) -> None:
+        """vn += coef * F(xn), F never materialised."""
+        if self.group == 'SU3':
+            ops.su3_force_kick_n(xn, _beta(beta), coef, vn, self.latvolume)
+        else:
+            ops.u1_force_kick_(xn, _beta(beta), coef, vn, self.latvolume)
+
+    def _potential_n(self, xn: Tensor, beta) -> Tensor:
+        if self.group == 'SU3':
+            return (-_beta(beta) / 3.0) * ops.su3_plaq_sums_n(xn, self.latvolume)[:, 0]
+        s = ops.u1_plaq_sums(xn, self.latvolume)
+        return _beta(beta) * (self.volume - s[:, 0])
+
+    def _kinetic_n(self, vn: Tensor) -> Tensor:
+        return ops.su3_kinetic_n(vn) if self.group == 'SU3' else ops.u1_kinetic(vn)
+
+    def _hamiltonian_n(self, xn: Tensor, vn: Tensor, beta) -> Tensor:
+        return self._kinetic_n(vn) + self._potential_n(xn, beta)
+
+    def _momentum_n(self, nb: int) -> Tensor:
+        """Fresh momenta (dynamics.py:844): SU3 8 x randn([nb,4,T,X,Y,Z]) in the reference's
+        order -> l2q_su3_assemble_tah; U1 randn(nb,2,T,X) flattened."""
+        inj = self._inject.get('normals') if self._inject else None
+        if self.group == 'SU3':
+            shape = (nb, 4, *self.latvolume)
+            if inj is not None:
+                nrm = torch.as_tensor(inj, dtype=torch.float64).to(DEVICE)
+            elif self.rng_device == 'cpu':
+                nrm = torch.stack([torch.randn(shape, dtype=torch.float64)
+                                   for _ in range(8)]).to(DEVICE)
+            else:
+                nrm = torch.randn((8, *shape), dtype=torch.float64, device=DEVICE)
+            return ops.su3_assemble_tah_n(nrm.reshape(8, nb, 4, self.volume))
+        shape = (nb, 2, *self.latvolume)
+        if inj is not None:
+            v = torch.as_tensor(inj).to(DEVICE)
+        else:
+            v = torch.randn(shape, device=self.rng_device).to(DEVICE)
+        return v.reshape(nb, -1).to(self._real_dtype()).contiguous()
+
+    def _real_dtype(self) -> torch.dtype:
+        return torch.float64 if self.group == 'SU3' else self._dtype
+
+    def _uniform(self, acc: Tensor) -> Tensor:
+        inj = self._inject.get('u') if self._inject else None
+        if inj is not None:
+            return torch.as_tensor(inj).to(device=DEVICE, dtype=acc.dtype)
+        if self.rng_device == 'cpu':
+            return torch.rand(acc.shape, dtype=acc.dtype).to(DEVICE)
+        return torch.rand_like(acc)
+
+    # ---- networks on native state
+    def _vnet_n(self, step: int, xn: Tensor, fn: Tensor):
+        vnet = self._get_vnet(step)
+        nb = xn.shape[0]
+        if not self._networks_built:
+            z = torch.zeros((nb, self.xdim), dtype=self._real_dtype(), device=DEVICE)
+            return z, z, z
+        if self.group == 'SU3':
+            p = self._perms()
+            w = vnet.kernel_weights(p['in'], p['out'])
+            xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
+            fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
+            return vnet.forward_flat(xv, fv, w)
+        x = xn
+        if isinstance(vnet.input_layer.conv_stack, ConvStack):
+            x = vnet.input_layer.conv_stack(xn)
+        return vnet.forward_flat(x.reshape(nb, -1), fn.reshape(nb, -1))
+
+    def _xnet_n(self, step: int, first: bool, xn: Tensor, vn: Tensor, mask: Tensor,
+                complement: bool):
+        """U1 only (SU3 never calls its xnet, dynamics.py:1420-1425)."""
+        xnet = self._get_xnet(step, first)
+        nb = xn.shape[0]
+        if not self._networks_built:
+            z = torch.zeros((nb, self.xdim), dtype=self._real_dtype(), device=DEVICE)
+            return z, z, z
+        xm = ops.u1_masked_cos_sin(xn, mask, complement, self.latvolume)
+        if isinstance(xnet.input_layer.conv_stack, ConvStack):
+            xm = xnet.input_layer.conv_stack(xm)
+        return xnet.forward_flat(xm.reshape(nb, -1), vn.reshape(nb, -1))
+
+    # ---- sub-updates on native state (in place on xn / vn)
+    def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool) -> Tensor:
+        fn = self._force_n(xn, beta)
+        s, t, q = self._vnet_n(step, xn, fn)
+        eps = self._eps('v', step)
+        nb = xn.shape[0]
+        return ops.v_update_(vn.reshape(nb, -1), fn.reshape(nb, -1), s, t, q, eps, forward)
+
+    def _update_x_n(self, step: int, xn: Tensor, vn: Tensor, mask: Tensor, complement: bool,
+                    forward: bool, first: bool) -> Optional[Tensor]:
+        eps = self._eps('x', step)
+        if self.group == 'SU3':
+            ops.su3_expm_mul_n(xn, vn, eps if forward else -eps, mask, complement, out=xn)
+            return None
+        s, t, q = self._xnet_n(step, first, xn, vn, mask, complement)
+        nb = xn.shape[0]
+        return ops.u1_x_update_(xn.reshape(nb, -1), vn, s, t, q, mask, complement, eps,
+                                forward, self.config.use_ncp)
+
+    def _lf_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool) -> Tensor:
+        """One generalised leapfrog step in place; returns logdet [nb]
+        (dynamics.py:1187-1228)."""
+        if forward:
+            st, order = step, ((False, True), (True, False))     # (complement, first)
+        else:
+            st = self.config.nleapfrog - step - 1
+            order = ((True, False), (False, True))
+        m = self._native_masks()[st]
+        ld = self._update_v_n(st, xn, vn, beta, forward)
+        for comp, first in order:
+            l = self._update_x_n(st, xn, vn, m, comp, forward, first)
+            if l is not None:
+                ld = ld + l
+        return ld + self._update_v_n(st, xn, vn, beta, forward)
+
+    # ------------------------------------------------------------------ public sub-updates
+    def group_to_vec(self, x: Tensor) -> Tensor:
+        return self.g.group_to_vec(self.unflatten(x))
+
+    def vec_to_group(self, x: Tensor) -> Tensor:
+        x = self.unflatten(x)
+        if self.group == 'SU3':
+            return self.g.vec_to_group(x)
+        return torch.complex(x[..., 0], x[..., 1])
+
+    def grad_potential(self, x: Tensor, beta: Tensor) -> Tensor:
+        return self.lattice.grad_action(x, beta)
+
+    def hamiltonian(self, state: State) -> Tensor:
+        return self.kinetic_energy(state.v) + self.potential_energy(state.x, state.beta)
+
+    def kinetic_energy(self, v: Tensor) -> Tensor:
+        return self._kinetic_n(self._pack(v) if self.group == 'SU3'
+                               else v.to(DEVICE).reshape(v.shape[0], -1).contiguous())
+
+    def potential_energy(self, x: Tensor, beta: Tensor):
+        return self.potential_fn(x, beta)
+
+    def _call_vnet(self, step: int, inputs: tuple[Tensor, Tensor]):
+        x, force = inputs
+        s, t, q = self._vnet_n(step, self._pack(x), self._pack(force))
+        return self._heads_to_reference(s, t, q)
+
+    def _call_xnet(self, step: int, inputs: tuple[Tensor, Tensor], first: bool = False):
+        """inputs = (m * x, v).  U1: network of [cos, sin] of the masked field."""
+        x, v = inputs
+        if self.group == 'SU3':
+            xnet = self._get_xnet(step, first)
+            x = torch.stack([x.real, x.imag], 1)
+            v = torch.stack([v.real, v.imag], 1)
+            return xnet((x, v))
+        ones = torch.ones(self.xdim, dtype=torch.float32, device=DEVICE)
+        return self._xnet_n(step, first, self._pack(x), v.to(DEVICE).reshape(x.shape[0], -1),
+                            ones, False)
+
+    def _heads_to_reference(self, s, t, q):
+        if self.group == 'SU3':
+            return tuple(ops.unpack_entries(a, self.volume) for a in (s, t, q))
+        return s, t, q
+
+    def _update_v(self, step: int, state: State, forward: bool) -> tuple[State, Tensor]:
+        xn = self._pack(state.x)
+        vn = self._pack(state.v) if self.group == 'SU3' else \
+            state.v.to(DEVICE).reshape(state.v.shape[0], -1).contiguous().clone()
+        ld = self._update_v_n(step, xn, vn, state.beta, forward)
+        v = self._unpack(vn) if self.group == 'SU3' else vn.reshape(state.v.shape)
+        return State(state.x, v, state.beta), ld
+
+    def _update_v_fwd(self, step: int, state: State) -> tuple[State, Tensor]:
+        """v' = exp(eps s/2) v - eps/2 (F exp(eps q) + t)  (dynamics.py:1266-1280)"""
+        return self._update_v(step, state, True)
+
+    def _update_v_bwd(self, step: int, state: State) -> tuple[State, Tensor]:
+        """v' = exp(-eps s/2) (v + eps/2 (F exp(eps q) + t))  (dynamics.py:1282-1297)"""
+        return self._update_v(step, state, False)
+
+    def _update_x(self, step: int, state: State, m: Tensor, first: bool, forward: bool):
+        xn = self._pack(state.x)
+        nb = xn.shape[0]
+        m = m.to(DEVICE).reshape(1, -1).float().contiguous()
+        if self.group == 'SU3':
+            vn = self._pack(state.v)
+            mask = ops.pack_entries(m, self.volume).reshape(-1)
+        else:
+            vn = state.v.to(DEVICE).reshape(nb, -1).contiguous()
+            mask = m.reshape(-1)
+        ld = self._update_x_n(step, xn, vn, mask, False, forward, first)
+        if ld is None:
+            ld = torch.zeros(nb, dtype=torch.get_default_dtype(), device=DEVICE)
+        return State(x=self._unpack(xn), v=state.v, beta=state.beta), ld
+
+    def _update_x_fwd(self, step: int, state: State, m: Tensor, first: bool):
+        """SU3: x' = m x + expm(eps v) @ ((1-m) x); U1: NCP update (dynamics.py:1386-1428)"""
+        return self._update_x(step, state, m, first, True)
+
+    def _update_x_bwd(self, step: int, state: State, m: Tensor, first: bool):
+        """(dynamics.py:1430-1477)"""
+        return self._update_x(step, state, m, first, False)
+
+    def _lf(self, step: int, state: State, forward: bool) -> tuple[State, Tensor]:
+        xn = self._pack(state.x)
+        nb = xn.shape[0]
+        vn = self._pack(state.v) if self.group == 'SU3' else \
+            state.v.to(DEVICE).reshape(nb, -1).contiguous().clone()
+        ld = self._lf_n(step, xn, vn, state.beta, forward)
+        v = self._unpack(vn) if self.group == 'SU3' else vn
+        return State(self._unpack(xn), v, state.beta), ld
+
+    def _forward_lf(self, step: int, state: State) -> tuple[State, Tensor]:
+        return self._lf(step, state, True)
+
+    def _backward_lf(self, step: int, state: State) -> tuple[State, Tensor]:
+        return self._lf(step, state, False)
+
+    def leapfrog_hmc(self, state: State, eps: Optional[float] = None) -> State:
+        """v1 = v - eps/2 F(x); x' = update_gauge(x, eps v1); v2 = v1 - eps/2 F(x')
+        (dynamics.py:900-913)"""
+        eps = self.config.eps if eps is None else eps
+        xn = self._pack(state.x)
+        nb = xn.shape[0]
+        vn = self._pack(state.v) if self.group == 'SU3' else \
+            state.v.to(DEVICE).reshape(nb, -1).contiguous().clone()
+        self._leapfrog_hmc_n(xn, vn, state.beta, eps)
+        v = self._unpack(vn) if self.group == 'SU3' else vn
+        return State(x=self._unpack(xn), v=v, beta=state.beta)
+
+    def _leapfrog_hmc_n(self, xn: Tensor, vn: Tensor, beta, eps: float) -> None:
+        self._kick_n(xn, vn, beta, -0.5 * eps)
+        if self.group == 'SU3':
+            ops.su3_expm_mul_n(xn, vn, eps, out=xn)
+        else:
+            ops.axpy_(xn.reshape(xn.shape[0], -1), vn, eps)
+        self._kick_n(xn, vn, beta, -0.5 * eps)
+
+    # ------------------------------------------------------------------ transition kernels
+    def _metrics_n(self, xn, vn, beta, logdet, step=None, extras=None) -> dict:
+        energy = self._hamiltonian_n(xn, vn, beta)
+        m = {'energy': energy, 'logprob': energy - logdet, 'logdet': logdet}
+        if extras is not None:
+            m.update(extras)
+        if step is not None:
+            m.update({'xeps': self.xeps[step], 'veps': self.veps[step]})
+        return m
+
+    @staticmethod
+    def update_history(metrics: dict, history: dict):
+        for key, val in metrics.items():
+            history.setdefault(key, []).append(val)
+        return history
+
+    @staticmethod
+    def _stack_history(history: dict) -> dict:
+        for key, val in history.items():
+            if isinstance(val, list) and isinstance(val[0], Tensor):
+                history[key] = torch.stack([v.detach() for v in val])
+        return history
+
+    def _zeros_nb(self, nb: int) -> Tensor:
+        return torch.zeros(nb, dtype=torch.get_default_dtype(), device=DEVICE)
+
+    def _accept_prob_n(self, h_init: Tensor, h_prop: Tensor, sumlogdet: Tensor) -> Tensor:
+        """exp(min(0, H_init - H_prop + sum logdet))  (dynamics.py:1065-1079) -> l2q_accept"""
+        acc, _ = ops.accept(h_init, h_prop, sumlogdet, torch.zeros_like(h_init))
+        return acc
+
+    def _kernel_hmc_n(self, xn, vn, beta, eps=None, nleapfrog=None):
+        """(dynamics.py:915-954) in place on clones; returns (x', v', history)."""
+        nb = xn.shape[0]
+        x_, v_ = xn.clone(), vn.clone()
+        sumlogdet = self._zeros_nb(nb)
+        history: dict = {}
+        h_init = self._hamiltonian_n(xn, vn, beta)
+        if self.config.verbose:
+            self.update_history({'energy': h_init, 'logprob': h_init - sumlogdet,
+                                 'logdet': sumlogdet}, history)
+        eps = self.config.eps_hmc if eps is None else eps
+        nlf = (self.config.nleapfrog if not self.config.merge_directions
+               else 2 * self.config.nleapfrog)
+        if eps is None:
+            eps = 1. / nlf
+        nleapfrog = nlf if nleapfrog is None else nleapfrog
+        h = h_init
+        for _ in range(nleapfrog):
+            self._leapfrog_hmc_n(x_, v_, beta, eps)
+            if self.config.verbose:
+                h = self._hamiltonian_n(x_, v_, beta)
+                self.update_history({'energy': h, 'logprob': h - sumlogdet,
+                                     'logdet': sumlogdet}, history)
+        if not self.config.verbose or nleapfrog == 0:
+            h = self._hamiltonian_n(x_, v_, beta)
+        acc = self._accept_prob_n(h_init, h, sumlogdet)
+        history.update({'acc': acc, 'sumlogdet': sumlogdet})
+        if self.config.verbose:
+            history = self._stack_history(history)
+        return x_, v_, history
+
+    def _kernel_fb_n(self, xn, vn, beta):
+        """Merged forward + backward trajectory (dynamics.py:956-1029)."""
+        nb = xn.shape[0]
+        x_, v_ = xn.clone(), vn.clone()
+        sumlogdet = self._zeros_nb(nb)
+        sldf = torch.zeros_like(sumlogdet)
+        sldb = torch.zeros_like(sumlogdet)
+        history: dict = {}
+        h_init = self._hamiltonian_n(xn, vn, beta)
+        verbose = self.config.verbose
+        if verbose:
+            m = {'energy': h_init, 'logprob': h_init - sumlogdet, 'logdet': sumlogdet,
+                 'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet,
+                 'xeps': self.xeps[0], 'veps': self.veps[0]}
+            self.update_history(m, history)
+        h = h_init
+        for step in range(self.config.nleapfrog):
+            logdet = self._lf_n(step, x_, v_, beta, True)
+            sumlogdet = sumlogdet + logdet
+            if verbose:
+                sldf = sldf + logdet
+                extras = {'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet}
+                self.update_history(self._metrics_n(x_, v_, beta, sumlogdet, step, extras),
+                                    history)
+        if self.group == 'SU3':
+            ops.scale(v_, -1.0, out=v_)
+        else:
+            v_ = -v_
+        for step in range(self.config.nleapfrog):
+            logdet = self._lf_n(step, x_, v_, beta, False)
+            sumlogdet = sumlogdet + logdet
+            if verbose:
+                sldb = sldb + logdet
+                extras = {'sldf': torch.zeros_like(sldb), 'sldb': sldb, 'sld': sumlogdet}
+                mt = self._metrics_n(x_, v_, beta, sumlogdet,
+                                     self.config.nleapfrog - step - 1, extras)
+                h = mt['energy']
+                self.update_history(mt, history)
+        if not verbose or self.config.nleapfrog == 0:
+            h = self._hamiltonian_n(x_, v_, beta)
+        acc = self._accept_prob_n(h_init, h, sumlogdet)
+        history.update({'acc': acc, 'sumlogdet': sumlogdet})
+        if verbose:
+            history = self._stack_history(history)
+        return x_, v_, history
+
+    def _kernel_n(self, xn, vn, beta, forward: bool):
+        """Single-direction kernel (dynamics.py:1031-1063), including the reference's swapped
+        arguments to compute_accept_prob."""
+        nb = xn.shape[0]
+        x_, v_ = xn.clone(), vn.clone()
+        sumlogdet = self._zeros_nb(nb)
+        history: dict = {}
+        h0 = self._hamiltonian_n(xn, vn, beta)
+        if self.config.verbose:
+            self.update_history({'energy': h0, 'logprob': h0 - sumlogdet,
+                                 'logdet': sumlogdet}, history)
+        for step in range(self.config.nleapfrog):
+            logdet = self._lf_n(step, x_, v_, beta, forward)
+            sumlogdet = sumlogdet + logdet
+            if self.config.verbose:
+                self.update_history(self._metrics_n(x_, v_, beta, sumlogdet, step), history)
+        h1 = self._hamiltonian_n(x_, v_, beta)
+        acc = self._accept_prob_n(h1, h0, sumlogdet)          # state_init=final, prop=initial
+        history.update({'acc': acc, 'sumlogdet': sumlogdet})
+        if self.config.verbose:
+            history = self._stack_history(history)
+        return x_, v_, history
+
+    # ---- reference-shaped wrappers
+    def _state_n(self, state: State):
+        xn = self._pack(state.x)
+        vn = self._pack(state.v) if self.group == 'SU3' else \
+            state.v.to(DEVICE).reshape(xn.shape[0], -1).contiguous()
+        return xn, vn
+
+    def _state_from_n(self, xn, vn, beta) -> State:
+        v = self._unpack(vn) if self.group == 'SU3' else vn
+        return State(x=self._unpack(xn), v=v, beta=beta)
+
+    def transition_kernel_hmc(self, state: State, eps: Optional[float] = None,
+                              nleapfrog: Optional[int] = None) -> tuple[State, dict]:
+        xn, vn = self._state_n(state)
+        x_, v_, hist = self._kernel_hmc_n(xn, vn, state.beta, eps, nleapfrog)
+        return self._state_from_n(x_, v_, state.beta), hist
+
+    def transition_kernel_fb(self, state: State) -> tuple[State, dict]:
+        xn, vn = self._state_n(state)
+        x_, v_, hist = self._kernel_fb_n(xn, vn, state.beta)
+        return self._state_from_n(x_, v_, state.beta), hist
+
+    def transition_kernel(self, state: State, forward: bool) -> tuple[State, dict]:
+        xn, vn = self._state_n(state)
+        x_, v_, hist = self._kernel_n(xn, vn, state.beta, forward)
+        return self._state_from_n(x_, v_, state.beta), hist
+
+    def compute_accept_prob(self, state_init: State, state_prop: State,
+                            sumlogdet: Tensor) -> Tensor:
+        return self._accept_prob_n(self.hamiltonian(state_init), self.hamiltonian(state_prop),
+                                   sumlogdet.to(DEVICE))
+
+    def _get_accept_masks(self, px: Tensor) -> tuple[Tensor, Tensor]:
+        """ma = (px > U[0,1)) as float32, mr = 1 - ma (dynamics.py:1081-1087)"""
+        u = self._uniform(px)
+        acc = (px > u).to(torch.float)
+        return acc, torch.ones_like(acc) - acc
+
+    @staticmethod
+    def _get_direction_masks(batch_size: int) -> tuple[Tensor, Tensor]:
+        fwd = (torch.rand(batch_size) > 0.5).to(torch.float).to(DEVICE)
+        return fwd, torch.ones_like(fwd) - fwd
+
+    # ------------------------------------------------------------------ full transitions
+    def _finish(self, xn, vn, x_, v_, beta, hist, with_sumlogdet: bool):
+        """accept/reject + select (dynamics.py:660-702); returns (x_out[nb, xdim], metrics)."""
+        nb = xn.shape[0]
+        acc = hist['acc']
+        u = self._uniform(acc)
+        ma = (acc > u).to(torch.float32)
+        xo_n = ops.select_rows(x_.reshape(nb, -1), xn.reshape(nb, -1), ma).reshape(xn.shape)
+        vo_n = ops.select_rows(v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)
+        init = self._state_from_n(xn, vn, beta)
+        prop = self._state_from_n(x_, v_, beta)
+        xout = self._unpack(xo_n).reshape(nb, -1)
+        vout = (self._unpack(vo_n) if self.group == 'SU3' else vo_n).reshape(nb, -1)
+        mc_states = MonteCarloStates(init=init, proposed=prop,
+                                     out=State(x=xout, v=vout, beta=beta))
+        if with_sumlogdet:
+            hist.update({'beta': beta, 'sumlogdet': ma * hist['sumlogdet']})
+        hist.update({'acc_mask': ma, 'mc_states': mc_states})
+        return xout, hist
+
+    def forward(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
+        return (self.apply_transition_fb(inputs) if self.config.merge_directions
+                else self.apply_transition(inputs))
+
+    def apply_transition_hmc(self, inputs: tuple[Tensor, Tensor], eps: Optional[float] = None,
+                             nleapfrog: Optional[int] = None) -> tuple[Tensor, dict]:
+        x, beta = inputs
+        xn = self._pack(x)
+        vn = self._momentum_n(xn.shape[0])
+        x_, v_, hist = self._kernel_hmc_n(xn, vn, beta, eps, nleapfrog)
+        return self._finish(xn, vn, x_, v_, beta, hist, with_sumlogdet=False)
+
+    def apply_transition_fb(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
+        x, beta = inputs
+        xn = self._pack(x)
+        vn = self._momentum_n(xn.shape[0])
+        x_, v_, hist = self._kernel_fb_n(xn, vn, beta)
+        return self._finish(xn, vn, x_, v_, beta, hist, with_sumlogdet=True)
+
+    def apply_transition(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
+        x, beta = inputs
+        forward = bool(torch.rand(1) > 0.5)
+        xn = self._pack(x)
+        vn = self._momentum_n(xn.shape[0])
+        x_, v_, hist = self._kernel_n(xn, vn, beta, forward)
+        return self._finish(xn, vn, x_, v_, beta, hist, with_sumlogdet=True)
+
+    def generate_proposal_hmc(self, inputs, eps=None, nleapfrog=None) -> dict:
+        x, beta = inputs
+        xn = self._pack(x)
+        vn = self._momentum_n(xn.shape[0])
+        x_, v_, hist = self._kernel_hmc_n(xn, vn, beta, eps, nleapfrog)
+        return {'init': self._state_from_n(xn, vn, beta),
+                'proposed': self._state_from_n(x_, v_, beta), 'metrics': hist}
+
+    def generate_proposal_fb(self, inputs) -> dict:
+        x, beta = inputs
+        xn = self._pack(x)
+        vn = self._momentum_n(xn.shape[0])
+        x_, v_, hist = self._kernel_fb_n(xn, vn, beta)
+        return {'init': self._state_from_n(xn, vn, beta),
+                'proposed': self._state_from_n(x_, v_, beta), 'metrics': hist}
+
+    def generate_proposal(self, inputs, forward: bool) -> dict:
+        x, beta = inputs
+        xn = self._pack(x)
+        vn = self._momentum_n(xn.shape[0])
+        x_, v_, hist = self._kernel_n(xn, vn, beta, forward)
+        return {'init': self._state_from_n(xn, vn, beta),
+                'proposed': self._state_from_n(x_, v_, beta), 'metrics': hist}
+
+    def random_state(self, beta: float) -> State:
+        x = self.g.random(list(self.xshape)).to(self.device)
+        v = self.g.random_momentum(list(self.xshape)).to(x.device)
+        return State(x=x, v=v, beta=torch.tensor(beta).to(self.device))
+
+    def test_reversibility(self) -> dict[str, Array]:
+        state = self.random_state(beta=1.)
+        state_fwd, _ = self.transition_kernel(state, forward=True)
+        state_, _ = self.transition_kernel(state_fwd, forward=False)
+        dx = torch.abs(state.x - state_.x.reshape(state.x.shape))
+        dv = torch.abs(state.v - state_.v.reshape(state.v.shape))
+        return {'dx': dx.detach().cpu().numpy(), 'dv': dv.detach().cpu().numpy()}

@@ -1,0 +1,128 @@
+"""SU(3) matrix utilities on the GPU -- API of the reference's
+``src/l2hmc/group/su3/pytorch/utils.py`` (projectSU :341-346, projectU :332-338, projectTAH
+:349-359, randTAH3 :171-195, su3_to_vec :394-420, vec_to_su3 :423-445, norm2 :157-168,
+checkU / checkSU :362-391, eyeOf :134-141).
+
+Every function takes tensors whose last two dims are the 3x3 matrix (reference layout),
+converts once to the native plane layout (``l2q_transpose``) and runs the register-resident
+HIP kernels of ``csrc/su3_kernels.hip``.  No PyTorch arithmetic fallback exists.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from l2hmc import DEVICE
+from l2hmc import _ops as ops
+
+Tensor = torch.Tensor
+C128 = torch.complex128
+
+NP_SQRT1by2 = np.sqrt(1. / 2.)
+NP_SQRT1by3 = np.sqrt(1. / 3.)
+ONE_HALF = 1. / 2.
+ONE_THIRD = 1. / 3.
+
+
+def _native(x: Tensor) -> Tensor:
+    """[..., 3, 3] -> [1, 1, 9, nlinks] native planes (one anonymous field)."""
+    x = x.to(device=DEVICE, dtype=C128).contiguous()
+    n = x.numel() // 9
+    return ops.transpose(x.reshape(1, n, 9), 1, n, 9).reshape(1, 1, 9, n)
+
+
+def _reference(xn: Tensor, shape: Sequence[int]) -> Tensor:
+    n = xn.shape[-1]
+    return ops.transpose(xn.reshape(1, 9, n), 1, 9, n).reshape(*shape)
+
+
+def eyeOf(x: Tensor) -> Tensor:
+    batch_dims = [1] * (len(x.shape) - 2)
+    eye = torch.zeros(batch_dims + [*x.shape[-2:]], device=x.device)
+    eye[-2:] = torch.eye(x.shape[-1], device=x.device)
+    return eye
+
+
+def norm2(x: Tensor, axis: Sequence[int] = (-2, -1),
+          exclude: Optional[Sequence[int]] = None) -> Tensor:
+    """No reduction if axis is empty (utils.py:157-168)."""
+    if x.is_complex():
+        x = x.abs()
+    n = x.square()
+    if exclude is None:
+        return n if len(axis) == 0 else n.sum(tuple(axis))
+    return n.sum([i for i in range(len(n.shape)) if i not in exclude])
+
+
+def randTAH3(shape: Sequence[int]) -> Tensor:
+    """Traceless anti-Hermitian matrices from 8 x randn(shape) drawn on the CPU torch
+    generator in the reference's order (parity is defined against the CPU path)."""
+    shape = tuple(int(i) for i in shape)
+    normals = torch.stack([torch.randn(shape, dtype=torch.float64) for _ in range(8)])
+    n = int(np.prod(shape))
+    vn = ops.su3_assemble_tah_n(normals.reshape(8, 1, n).to(DEVICE))
+    return _reference(vn.reshape(1, 1, 9, n), (*shape, 3, 3))
+
+
+def projectU(x: Tensor) -> Tensor:
+    """x (x^H x)^{-1/2}"""
+    return _reference(ops.su3_project_u_n(_native(x)), x.shape)
+
+
+def projectSU(x: Tensor) -> Tensor:
+    return _reference(ops.su3_project_su_n(_native(x)), x.shape)
+
+
+def projectTAH(x: Tensor) -> Tensor:
+    """R = 1/2 (X - X^H) - 1/(2 N) tr(X - X^H)"""
+    return _reference(ops.su3_project_tah_n(_native(x)), x.shape)
+
+
+def checkSU(x: Tensor) -> tuple[Tensor, Tensor]:
+    """(average, maximum) deviation of x^H x and det x from SU(3), per chain."""
+    nb = x.shape[0]
+    n = x.numel() // (9 * nb)
+    if n % 4:
+        raise ValueError('checkSU expects [nb, 4, ..., 3, 3]')
+    r = ops.su3_check_su_n(ops.su3_pack(x.to(DEVICE)))
+    return r[:, 0], r[:, 1]
+
+
+def checkU(x: Tensor) -> tuple[Tensor, Tensor]:
+    d = norm2(torch.matmul(x.adjoint(), x) - eyeOf(x).to(x.dtype))
+    d_ = d.flatten(1)
+    c = 2 * (3 * 3 + 1)
+    return (d_.mean(-1) / c).sqrt(), (d_.max(-1)[0] / c).sqrt()
+
+
+def su3_to_vec(x: Tensor) -> Tensor:
+    """8 real numbers X^a with X = X^a T^a (anti-Hermitian input); pure indexing."""
+    c = -2
+    x00, x01, x02 = x[..., 0, 0], x[..., 0, 1], x[..., 0, 2]
+    x11, x12, x22 = x[..., 1, 1], x[..., 1, 2], x[..., 2, 2]
+    return torch.stack([
+        c * x01.imag, c * x01.real, x11.imag - x00.imag, c * x02.imag, c * x02.real,
+        c * x12.imag, c * x12.real,
+        NP_SQRT1by3 * ((2 * x22.imag) - x11.imag - x00.imag),
+    ], dim=-1)
+
+
+def vec_to_su3(v: Tensor) -> Tensor:
+    s3 = NP_SQRT1by3
+    c = -0.5
+    zero = torch.zeros_like(v[..., 0])
+    x01 = c * torch.complex(v[..., 1], v[..., 0])
+    x02 = c * torch.complex(v[..., 4], v[..., 3])
+    x12 = c * torch.complex(v[..., 6], v[..., 5])
+    x2i = s3 * v[..., 7]
+    x0i = c * (x2i + v[..., 2])
+    x1i = c * (x2i - v[..., 2])
+    v00, v11, v22 = (torch.complex(zero, x0i), torch.complex(zero, x1i),
+                     torch.complex(zero, x2i))
+    return torch.stack([
+        torch.stack([v00, -x01.conj(), -x02.conj()], -1),
+        torch.stack([x01, v11, -x12.conj()], -1),
+        torch.stack([x02, x12, v22], -1),
+    ], -1)

@@ -1,0 +1,127 @@
+"""``LatticeSU3`` -- API of src/l2hmc/lattice/su3/pytorch/lattice.py:39-349 on HIP kernels.
+
+The reference builds ~18 lattice-sized temporaries per action call (roll / bmm / stack) and
+gets the force by autograd; here ``action``, ``plaqs`` and the charges come from ONE pass of
+``l2q_su3_plaq_reduce`` (576 B per chain-site) and the force from ``l2q_su3_force``
+(explicit staples + TAH, 1152 B per chain-site).  Only the c1 == 0 (Wilson) action is built;
+the DBW2 rectangle term (lattice.py:96-112, 180-196) is SURVEY.md 8(f) item 4.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+import l2hmc.group.su3.pytorch.group as g
+from l2hmc import DEVICE
+from l2hmc import _ops as ops
+from l2hmc.configs import Charges
+from l2hmc.lattice.lattice import Lattice
+
+Tensor = torch.Tensor
+PI = np.pi
+TWO_PI = 2. * np.pi
+
+
+def _beta(beta) -> float:
+    return float(beta.item()) if isinstance(beta, torch.Tensor) else float(beta)
+
+
+class PlaqSums:
+    """What the reference calls ``wloops`` ([6, nb, T, X, Y, Z] complex traces) is only ever
+    reduced over everything but the chain; this carries the two per-chain sums instead."""
+
+    def __init__(self, sums: Tensor):
+        self.re = sums[:, 0].contiguous()
+        self.im = sums[:, 1].contiguous()
+
+
+class LatticeSU3(Lattice):
+    """4D lattice with SU(3) links: x.shape = [nb, 4, nt, nx, ny, nz, 3, 3] complex128."""
+    dim = 4
+
+    def __init__(self, nchains: int, shape: list[int], c1: float = 0.0) -> None:
+        assert len(shape) == 4
+        if c1 != 0.0:
+            raise NotImplementedError('DBW2 rectangle action (c1 != 0) is not built yet')
+        self.g = g.SU3()
+        self.nt, self.nx, self.ny, self.nz = shape
+        self.c1 = c1
+        super().__init__(group=self.g, nchains=nchains, shape=list(shape))
+        self.volume = self.nt * self.nx * self.ny * self.nz
+
+    # ------------------------------------------------------------ native-layout core
+    def pack(self, x: Tensor) -> Tensor:
+        return ops.su3_pack(x.to(DEVICE).reshape(x.shape[0], -1))
+
+    def unpack(self, xn: Tensor) -> Tensor:
+        return ops.su3_unpack(xn, self._lattice_shape)
+
+    def plaq_sums_n(self, xn: Tensor) -> Tensor:
+        return ops.su3_plaq_sums_n(xn, self._lattice_shape)
+
+    def action_n(self, xn: Tensor, beta) -> Tensor:
+        return (-_beta(beta) / 3.0) * self.plaq_sums_n(xn)[:, 0]
+
+    def grad_action_n(self, xn: Tensor, beta) -> Tensor:
+        return ops.su3_force_n(xn, _beta(beta), self._lattice_shape)
+
+    # ------------------------------------------------------------ reference API
+    def coeffs(self, beta: Tensor) -> dict[str, Tensor]:
+        return {'plaq': beta * (1.0 - 8.0 * self.c1), 'rect': beta * self.c1}
+
+    def wilson_loops(self, x: Tensor) -> PlaqSums:
+        return PlaqSums(self.plaq_sums_n(self.pack(x)))
+
+    def _wilson_loops(self, x: Tensor, needs_rect: bool = False):
+        return self.wilson_loops(x), None
+
+    def _plaquettes(self, x: Tensor) -> Tensor:
+        return self._plaqs(self.wilson_loops(x))
+
+    def _plaqs(self, wloops: PlaqSums) -> Tensor:
+        return wloops.re / (6 * 3 * self.volume)
+
+    def _charges(self, wloops: PlaqSums) -> Charges:
+        return Charges(intQ=self._int_charges(wloops), sinQ=self._sin_charges(wloops))
+
+    def _int_charges(self, wloops: PlaqSums) -> Tensor:
+        return wloops.im / (32 * (np.pi ** 2))
+
+    def _sin_charges(self, wloops: PlaqSums) -> Tensor:
+        return wloops.im / (6 * 3 * self.volume)
+
+    def kinetic_energy(self, v: Tensor) -> Tensor:
+        return self.g.kinetic_energy(v)
+
+    def action(self, x: Tensor, beta: Tensor) -> Tensor:
+        """-(beta/3) sum Re tr P (lattice.py:252-269)"""
+        return self.action_n(self.pack(x), beta)
+
+    def action_with_grad(self, x: Tensor, beta: Tensor) -> tuple[Tensor, Tensor]:
+        xn = self.pack(x)
+        return self.action_n(xn, beta), self.unpack(self.grad_action_n(xn, beta))
+
+    def grad_action(self, x: Tensor, beta: Tensor) -> Tensor:
+        """(beta/3) TAH(U * staples)  ==  projectTAH(autograd dS/dx @ x^H) (lattice.py:299-308)"""
+        return self.unpack(self.grad_action_n(self.pack(x), beta))
+
+    def calc_metrics(self, x: Tensor, beta: Optional[Tensor] = None,
+                     xinit: Optional[Tensor] = None) -> dict[str, Tensor]:
+        w = self.wilson_loops(x)
+        q = self._charges(w)
+        metrics = {'plaqs': self._plaqs(w), 'sinQ': q.sinQ, 'intQ': q.intQ}
+        if beta is not None:
+            s, dsdx = self.action_with_grad(x, beta)
+            metrics.update({'action': s, 'dsdx': dsdx})
+            if xinit is not None:
+                s_, dsdx_ = self.action_with_grad(xinit, beta)
+                metrics.update({'daction': (s - s_).abs(), 'dsdx': (dsdx - dsdx_).abs()})
+        if xinit is not None:
+            w_ = self.wilson_loops(xinit)
+            q_ = self._charges(w_)
+            metrics.update({'dplaqs': (metrics['plaqs'] - self._plaqs(w_)).abs(),
+                            'dQint': (q.intQ - q_.intQ).abs(),
+                            'dQsin': (q.sinQ - q_.sinQ).abs()})
+        return metrics

@@ -1,0 +1,157 @@
+"""``LatticeU1`` -- API of src/l2hmc/lattice/u1/pytorch/lattice.py:50-317 on HIP kernels."""
+from __future__ import annotations
+
+from math import pi as PI
+from typing import Optional
+
+import torch
+from torch.special import i0, i1
+
+import l2hmc.group.u1.pytorch.group as g
+from l2hmc import DEVICE
+from l2hmc import _ops as ops
+from l2hmc.configs import Charges, LatticeMetrics
+from l2hmc.lattice.lattice import Lattice
+
+TWOPI = 2. * PI
+Tensor = torch.Tensor
+
+
+def area_law(beta: float, nplaqs: int):
+    return (i1(beta) / i0(beta)) ** nplaqs
+
+
+def plaq_exact(beta: float | Tensor):
+    """I1(beta)/I0(beta), computed in fp32 like the reference (lattice.py:37-42)."""
+    beta = torch.as_tensor(beta, dtype=torch.float32)
+    return (i1(beta) / i0(beta)).to(torch.get_default_dtype())
+
+
+def project_angle(x: Tensor) -> Tensor:
+    """For x in [-4pi, 4pi], returns x in [-pi, pi]."""
+    return x - TWOPI * torch.floor((x + PI) / TWOPI)
+
+
+def _beta(beta) -> float:
+    return float(beta.item()) if isinstance(beta, torch.Tensor) else float(beta)
+
+
+class PlaqSumsU1:
+    """per-chain sums of cos / sin / project_angle of the plaquette angle (what every
+    consumer of the reference's ``wloops`` reduces to)."""
+
+    def __init__(self, sums: Tensor):
+        self.cos, self.sin, self.proj = (sums[:, i].contiguous() for i in range(3))
+
+
+class LatticeU1(Lattice):
+    def __init__(self, nchains: int, shape: list[int]):
+        assert len(shape) == 2
+        self.g = g.U1Phase()
+        self.nt, self.nx = shape
+        self.nplaqs = self.nt * self.nx
+        super().__init__(group=self.g, nchains=nchains, shape=list(shape))
+        self.volume = self.nt * self.nx
+
+    def _x(self, x: Tensor) -> Tensor:
+        return x.to(DEVICE).reshape(-1, *self.xshape).contiguous()
+
+    def wilson_loops(self, x: Tensor) -> PlaqSumsU1:
+        """theta = U0(t,x) + U1(t+1,x) - U0(t,x+1) - U1(t,x), reduced per chain."""
+        return PlaqSumsU1(ops.u1_plaq_sums(self._x(x), self._lattice_shape))
+
+    def _get_wloops(self, x: Optional[Tensor] = None) -> PlaqSumsU1:
+        if x is None:
+            raise ValueError('One of `x` or `wloops` must be specified.')
+        return self.wilson_loops(x)
+
+    def kinetic_energy(self, v: Tensor) -> Tensor:
+        return 0.5 * v.flatten(1) ** 2
+
+    def action(self, x: Tensor, beta: Tensor) -> Tensor:
+        """beta * sum(1 - cos theta) (lattice.py:80-86)"""
+        return self._action(self.wilson_loops(x), beta)
+
+    def _action(self, wloops: PlaqSumsU1, beta: Tensor) -> Tensor:
+        return _beta(beta) * (self.volume - wloops.cos)
+
+    def action_with_grad(self, x: Tensor, beta: Tensor) -> tuple[Tensor, Tensor]:
+        return self.action(x, beta), self.grad_action(x, beta)
+
+    def grad_action(self, x: Tensor, beta: Tensor, create_graph: bool = True) -> Tensor:
+        """F0 = beta[sin th - sin th(t,x-1)], F1 = beta[-sin th + sin th(t-1,x)]: the closed
+        form of the reference's autograd (lattice.py:102-117)."""
+        xx = self._x(x)
+        return ops.u1_force(xx, _beta(beta), self._lattice_shape).reshape(x.shape)
+
+    def plaqs_diff(self, beta: float, x: Optional[Tensor] = None,
+                   wloops: Optional[PlaqSumsU1] = None) -> Tensor:
+        wloops = self._get_wloops(x) if wloops is None else wloops
+        plaqs = self._plaqs(wloops)
+        return plaq_exact(torch.as_tensor(beta)).to(plaqs.device) * torch.ones_like(plaqs) - plaqs
+
+    def calc_metrics(self, x: Tensor, beta: Optional[Tensor] = None) -> dict[str, Tensor]:
+        w = self.wilson_loops(x)
+        return {'plaqs': self._plaqs(w), 'intQ': self._int_charges(w),
+                'sinQ': self._sin_charges(w)}
+
+    def observables(self, x: Tensor) -> LatticeMetrics:
+        w = self.wilson_loops(x)
+        return LatticeMetrics(p4x4=self.plaqs4x4(x=x), plaqs=self._plaqs(w),
+                              charges=self._charges(w))
+
+    def plaqs(self, x: Optional[Tensor] = None, wloops: Optional[PlaqSumsU1] = None) -> Tensor:
+        if wloops is None:
+            if x is None:
+                raise ValueError('One of `x` or `wloops` must be specified.')
+            wloops = self.wilson_loops(x)
+        return self._plaqs(wloops)
+
+    def _plaqs(self, wloops: PlaqSumsU1) -> Tensor:
+        return wloops.cos / self.volume
+
+    def wilson_loops4x4(self, x: Tensor) -> Tensor:
+        """4x4 Wilson loops (lattice.py:161-186); an observable outside the leapfrog path,
+        kept as plain tensor indexing."""
+        x = x.reshape(-1, *self.xshape)
+        xu, xv = x[:, 0], x[:, 1]
+        return (
+            xu + xu.roll(-1, dims=2) + xu.roll(-2, dims=2) + xu.roll(-3, dims=2)
+            + xu.roll(-4, dims=2) + xv.roll((-4, -1), dims=(2, 1))
+            + xv.roll((-4, -2), dims=(2, 1)) + xv.roll((-4, -3), dims=(2, 1))
+            - xu.roll((-3, -4), dims=(2, 1)) - xu.roll((-2, -4), dims=(2, 1))
+            - xu.roll((-1, -4), dims=(2, 1)) - xv.roll(-4, dims=1) - xv.roll(-3, dims=1)
+            - xv.roll(-2, dims=1) - xv.roll(-1, dims=1) - xv
+        ).T
+
+    def plaqs4x4(self, x: Optional[Tensor] = None,
+                 wloops4x4: Optional[Tensor] = None) -> Tensor:
+        if wloops4x4 is None:
+            if x is None:
+                raise ValueError('One of `x` or `wloops` must be specified.')
+            wloops4x4 = self.wilson_loops4x4(x)
+        return wloops4x4.cos().mean((1, 2))
+
+    def _sin_charges(self, wloops: PlaqSumsU1) -> Tensor:
+        return wloops.sin / TWOPI
+
+    def _int_charges(self, wloops: PlaqSumsU1) -> Tensor:
+        return wloops.proj / TWOPI
+
+    def sin_charges(self, x: Optional[Tensor] = None,
+                    wloops: Optional[PlaqSumsU1] = None) -> Tensor:
+        wloops = self._get_wloops(x) if wloops is None else wloops
+        return self._sin_charges(wloops)
+
+    def int_charges(self, x: Optional[Tensor] = None,
+                    wloops: Optional[PlaqSumsU1] = None) -> Tensor:
+        wloops = self._get_wloops(x) if wloops is None else wloops
+        return self._int_charges(wloops)
+
+    def charges(self, x: Optional[Tensor] = None,
+                wloops: Optional[PlaqSumsU1] = None) -> Charges:
+        wloops = self._get_wloops(x) if wloops is None else wloops
+        return self._charges(wloops)
+
+    def _charges(self, wloops: PlaqSumsU1) -> Charges:
+        return Charges(intQ=self._int_charges(wloops), sinQ=self._sin_charges(wloops))

@@ -35,6 +35,8 @@ SIGNATURES = {
     'l2q_su3_project_su': (I, [P, P, L, L, P]),
     'l2q_su3_projsu_vec8': (I, [P, P, L, L, P]),
     'l2q_su3_project_tah': (I, [P, P, L, L, P]),
+    'l2q_su3_project_u': (I, [P, P, L, L, P]),
+    'l2q_su3_mul': (I, [P, P, I, I, P, L, L, P]),
     'l2q_su3_kinetic_reduce': (I, [P, I, L, P, P, Z, P]),
     'l2q_su3_assemble_tah': (I, [P, P, L, L, P]),
     'l2q_su3_check_su': (I, [P, I, L, P, P, Z, P]),

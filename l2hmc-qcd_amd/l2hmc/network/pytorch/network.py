@@ -1,0 +1,382 @@
+"""xnet / vnet leapfrog networks -- API and ``state_dict`` key layout of the reference's
+``src/l2hmc/network/pytorch/network.py`` (PeriodicPadding :151-172, ScaledTanh :175-206,
+ConvStack :240-346, InputLayer :349-451, LeapfrogLayer :454-551, NetworkFactory :634-801).
+
+The modules only *hold* parameters (so ``state_dict`` / ``parameters()`` / checkpoints look
+like the reference's); the arithmetic of ``forward`` is the MFMA GEMM with fused
+bias + activation + ScaledTanh epilogues (``l2q_gemm_f64`` / ``l2q_gemm_f32``) and the fused
+periodic-pad conv + max-pool kernel (``l2q_conv2d_periodic_f32``).  Eval-mode semantics
+(dropout off, batch-norm running statistics) -- the training path is SURVEY.md 8(f) item 1.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Callable, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from l2hmc import DEVICE
+from l2hmc import _ops as ops
+from l2hmc.configs import ConvolutionConfig, NetWeight, NetworkConfig
+from l2hmc.group.su3.pytorch.group import SU3
+from l2hmc.group.u1.pytorch.group import U1Phase
+from l2hmc.network.factory import BaseNetworkFactory
+
+log = logging.getLogger(__name__)
+Tensor = torch.Tensor
+
+ACTIVATION_FNS = {
+    'elu': nn.ELU(inplace=True),
+    'tanh': nn.Tanh(),
+    'relu': nn.ReLU(inplace=True),
+    'swish': nn.SiLU(),
+    'leaky_relu': nn.LeakyReLU(inplace=True),
+}
+_ACT_NAME = {nn.ELU: 'elu', nn.Tanh: 'tanh', nn.ReLU: 'relu', nn.SiLU: 'swish',
+             nn.LeakyReLU: 'leaky_relu'}
+
+
+def act_name(fn: Any) -> str:
+    if isinstance(fn, str):
+        return fn
+    for cls, name in _ACT_NAME.items():
+        if isinstance(fn, cls):
+            return name
+    raise ValueError(f'unsupported activation {fn}')
+
+
+def flatten(x: Tensor) -> Tensor:
+    return x.reshape(x.shape[0], -1)
+
+
+def dummy_network(inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, Tensor, Tensor]:
+    x, _ = inputs
+    return torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+
+
+def zero_weights(m):
+    if isinstance(m, nn.Linear):
+        nn.init.zeros_(m.weight.data)
+        if m.bias is not None:
+            nn.init.constant_(m.bias.data, 0)
+
+
+class PeriodicPadding(nn.Module):
+    """Parameter-free; kept so that ConvStack.layers has the reference's numbering.  Inside
+    ConvStack the padding is fused into the conv kernel (index arithmetic, no copy)."""
+
+    def __init__(self, size: int):
+        super().__init__()
+        self.size = size
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = torch.concat([x[:, :, -self.size:, :], x, x[:, :, 0:self.size, :]], 2)
+        return torch.concat([x[:, :, :, -self.size:], x, x[:, :, :, 0:self.size]], 3)
+
+
+class ScaledTanh(nn.Module):
+    """exp(coeff) * tanh(W z + b)  (network.py:175-206) -- one GEMM with fused epilogue."""
+
+    def __init__(self, in_features: int, out_features: int) -> None:
+        super().__init__()
+        self.coeff = nn.parameter.Parameter(torch.zeros(1, out_features, device=DEVICE))
+        self.layer = nn.Linear(in_features=in_features, out_features=out_features,
+                               device=DEVICE)
+
+    def forward(self, x):
+        return ops.gemm(x.to(DEVICE).contiguous(), self.layer.weight.detach(),
+                        self.layer.bias.detach(), coeff=self.coeff.detach().reshape(-1),
+                        act='tanh')
+
+
+class ConvStack(nn.Module):
+    def __init__(self, xshape: Sequence[int], conv_config: ConvolutionConfig,
+                 activation_fn: Any, use_batch_norm: bool = False,
+                 in_channels: Optional[int] = None) -> None:
+        super().__init__()
+        if len(xshape) == 3:
+            d, nt, nx = xshape[0], xshape[1], xshape[2]
+        elif len(xshape) == 4:
+            _, d, nt, nx = xshape
+        else:
+            raise ValueError(f'ConvStack is 2D only (U1); got xshape {xshape}')
+        self.d, self.nt, self.nx = d, nt, nx
+        self.xshape = xshape
+        self.xdim = int(np.cumprod(xshape[1:])[-1])
+        self.activation_fn = activation_fn
+        self.act = act_name(activation_fn)
+        self.layers = nn.ModuleList()
+        cin = (d + 2) if in_channels is None else in_channels
+        self.in_channels = cin
+        self.plan = []                       # (layer index of conv, k, pool, act)
+        h, w = nt, nx
+        filters = list(conv_config.filters or [])
+        sizes = list(conv_config.sizes or [])
+        if filters:
+            assert len(filters) == len(sizes)
+            self.layers.append(PeriodicPadding(sizes[0] - 1))
+            self.layers.append(nn.Conv2d(cin, filters[0], sizes[0], device=DEVICE))
+            self.plan.append((1, sizes[0], 1, None))          # no activation after conv #1
+            h, w, cin = h + sizes[0] - 1, w + sizes[0] - 1, filters[0]
+            for idx, (f, n) in enumerate(zip(filters[1:], sizes[1:])):
+                self.layers.append(PeriodicPadding(n - 1))
+                self.layers.append(nn.Conv2d(cin, f, n, device=DEVICE))
+                ci = len(self.layers) - 1
+                pool = 1
+                if (idx + 1) % 2 == 0:
+                    pool = 2 if conv_config.pool is None else int(conv_config.pool[idx])
+                    self.layers.append(nn.MaxPool2d(pool))
+                self.layers.append(self.activation_fn)
+                self.plan.append((ci, n, pool, self.act))
+                h, w, cin = (h + n - 1) // pool, (w + n - 1) // pool, f
+        self.layers.append(nn.Flatten())
+        if use_batch_norm:
+            raise NotImplementedError('ConvStack(use_batch_norm=True) is never used by the '
+                                      'reference (network.py:407-411)')
+        self.layers.append(nn.Linear(cin * h * w, self.xdim, device=DEVICE))
+        self.linear_index = len(self.layers) - 1
+        self.layers.append(self.activation_fn)
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = x.to(DEVICE)
+        x = x.reshape(x.shape[0], self.in_channels, self.nt, self.nx).contiguous()
+        if x.dtype != torch.float32:
+            raise NotImplementedError('the conv kernels are fp32 (the U(1) configs)')
+        for ci, k, pool, act in self.plan:
+            conv = self.layers[ci]
+            x = ops.conv2d_periodic(x, conv.weight.detach(), conv.bias.detach(), pool, act)
+        lin = self.layers[self.linear_index]
+        return ops.gemm(flatten(x).contiguous(), lin.weight.detach(), lin.bias.detach(),
+                        act=self.act)
+
+
+class InputLayer(nn.Module):
+    def __init__(self, xshape: Sequence[int], network_config: NetworkConfig,
+                 activation_fn: Callable[[Tensor], Tensor],
+                 conv_config: Optional[ConvolutionConfig] = None,
+                 input_shapes: Optional[dict[str, Sequence[int] | int]] = None,
+                 x_features: Optional[int] = None, v_features: Optional[int] = None,
+                 conv_channels: Optional[int] = None) -> None:
+        super().__init__()
+        self.xshape = xshape
+        self.net_config = network_config
+        self.units = self.net_config.units
+        self.xdim = int(np.cumprod(self.xshape[1:])[-1])
+        if input_shapes is None:
+            input_shapes = {'x': self.xdim, 'v': self.xdim}
+        self.input_shapes = {k: (v if isinstance(v, int) else int(np.cumprod(v)[-1]))
+                             for k, v in input_shapes.items()}
+        self.conv_config = conv_config
+        self.activation_fn = activation_fn
+        self.act = act_name(activation_fn)
+        conv_stack: nn.Module = nn.Identity()
+        if conv_config is not None and conv_config.filters is not None \
+                and len(conv_config.filters) > 0:
+            conv_stack = ConvStack(xshape=xshape, conv_config=conv_config,
+                                   activation_fn=self.activation_fn,
+                                   in_channels=conv_channels)
+        self.conv_stack = conv_stack
+        has_conv = isinstance(conv_stack, ConvStack)
+        xin = self.xdim if has_conv else (x_features or self.input_shapes['x'])
+        vin = v_features or self.input_shapes['v']
+        self.xlayer = nn.Linear(xin, self.net_config.units[0], device=DEVICE)
+        self.vlayer = nn.Linear(vin, self.net_config.units[0], device=DEVICE)
+
+    def forward(self, inputs: tuple[Tensor, Tensor]) -> Tensor:
+        x, v = inputs
+        x, v = x.to(DEVICE), v.to(DEVICE)
+        if isinstance(self.conv_stack, ConvStack):
+            x = self.conv_stack(x)
+        return ops.gemm(flatten(x).contiguous(), self.xlayer.weight.detach(),
+                        self.xlayer.bias.detach(), a2=flatten(v).contiguous(),
+                        w2=self.vlayer.weight.detach(), bias2=self.vlayer.bias.detach(),
+                        act=self.act)
+
+
+class LeapfrogLayer(nn.Module):
+    def __init__(self, xshape: Sequence[int], network_config: NetworkConfig,
+                 input_shapes: Optional[dict[str, int | Sequence[int]]] = None,
+                 net_weight: Optional[NetWeight] = None,
+                 conv_config: Optional[ConvolutionConfig] = None,
+                 name: Optional[str] = None, x_features: Optional[int] = None,
+                 v_features: Optional[int] = None, conv_channels: Optional[int] = None):
+        super().__init__()
+        if net_weight is None:
+            net_weight = NetWeight(1., 1., 1.)
+        self.xshape = xshape
+        self.nw = net_weight
+        self.net_config = network_config
+        self.name = name if name is not None else 'network'
+        self.xdim = int(np.cumprod(xshape[1:])[-1])
+        act_fn = self.net_config.activation_fn
+        if isinstance(act_fn, str):
+            act_fn = ACTIVATION_FNS.get(act_fn, None)
+        assert isinstance(act_fn, Callable)
+        self.activation_fn = act_fn
+        self.act = act_name(act_fn)
+        self.input_layer = InputLayer(
+            xshape=xshape, network_config=network_config, activation_fn=self.activation_fn,
+            conv_config=conv_config, input_shapes=input_shapes, x_features=x_features,
+            v_features=v_features, conv_channels=conv_channels)
+        self.units = self.net_config.units
+        self.hidden_layers = nn.ModuleList()
+        for idx, units in enumerate(self.units[1:]):
+            self.hidden_layers.append(nn.Linear(self.units[idx], units, device=DEVICE))
+        self.scale = ScaledTanh(self.units[-1], self.xdim)
+        self.transf = ScaledTanh(self.units[-1], self.xdim)
+        self.transl = nn.Linear(self.units[-1], self.xdim, device=DEVICE)
+        self.dropout = nn.Dropout(self.net_config.dropout_prob)
+        if self.net_config.use_batch_norm:
+            self.batch_norm = nn.BatchNorm1d(self.units[-1], device=DEVICE)
+        self._head_cache: dict = {}
+
+    def set_net_weight(self, net_weight: NetWeight):
+        self.nw = net_weight
+
+    # -------------------------------------------------------------- weights for the kernels
+    def _versions(self):
+        vs = [p._version for p in self.parameters()]
+        vs += [b._version for b in self.buffers()]
+        return tuple(vs) + (self.nw.s, self.nw.t, self.nw.q)
+
+    def kernel_weights(self, in_perm: Optional[Tensor] = None,
+                       out_perm: Optional[Tensor] = None) -> dict:
+        """Contiguous (optionally permuted) weight copies the GEMM kernels read.
+
+        in_perm / out_perm: ``idx[j_native] = j_reference`` maps (SU(3) native layout, see
+        include/l2q.h) applied to the input columns of xlayer/vlayer and to the output rows of
+        the three heads.  Eval-mode BatchNorm1d is folded into the heads:
+        W (a*z + c) + b = (W diag(a)) z + (W c + b).  Rebuilt when any parameter changes."""
+        key = (None if in_perm is None else in_perm.data_ptr(),
+               None if out_perm is None else out_perm.data_ptr())
+        ver = self._versions()
+        hit = self._head_cache.get(key)
+        if hit is not None and hit['ver'] == ver:
+            return hit
+        with torch.no_grad():
+            il = self.input_layer
+            wx, wv = il.xlayer.weight, il.vlayer.weight
+            if in_perm is not None and not isinstance(il.conv_stack, ConvStack):
+                wx = wx[:, in_perm]
+            if in_perm is not None:
+                wv = wv[:, in_perm]
+            out = {'ver': ver, 'wx': wx.contiguous(), 'bx': il.xlayer.bias.contiguous(),
+                   'wv': wv.contiguous(), 'bv': il.vlayer.bias.contiguous(),
+                   'hidden': [(h.weight.contiguous(), h.bias.contiguous())
+                              for h in self.hidden_layers]}
+            heads = {}
+            for nm, lin, coeff in (('s', self.scale.layer, self.scale.coeff),
+                                   ('t', self.transl, None),
+                                   ('q', self.transf.layer, self.transf.coeff)):
+                w, b = lin.weight, lin.bias
+                if self.net_config.use_batch_norm:
+                    bn = self.batch_norm
+                    a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    c = bn.bias - bn.running_mean * a
+                    b = b + w @ c
+                    w = w * a[None, :]
+                co = None if coeff is None else coeff.reshape(-1)
+                if out_perm is not None:
+                    w, b = w[out_perm], b[out_perm]
+                    co = None if co is None else co[out_perm]
+                heads[nm] = (w.contiguous(), b.contiguous(),
+                             None if co is None else co.contiguous())
+            out['heads'] = heads
+        self._head_cache[key] = out
+        return out
+
+    def _check_mode(self):
+        if self.training and (self.net_config.dropout_prob > 0 or self.net_config.use_batch_norm):
+            raise NotImplementedError(
+                'LeapfrogLayer: train-mode dropout / batch-norm statistics are part of the '
+                'training path (SURVEY.md 8(f) item 1), not built yet -- call .eval()')
+
+    def forward_flat(self, x: Tensor, v: Tensor, w: Optional[dict] = None
+                     ) -> tuple[Tensor, Tensor, Tensor]:
+        """(s, t, q) from already flattened inputs [nb, Kx], [nb, Kv] (conv stack, if any,
+        already applied to x)."""
+        self._check_mode()
+        w = self.kernel_weights() if w is None else w
+        z = ops.gemm(x, w['wx'], w['bx'], a2=v, w2=w['wv'], bias2=w['bv'], act=self.act)
+        for hw, hb in w['hidden']:
+            z = ops.gemm(z, hw, hb, act=self.act)
+        ws, bs, cs = w['heads']['s']
+        wt, bt, _ = w['heads']['t']
+        wq, bq, cq = w['heads']['q']
+        s = ops.gemm(z, ws, bs, coeff=cs, scale=self.nw.s, act='tanh')
+        t = ops.gemm(z, wt, bt, scale=self.nw.t)
+        q = ops.gemm(z, wq, bq, coeff=cq, scale=self.nw.q, act='tanh')
+        return s, t, q
+
+    def forward(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, Tensor, Tensor]:
+        x, v = inputs
+        x, v = x.to(DEVICE), v.to(DEVICE)
+        if isinstance(self.input_layer.conv_stack, ConvStack):
+            x = self.input_layer.conv_stack(x)
+        dt = self.transl.weight.dtype
+        return self.forward_flat(flatten(x).to(dt).contiguous(), flatten(v).to(dt).contiguous())
+
+
+def get_network(xshape, network_config, input_shapes=None, net_weight=None, conv_config=None,
+                name=None, **kw) -> LeapfrogLayer:
+    return LeapfrogLayer(xshape=xshape, network_config=network_config,
+                         input_shapes=input_shapes, net_weight=net_weight,
+                         conv_config=conv_config, name=name, **kw)
+
+
+def get_and_call_network(xshape: Sequence[int], *, network_config: NetworkConfig,
+                         is_xnet: bool, group: U1Phase | SU3,
+                         input_shapes: Optional[dict[str, int | Sequence[int]]] = None,
+                         net_weight: Optional[NetWeight] = None,
+                         conv_config: Optional[ConvolutionConfig] = None,
+                         name: Optional[str] = None) -> LeapfrogLayer:
+    """The reference materialises its Lazy layers with one dummy forward
+    (network.py:572-631); the widths that call would discover are computed directly here:
+    U1 xnet sees [cos, sin] (4 channels, 2*xdim features), SU3 xnet sees real||imag
+    (2*xdim features), SU3 vnet sees the 8-component vectors (input_shapes)."""
+    xdim = int(np.cumprod(xshape[1:])[-1])
+    kw: dict = {}
+    if isinstance(group, SU3) or getattr(group, '_name', None) == 'SU3':
+        if is_xnet:
+            kw.update(x_features=2 * xdim, v_features=2 * xdim)
+    else:
+        kw['conv_channels'] = 4 if is_xnet else 2
+        if is_xnet:
+            kw['x_features'] = 2 * xdim
+    return get_network(xshape=xshape, network_config=network_config, input_shapes=input_shapes,
+                       net_weight=net_weight, conv_config=conv_config, name=name, **kw)
+
+
+class NetworkFactory(BaseNetworkFactory):
+    def build_xnet(self, group: SU3 | U1Phase, name: Optional[str] = None) -> LeapfrogLayer:
+        xname = 'xnet' if name is None else f'xnet/{name}'
+        return get_and_call_network(
+            xshape=self.input_spec.xshape, network_config=self.network_config, is_xnet=True,
+            group=group, input_shapes=self.input_spec.xnet, net_weight=self.nw.x,
+            conv_config=self.conv_config, name=xname)
+
+    def build_vnet(self, group: SU3 | U1Phase, name: Optional[str] = None) -> LeapfrogLayer:
+        vname = 'vnet' if name is None else f'vnet/{name}'
+        return get_and_call_network(
+            xshape=self.input_spec.xshape, network_config=self.network_config, is_xnet=False,
+            group=group, input_shapes=self.input_spec.vnet, net_weight=self.nw.v,
+            conv_config=self.conv_config, name=vname)
+
+    def build_networks(self, n: int, split_xnets: bool, group: SU3 | U1Phase) -> nn.ModuleDict:
+        assert n >= 1, 'Must build at least one network'
+        if n == 1:
+            return nn.ModuleDict({'xnet': self.build_xnet(group=group),
+                                  'vnet': self.build_vnet(group=group)})
+        vnet = nn.ModuleDict()
+        xnet = nn.ModuleDict()
+        for lf in range(n):
+            vnet[f'{lf}'] = self.build_vnet(group=group, name=f'{lf}')
+            if split_xnets:
+                xnet[f'{lf}'] = nn.ModuleDict({
+                    'first': self.build_xnet(group=group, name=f'{lf}/first'),
+                    'second': self.build_xnet(group=group, name=f'{lf}/second')})
+            else:
+                xnet[f'{lf}'] = self.build_xnet(group=group, name=f'{lf}')
+        return nn.ModuleDict({'xnet': xnet, 'vnet': vnet})

@@ -1,0 +1,213 @@
+"""GPU parity of the product ``l2hmc.Dynamics`` (HIP kernels through the C ABI) against the
+golden vectors produced by the reference's PyTorch-CPU path on identical (lattice, beta, draws):
+bit-exact accept/reject masks; plaquette / charge / dH within the stated tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_su3_dynamics, build_u1_dynamics, su3_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max())
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(autouse=True)
+def _f64_default():
+    old = torch.get_default_dtype()
+    yield
+    torch.set_default_dtype(old)
+
+
+def test_su3_lattice_api(golden):
+    torch.set_default_dtype(torch.float64)
+    g = golden('su3_ops')
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.group.su3.pytorch import utils as U
+    L = [int(i) for i in g['latvolume']]
+    lat = LatticeSU3(2, L)
+    x, beta = dev(g['x']), torch.tensor(float(g['beta']))
+    assert err(host(lat.action(x, beta)), g['action']) < 1e-10
+    assert err(host(lat._plaquettes(x)), g['plaqs']) < 1e-14
+    assert err(host(lat.sin_charges(x)), g['sinQ']) < 1e-14
+    assert err(host(lat.int_charges(x)), g['intQ']) < 1e-13
+    assert err(host(lat.grad_action(x, beta)), g['force']) < 1e-13
+    assert err(host(lat.kinetic_energy(dev(g['v']))), g['kinetic']) < 1e-10
+    m = lat.calc_metrics(x)
+    assert err(host(m['plaqs']), g['plaqs']) < 1e-14
+    gen = dev(g['general'])
+    assert err(host(U.projectSU(gen)), g['projsu_general']) < 1e-12
+    assert err(host(U.projectTAH(gen)), g['tah_general']) < 1e-15
+    assert err(host(lat.g.exp(gen)), g['expm_general']) < 1e-11
+    assert err(host(lat.g.group_to_vec(x)), g['vec_x']) < 1e-12
+    assert err(host(lat.g.update_gauge(x, 0.3 * dev(g['v']))), g['expm_v_x']) < 1e-13
+    a, b = gen, dev(g['projsu_general'])
+    assert err(host(lat.g.mul(a, b, adjoint_b=True)), g['general'] @ np.conj(np.swapaxes(g['projsu_general'], -1, -2))) < 1e-13
+    av, mx = U.checkSU(x)
+    assert err(np.stack([host(av), host(mx)]), g['checksu_x']) < 1e-14
+    torch.manual_seed(22)
+    v = lat.random_momentum()
+    assert err(host(v), g['v']) < 1e-15        # same CPU generator stream as the reference
+
+
+def test_su3_hmc_trajectory(golden):
+    torch.set_default_dtype(torch.float64)
+    g = golden('su3_hmc')
+    dyn, lat = build_su3_dynamics(g, with_nets=False)
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    xo, m = dyn.apply_transition_hmc((dev(g['x']), torch.tensor(float(g['beta']))),
+                                     eps=float(g['eps']), nleapfrog=int(g['nleapfrog']))
+    mc = m['mc_states']
+    assert err(host(mc.init.v), g['v_init']) < 1e-15
+    assert err(host(mc.proposed.x), g['x_prop']) < 1e-12
+    assert err(host(mc.proposed.v), g['v_prop']) < 1e-11
+    assert err(host(m['energy']), g['energy']) < 1e-8         # |H| ~ 2e3
+    assert err(host(m['acc']), g['acc']) < 1e-8
+    assert np.array_equal(host(m['acc_mask']), g['acc_mask'])  # bit-exact accept/reject
+    assert err(host(xo), g['x_out'].reshape(xo.shape)) < 1e-12
+    margin = np.abs(g['acc'] - g['u']).min()
+    assert margin > 1e-3, margin
+
+
+def test_su3_l2hmc_subupdates(golden):
+    torch.set_default_dtype(torch.float64)
+    from l2hmc.dynamics.pytorch.dynamics import State
+    g = golden('su3_l2hmc')
+    dyn, lat = build_su3_dynamics(g)
+    beta = torch.tensor(float(g['beta']))
+    x, v = dev(g['x']), dev(g['v0'])
+    f = dyn.grad_potential(x, beta)
+    assert err(host(f), g['force0']) < 1e-12
+    s, t, q = dyn._call_vnet(0, (x, f))
+    # vnet input = su3_to_vec(projectSU(force)): ill-conditioned in the reference itself
+    # (numpy vs torch on identical input differ by 3e-9, tests/test_oracle_golden.py)
+    tol = 1e-6
+    assert max(err(host(s), g['s']), err(host(t), g['t']), err(host(q), g['q'])) < tol
+    st, ld = dyn._update_v_fwd(0, State(x, v, beta))
+    assert err(host(st.v), g['v_fwd']) < 1e-7 and err(host(ld), g['logdet_v_fwd']) < 1e-7
+    st, ld = dyn._update_v_bwd(1, State(x, v, beta))
+    assert err(host(st.v), g['v_bwd']) < 1e-7 and err(host(ld), g['logdet_v_bwd']) < 1e-7
+    m0, mb0 = dyn._get_mask(0)
+    st, ld = dyn._update_x_fwd(0, State(x, dev(g['v_fwd']), beta), m0, first=True)
+    assert err(host(st.x), g['x_fwd']) < 1e-13 and float(ld.abs().max()) == 0.0
+    st, _ = dyn._update_x_bwd(1, State(x, dev(g['v_fwd']), beta), mb0, first=False)
+    assert err(host(st.x), g['x_bwd']) < 1e-13
+    st, ld = dyn._forward_lf(0, State(x, v, beta))
+    assert err(host(st.x), g['lf_fwd_x']) < 1e-8 and err(host(st.v), g['lf_fwd_v']) < 1e-7
+    assert err(host(ld), g['lf_fwd_logdet']) < 1e-7
+
+
+def test_su3_l2hmc_trajectory(golden):
+    torch.set_default_dtype(torch.float64)
+    g = golden('su3_l2hmc')
+    dyn, lat = build_su3_dynamics(g)
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    xo, m = dyn((dev(g['x']), torch.tensor(float(g['beta']))))
+    mc = m['mc_states']
+    assert err(host(mc.init.v), g['v_init']) < 1e-15
+    assert err(host(mc.proposed.x), g['x_prop']) < 1e-7
+    assert err(host(mc.proposed.v), g['v_prop']) < 1e-6
+    assert err(host(m['energy']), g['energy']) < 1e-5          # dH tolerance, |H| ~ 2.4e3
+    assert err(host(m['logdet']), g['logdet']) < 1e-6
+    assert err(host(m['acc']), g['acc']) < 1e-5
+    assert np.array_equal(host(m['acc_mask']), g['acc_mask'])  # bit-exact accept/reject
+    assert err(host(m['sumlogdet']), g['sumlogdet']) < 1e-6
+    assert err(host(xo), g['x_out'].reshape(xo.shape)) < 1e-7
+    # observables of the output configuration vs the reference's
+    from oracle import su3 as osu3
+    xo_ref = g['x_out'].reshape(g['x'].shape)
+    met = lat.calc_metrics(xo.reshape(g['x'].shape))
+    assert err(host(met['plaqs']), osu3.plaqs(xo_ref)) < 1e-9
+    assert err(host(met['intQ']), osu3.int_charges(xo_ref)) < 1e-9
+    # verbose=False takes the lean path and must give the same proposal
+    dyn.config.verbose = False
+    xo2, m2 = dyn((dev(g['x']), torch.tensor(float(g['beta']))))
+    assert err(host(xo2), host(xo)) == 0.0 and err(host(m2['acc']), host(m['acc'])) == 0.0
+    assert m2['acc'].dtype == torch.float64 and m2['acc_mask'].dtype == torch.float32
+
+
+@pytest.mark.parametrize('name', ['u1_conv', 'u1_c1'])
+def test_u1_trajectories(golden, name):
+    torch.set_default_dtype(torch.float32)
+    from l2hmc.dynamics.pytorch.dynamics import State
+    g = golden(name)
+    dyn, lat = build_u1_dynamics(g)
+    beta = torch.tensor(float(g['beta']))
+    x = dev(g['x'])
+    nb = x.shape[0]
+    assert err(host(lat.action(x, beta)), g['action']) < 2e-4
+    assert err(host(lat.grad_action(x, beta)), g['force']) < 1e-5
+    assert err(host(lat.plaqs(x)), g['plaqs']) < 1e-6
+    assert err(host(lat.int_charges(x)), g['intQ']) < 1e-5
+    v = dev(g['normals'].reshape(nb, -1))
+    f = dyn.grad_potential(x, beta)
+    s, t, q = dyn._call_vnet(0, (x, f))
+    assert max(err(host(s), g['vnet_s']), err(host(t), g['vnet_t']), err(host(q), g['vnet_q'])) < 2e-5
+    st, ld = dyn._update_v_fwd(0, State(x, v, beta))
+    assert err(host(st.v), g['v_fwd']) < 2e-5 and err(host(ld), g['logdet_v_fwd']) < 1e-4
+    m0, mb0 = dyn._get_mask(0)
+    xm = dyn.unflatten(m0.cuda()) * x
+    s, t, q = dyn._call_xnet(0, (xm, v), first=True)
+    assert max(err(host(s), g['xnet_s']), err(host(t), g['xnet_t']), err(host(q), g['xnet_q'])) < 2e-5
+    st, ld = dyn._update_x_fwd(0, State(x, v, beta), m0, first=True)
+    d = np.abs(np.angle(np.exp(1j * (host(st.x) - g['x_fwd']))))
+    assert d.max() < 3e-5 and err(host(ld), g['logdet_x_fwd']) < 1e-4
+    st, ld = dyn._update_x_bwd(0, State(x, v, beta), mb0, first=False)
+    d = np.abs(np.angle(np.exp(1j * (host(st.x) - g['x_bwd']))))
+    assert d.max() < 3e-5 and err(host(ld), g['logdet_x_bwd']) < 1e-4
+    # plain HMC
+    dyn._inject = {'normals': g['hmc_normals'], 'u': g['hmc_u']}
+    xo, m = dyn.apply_transition_hmc((x, beta), eps=float(g['hmc_eps']),
+                                     nleapfrog=int(g['hmc_nleapfrog']))
+    assert err(host(m['energy']), g['hmc_energy']) < 5e-3
+    assert err(host(m['acc']), g['hmc_acc']) < 5e-3
+    assert np.array_equal(host(m['acc_mask']), g['hmc_acc_mask'])
+    d = np.abs(np.angle(np.exp(1j * (host(xo) - g['hmc_x_out'].reshape(nb, -1)))))
+    assert d.max() < 1e-4
+    # merged L2HMC trajectory
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    xo, m = dyn((x, beta))
+    assert err(host(m['energy']), g['energy']) < 2e-2
+    assert err(host(m['logdet']), g['logdet']) < 2e-3
+    assert err(host(m['acc']), g['acc']) < 1e-2
+    assert np.array_equal(host(m['acc_mask']), g['acc_mask'])  # bit-exact accept/reject
+    d = np.abs(np.angle(np.exp(1j * (host(xo) - g['x_out'].reshape(nb, -1)))))
+    assert d.max() < 2e-3
+    assert sorted(k for k in m if k != 'mc_states') == sorted(
+        ['energy', 'logprob', 'logdet', 'sldf', 'sldb', 'sld', 'xeps', 'veps', 'acc',
+         'sumlogdet', 'acc_mask', 'beta'])
+
+
+def test_state_dict_layout():
+    """networks listed under both `networks.*` and `xnet.*`/`vnet.*` plus xeps/veps
+    (50 keys / 26 unique parameters for the smallest SU(3) model)."""
+    torch.set_default_dtype(torch.float64)
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.network.pytorch.network import NetworkFactory
+    L = [2, 2, 2, 2]
+    dc = cfgs.DynamicsConfig(nchains=2, group='SU3', latvolume=L, nleapfrog=1,
+                             use_split_xnets=False, use_separate_networks=False)
+    nc = cfgs.NetworkConfig(units=[1], activation_fn='tanh', dropout_prob=0.0, use_batch_norm=False)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [512], 'v': [512]},
+                          vnet={'x': [512], 'v': [512]})
+    dyn = Dynamics(LatticeSU3(2, L).action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig()))
+    keys = list(dyn.state_dict().keys())
+    assert len(keys) == 50 and len(list(dyn.parameters())) == 26
+    assert 'networks.vnet.scale.coeff' in keys and 'vnet.scale.coeff' in keys and 'xeps.0' in keys
+    assert dyn.xnet.input_layer.xlayer.weight.shape == (1, 2 * 36 * 16)
+    m = dyn.masks[0]
+    assert m.shape == (1, dyn.xdim) and m.dtype == torch.float32 and int(m.sum()) == dyn.xdim // 2
