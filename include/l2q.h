@@ -149,6 +149,20 @@ int l2q_gemm_f64(const double* A, const double* W, int M, int N, long K, const d
                  const double* coeff, double scale, int act, double* C, void* ws,
                  size_t ws_bytes, void* stream);
 size_t l2q_gemm_ws_bytes(int M, int N, long K, long K2);
+/* The three output heads of a LeapfrogLayer AND the generalised momentum update in one kernel
+ * (network.py:547-551 + dynamics.py:1266-1297): for chain m, entry n
+ *   s = cs[n] tanh(Z.Ws[n] + bs[n]);  t = scale_t (Z.Wt[n] + bt[n]);  q = cq[n] tanh(Z.Wq[n] + bq[n])
+ *   v' and logdet as in l2q_v_update.   s, t, q are never written to memory.
+ * cs / cq: per-entry scale nw.s * exp(coeff_s[n]) (NULL -> the scalar scale_s / scale_q).
+ * Z [M][K] (K even), W* [N][K], v / force [M][N] real or complex128, logdet [M]. */
+int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const double* Ws,
+                               const double* bs, const double* cs, double scale_s,
+                               const double* Wt, const double* bt, double scale_t,
+                               const double* Wq, const double* bq, const double* cq,
+                               double scale_q, void* v, const void* force, int is_complex,
+                               double eps, int forward, double* logdet, void* ws,
+                               size_t ws_bytes, void* stream);
+size_t l2q_vnet_heads_ws_bytes(int M, long N);
 /* fp32 variant on v_mfma_f32_16x16x4_f32 (U(1) networks). */
 int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const float* A2,
                  const float* W2, long K2, const float* bias, const float* bias2,

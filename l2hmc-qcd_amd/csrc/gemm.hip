@@ -4,16 +4,19 @@
 //
 // Both operands are K-contiguous (nn.Linear weight layout), so one LDS-tiled "NT" kernel
 // serves every layer.  fp64 uses v_mfma_f64_16x16x4_f64, fp32 v_mfma_f32_16x16x4_f32 (exact
-// IEEE fma chains, no reduced-precision path).  Tile 128x128x16 per 256-thread workgroup,
-// each of the 4 wavefronts owns a 64x64 quadrant = 4x4 MFMA tiles (64 accumulators/lane).
+// IEEE fma chains, no reduced-precision path).  256-thread workgroups = 2x2 wavefronts, each
+// owning a (BM/2)x(BN/2) quadrant of 16x16 MFMA tiles; operands are staged through LDS in
+// K-slabs of 16 with 16-byte global loads and a register prefetch of the next slab.
 // The L2HMC layers are skinny (M = #chains <= a few hundred, K or N = 32V..36V ~ 1e5), so
-// the K loop is split across workgroups (split-K) with a fixed-order second-stage reduce:
-// deterministic, no atomics.
+// the input layer splits K across workgroups with a fixed-order second-stage reduce
+// (deterministic, no atomics), and the three output heads (s, t, q) are computed together
+// and consumed in registers by the generalised momentum update (fused_heads_vupdate):
+// s, t, q are never written to HBM.
 #include "l2q_common.hpp"
 
 namespace l2q {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDP = BK + 2;   // +2: conflict-free ds_read_b64/b32
+constexpr int BK = 16, LDP = BK + 2;   // +2: conflict-free ds_read_b64 / ds_read_b32 fragments
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef float v4f32 __attribute__((ext_vector_type(4)));
@@ -21,6 +24,8 @@ typedef float v4f32 __attribute__((ext_vector_type(4)));
 template <typename T> struct Mfma;
 template <> struct Mfma<double> {
   using acc_t = v4f64;
+  using vec_t = double2;
+  static constexpr int VEC = 2;
   static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
@@ -29,6 +34,8 @@ template <> struct Mfma<double> {
 };
 template <> struct Mfma<float> {
   using acc_t = v4f32;
+  using vec_t = float4;
+  static constexpr int VEC = 4;
   static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
@@ -36,10 +43,16 @@ template <> struct Mfma<float> {
   static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
 
+__device__ __forceinline__ double fast_tanh(double x) {
+  // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates correctly for |x| large (exp -> inf / 0)
+  return 1.0 - 2.0 / (exp(2.0 * x) + 1.0);
+}
+__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+
 template <typename T>
 __device__ __forceinline__ T apply_act(T z, int act) {
   switch (act) {
-    case L2Q_ACT_TANH: return tanh(z);
+    case L2Q_ACT_TANH: return fast_tanh(z);
     case L2Q_ACT_RELU: return z > (T)0 ? z : (T)0;
     case L2Q_ACT_LEAKY_RELU: return z > (T)0 ? z : (T)0.01 * z;
     case L2Q_ACT_ELU: return z > (T)0 ? z : expm1(z);
@@ -48,6 +61,7 @@ __device__ __forceinline__ T apply_act(T z, int act) {
   }
 }
 
+// y = scale * exp(coeff[n]) * act(acc + bias[n] + bias2[n])
 template <typename T>
 struct Epilogue {
   const T* bias;
@@ -55,33 +69,99 @@ struct Epilogue {
   const T* coeff;
   T scale;
   int act;
-  __device__ __forceinline__ T operator()(T acc, int n) const {
-    T z = acc;
-    if (bias) z += bias[n];
-    if (bias2) z += bias2[n];
-    z = apply_act<T>(z, act);
-    return coeff ? scale * exp(coeff[n]) * z : scale * z;
+  __device__ __forceinline__ T colscale(int n) const {
+    return coeff ? scale * exp(coeff[n]) : scale;
+  }
+  __device__ __forceinline__ T colbias(int n) const {
+    T b = (T)0;
+    if (bias) b += bias[n];
+    if (bias2) b += bias2[n];
+    return b;
   }
 };
 
-// element (row, kk) of the virtual K-concatenated operand [P | P2], zero outside
-template <typename T>
-__device__ __forceinline__ T load_cat(const T* __restrict__ p, const T* __restrict__ p2, long row,
-                                      long nrows, long kk, long K, long K2) {
-  if (row >= nrows) return (T)0;
-  if (kk < K) return p[row * K + kk];
-  kk -= K;
-  if (kk < K2) return p2[row * K2 + kk];
-  return (T)0;
-}
+// Operand tile loader: ROWS x BK elements of the virtual K-concatenated matrix [P | P2]
+// (row stride K resp. K2), zero outside [kbeg, kend) and beyond nrows.  VECLOAD: 16-byte
+// loads (needs K, K2, kbeg multiples of VEC and 16-byte aligned bases), else scalar.
+template <typename T, int ROWS, bool VECLOAD>
+struct TileLoader {
+  using vec_t = typename Mfma<T>::vec_t;
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int VPR = BK / VEC;                 // vectors per row
+  static constexpr int RPP = kBlock / VPR;             // rows per pass
+  static constexpr int NP = (ROWS + RPP - 1) / RPP;    // passes
+  static constexpr int SRPP = kBlock / BK;             // scalar path: rows per pass
+  static constexpr int SNP = (ROWS + SRPP - 1) / SRPP;
+  T reg[VECLOAD ? NP * VEC : SNP];
 
-// grid: x = N tiles, y = M tiles, z = K splits.  FUSED: splits == 1, epilogue applied here;
-// otherwise raw partial sums go to part[z][M][N].
-template <typename T, bool FUSED>
+  __device__ __forceinline__ void fetch(const T* __restrict__ p, const T* __restrict__ p2,
+                                        long row0, long nrows, long k0, long K, long K2,
+                                        long kend) {
+    const int tid = threadIdx.x;
+    if (VECLOAD) {
+      const int kv = (tid % VPR) * VEC, r = tid / VPR;
+      const long kk = k0 + kv;
+      const T* base = p;
+      long ld = K, kc = kk;
+      if (kk >= K) { base = p2; ld = K2; kc = kk - K; }
+      const bool kin = kk < kend;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const long row = row0 + r + (long)i * RPP;
+        vec_t v;
+        if (kin && row < nrows && (r + i * RPP) < ROWS) {
+          v = *reinterpret_cast<const vec_t*>(base + row * ld + kc);
+        } else {
+          v = vec_t{};
+        }
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) reg[i * VEC + j] = e[j];
+      }
+    } else {
+      const int kq = tid % BK, r = tid / BK;
+      const long kk = k0 + kq;
+#pragma unroll
+      for (int i = 0; i < SNP; ++i) {
+        const long row = row0 + r + (long)i * SRPP;
+        T v = (T)0;
+        if (kk < kend && row < nrows && (r + i * SRPP) < ROWS) {
+          if (kk < K) v = p[row * K + kk];
+          else if (kk - K < K2) v = p2[row * K2 + (kk - K)];
+        }
+        reg[i] = v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(T (*lds)[LDP]) const {
+    const int tid = threadIdx.x;
+    if (VECLOAD) {
+      const int kv = (tid % VPR) * VEC, r = tid / VPR;
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (r + i * RPP < ROWS) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) lds[r + i * RPP][kv + j] = reg[i * VEC + j];
+        }
+    } else {
+      const int kq = tid % BK, r = tid / BK;
+#pragma unroll
+      for (int i = 0; i < SNP; ++i)
+        if (r + i * SRPP < ROWS) lds[r + i * SRPP][kq] = reg[i];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Generic layer: grid x = N tiles, y = M tiles, z = K splits.  FUSED: splits == 1 and the
+// epilogue is applied here; otherwise raw partial sums go to part[z][M][N].
+template <typename T, bool FUSED, bool VECLOAD>
 __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
     const T* __restrict__ A, const T* __restrict__ W, const T* __restrict__ A2,
     const T* __restrict__ W2, int M, int N, long K, long K2, long kchunk, Epilogue<T> epi,
     T* __restrict__ C, T* __restrict__ part) {
+  constexpr int BM = 128, BN = 128;
   using acc_t = typename Mfma<T>::acc_t;
   __shared__ T As[BM][LDP];
   __shared__ T Ws[BN][LDP];
@@ -99,28 +179,19 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
 
-  // global -> register staging: thread owns column kq of 8 rows (rq + 16 i)
-  const int kq = tid & 15, rq = tid >> 4;
-  T ra[8], rw[8];
-  auto fetch = [&](long k0) {
-    const long kk = k0 + kq;
-    const bool kin = kk < kend;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      ra[i] = kin ? load_cat<T>(A, A2, m0 + rq + 16 * i, M, kk, K, K2) : (T)0;
-      rw[i] = kin ? load_cat<T>(W, W2, n0 + rq + 16 * i, N, kk, K, K2) : (T)0;
-    }
-  };
-  fetch(kbeg);
+  TileLoader<T, BM, VECLOAD> la;
+  TileLoader<T, BN, VECLOAD> lw;
+  la.fetch(A, A2, m0, M, kbeg, K, K2, kend);
+  lw.fetch(W, W2, n0, N, kbeg, K, K2, kend);
   for (long k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();                                 // previous tile fully consumed
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      As[rq + 16 * i][kq] = ra[i];
-      Ws[rq + 16 * i][kq] = rw[i];
-    }
+    __syncthreads();                                 // previous slab fully consumed
+    la.store(As);
+    lw.store(Ws);
     __syncthreads();
-    if (k0 + BK < kend) fetch(k0 + BK);              // overlap next tile's HBM/L2 latency
+    if (k0 + BK < kend) {                            // overlap the next slab's latency
+      la.fetch(A, A2, m0, M, k0 + BK, K, K2, kend);
+      lw.fetch(W, W2, n0, N, k0 + BK, K, K2, kend);
+    }
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
       T fa[4], fb[4];
@@ -138,18 +209,22 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
 
   T* dst = FUSED ? C : part + (long)blockIdx.z * M * N;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 4; ++j) {
+    const long n = n0 + wn + 16 * j + (lane & 15);
+    if (n >= N) continue;
+    T cs = (T)1, cb = (T)0;
+    if (FUSED) { cs = epi.colscale((int)n); cb = epi.colbias((int)n); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
-        const long n = n0 + wn + 16 * j + (lane & 15);
-        if (m < M && n < N) {
+        if (m < M) {
           const T v = acc[i][j][r];
-          dst[m * N + n] = FUSED ? epi(v, (int)n) : v;
+          dst[m * N + n] = FUSED ? cs * apply_act<T>(v + cb, epi.act) : v;
         }
       }
+  }
 }
 
 template <typename T>
@@ -160,17 +235,169 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const T* __restri
   if (i >= MN) return;
   T s = (T)0;
   for (int z = 0; z < splits; ++z) s += part[(long)z * MN + i];     // fixed order
-  C[i] = epi(s, (int)(i % N));
+  const int n = (int)(i % N);
+  C[i] = epi.colscale(n) * apply_act<T>(s + epi.colbias(n), epi.act);
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused output heads + generalised momentum update (dynamics.py:1266-1297 with
+// network.py:547-551):  for every chain m and entry n
+//     s = cs[n] tanh(z.Ws[n] + bs[n]),  t = ct (z.Wt[n] + bt[n]),  q = cq[n] tanh(z.Wq[n] + bq[n])
+//     forward : v' = exp(eps s/2) v - eps/2 (F exp(eps q) + t)
+//     backward: v' = exp(-eps s/2) (v + eps/2 (F exp(eps q) + t))
+//     logdet_part[m][.] = +- sum_n eps s / 2
+// Tile 64 (chains) x 64 (entries), each wavefront 32 x 32 = 2x2 MFMA tiles for each of the
+// three heads (48 fp64 accumulators / lane, no spills at 2 waves/SIMD).  The three W tiles share the staged Z tile.
+// CPLX: v, F are complex (SU(3)); the real heads act on both parts, t on the real part.
+constexpr int kHeadsBN = 64;
+
+struct HeadsArgs {
+  const double* Z;        // [M][K]
+  const double* W[3];     // s, t, q weights [N][K]
+  const double* b[3];     // biases [N]
+  const double* cs;       // per-column scale of s: nw.s * exp(coeff_s[n])   (may be null -> ss)
+  const double* cq;       // per-column scale of q
+  double ss, st, sq;      // scalar scales (used where the vector is null; st always)
+  double eps;
+  double* v;              // [M][N] (x2 if complex), updated in place
+  const double* F;        // [M][N] (x2 if complex)
+  double* logdet_part;    // [M][ncols_part]
+  int M, N, K, ncols_part;
+};
+
+template <bool CPLX, bool FWD>
+__global__ __launch_bounds__(kBlock, 2) void fused_heads_vupdate_kernel(HeadsArgs a, int swz) {
+  constexpr int BM = 64, BN = kHeadsBN, NJ = BN / 32;
+  using T = double;
+  using acc_t = v4f64;
+  __shared__ T Zs[BM][LDP];
+  __shared__ T Ws[3][BN][LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * (BN / 2);
+  // logical block order: m fastest, so the M/64 blocks that share a W tile are adjacent and
+  // (after the XCD swizzle) on the same XCD's L2
+  const long mt = (a.M + BM - 1) / BM;
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const long m0 = (w % mt) * BM, n0 = (w / mt) * BN;
+
+  acc_t acc[3][2][NJ];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[h][i][j] = (acc_t){0, 0, 0, 0};
+
+  TileLoader<T, BM, true> lz;
+  TileLoader<T, BN, true> lw0, lw1, lw2;
+  const long K = a.K;
+  lz.fetch(a.Z, nullptr, m0, a.M, 0, K, 0, K);
+  lw0.fetch(a.W[0], nullptr, n0, a.N, 0, K, 0, K);
+  lw1.fetch(a.W[1], nullptr, n0, a.N, 0, K, 0, K);
+  lw2.fetch(a.W[2], nullptr, n0, a.N, 0, K, 0, K);
+  for (long k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    lz.store(Zs);
+    lw0.store(Ws[0]);
+    lw1.store(Ws[1]);
+    lw2.store(Ws[2]);
+    __syncthreads();
+    if (k0 + BK < K) {
+      lz.fetch(a.Z, nullptr, m0, a.M, k0 + BK, K, 0, K);
+      lw0.fetch(a.W[0], nullptr, n0, a.N, k0 + BK, K, 0, K);
+      lw1.fetch(a.W[1], nullptr, n0, a.N, k0 + BK, K, 0, K);
+      lw2.fetch(a.W[2], nullptr, n0, a.N, k0 + BK, K, 0, K);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      T fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = Zs[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+      for (int h = 0; h < 3; ++h) {
+        T fb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = Ws[h][wn + 16 * j + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[h][i][j] = Mfma<T>::run(fa[i], fb[j], acc[h][i][j]);
+      }
+    }
+  }
+
+  // ---- epilogue: heads -> momentum update in registers
+  const double eps = a.eps, heps = 0.5 * a.eps;
+  double ld[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ld[i][r] = 0.0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long n = n0 + wn + 16 * j + (lane & 15);
+    if (n >= a.N) continue;
+    const double bs = a.b[0][n], bt = a.b[1][n], bq = a.b[2][n];
+    const double cs = a.cs ? a.cs[n] : a.ss;
+    const double cq = a.cq ? a.cq[n] : a.sq;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+        if (m >= a.M) continue;
+        const double s = cs * fast_tanh(acc[0][i][j][r] + bs);
+        const double t = a.st * (acc[1][i][j][r] + bt);
+        const double q = cq * fast_tanh(acc[2][i][j][r] + bq);
+        const double lj = FWD ? heps * s : -heps * s;
+        ld[i][r] += lj;
+        const double es = exp(lj), eq = exp(eps * q);
+        const long o = m * (long)a.N + n;
+        if (CPLX) {
+          const double2 vv = reinterpret_cast<const double2*>(a.v)[o];
+          const double2 ff = reinterpret_cast<const double2*>(a.F)[o];
+          const double fr = ff.x * eq + t, fi = ff.y * eq;
+          double2 out;
+          if (FWD) { out.x = es * vv.x - heps * fr; out.y = es * vv.y - heps * fi; }
+          else { out.x = es * (vv.x + heps * fr); out.y = es * (vv.y + heps * fi); }
+          reinterpret_cast<double2*>(a.v)[o] = out;
+        } else {
+          const double f = a.F[o] * eq + t;
+          a.v[o] = FWD ? (es * a.v[o] - heps * f) : (es * (a.v[o] + heps * f));
+        }
+      }
+  }
+  // row partial of logdet over this wave's columns: butterfly over the 16 column lanes
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double x = ld[i][r];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+      if ((lane & 15) == 0 && m < a.M) {
+        const long col = (n0 / BN) * 2 + (wave & 1);
+        a.logdet_part[m * a.ncols_part + col] = x;
+      }
+    }
 }
 
 static int pick_splits(int M, int N, long Kt) {
-  const long tiles = cdiv(M, BM) * cdiv(N, BN);
+  const long tiles = cdiv(M, 128) * cdiv(N, 128);
   if (tiles >= 256 || Kt <= 8 * BK) return 1;
   long s = cdiv(512, tiles);
   const long maxs = Kt / (4 * BK) > 0 ? Kt / (4 * BK) : 1;
   if (s > maxs) s = maxs;
   if (s > 128) s = 128;
   return (int)(s < 1 ? 1 : s);
+}
+
+template <typename T>
+static bool vec_ok(const T* A, const T* W, const T* A2, const T* W2, long K, long K2) {
+  constexpr long V = Mfma<T>::VEC;
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return K % V == 0 && K2 % V == 0 && al(A) && al(W) && al(A2) && al(W2);
 }
 
 template <typename T>
@@ -182,18 +409,24 @@ static int gemm_launch(const T* A, const T* W, int M, int N, long K, const T* A2
   long kchunk = cdiv(cdiv(Kt, splits), BK) * BK;
   splits = (int)cdiv(Kt, kchunk);
   Epilogue<T> epi{bias, bias2, coeff, scale, act};
-  const dim3 grid((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM), (unsigned)splits);
-  if (splits == 1) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(kBlock), 0, st, A, W, A2, W2, M, N, K,
-                       K2, kchunk, epi, C, (T*)nullptr);
-  } else {
+  const dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)splits);
+  const bool vec = vec_ok<T>(A, W, A2, W2, K, K2);
+  T* part = nullptr;
+  if (splits > 1) {
     const size_t need = (size_t)splits * M * N * sizeof(T);
     if (!ws || ws_bytes < need) {
       set_error("l2q_gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
       return L2Q_ESHAPE;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(kBlock), 0, st, A, W, A2, W2, M, N,
-                       K, K2, kchunk, epi, (T*)nullptr, (T*)ws);
+    part = (T*)ws;
+  }
+#define L2Q_GEMM(F, V)                                                                       \
+  hipLaunchKernelGGL((gemm_nt_kernel<T, F, V>), grid, dim3(kBlock), 0, st, A, W, A2, W2, M, N, \
+                     K, K2, kchunk, epi, C, part)
+  if (splits == 1) { if (vec) L2Q_GEMM(true, true); else L2Q_GEMM(true, false); }
+  else { if (vec) L2Q_GEMM(false, true); else L2Q_GEMM(false, false); }
+#undef L2Q_GEMM
+  if (splits > 1) {
     const long MN = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)cdiv(MN, kBlock)), dim3(kBlock), 0,
                        st, (const T*)ws, splits, MN, N, epi, C);
@@ -235,6 +468,49 @@ int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const flo
   L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
   return gemm_launch<float>(A, W, M, N, K, A2, W2, K2, bias, bias2, coeff, scale, act, C, ws,
                             ws_bytes, (hipStream_t)stream);
+}
+
+size_t l2q_vnet_heads_ws_bytes(int M, long N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)M * (size_t)(cdiv(N, kHeadsBN) * 2) * sizeof(double) + 256;
+}
+
+int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const double* Ws,
+                               const double* bs, const double* cs, double scale_s,
+                               const double* Wt, const double* bt, double scale_t,
+                               const double* Wq, const double* bq, const double* cq,
+                               double scale_q, void* v, const void* force, int is_complex,
+                               double eps, int forward, double* logdet, void* ws, size_t ws_bytes,
+                               void* stream) {
+  L2Q_REQUIRE(Z && Ws && bs && Wt && bt && Wq && bq && v && force && logdet && ws, L2Q_EINVAL,
+              "null pointer");
+  L2Q_REQUIRE(M > 0 && K > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(K % 2 == 0, L2Q_ESHAPE, "K (last hidden width) must be even");
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  L2Q_REQUIRE(al(Z) && al(Ws) && al(Wt) && al(Wq) && al(v) && al(force), L2Q_ESHAPE,
+              "operands must be 16-byte aligned");
+  const long ntile = cdiv(N, kHeadsBN), mtile = cdiv(M, 64);
+  const int ncols = (int)(ntile * 2);
+  L2Q_REQUIRE(ws_bytes >= (size_t)M * ncols * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  HeadsArgs a;
+  a.Z = Z; a.W[0] = Ws; a.W[1] = Wt; a.W[2] = Wq; a.b[0] = bs; a.b[1] = bt; a.b[2] = bq;
+  a.cs = cs; a.cq = cq; a.ss = scale_s; a.st = scale_t; a.sq = scale_q; a.eps = eps;
+  a.v = (double*)v; a.F = (const double*)force; a.logdet_part = (double*)ws;
+  a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncols;
+  const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
+  const int swz = tuning().xcd_swizzle;
+  // partial columns of wave tiles that fall entirely beyond N are never written: clear first
+  (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * sizeof(double), st);
+  if (is_complex) {
+    if (forward) hipLaunchKernelGGL((fused_heads_vupdate_kernel<true, true>), grid, block, 0, st, a, swz);
+    else hipLaunchKernelGGL((fused_heads_vupdate_kernel<true, false>), grid, block, 0, st, a, swz);
+  } else {
+    if (forward) hipLaunchKernelGGL((fused_heads_vupdate_kernel<false, true>), grid, block, 0, st, a, swz);
+    else hipLaunchKernelGGL((fused_heads_vupdate_kernel<false, false>), grid, block, 0, st, a, swz);
+  }
+  launch_finalize((const double*)ws, logdet, M, ncols, 1, 1.0, 0.0, st);
+  return check_launch("l2q_vnet_heads_vupdate_f64");
 }
 
 }  // extern "C"

@@ -246,6 +246,25 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
+                        force: torch.Tensor, eps: float, forward: bool) -> torch.Tensor:
+    """Fused (s, t, q) heads + generalised momentum update, v in place; returns logdet [nb].
+    heads: {'s': (W, b, colscale|None), 't': (W, b, None), 'q': (W, b, colscale|None)};
+    scales = (nw.s, nw.t, nw.q) used where no per-column scale is given."""
+    m, k = z.shape
+    ws_, bs, cs = heads['s']
+    wt, bt, _ = heads['t']
+    wq, bq, cq = heads['q']
+    n = ws_.shape[0]
+    logdet = torch.empty(m, dtype=torch.float64, device=z.device)
+    nbytes = int(N.load().l2q_vnet_heads_ws_bytes(m, n))
+    ws = N.workspace(nbytes, z.device)
+    N.call('l2q_vnet_heads_vupdate_f64', z, m, k, n, ws_, bs, cs, float(scales[0]), wt, bt,
+           float(scales[1]), wq, bq, cq, float(scales[2]), v, force, int(v.is_complex()),
+           float(eps), int(forward), logdet, ws, ws.numel())
+    return logdet
+
+
 # ---------------------------------------------------------------------------- U(1)
 def u1_plaq_sums(x: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
     """[nb, 3]: sum cos(theta), sum sin(theta), sum project_angle(theta)."""

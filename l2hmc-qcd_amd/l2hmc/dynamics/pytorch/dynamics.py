@@ -133,6 +133,7 @@ class Dynamics(nn.Module):
         # l2hmc.DEVICE (utils.py:173-189, dynamics.py:1083-1085); parity against its CPU path
         # uses rng_device = 'cpu' (same generator stream) or injected draws.
         self.rng_device = DEVICE
+        self.fuse_heads = True      # SU3: fused heads + v-update kernel (same results)
         self._inject: Optional[dict] = None
         self._eps_cache: dict = {}
         self._masks_native: Optional[list] = None
@@ -404,9 +405,20 @@ class Dynamics(nn.Module):
     # ---- sub-updates on native state (in place on xn / vn)
     def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool) -> Tensor:
         fn = self._force_n(xn, beta)
-        s, t, q = self._vnet_n(step, xn, fn)
         eps = self._eps('v', step)
         nb = xn.shape[0]
+        vnet = self._get_vnet(step)
+        if (self.fuse_heads and self._networks_built and self.group == 'SU3'
+                and vnet.units[-1] % 2 == 0):
+            # heads + momentum update in one kernel: s, t, q never reach HBM
+            p = self._perms()
+            w = vnet.kernel_weights(p['in'], p['out'])
+            xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
+            fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
+            z = vnet.hidden_flat(xv, fv, w)
+            return ops.vnet_heads_vupdate_(z, w['heads_scaled'], (vnet.nw.s, vnet.nw.t, vnet.nw.q),
+                                           vn.reshape(nb, -1), fn.reshape(nb, -1), eps, forward)
+        s, t, q = self._vnet_n(step, xn, fn)
         return ops.v_update_(vn.reshape(nb, -1), fn.reshape(nb, -1), s, t, q, eps, forward)
 
     def _update_x_n(self, step: int, xn: Tensor, vn: Tensor, mask: Tensor, complement: bool,

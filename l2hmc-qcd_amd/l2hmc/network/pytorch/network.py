@@ -284,6 +284,12 @@ class LeapfrogLayer(nn.Module):
                 heads[nm] = (w.contiguous(), b.contiguous(),
                              None if co is None else co.contiguous())
             out['heads'] = heads
+            # per-entry multipliers nw * exp(coeff) for the fused heads + v-update kernel
+            out['heads_scaled'] = {
+                's': (heads['s'][0], heads['s'][1], (self.nw.s * heads['s'][2].exp()).contiguous()),
+                't': (heads['t'][0], heads['t'][1], None),
+                'q': (heads['q'][0], heads['q'][1], (self.nw.q * heads['q'][2].exp()).contiguous()),
+            }
         self._head_cache[key] = out
         return out
 
@@ -309,6 +315,14 @@ class LeapfrogLayer(nn.Module):
         t = ops.gemm(z, wt, bt, scale=self.nw.t)
         q = ops.gemm(z, wq, bq, coeff=cq, scale=self.nw.q, act='tanh')
         return s, t, q
+
+    def hidden_flat(self, x: Tensor, v: Tensor, w: dict) -> Tensor:
+        """z = last hidden activation [nb, units[-1]] (input layer + hidden layers)."""
+        self._check_mode()
+        z = ops.gemm(x, w['wx'], w['bx'], a2=v, w2=w['wv'], bias2=w['bv'], act=self.act)
+        for hw, hb in w['hidden']:
+            z = ops.gemm(z, hw, hb, act=self.act)
+        return z
 
     def forward(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, Tensor, Tensor]:
         x, v = inputs

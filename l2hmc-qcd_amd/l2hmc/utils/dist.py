@@ -1,0 +1,120 @@
+"""Single-node data parallelism for the L2HMC sampler/trainer: independent Markov chains are
+sharded across ranks (one process per GPU); the only exchange is one all-reduce(mean) of the
+flattened parameter gradient per training step.
+
+Counterpart of the reference's ``src/l2hmc/utils/dist.py`` (mpi4py bootstrap + NCCL/Gloo,
+:115-346) and of ``DDP(dynamics)`` in ``trainers/pytorch/trainer.py:246-257``, without mpi4py /
+horovod / deepspeed: rank and world size come from the torchrun-style environment
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); backend ``nccl`` is RCCL over
+xGMI on MI355X, ``gloo`` on CPU (tests).
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def query_environment() -> dict[str, int]:
+    """(dist.py:157-162 of the reference, minus MPI)"""
+    return {'rank': int(os.environ.get('RANK', 0)),
+            'local_rank': int(os.environ.get('LOCAL_RANK', 0)),
+            'world_size': int(os.environ.get('WORLD_SIZE', 1))}
+
+
+def seed_everything(seed: int) -> None:
+    """random / numpy / torch, like common.py:115-121 of the reference"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def setup_torch_distributed(backend: Optional[str] = None, port: str = '2345') -> dict[str, int]:
+    env = query_environment()
+    if env['world_size'] > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(port))
+        if backend is None or backend.upper() in ('DDP', 'NCCL', 'RCCL'):
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if torch.cuda.is_available():
+            torch.cuda.set_device(env['local_rank'])
+        dist.init_process_group(backend=backend.lower(), rank=env['rank'],
+                                world_size=env['world_size'])
+    return env
+
+
+def setup_torch(seed: int, backend: Optional[str] = None, port: str = '2345') -> int:
+    """Initialise the process group and the RNGs.  Weights and masks must be identical on
+    every rank, so the *model* seed is the base seed; per-rank streams (chains, momenta)
+    use ``chain_seed`` (the reference seeds everything with seed*(rank+1)*(local_rank+1),
+    dist.py:340, which makes the numpy masks differ per rank -- SURVEY.md 8(e))."""
+    env = setup_torch_distributed(backend, port)
+    seed_everything(seed)
+    return env['rank']
+
+
+def chain_seed(seed: int, rank: Optional[int] = None) -> int:
+    rank = query_environment()['rank'] if rank is None else rank
+    return int(seed) * (rank + 1)
+
+
+def shard_chains(nchains_global: int, rank: Optional[int] = None,
+                 world_size: Optional[int] = None) -> tuple[int, int]:
+    """[start, stop) of this rank's contiguous block of the global chain index; chains never
+    straddle ranks and every rank gets the same count (global batch must divide evenly, as with
+    the reference's per-rank ``nchains``)."""
+    env = query_environment()
+    rank = env['rank'] if rank is None else rank
+    world_size = env['world_size'] if world_size is None else world_size
+    if nchains_global % world_size:
+        raise ValueError(f'{nchains_global} chains do not divide over {world_size} ranks')
+    per = nchains_global // world_size
+    return rank * per, (rank + 1) * per
+
+
+def flatten_grads(params: Iterable[torch.nn.Parameter]) -> tuple[torch.Tensor, list]:
+    """One flat buffer of all existing gradients (params without grad -- e.g. the never-called
+    SU(3) xnet -- are skipped, the ``find_unused_parameters`` case of trainer.py:249-251)."""
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return torch.zeros(0), ps
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    return flat, ps
+
+
+def allreduce_grads(params: Iterable[torch.nn.Parameter]) -> int:
+    """grad <- mean over ranks, as ONE collective on one flat buffer (vs DDP's 25 MB buckets):
+    xGMI is a point-to-point mesh, so a single large reduce-scatter + all-gather keeps all 7
+    links busy.  Returns the number of elements reduced."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    flat, ps = flatten_grads(params)
+    if flat.numel() == 0:
+        return 0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].reshape(p.grad.shape))
+        off += n
+    return int(flat.numel())
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """rank-0 parameters / buffers to every rank (DDP constructor semantics)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+def cleanup() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

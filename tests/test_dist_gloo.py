@@ -1,0 +1,75 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: chain sharding, per-rank seeds, the single
+flat gradient all-reduce and parameter broadcast."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from l2hmc.utils import dist as D
+    assert D.setup_torch(seed=1234, backend='gloo') == rank
+    lo, hi = D.shard_chains(16)
+    # identical model on every rank (base seed), different chains
+    model = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
+    unused = torch.nn.Linear(3, 3)                  # never gets a gradient (SU3 xnet case)
+    w0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    g = torch.Generator().manual_seed(99)           # the same global data on both ranks
+    data = torch.randn(16, 6, generator=g)
+    loss = model(data[lo:hi]).pow(2).mean()
+    loss.backward()
+    n = D.allreduce_grads(list(model.parameters()) + list(unused.parameters()))
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(float(rank + 1))                 # make the replicas diverge
+    D.broadcast_parameters(model, src=0)
+    w1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    torch.save({'lo': lo, 'hi': hi, 'w0': w0, 'grads': grads, 'n': n, 'w1': w1,
+                'chain_seed': D.chain_seed(1234)}, os.path.join(out, f'r{rank}.pt'))
+    D.cleanup()
+
+
+def test_two_rank_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
+    assert (r[0]['lo'], r[0]['hi'], r[1]['lo'], r[1]['hi']) == (0, 8, 8, 16)
+    assert torch.equal(r[0]['w0'], r[1]['w0'])                     # same weights everywhere
+    assert r[0]['chain_seed'] != r[1]['chain_seed']
+    assert torch.equal(r[0]['grads'], r[1]['grads'])               # averaged gradient
+    # equals the single-process gradient of the global-batch mean loss
+    torch.manual_seed(1234)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
+    g = torch.Generator().manual_seed(99)
+    data = torch.randn(16, 6, generator=g)
+    model(data).pow(2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.allclose(r[0]['grads'], ref, atol=1e-7)
+    assert r[0]['n'] == ref.numel()                                # unused params skipped
+    assert torch.equal(r[0]['w1'], r[1]['w1'])                     # broadcast from rank 0
+    assert torch.allclose(r[0]['w1'], r[0]['w0'] + 1.0)
+
+
+def test_shard_chains_errors():
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    from l2hmc.utils import dist as D
+    assert D.shard_chains(2048, rank=3, world_size=8) == (768, 1024)
+    with pytest.raises(ValueError):
+        D.shard_chains(10, rank=0, world_size=4)

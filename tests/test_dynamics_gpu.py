@@ -136,6 +136,10 @@ def test_su3_l2hmc_trajectory(golden):
     xo2, m2 = dyn((dev(g['x']), torch.tensor(float(g['beta']))))
     assert err(host(xo2), host(xo)) == 0.0 and err(host(m2['acc']), host(m['acc'])) == 0.0
     assert m2['acc'].dtype == torch.float64 and m2['acc_mask'].dtype == torch.float32
+    # un-fused heads / v-update path gives the same trajectory
+    dyn.fuse_heads = False
+    xo3, m3 = dyn((dev(g['x']), torch.tensor(float(g['beta']))))
+    assert err(host(xo3), host(xo)) < 1e-12 and err(host(m3['acc']), host(m['acc'])) < 1e-9
 
 
 @pytest.mark.parametrize('name', ['u1_conv', 'u1_c1'])

@@ -241,3 +241,40 @@ def test_accept_select(ops):
     a = dev(np.arange(4 * 6, dtype=np.float64).reshape(4, 6)); b = -a
     out = host(ops.select_rows(a, b, mask))
     assert np.array_equal(out, np.where(host(mask)[:, None] > 0, host(a), host(b)))
+
+
+@pytest.mark.parametrize('cplx', [True, False])
+@pytest.mark.parametrize('shape', [(3, 4, 3888), (70, 16, 200), (130, 256, 1000)])
+def test_fused_heads_vupdate(ops, cplx, shape):
+    """the fused (s,t,q)-heads + momentum-update kernel == three GEMMs + l2q_v_update"""
+    m, k, n = shape
+    rng = np.random.default_rng(11)
+    z = dev(rng.normal(size=(m, k)))
+    heads, scaled = {}, {}
+    for nm in 'stq':
+        w = dev(rng.normal(size=(n, k)) / np.sqrt(k)); b = dev(0.1 * rng.normal(size=n))
+        co = None if nm == 't' else dev(0.3 * rng.normal(size=n))
+        heads[nm] = (w, b, co)
+    nw = (0.9, 1.1, 0.8)
+    scaled = {'s': (heads['s'][0], heads['s'][1], nw[0] * heads['s'][2].exp()),
+              't': (heads['t'][0], heads['t'][1], None),
+              'q': (heads['q'][0], heads['q'][1], nw[2] * heads['q'][2].exp())}
+    if cplx:
+        v = dev(rng.normal(size=(m, n)) + 1j * rng.normal(size=(m, n)))
+        f = dev(rng.normal(size=(m, n)) + 1j * rng.normal(size=(m, n)))
+    else:
+        v = dev(rng.normal(size=(m, n))); f = dev(rng.normal(size=(m, n)))
+    for fwd in (True, False):
+        s = ops.gemm(z, heads['s'][0], heads['s'][1], coeff=heads['s'][2], scale=nw[0], act='tanh')
+        t = ops.gemm(z, heads['t'][0], heads['t'][1], scale=nw[1])
+        q = ops.gemm(z, heads['q'][0], heads['q'][1], coeff=heads['q'][2], scale=nw[2], act='tanh')
+        v1 = v.clone(); ld1 = ops.v_update_(v1, f, s, t, q, 0.07, fwd)
+        v2 = v.clone(); ld2 = ops.vnet_heads_vupdate_(z, scaled, nw, v2, f, 0.07, fwd)
+        assert float((v1 - v2).abs().max()) < 1e-12
+        assert err(host(ld1), host(ld2)) < 1e-11
+        # and against numpy
+        sn, tn, qn = host(s), host(t), host(q)
+        lj = (0.035 if fwd else -0.035) * sn
+        fn = host(f) * np.exp(0.07 * qn) + tn
+        want = np.exp(lj) * host(v) - 0.035 * fn if fwd else np.exp(lj) * (host(v) + 0.035 * fn)
+        assert err(host(v2), want) < 1e-12 and err(host(ld2), lj.sum(1)) < 1e-11

@@ -106,6 +106,10 @@ def main():
         print(f'{"gemm head [nb,h]x[36V,h]":34s} {t*1e3:8.3f} ms  {fl/t/1e12:7.2f} TFLOP/s fp64', flush=True)
         t = timeit(lambda: torch.addmm(bs, z, ws_.t()), iters=5, warm=2)
         print(f'{"  (rocBLAS addmm)":34s} {t*1e3:8.3f} ms  {fl/t/1e12:7.2f} TFLOP/s fp64', flush=True)
+        heads = {'s': (ws_, bs, co.exp()), 't': (ws_.clone(), bs, None), 'q': (ws_.clone(), bs, co.exp())}
+        vv = vn.reshape(nb, -1).clone(); ff = f.reshape(nb, -1)
+        t = timeit(lambda: ops.vnet_heads_vupdate_(z, heads, (1., 1., 1.), vv, ff, 0.01, True), iters=5, warm=2)
+        print(f'{"fused 3 heads + v_update":34s} {t*1e3:8.3f} ms  {3*fl/t/1e12:7.2f} TFLOP/s fp64', flush=True)
 
 
 if __name__ == '__main__':

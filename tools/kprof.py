@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Run each hot kernel a few times at the cfg-4 size -- the target of rocprofv3 --pmc passes."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+from l2hmc import _ops as ops, native  # noqa: E402
+
+nb, L = 256, (8, 8, 8, 8)
+V = 4096
+torch.manual_seed(0)
+xn = ops.su3_project_su_n(torch.randn(nb, 4, 9, V, dtype=torch.complex128, device='cuda'))
+vn = ops.su3_assemble_tah_n(torch.randn(8, nb, 4, V, dtype=torch.float64, device='cuda'))
+f = torch.empty_like(xn)
+h = 256
+z = torch.randn(nb, h, dtype=torch.float64, device='cuda')
+N_ = 36 * V
+heads = {k: (torch.randn(N_, h, dtype=torch.float64, device='cuda') / 16,
+             torch.randn(N_, dtype=torch.float64, device='cuda'),
+             None if k == 't' else torch.ones(N_, dtype=torch.float64, device='cuda')) for k in 'stq'}
+K = 32 * V
+xv = torch.randn(nb, K, dtype=torch.float64, device='cuda')
+fv = torch.randn(nb, K, dtype=torch.float64, device='cuda')
+wx = torch.randn(h, K, dtype=torch.float64, device='cuda') / K ** 0.5
+wv = torch.randn(h, K, dtype=torch.float64, device='cuda') / K ** 0.5
+bx = torch.randn(h, dtype=torch.float64, device='cuda')
+for _ in range(3):
+    ops.su3_plaq_sums_n(xn, L)
+    native.call('l2q_su3_force', xn, 6.0, f, nb, *L)
+    ops.su3_expm_mul_n(xn, vn, 0.01)
+    ops.su3_projsu_vec8_n(xn)
+    ops.gemm(xv, wx, bx, a2=fv, w2=wv, bias2=bx, act='tanh')
+    ops.vnet_heads_vupdate_(z, heads, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True)
+torch.cuda.synchronize()
+print('kprof done')
