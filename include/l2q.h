@@ -92,6 +92,12 @@ int l2q_su3_force_kick(const void* xn, double beta, double coef, void* vn, int n
  * `out` may alias xn. */
 int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* mask_n,
                      int complement, void* out, int nb, long V, void* stream);
+/* Both half-updates of one leapfrog step in one pass (dynamics.py:1199-1203 forward:
+ * keep = m then keep = 1-m; :1221-1225 backward: keep = 1-m then keep = m, i.e.
+ * complement_first = 1), sharing one expm(eps v).  Equal to two l2q_su3_expm_mul calls up to
+ * FMA contraction (1e-16).  `out` may alias xn. */
+int l2q_su3_expm_mul2(const void* xn, const void* vn, double eps, const float* mask_n,
+                      int complement_first, void* out, int nb, long V, void* stream);
 /* projectSU on every link (group/su3/pytorch/utils.py:341-346); out may alias in. */
 int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* stream);
 /* su3_to_vec(projectSU(.)) -> vec[nfields][8][V] double (group.py:138-147); the vnet

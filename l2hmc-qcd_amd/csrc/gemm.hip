@@ -16,7 +16,13 @@
 
 namespace l2q {
 
-constexpr int BK = 16, LDP = BK + 2;   // +2: conflict-free ds_read_b64 / ds_read_b32 fragments
+#ifndef L2Q_BK
+#define L2Q_BK 16
+#endif
+#ifndef L2Q_HEADS_OCC
+#define L2Q_HEADS_OCC 2
+#endif
+constexpr int BK = L2Q_BK, LDP = BK + 2;   // +2: conflict-free ds_read_b64 / ds_read_b32 fragments
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef float v4f32 __attribute__((ext_vector_type(4)));
@@ -266,7 +272,7 @@ struct HeadsArgs {
 };
 
 template <bool CPLX, bool FWD>
-__global__ __launch_bounds__(kBlock, 2) void fused_heads_vupdate_kernel(HeadsArgs a, int swz) {
+__global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_kernel(HeadsArgs a, int swz) {
   constexpr int BM = 64, BN = kHeadsBN, NJ = BN / 32;
   using T = double;
   using acc_t = v4f64;

@@ -14,6 +14,8 @@ struct Tuning {
   int plaq_occ = 2;
   int force_occ = 2;
   int xcd_swizzle = 1;
+  int plaq_sweep = 0;     // 1: t-sweep plaquette kernel (measured slower: L2 cannot hold the slices)
+  int force_tile = 1;     // LDS-tiled force kernel (0: flat thread-per-link grid)
 };
 Tuning& tuning();
 

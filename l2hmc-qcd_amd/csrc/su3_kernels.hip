@@ -165,8 +165,156 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_kernel(const double2* _
   }
 }
 
+// ------------------------------------------------------------------ plaquette, t-sweep
+// One workgroup = 256 spatial sites of one chain, sweeping a range of t.  The +t neighbours
+// loaded in iteration t (U_x, U_y, U_z at t+1) are the same lines the block asks for as its
+// own links one iteration later, i.e. within ~1 us on the same XCD -> L2 hits instead of a
+// second trip through the fabric (the flat kernel re-fetched them: 2.7x algorithmic bytes).
+template <int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void su3_plaq_sweep_kernel(
+    const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz,
+    double* __restrict__ partial) {
+  __shared__ double lds[8];
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const int per_chain = nsb * tsplit;
+  const long c = w / per_chain;
+  const int r = (int)(w % per_chain);
+  const int tc = r / nsb, sb = r % nsb;
+  const int Vs = d.X * d.Y * d.Z;
+  const int sp = sb * kBlock + threadIdx.x;             // spatial site
+  const int tlen = (d.T + tsplit - 1) / tsplit;
+  const int t0 = tc * tlen, t1 = min(d.T, t0 + tlen);
+  double sr = 0.0, si = 0.0;
+  if (sp < Vs) {
+    const double2* xc = xn + c * 36L * d.V;
+    const int V = d.V;
+    Site p = site_coords(sp, d);                         // p.t == 0 here (sp < Vs)
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+      p.t = t;
+      const int s = t * Vs + sp;
+#pragma unroll 1
+      for (int u = 1; u < 4; ++u) {
+        const int s_pu = fwd(s, coord_of(p, u), d, u);
+        M3 au;
+        load_link(au, xc + u * 9 * V, V, s);
+#pragma unroll 1
+        for (int v = 0; v < u; ++v) {
+          const int s_pv = fwd(s, coord_of(p, v), d, v);
+          M3 a, b, yuv;
+          load_link(b, xc + v * 9 * V, V, s_pu);
+          m3_mul_nn(yuv, au, b);
+          load_link(a, xc + v * 9 * V, V, s);
+          load_link(b, xc + u * 9 * V, V, s_pv);
+          m3_trace_y_abh(sr, si, yuv, a, b);
+        }
+      }
+    }
+  }
+  const double br = block_sum(sr, lds);
+  const double bi = block_sum(si, lds + 4);
+  if (threadIdx.x == 0) {
+    partial[(c * per_chain + r) * 2 + 0] = br;
+    partial[(c * per_chain + r) * 2 + 1] = bi;
+  }
+}
+
+// ------------------------------------------------------------------ staple force, LDS tile
+// One workgroup = 64 consecutive sites x 4 directions (wavefront w <-> mu = w).  The 4 own
+// links of the 64 sites are staged once in LDS ([4][9][64] complex = 36 KiB); every operand
+// whose site falls inside the tile (the site itself and, for 8^4 / 16^4 lattices, all +-y,
+// +-z neighbours of a (y,z) plane) is then an LDS read instead of a 9 KiB trip to L2.
+// For 8^4 that turns 42 of the 76 matrix loads per site into LDS reads (the flat kernel is
+// L2-bandwidth-bound: 12 GB of L2->L1 traffic per launch at cfg-4).
+struct TileRef {
+  const double2* lds;    // [4][9][64]
+  int s0;                // first site of the tile
+};
+
+// One code path for both sources: a generic (flat) pointer that is either the lane's slot in
+// the LDS tile (stride 64) or the global plane (stride V), chosen wave-uniformly.
+__device__ __forceinline__ void load_link_tiled(M3& m, const double2* __restrict__ xc,
+                                                const TileRef& tr, int rho, int V, int s) {
+  const int li = s - tr.s0;
+  const bool in = __all((unsigned)li < 64u);
+  const double2* base = in ? (tr.lds + rho * 9 * 64 + li) : (xc + rho * 9 * V + s);
+  const int stride = in ? 64 : V;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double2 dd = base[e * stride];
+    m.re[e] = dd.x; m.im[e] = dd.y;
+  }
+}
+
+template <bool KICK, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void su3_force_tile_kernel(
+    const double2* __restrict__ xn, Dims d, long ntile, int swz, double coef,
+    double2* __restrict__ out) {
+  __shared__ double2 tile[4 * 9 * 64];
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const long c = w / ntile, tb = w % ntile;
+  const int mu = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int V = d.V;
+  const int s0 = (int)tb * 64;
+  const bool live = s0 + lane < V;
+  const int s = live ? s0 + lane : V - 1;             // clamp: dead lanes still take part
+  const double2* xc = xn + c * 36L * V;
+  {
+    const double2* g = xc + mu * 9 * V;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tile[(mu * 9 + e) * 64 + lane] = g[e * V + s];
+  }
+  __syncthreads();
+  TileRef tr{tile, live ? s0 : -1000000};
+  if (!__all(live)) tr.s0 = -1000000;                 // ragged last tile: global path only
+  const Site p = site_coords(s, d);
+  const int cmu = coord_of(p, mu);
+  const int s_pmu = fwd(s, cmu, d, mu);
+  M3 acc;
+  m3_zero(acc);
+#pragma unroll 1
+  for (int nu = 0; nu < 4; ++nu) {
+    if (nu == mu) continue;
+    const int cnu = coord_of(p, nu);
+    const int s_pnu = fwd(s, cnu, d, nu);
+    const int s_mnu = bwd(s, cnu, d, nu);
+    const int s_pmu_mnu = bwd(s_pmu, cnu, d, nu);
+    M3 a, b, t;
+    // up:   U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H
+    load_link_tiled(a, xc, tr, nu, V, s_pmu);
+    load_link_tiled(b, xc, tr, mu, V, s_pnu);
+    m3_mul_na(t, a, b);
+    load_link_tiled(a, xc, tr, nu, V, s);
+    m3_mac_na(acc, t, a);
+    // down: U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu)
+    load_link_tiled(a, xc, tr, nu, V, s_pmu_mnu);
+    load_link_tiled(b, xc, tr, mu, V, s_mnu);
+    m3_mul_aa(t, a, b);
+    load_link_tiled(a, xc, tr, nu, V, s_mnu);
+    m3_mac_nn(acc, t, a);
+  }
+  M3 u, ua, f;
+  load_link_tiled(u, xc, tr, mu, V, s);
+  m3_mul_nn(ua, u, acc);
+  m3_tah(f, ua);
+  if (!live) return;
+  double2* o = out + (c * 4 + mu) * 9L * V;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    double2 r = make_double2(coef * f.re[e], coef * f.im[e]);
+    if (KICK) {
+      const double2 v = o[e * V + s];
+      r.x += v.x; r.y += v.y;
+    }
+    o[e * V + s] = r;
+  }
+}
+
 // ------------------------------------------------------------------ per-link kernels
-// out = keep (.) x + expm(eps v) @ ((1-keep) (.) x)
+// out = keep (.) x + expm(eps v) @ ((1-keep) (.) x).  TWO: the two half-updates of one
+// leapfrog step (keep = mask then keep = 1 - mask, or the reverse order when `complement`)
+// applied back to back with ONE expm(eps v) and one pass over x -- both are local to a link.
+template <bool TWO>
 __global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
                                                               const double2* __restrict__ vn,
                                                               double eps,
@@ -183,18 +331,28 @@ __global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
 #pragma unroll
   for (int i = 0; i < 9; ++i) { a.re[i] *= eps; a.im[i] *= eps; }
   m3_expm(e, a);
-  M3 kept, moved, r;
+  M3 r;
   if (mask != nullptr) {
     const float* mk = mask + mu * 9 * V;
+    double keep[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      double k = (double)mk[i * V + s];
-      if (complement) k = 1.0 - k;
-      kept.re[i] = k * x.re[i]; kept.im[i] = k * x.im[i];
-      moved.re[i] = (1.0 - k) * x.re[i]; moved.im[i] = (1.0 - k) * x.im[i];
+      const double k = (double)mk[i * V + s];
+      keep[i] = complement ? 1.0 - k : k;
     }
-    m3_mul_nn(r, e, moved);
-    m3_add(r, kept);
+#pragma unroll 1
+    for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
+      M3 kept, moved;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double k = pass == 0 ? keep[i] : 1.0 - keep[i];
+        kept.re[i] = k * x.re[i]; kept.im[i] = k * x.im[i];
+        moved.re[i] = (1.0 - k) * x.re[i]; moved.im[i] = (1.0 - k) * x.im[i];
+      }
+      m3_mul_nn(r, e, moved);
+      m3_add(r, kept);
+      x = r;
+    }
   } else {
     m3_mul_nn(r, e, x);
   }
@@ -345,6 +503,17 @@ using namespace l2q;
 template <bool KICK>
 static void launch_force(const double2* xn, Dims d, int nb, long nblk, double coef, double2* out,
                          hipStream_t st) {
+  if (tuning().force_tile) {
+    const long ntile = cdiv(d.V, 64);
+    const dim3 grid((unsigned)(nb * ntile)), block(kBlock);
+    const int swz = tuning().xcd_swizzle;
+    switch (tuning().force_occ) {
+      case 4: hipLaunchKernelGGL((su3_force_tile_kernel<KICK, 4>), grid, block, 0, st, xn, d, ntile, swz, coef, out); break;
+      case 3: hipLaunchKernelGGL((su3_force_tile_kernel<KICK, 3>), grid, block, 0, st, xn, d, ntile, swz, coef, out); break;
+      default: hipLaunchKernelGGL((su3_force_tile_kernel<KICK, 2>), grid, block, 0, st, xn, d, ntile, swz, coef, out); break;
+    }
+    return;
+  }
   const dim3 grid((unsigned)(nb * nblk * 4)), block(kBlock);
   const int swz = tuning().xcd_swizzle;
   switch (tuning().force_occ) {
@@ -371,12 +540,32 @@ int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, doub
   L2Q_REQUIRE(xn && out && ws, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
   Dims d{T, X, Y, Z, T * X * Y * Z};
-  const long nblk = cdiv(d.V, kBlock);
-  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * 2 * sizeof(double), L2Q_ESHAPE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)ws;
-  const dim3 grid((unsigned)(nb * nblk)), block(kBlock);
   const int swz = tuning().xcd_swizzle;
+  if (tuning().plaq_sweep) {
+    const int Vs = X * Y * Z;
+    const int nsb = (int)cdiv(Vs, kBlock);
+    int tsplit = (int)cdiv(1024, (long)nb * nsb);      // keep >= ~1024 workgroups in flight
+    if (tsplit > T) tsplit = T;
+    if (tsplit < 1) tsplit = 1;
+    const int tlen = (int)cdiv(T, tsplit);
+    tsplit = (int)cdiv(T, tlen);
+    const long per_chain = (long)nsb * tsplit;
+    L2Q_REQUIRE(ws_bytes >= (size_t)nb * per_chain * 2 * sizeof(double), L2Q_ESHAPE,
+                "workspace too small");
+    const dim3 grid((unsigned)(nb * per_chain)), block(kBlock);
+    switch (tuning().plaq_occ) {
+      case 4: hipLaunchKernelGGL(su3_plaq_sweep_kernel<4>, grid, block, 0, st, (const double2*)xn, d, nsb, tsplit, swz, partial); break;
+      case 3: hipLaunchKernelGGL(su3_plaq_sweep_kernel<3>, grid, block, 0, st, (const double2*)xn, d, nsb, tsplit, swz, partial); break;
+      default: hipLaunchKernelGGL(su3_plaq_sweep_kernel<2>, grid, block, 0, st, (const double2*)xn, d, nsb, tsplit, swz, partial); break;
+    }
+    launch_finalize(partial, out, nb, per_chain, 2, 1.0, 0.0, st);
+    return check_launch("l2q_su3_plaq_reduce");
+  }
+  const long nblk = cdiv(d.V, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * 2 * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  const dim3 grid((unsigned)(nb * nblk)), block(kBlock);
   switch (tuning().plaq_occ) {
     case 4: hipLaunchKernelGGL(su3_plaq_kernel<4>, grid, block, 0, st, (const double2*)xn, d, nblk, swz, partial); break;
     case 3: hipLaunchKernelGGL(su3_plaq_kernel<3>, grid, block, 0, st, (const double2*)xn, d, nblk, swz, partial); break;
@@ -412,10 +601,21 @@ int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* ma
   L2Q_REQUIRE(xn && vn && out, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
-  hipLaunchKernelGGL(su3_expm_mul_kernel, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock), 0,
-                     (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
+  hipLaunchKernelGGL(su3_expm_mul_kernel<false>, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
+                     0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
                      complement, (double2*)out, (int)V, nblk);
   return check_launch("l2q_su3_expm_mul");
+}
+
+int l2q_su3_expm_mul2(const void* xn, const void* vn, double eps, const float* mask_n,
+                      int complement_first, void* out, int nb, long V, void* stream) {
+  L2Q_REQUIRE(xn && vn && out && mask_n, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_expm_mul_kernel<true>, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
+                     0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
+                     complement_first, (double2*)out, (int)V, nblk);
+  return check_launch("l2q_su3_expm_mul2");
 }
 
 int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* stream) {

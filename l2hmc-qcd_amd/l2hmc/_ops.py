@@ -107,6 +107,15 @@ def su3_expm_mul_n(xn: torch.Tensor, vn: torch.Tensor, eps: float,
     return out
 
 
+def su3_expm_mul2_n(xn: torch.Tensor, vn: torch.Tensor, eps: float, mask_n: torch.Tensor,
+                    complement_first: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Both masked half-updates of one leapfrog step with one expm (== two calls to rounding)."""
+    nb, _, _, V = xn.shape
+    out = torch.empty_like(xn) if out is None else out
+    N.call('l2q_su3_expm_mul2', xn, vn, float(eps), mask_n, int(complement_first), out, nb, V)
+    return out
+
+
 def su3_project_su_n(xn: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(xn)
     nf, V = xn.numel() // (9 * xn.shape[-1]), xn.shape[-1]

@@ -134,6 +134,8 @@ class Dynamics(nn.Module):
         # uses rng_device = 'cpu' (same generator stream) or injected draws.
         self.rng_device = DEVICE
         self.fuse_heads = True      # SU3: fused heads + v-update kernel (same results)
+        self.fuse_x_updates = True  # SU3: both x half-updates of a LF step in one kernel
+        self.reuse_v_inputs = True  # force / vec8 / hidden activation once per distinct x
         self._inject: Optional[dict] = None
         self._eps_cache: dict = {}
         self._masks_native: Optional[list] = None
@@ -403,19 +405,41 @@ class Dynamics(nn.Module):
         return xnet.forward_flat(xm.reshape(nb, -1), vn.reshape(nb, -1))
 
     # ---- sub-updates on native state (in place on xn / vn)
-    def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool) -> Tensor:
-        fn = self._force_n(xn, beta)
+    def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
+                    cache: Optional[dict] = None) -> Tensor:
+        """v-update in place; returns logdet.  `cache` (trajectory-local): the force, the
+        vec8 network inputs and the hidden activation depend only on x (and the network), and
+        x does not change between the closing v-update of one leapfrog step and the opening
+        v-update of the next (nor across the momentum flip), so they are computed once per
+        distinct x -- 9 instead of 16 evaluations in a merged nlf = 4 trajectory.  Same inputs,
+        same deterministic kernels: bitwise identical results."""
         eps = self._eps('v', step)
         nb = xn.shape[0]
         vnet = self._get_vnet(step)
+        hit = cache is not None and cache.get('valid', False)
+        fn = cache['F'] if hit else self._force_n(xn, beta)
+        if cache is not None and not hit:
+            cache.clear()
+            cache.update({'valid': True, 'F': fn})
         if (self.fuse_heads and self._networks_built and self.group == 'SU3'
                 and vnet.units[-1] % 2 == 0):
             # heads + momentum update in one kernel: s, t, q never reach HBM
             p = self._perms()
             w = vnet.kernel_weights(p['in'], p['out'])
-            xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
-            fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
-            z = vnet.hidden_flat(xv, fv, w)
+            zkey = ('z', id(vnet))
+            if cache is not None and zkey in cache:
+                z = cache[zkey]
+            else:
+                if cache is not None and 'xv' in cache:
+                    xv, fv = cache['xv'], cache['fv']
+                else:
+                    xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
+                    fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
+                    if cache is not None:
+                        cache['xv'], cache['fv'] = xv, fv
+                z = vnet.hidden_flat(xv, fv, w)
+                if cache is not None:
+                    cache[zkey] = z
             return ops.vnet_heads_vupdate_(z, w['heads_scaled'], (vnet.nw.s, vnet.nw.t, vnet.nw.q),
                                            vn.reshape(nb, -1), fn.reshape(nb, -1), eps, forward)
         s, t, q = self._vnet_n(step, xn, fn)
@@ -432,7 +456,8 @@ class Dynamics(nn.Module):
         return ops.u1_x_update_(xn.reshape(nb, -1), vn, s, t, q, mask, complement, eps,
                                 forward, self.config.use_ncp)
 
-    def _lf_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool) -> Tensor:
+    def _lf_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
+              cache: Optional[dict] = None) -> Tensor:
         """One generalised leapfrog step in place; returns logdet [nb]
         (dynamics.py:1187-1228)."""
         if forward:
@@ -441,12 +466,19 @@ class Dynamics(nn.Module):
             st = self.config.nleapfrog - step - 1
             order = ((True, False), (False, True))
         m = self._native_masks()[st]
-        ld = self._update_v_n(st, xn, vn, beta, forward)
-        for comp, first in order:
-            l = self._update_x_n(st, xn, vn, m, comp, forward, first)
-            if l is not None:
-                ld = ld + l
-        return ld + self._update_v_n(st, xn, vn, beta, forward)
+        ld = self._update_v_n(st, xn, vn, beta, forward, cache)
+        if self.group == 'SU3' and self.fuse_x_updates:
+            # both half-updates share expm(eps v): one kernel, one pass over x
+            eps = self._eps('x', st)
+            ops.su3_expm_mul2_n(xn, vn, eps if forward else -eps, m, not forward, out=xn)
+        else:
+            for comp, first in order:
+                l = self._update_x_n(st, xn, vn, m, comp, forward, first)
+                if l is not None:
+                    ld = ld + l
+        if cache is not None:
+            cache['valid'] = False                     # x changed
+        return ld + self._update_v_n(st, xn, vn, beta, forward, cache)
 
     # ------------------------------------------------------------------ public sub-updates
     def group_to_vec(self, x: Tensor) -> Tensor:
@@ -645,8 +677,9 @@ class Dynamics(nn.Module):
                  'xeps': self.xeps[0], 'veps': self.veps[0]}
             self.update_history(m, history)
         h = h_init
+        cache = {} if self.reuse_v_inputs else None
         for step in range(self.config.nleapfrog):
-            logdet = self._lf_n(step, x_, v_, beta, True)
+            logdet = self._lf_n(step, x_, v_, beta, True, cache)
             sumlogdet = sumlogdet + logdet
             if verbose:
                 sldf = sldf + logdet
@@ -658,7 +691,7 @@ class Dynamics(nn.Module):
         else:
             v_ = -v_
         for step in range(self.config.nleapfrog):
-            logdet = self._lf_n(step, x_, v_, beta, False)
+            logdet = self._lf_n(step, x_, v_, beta, False, cache)
             sumlogdet = sumlogdet + logdet
             if verbose:
                 sldb = sldb + logdet
@@ -686,8 +719,9 @@ class Dynamics(nn.Module):
         if self.config.verbose:
             self.update_history({'energy': h0, 'logprob': h0 - sumlogdet,
                                  'logdet': sumlogdet}, history)
+        cache = {} if self.reuse_v_inputs else None
         for step in range(self.config.nleapfrog):
-            logdet = self._lf_n(step, x_, v_, beta, forward)
+            logdet = self._lf_n(step, x_, v_, beta, forward, cache)
             sumlogdet = sumlogdet + logdet
             if self.config.verbose:
                 self.update_history(self._metrics_n(x_, v_, beta, sumlogdet, step), history)

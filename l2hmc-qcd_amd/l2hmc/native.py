@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_lib', 'libl2q.so')
+LIB_PATH = os.path.join(_HERE, '_lib', os.environ.get('L2Q_LIB_NAME', 'libl2q.so'))
 
 ACT = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'leaky_relu': 3, 'elu': 4, 'swish': 5}
 
@@ -32,6 +32,7 @@ SIGNATURES = {
     'l2q_su3_force': (I, [P, D, P, I, I, I, I, I, P]),
     'l2q_su3_force_kick': (I, [P, D, D, P, I, I, I, I, I, P]),
     'l2q_su3_expm_mul': (I, [P, P, D, P, I, P, I, L, P]),
+    'l2q_su3_expm_mul2': (I, [P, P, D, P, I, P, I, L, P]),
     'l2q_su3_project_su': (I, [P, P, L, L, P]),
     'l2q_su3_projsu_vec8': (I, [P, P, L, L, P]),
     'l2q_su3_project_tah': (I, [P, P, L, L, P]),

@@ -50,18 +50,22 @@ def main():
         print(f'{name:34s} {t*1e3:8.3f} ms  {gbs:8.1f} GB/s  ({gbs/8000*100:5.1f}% of 8 TB/s)'
               + (f'  {tf:6.2f} TFLOP/s' if flop_per_site else ''), flush=True)
 
-    for occ in (2, 3, 4):
-        native.set_tuning('plaq_occ', occ)
-        rec(f'su3_plaq_reduce occ={occ}', timeit(lambda: ops.su3_plaq_sums_n(xn, L)), 576, 2800)
+    for sweep in (0, 1):
+        native.set_tuning('plaq_sweep', sweep)
+        for occ in (2, 3, 4):
+            native.set_tuning('plaq_occ', occ)
+            rec(f'su3_plaq_reduce sweep={sweep} occ={occ}', timeit(lambda: ops.su3_plaq_sums_n(xn, L)), 576, 2800)
     native.set_tuning('plaq_occ', 2)
     native.set_tuning('xcd_swizzle', 0)
     rec('su3_plaq_reduce occ=2 noswz', timeit(lambda: ops.su3_plaq_sums_n(xn, L)), 576, 2800)
     native.set_tuning('xcd_swizzle', 1)
     f = torch.empty_like(xn)
-    for occ in (2, 3, 4):
-        native.set_tuning('force_occ', occ)
-        rec(f'su3_force occ={occ}', timeit(lambda: native.call(
-            'l2q_su3_force', xn, 6.0, f, nb, *L)), 1152, 11200)
+    for tile in (0, 1):
+        native.set_tuning('force_tile', tile)
+        for occ in (2, 3):
+            native.set_tuning('force_occ', occ)
+            rec(f'su3_force tile={tile} occ={occ}', timeit(lambda: native.call(
+                'l2q_su3_force', xn, 6.0, f, nb, *L)), 1152, 11200)
     native.set_tuning('force_occ', 2)
     native.set_tuning('xcd_swizzle', 0)
     rec('su3_force occ=2 noswz', timeit(lambda: native.call(
