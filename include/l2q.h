@@ -213,6 +213,16 @@ int l2q_conv2d_periodic_f32(const float* in, const float* w, const float* bias, 
                             int nb, int cin, int H, int W, int cout, int k, int pool, int act,
                             void* stream);
 
+/* The same conv layer as an implicit GEMM (the fast path of ConvStack): periodic im2col
+ *   col[(b*Ho + ho)*Wo + wo][(ci*k + i)*k + j] = in[b, ci, (ho+i-k+1) mod H, (wo+j-k+1) mod W]
+ * with Ho = H+k-1, Wo = W+k-1 and generic element strides (sn, sc, sh, sw) of `in` (NCHW for
+ * the first layer, the GEMM's NHWC output afterwards); then l2q_gemm_f32(col, weight[cout][cin k k])
+ * gives the NHWC activation; l2q_maxpool_act_nhwc_f32 applies MaxPool2d(pool) + activation. */
+int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
+                            int H, int W, int k, float* col, void* stream);
+int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int pool, int act,
+                             float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,6 +209,45 @@ __global__ __launch_bounds__(kBlock) void conv2d_periodic_kernel(
   out[idx] = act_f32(best, act);
 }
 
+// ---- conv stack as implicit GEMM: periodic im2col -> MFMA GEMM (gemm.hip) -> pool + act.
+// col[m][kk], m = (b*Ho + ho)*Wo + wo, kk = (ci*k + i)*k + j (the flatten order of a Conv2d
+// weight [cout][cin][k][k]); source pixel ((ho + i - (k-1)) mod H, (wo + j - (k-1)) mod W).
+// Generic input strides so the first layer reads NCHW and later layers the GEMM's NHWC output.
+__global__ __launch_bounds__(kBlock) void im2col_periodic_kernel(
+    const float* __restrict__ in, long sn, long sc, long sh, long sw, int C, int H, int W, int k,
+    int Ho, int Wo, int Kc, long total, float* __restrict__ col) {
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= total) return;
+  const int kk = (int)(idx % Kc);
+  const long m = idx / Kc;
+  const int wo = (int)(m % Wo);
+  const int ho = (int)((m / Wo) % Ho);
+  const long b = m / ((long)Wo * Ho);
+  const int j = kk % k, i = (kk / k) % k, ci = kk / (k * k);
+  int r = (ho + i - (k - 1)) % H; if (r < 0) r += H;
+  int c = (wo + j - (k - 1)) % W; if (c < 0) c += W;
+  col[idx] = in[b * sn + ci * sc + r * sh + c * sw];
+}
+
+// NHWC max-pool (floor mode, stride = window) followed by the activation
+__global__ __launch_bounds__(kBlock) void maxpool_act_nhwc_kernel(const float* __restrict__ in,
+                                                                  int H, int W, int C, int pool,
+                                                                  int act, int Ho, int Wo,
+                                                                  long total,
+                                                                  float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const int wo = (int)((idx / C) % Wo);
+  const int ho = (int)((idx / ((long)C * Wo)) % Ho);
+  const long b = idx / ((long)C * Wo * Ho);
+  float best = -3.402823466e38f;
+  for (int ph = 0; ph < pool; ++ph)
+    for (int pw = 0; pw < pool; ++pw)
+      best = fmaxf(best, in[((b * H + ho * pool + ph) * W + wo * pool + pw) * C + c]);
+  out[idx] = act_f32(best, act);
+}
+
 }  // namespace l2q
 
 using namespace l2q;
@@ -305,6 +344,30 @@ int l2q_conv2d_periodic_f32(const float* in, const float* w, const float* bias, 
                      (hipStream_t)stream, in, w, bias, out, cin, H, W, cout, k, pool, act, Ho, Wo,
                      total);
   return check_launch("l2q_conv2d_periodic_f32");
+}
+
+int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
+                            int H, int W, int k, float* col, void* stream) {
+  L2Q_REQUIRE(in && col, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0, L2Q_EINVAL, "non-positive size");
+  const int Ho = H + k - 1, Wo = W + k - 1, Kc = C * k * k;
+  const long total = (long)nb * Ho * Wo * Kc;
+  L2Q_REQUIRE(cdiv(total, kBlock) < 0x7fffffffL, L2Q_ESHAPE, "grid too large");
+  hipLaunchKernelGGL(im2col_periodic_kernel, dim3((unsigned)cdiv(total, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, in, sn, sc, sh, sw, C, H, W, k, Ho, Wo, Kc, total, col);
+  return check_launch("l2q_im2col_periodic_f32");
+}
+
+int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int pool, int act,
+                             float* out, void* stream) {
+  L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && H > 0 && W > 0 && C > 0 && pool > 0, L2Q_EINVAL, "non-positive size");
+  const int Ho = H / pool, Wo = W / pool;
+  L2Q_REQUIRE(Ho > 0 && Wo > 0, L2Q_ESHAPE, "pooling window larger than the image");
+  const long total = (long)nb * Ho * Wo * C;
+  hipLaunchKernelGGL(maxpool_act_nhwc_kernel, dim3((unsigned)cdiv(total, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, in, H, W, C, pool, act, Ho, Wo, total, out);
+  return check_launch("l2q_maxpool_act_nhwc_f32");
 }
 
 }  // extern "C"

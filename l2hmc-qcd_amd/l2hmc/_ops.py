@@ -343,3 +343,30 @@ def conv2d_periodic(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, pool: int
     N.call('l2q_conv2d_periodic_f32', x.float().contiguous(), w.float().contiguous(),
            b.float().contiguous(), out, nb, cin, H, W, cout, k, pool, N.ACT[act])
     return out
+
+
+def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch.Tensor,
+                         pool: int = 1, act: Optional[str] = None) -> torch.Tensor:
+    """PeriodicPadding(k-1) -> Conv2d(k) -> [MaxPool2d(pool)] -> [act] as implicit GEMM on
+    the f32 MFMA kernel.  x: [nb, C, H, W] if layout == 'nchw' else [nb, H, W, C];
+    returns NHWC [nb, Ho, Wo, cout]."""
+    x = x.contiguous()
+    if layout == 'nchw':
+        nb, C, H, W = x.shape
+        sn, sc, sh, sw = C * H * W, H * W, W, 1
+    else:
+        nb, H, W, C = x.shape
+        sn, sc, sh, sw = H * W * C, 1, W * C, C
+    cout, cin, k, _ = w.shape
+    assert cin == C
+    Ho, Wo, Kc = H + k - 1, W + k - 1, C * k * k
+    col = torch.empty((nb * Ho * Wo, Kc), dtype=torch.float32, device=x.device)
+    N.call('l2q_im2col_periodic_f32', x, sn, sc, sh, sw, nb, C, H, W, k, col)
+    pool = max(int(pool), 1)
+    y = gemm(col, w.reshape(cout, Kc).contiguous(), b.contiguous(),
+             act=None if pool > 1 else act)
+    if pool == 1:
+        return y.reshape(nb, Ho, Wo, cout)
+    out = torch.empty((nb, Ho // pool, Wo // pool, cout), dtype=torch.float32, device=x.device)
+    N.call('l2q_maxpool_act_nhwc_f32', y, nb, Ho, Wo, cout, pool, N.ACT[act], out)
+    return out

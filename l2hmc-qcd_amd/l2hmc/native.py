@@ -58,6 +58,8 @@ SIGNATURES = {
     'l2q_axpy': (I, [P, D, P, L, I, P]),
     'l2q_u1_masked_cos_sin': (I, [P, P, I, P, I, L, I, P]),
     'l2q_conv2d_periodic_f32': (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    'l2q_im2col_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, P]),
+    'l2q_maxpool_act_nhwc_f32': (I, [P, I, I, I, I, I, I, P, P]),
 }
 
 _lib: Optional[C.CDLL] = None

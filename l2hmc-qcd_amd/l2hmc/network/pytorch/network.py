@@ -144,12 +144,19 @@ class ConvStack(nn.Module):
         x = x.reshape(x.shape[0], self.in_channels, self.nt, self.nx).contiguous()
         if x.dtype != torch.float32:
             raise NotImplementedError('the conv kernels are fp32 (the U(1) configs)')
+        # implicit GEMM: periodic im2col -> f32 MFMA GEMM (NHWC activations) -> pool + act
+        layout = 'nchw'
         for ci, k, pool, act in self.plan:
             conv = self.layers[ci]
-            x = ops.conv2d_periodic(x, conv.weight.detach(), conv.bias.detach(), pool, act)
+            x = ops.conv2d_periodic_gemm(x, layout, conv.weight.detach(), conv.bias.detach(),
+                                         pool, act)
+            layout = 'nhwc'
+        if layout == 'nhwc':                       # reference flattens NCHW
+            nb, H, W, C = x.shape
+            x = ops.transpose(x.reshape(nb, H * W, C), nb, H * W, C)
         lin = self.layers[self.linear_index]
-        return ops.gemm(flatten(x).contiguous(), lin.weight.detach(), lin.bias.detach(),
-                        act=self.act)
+        return ops.gemm(x.reshape(x.shape[0], -1).contiguous(), lin.weight.detach(),
+                        lin.bias.detach(), act=self.act)
 
 
 class InputLayer(nn.Module):

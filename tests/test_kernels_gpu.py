@@ -241,6 +241,12 @@ def test_conv2d_periodic(ops):
             want = onet.act(act, want)
         got = host(ops.conv2d_periodic(dev(x), dev(w), dev(b), pool, act))
         assert got.shape == want.shape and err(got, want) < 1e-4
+        # implicit-GEMM path (NHWC out), from NCHW and from NHWC input
+        g1 = host(ops.conv2d_periodic_gemm(dev(x), 'nchw', dev(w), dev(b), pool, act))
+        assert err(g1.transpose(0, 3, 1, 2), want) < 1e-4
+        xh = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+        g2 = host(ops.conv2d_periodic_gemm(xh, 'nhwc', dev(w), dev(b), pool, act))
+        assert err(g2.transpose(0, 3, 1, 2), want) < 1e-4
 
 
 def test_accept_select(ops):

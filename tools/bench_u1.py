@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""U(1) configs of BASELINE.json (cfg-1 / cfg-2): chain*LF/s of Dynamics.forward and plain HMC."""
+import argparse, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+import l2hmc.configs as cfgs  # noqa: E402
+from l2hmc.dynamics.pytorch.dynamics import Dynamics  # noqa: E402
+from l2hmc.lattice.u1.pytorch.lattice import LatticeU1  # noqa: E402
+from l2hmc.network.pytorch.network import NetworkFactory  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--L', type=int, nargs=2, default=[16, 16])
+ap.add_argument('--nb', type=int, default=2048)
+ap.add_argument('--nlf', type=int, default=8)
+ap.add_argument('--beta', type=float, default=4.0)
+ap.add_argument('--conv', action='store_true')
+ap.add_argument('--steps', type=int, default=5)
+a = ap.parse_args()
+torch.manual_seed(9992); np.random.seed(9992)
+dc = cfgs.DynamicsConfig(nchains=a.nb, group='U1', latvolume=a.L, nleapfrog=a.nlf, eps=0.1,
+                         eps_hmc=0.1, verbose=False)
+nc = cfgs.NetworkConfig(units=[16, 16, 16, 16], activation_fn='leaky_relu', dropout_prob=0.2,
+                        use_batch_norm=True)
+cc = cfgs.ConvolutionConfig(filters=[8, 16, 32, 64, 128], sizes=[5, 3, 3, 3, 2],
+                            pool=[2, 2, 2, 2, 2]) if a.conv else cfgs.ConvolutionConfig()
+spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                      vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+lat = LatticeU1(a.nb, a.L)
+dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cc)).eval()
+x = lat.random()
+beta = torch.tensor(a.beta)
+for name, fn, nlf in (('Dynamics.forward (L2HMC)', lambda x: dyn((x, beta)), 2 * a.nlf),
+                      ('apply_transition_hmc', lambda x: dyn.apply_transition_hmc((x, beta), eps=0.1, nleapfrog=2 * a.nlf), 2 * a.nlf)):
+    for _ in range(2):
+        xo, m = fn(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        xo, m = fn(x)
+        x = dyn.g.compat_proj(xo.reshape(x.shape))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+    print(f'U(1) {a.L} nb={a.nb} nlf={a.nlf} conv={a.conv} {name}: {dt*1e3:.2f} ms/step '
+          f'{a.nb * nlf / dt:.3e} chain*LF/s  acc={float(m["acc"].mean()):.3f}')
