@@ -76,6 +76,14 @@ int l2q_su3_unpack(const void* x_nat, void* x_ref, int nb, long V, void* stream)
  *   intQ = out[c][1]/(32 pi^2).   Algorithmic traffic: 576 B per (chain, site). */
 int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, double* out,
                         void* ws, size_t ws_bytes, void* stream);
+/* The same sums kept per plane: out[c][p][0|1], p = 0..5 in the reference's order
+ * (u,v) = (1,0),(2,0),(2,1),(3,0),(3,1),(3,2) -- what LatticeLoss._plaq_loss reduces to
+ * (loss/pytorch/loss.py:57-70).  ws >= nb * ceil(V/256) * 12 doubles. */
+int l2q_su3_plaq_planes(const void* xn, int nb, int T, int X, int Y, int Z, double* out, void* ws,
+                        size_t ws_bytes, void* stream);
+/* out[c] = sum_j (a[c][j] - b[c][j])^2 over n doubles (rmse loss, loss.py:131-148). */
+int l2q_diff_norm2_reduce(const double* a, const double* b, int nb, long n, double* out, void* ws,
+                          size_t ws_bytes, void* stream);
 /* F = (beta/3) TAH(U_mu(x) * sum of 6 staples), written in native layout.
  * Replaces LatticeSU3.grad_action (autograd + projectTAH, lattice.py:299-308).
  * Algorithmic traffic: 1152 B per (chain, site). */

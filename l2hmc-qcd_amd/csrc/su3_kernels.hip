@@ -165,6 +165,65 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_kernel(const double2* _
   }
 }
 
+// Per-plane variant for LatticeLoss._plaq_loss (loss/pytorch/loss.py:57-70 sums each of the 6
+// planes separately): partial[c][blk][plane][re|im]; same site loop, one block reduction per
+// plane.
+__global__ __launch_bounds__(kBlock, 2) void su3_plaq_planes_kernel(const double2* __restrict__ xn,
+                                                                    Dims d, long nblk,
+                                                                    double* __restrict__ partial) {
+  __shared__ double lds[8];
+  const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  const bool live = s < d.V;
+  const double2* xc = xn + c * 36L * d.V;
+  const Site p = site_coords(live ? s : 0, d);
+  const int V = d.V, ss = live ? s : 0;
+  int plane = 0;
+#pragma unroll 1
+  for (int u = 1; u < 4; ++u) {
+    const int s_pu = fwd(ss, coord_of(p, u), d, u);
+#pragma unroll 1
+    for (int v = 0; v < u; ++v, ++plane) {
+      const int s_pv = fwd(ss, coord_of(p, v), d, v);
+      double sr = 0.0, si = 0.0;
+      M3 a, b, yuv;
+      load_link(a, xc + u * 9 * V, V, ss);
+      load_link(b, xc + v * 9 * V, V, s_pu);
+      m3_mul_nn(yuv, a, b);
+      load_link(a, xc + v * 9 * V, V, ss);
+      load_link(b, xc + u * 9 * V, V, s_pv);
+      m3_trace_y_abh(sr, si, yuv, a, b);
+      if (!live) { sr = 0.0; si = 0.0; }
+      const double br = block_sum(sr, lds);
+      const double bi = block_sum(si, lds + 4);
+      if (threadIdx.x == 0) {
+        partial[((c * nblk + blk) * 6 + plane) * 2 + 0] = br;
+        partial[((c * nblk + blk) * 6 + plane) * 2 + 1] = bi;
+      }
+    }
+  }
+}
+
+// per-chain sum |a - b|^2 over n doubles (complex fields pass 2n)
+__global__ __launch_bounds__(kBlock) void diff_norm2_kernel(const double* __restrict__ a,
+                                                            const double* __restrict__ b, long n,
+                                                            long nblk, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  double acc = 0.0;
+  const long base = blk * (4L * kBlock);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long j = base + (long)k * kBlock + threadIdx.x;
+    if (j < n) {
+      const double dlt = a[c * n + j] - b[c * n + j];
+      acc = fma(dlt, dlt, acc);
+    }
+  }
+  const double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partial[c * nblk + blk] = r;
+}
+
 // ------------------------------------------------------------------ plaquette, t-sweep
 // One workgroup = 256 spatial sites of one chain, sweeping a range of t.  The +t neighbours
 // loaded in iteration t (U_x, U_y, U_z at t+1) are the same lines the block asks for as its
@@ -573,6 +632,33 @@ int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, doub
   }
   launch_finalize(partial, out, nb, nblk, 2, 1.0, 0.0, st);
   return check_launch("l2q_su3_plaq_reduce");
+}
+
+int l2q_su3_plaq_planes(const void* xn, int nb, int T, int X, int Y, int Z, double* out, void* ws,
+                        size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(xn && out && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * 12 * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(su3_plaq_planes_kernel, dim3((unsigned)(nb * nblk)), dim3(kBlock), 0, st,
+                     (const double2*)xn, d, nblk, (double*)ws);
+  launch_finalize((const double*)ws, out, nb, nblk, 12, 1.0, 0.0, st);
+  return check_launch("l2q_su3_plaq_planes");
+}
+
+int l2q_diff_norm2_reduce(const double* a, const double* b, int nb, long n, double* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(a && b && out && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
+  const long nblk = cdiv(n, 4L * kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(diff_norm2_kernel, dim3((unsigned)(nb * nblk)), dim3(kBlock), 0, st, a, b, n,
+                     nblk, (double*)ws);
+  launch_finalize((const double*)ws, out, nb, nblk, 1, 1.0, 0.0, st);
+  return check_launch("l2q_diff_norm2_reduce");
 }
 
 int l2q_su3_force(const void* xn, double beta, void* fn, int nb, int T, int X, int Y, int Z,

@@ -82,6 +82,27 @@ def su3_plaq_sums_n(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
     return out
 
 
+def su3_plaq_planes_n(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    """[nb, 6, 2]: per-plane (sum Re tr P, sum Im tr P)."""
+    nb = xn.shape[0]
+    T, X, Y, Z = (int(i) for i in lat)
+    out = torch.empty((nb, 6, 2), dtype=torch.float64, device=xn.device)
+    ws = N.workspace(N.reduce_ws_bytes(nb, T * X * Y * Z) * 4, xn.device)
+    N.call('l2q_su3_plaq_planes', xn, nb, T, X, Y, Z, out, ws, ws.numel())
+    return out
+
+
+def diff_norm2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """per-chain sum |a - b|^2 (float64 / complex128 tensors of equal shape)."""
+    nb = a.shape[0]
+    a, b = a.contiguous(), b.contiguous()
+    n = a.numel() // nb * (2 if a.is_complex() else 1)
+    out = torch.empty(nb, dtype=torch.float64, device=a.device)
+    ws = _ws(nb, n, a.device)
+    N.call('l2q_diff_norm2_reduce', a, b, nb, n, out, ws, ws.numel())
+    return out
+
+
 def su3_force_n(xn: torch.Tensor, beta: float, lat: Sequence[int]) -> torch.Tensor:
     nb = xn.shape[0]
     T, X, Y, Z = (int(i) for i in lat)

@@ -1,0 +1,38 @@
+"""``Experiment`` -- API shape of src/l2hmc/experiment/pytorch/experiment.py:141-450
+(``Experiment(cfg).evaluate(job_type)``, ``.trainer``) without the tracking back-ends."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+import l2hmc.configs as cfgs
+from l2hmc.trainers.pytorch.trainer import Trainer
+from l2hmc.utils.dist import setup_torch
+
+
+class Experiment:
+    def __init__(self, cfg: dict | cfgs.ExperimentConfig, build_networks: bool = True,
+                 keep=None, skip=None) -> None:
+        self.cfg = cfg
+        self.config = cfgs.instantiate(cfg) if isinstance(cfg, dict) else cfg
+        self._rank = setup_torch(seed=self.config.seed, backend=self.config.backend,
+                                 port=self.config.port)
+        self.trainer = Trainer(self.config, build_networks=build_networks)
+        self.lattice = self.trainer.lattice
+
+    def build_trainer(self, **kw) -> Trainer:
+        return self.trainer
+
+    def train(self, *a, **kw):
+        return self.trainer.train_step(None)
+
+    def evaluate(self, job_type: str, beta: Optional[float] = None, nsteps: Optional[int] = None,
+                 eps: Optional[float] = None, nleapfrog: Optional[int] = None,
+                 x: Optional[torch.Tensor] = None) -> Optional[dict]:
+        """'eval' (trained sampler) or 'hmc' (baseline); rank 0 only like the reference
+        (experiment.py:419-420)."""
+        if self._rank != 0:
+            return None
+        return self.trainer.eval(beta=beta, x=x, job_type=job_type, nsteps=nsteps, eps=eps,
+                                 nleapfrog=nleapfrog)

@@ -1,0 +1,105 @@
+"""``LatticeLoss`` (forward value) -- API of src/l2hmc/loss/pytorch/loss.py:21-210.
+
+The value is computed from per-chain reductions done by the HIP kernels
+(``l2q_su3_plaq_planes``, ``l2q_u1_plaq_reduce``, ``l2q_diff_norm2_reduce``); no autograd graph
+is attached (the training-gradient path is SURVEY.md 8(f) item 1).  Used by the trainer's
+``eval_step`` / ``hmc_step`` to report ``loss`` exactly like the reference.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from l2hmc import DEVICE
+from l2hmc import _ops as ops
+from l2hmc.configs import LossConfig
+from l2hmc.group.su3.pytorch.group import SU3
+from l2hmc.group.u1.pytorch.group import U1Phase
+from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+
+Tensor = torch.Tensor
+
+
+class LatticeLoss:
+    def __init__(self, lattice: LatticeU1 | LatticeSU3, loss_config: LossConfig):
+        self.lattice = lattice
+        self.config = loss_config
+        self.xshape = self.lattice.xshape
+        self.plaq_weight = torch.tensor(self.config.plaq_weight, dtype=torch.float)
+        self.charge_weight = torch.tensor(self.config.charge_weight, dtype=torch.float)
+        self.rmse_weight = torch.tensor(self.config.rmse_weight, dtype=torch.float)
+        if isinstance(self.lattice, LatticeU1):
+            self.g = U1Phase()
+        elif isinstance(self.lattice, LatticeSU3):
+            self.g = SU3()
+        else:
+            raise ValueError(f'Unexpected lattice: {type(lattice)}')
+
+    def __call__(self, x_init: Tensor, x_prop: Tensor, acc: Tensor) -> Tensor:
+        return self.calc_loss(x_init=x_init, x_prop=x_prop, acc=acc)
+
+    @staticmethod
+    def mixed_loss(loss: Tensor, weight: Tensor) -> Tensor:
+        return (weight / loss) - (loss / weight)
+
+    # per-plane real sums [6, nb] (SU3) -- what `w.real.sum(range(2, ndim))` gives (loss.py:64-65)
+    def _plane_sums(self, x: Tensor) -> Tensor:
+        assert isinstance(self.lattice, LatticeSU3)
+        s = ops.su3_plaq_planes_n(self.lattice.pack(x), self.lattice._lattice_shape)
+        return s[:, :, 0].transpose(0, 1)
+
+    def _mixed(self, loss: Tensor, weight: Tensor, use_mixed_loss: Optional[bool]) -> Tensor:
+        use_mixed = self.config.use_mixed_loss if use_mixed_loss is None else use_mixed_loss
+        weight = weight.to(loss.device)
+        if use_mixed:
+            return self.mixed_loss(loss + 1e-4, weight).mean()
+        return (-loss / weight).mean()
+
+    def plaq_loss(self, x_init: Tensor, x_prop: Tensor, acc: Tensor,
+                  use_mixed_loss: Optional[bool] = None) -> Tensor:
+        if not isinstance(self.lattice, LatticeSU3):
+            raise NotImplementedError('U(1) plaq_loss broadcasts acc[nb] against [nb, T] in the '
+                                      'reference (loss.py:64-66) and is unused (plaq_weight = 0)')
+        p1, p2 = self._plane_sums(x_init), self._plane_sums(x_prop)
+        ploss = acc.to(DEVICE) * (p2 - p1) ** 2
+        # NB the reference's _plaq_loss takes use_mixed_loss literally (None -> not mixed)
+        if use_mixed_loss:
+            return self.mixed_loss(ploss + 1e-4, self.plaq_weight.to(DEVICE)).mean()
+        return (-ploss / self.plaq_weight.to(DEVICE)).mean()
+
+    def charge_loss(self, x_init: Tensor, x_prop: Tensor, acc: Tensor,
+                    use_mixed_loss: Optional[bool] = None) -> Tensor:
+        q1 = self.lattice._sin_charges(self.lattice.wilson_loops(x_init))
+        q2 = self.lattice._sin_charges(self.lattice.wilson_loops(x_prop))
+        return self._mixed(acc.to(DEVICE) * (q2 - q1) ** 2, self.charge_weight, use_mixed_loss)
+
+    def rmse_loss(self, x_init: Tensor, x_prop: Tensor, acc: Tensor,
+                  use_mixed_loss: Optional[bool] = None) -> Tensor:
+        nb = x_init.shape[0]
+        a = x_prop.to(DEVICE).reshape(nb, -1)
+        b = x_init.to(DEVICE).reshape(nb, -1)
+        if not a.is_complex():
+            # same failure as the reference, whose rmse_loss takes `dx.imag` (loss.py:139)
+            raise RuntimeError('imag is not implemented for tensors with non-complex dtypes.')
+        d2 = ops.diff_norm2(a.to(torch.complex128), b.to(torch.complex128))
+        nelem = a.shape[1]
+        return self._mixed(acc.to(DEVICE) * (d2 / nelem).to(acc.dtype), self.rmse_weight,
+                           use_mixed_loss)
+
+    def lattice_metrics(self, xinit: Tensor, xout: Optional[Tensor] = None) -> dict[str, Tensor]:
+        metrics = self.lattice.calc_metrics(x=xinit)
+        if xout is not None:
+            w = self.lattice.wilson_loops(x=xout.reshape(xinit.shape))
+            metrics.update({'dQint': (self.lattice._int_charges(w) - metrics['intQ']).abs(),
+                            'dQsin': (self.lattice._sin_charges(w) - metrics['sinQ']).abs()})
+        return metrics
+
+    def calc_loss(self, x_init: Tensor, x_prop: Tensor, acc: Tensor) -> Tensor:
+        """plaq + charge + rmse terms (loss.py:194-210)"""
+        zero = torch.zeros((), dtype=acc.dtype, device=DEVICE)
+        rmse = self.rmse_loss(x_init, x_prop, acc) if self.rmse_weight > 0 else zero
+        plaq = self.plaq_loss(x_init, x_prop, acc) if self.plaq_weight > 0 else zero
+        charge = self.charge_loss(x_init, x_prop, acc) if self.charge_weight > 0 else zero
+        return plaq + charge + rmse

@@ -29,6 +29,8 @@ SIGNATURES = {
     'l2q_su3_pack': (I, [P, P, I, L, P]),
     'l2q_su3_unpack': (I, [P, P, I, L, P]),
     'l2q_su3_plaq_reduce': (I, [P, I, I, I, I, I, P, P, Z, P]),
+    'l2q_su3_plaq_planes': (I, [P, I, I, I, I, I, P, P, Z, P]),
+    'l2q_diff_norm2_reduce': (I, [P, P, I, L, P, P, Z, P]),
     'l2q_su3_force': (I, [P, D, P, I, I, I, I, I, P]),
     'l2q_su3_force_kick': (I, [P, D, D, P, I, I, I, I, I, P]),
     'l2q_su3_expm_mul': (I, [P, P, D, P, I, P, I, L, P]),

@@ -1,0 +1,150 @@
+"""Thin ``Trainer`` counterpart driving the hot path: ``hmc_step`` / ``eval_step`` /
+``eval`` / ``warmup`` with the reference's step sequence (per-step ``compat_proj``, loss and
+lattice metrics, ``trainers/pytorch/trainer.py:904-956, 1085-1252, 1699-1744``).
+
+Out of scope here: optimizers / DDP wrappers / wandb / aim /
+rich live displays / checkpoint directories.  ``train_step`` needs the training-gradient
+path and raises until that is built.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+import l2hmc.configs as cfgs
+from l2hmc import DEVICE
+from l2hmc.dynamics.pytorch.dynamics import Dynamics
+from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+from l2hmc.lattice.u1.pytorch.lattice import LatticeU1, plaq_exact
+from l2hmc.loss.pytorch.loss import LatticeLoss
+from l2hmc.network.pytorch.network import NetworkFactory
+from l2hmc.utils.step_timer import StepTimer
+
+Tensor = torch.Tensor
+
+
+class Trainer:
+    def __init__(self, cfg: cfgs.ExperimentConfig | dict, build_networks: bool = True):
+        if isinstance(cfg, dict):
+            cfg = cfgs.instantiate(cfg)
+        self.config = cfg
+        if cfg.precision == 'float64' or cfg.dynamics.group.upper() == 'SU3':
+            torch.set_default_dtype(torch.float64)
+        self.device = DEVICE
+        self.lattice = self.build_lattice()
+        self.g = self.lattice.g
+        self.loss_fn = LatticeLoss(lattice=self.lattice, loss_config=cfg.loss)
+        self.dynamics = self.build_dynamics(build_networks)
+        evals = 2 * cfg.dynamics.nleapfrog if cfg.dynamics.merge_directions \
+            else cfg.dynamics.nleapfrog
+        self.timers = {k: StepTimer(evals_per_step=evals) for k in ('train', 'eval', 'hmc')}
+        self._estep = self._hstep = 0
+
+    # -- construction (trainer.py:490-562, trainers/trainer.py:292-309)
+    def build_lattice(self):
+        d = self.config.dynamics
+        if d.group.upper() == 'U1':
+            return LatticeU1(d.nchains, list(d.latvolume))
+        return LatticeSU3(d.nchains, list(d.latvolume), c1=self.config.c1)
+
+    def get_input_spec(self) -> cfgs.InputSpec:
+        d = self.config.dynamics
+        xshape = d.xshape
+        if d.group.upper() == 'U1':
+            dims = {'xnet': {'x': [d.xdim, 2], 'v': [d.xdim]},
+                    'vnet': {'x': [d.xdim], 'v': [d.xdim]}}
+        else:
+            xdim = int(np.cumprod(xshape[1:-2])[-1]) * 8
+            dims = {'xnet': {'x': [xdim], 'v': [xdim]}, 'vnet': {'x': [xdim], 'v': [xdim]}}
+        return cfgs.InputSpec(xshape=tuple(xshape), **dims)
+
+    def build_dynamics(self, build_networks: bool = True) -> Dynamics:
+        nf = None
+        if build_networks:
+            nf = NetworkFactory(input_spec=self.get_input_spec(),
+                                network_config=self.config.network,
+                                conv_config=self.config.conv,
+                                net_weights=self.config.net_weights)
+        return Dynamics(potential_fn=self.lattice.action, config=self.config.dynamics,
+                        network_factory=nf)
+
+    # -- steps
+    def _prep(self, x: Tensor) -> Tensor:
+        """every step starts with compat_proj (U1: mod 2 pi, SU3: projectSU) trainer.py:915-917"""
+        return self.g.compat_proj(self.dynamics.unflatten(x.to(self.device)))
+
+    def _finish(self, xi, xo, metrics, timer_key) -> tuple[Tensor, dict]:
+        xp = metrics.pop('mc_states').proposed.x
+        loss = self.loss_fn(x_init=xi, x_prop=xp, acc=metrics['acc'])
+        if self.config.dynamics.verbose:
+            metrics.update(self.loss_fn.lattice_metrics(xinit=xi, xout=xo))
+        metrics.update({'loss': loss.item()})
+        return xo.detach(), metrics
+
+    def hmc_step(self, inputs, eps: Optional[float] = None,
+                 nleapfrog: Optional[int] = None) -> tuple[Tensor, dict]:
+        self.dynamics.eval()
+        xi, beta = inputs
+        beta = torch.as_tensor(beta, dtype=torch.get_default_dtype())
+        xi = self._prep(xi)
+        xo, metrics = self.dynamics.apply_transition_hmc((xi, beta), eps=eps, nleapfrog=nleapfrog)
+        self._hstep += 1
+        return self._finish(xi, xo, metrics, 'hmc')
+
+    def eval_step(self, inputs) -> tuple[Tensor, dict]:
+        self.dynamics.eval()
+        xinit, beta = inputs
+        beta = torch.as_tensor(beta, dtype=torch.get_default_dtype())
+        xinit = self._prep(xinit)
+        xout, metrics = self.dynamics((xinit, beta))
+        self._estep += 1
+        return self._finish(xinit, xout, metrics, 'eval')
+
+    def train_step(self, inputs):
+        raise NotImplementedError(
+            'train_step needs the training-gradient path (backward kernels + Adam), '
+            'SURVEY.md section 8(f) item 1 -- not built yet')
+
+    def warmup(self, beta: float, nsteps: int = 100, tol: float = 1e-5,
+               x: Optional[Tensor] = None) -> Tensor:
+        """<= nsteps HMC steps; U(1) stops when |<plaq> - I1/I0| < tol (trainer.py:1699-1744)."""
+        x = self.lattice.random() if x is None else x
+        is_u1 = isinstance(self.lattice, LatticeU1)
+        pexact = plaq_exact(torch.tensor(beta)) if is_u1 else None
+        for _ in range(nsteps):
+            x, metrics = self.hmc_step((x, beta))
+            if is_u1:
+                plaqs = metrics.get('plaqs', self.lattice.plaqs(self._prep(x)))
+                if float((plaqs.mean().cpu() - pexact).abs()) < tol:
+                    break
+        return x
+
+    def eval(self, beta: Optional[float] = None, x: Optional[Tensor] = None,
+             job_type: str = 'eval', nsteps: Optional[int] = None, eps: Optional[float] = None,
+             nleapfrog: Optional[int] = None) -> dict:
+        """(trainer.py:1085-1252) returns {'history': {key: [per-step tensors]}, 'x': x}"""
+        assert job_type in ('eval', 'hmc')
+        beta = self.config.annealing_schedule.beta_final if beta is None else beta
+        nsteps = self.config.steps.test if nsteps is None else nsteps
+        x = self.lattice.random() if x is None else x
+        timer = self.timers[job_type]
+        history: dict[str, list] = {}
+        for step in range(nsteps):
+            timer.start()
+            if job_type == 'hmc':
+                x, metrics = self.hmc_step((x, beta), eps=eps, nleapfrog=nleapfrog)
+            else:
+                x, metrics = self.eval_step((x, beta))
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            dt = timer.stop()
+            record = {'step': step, 'dt': dt, 'beta': beta}
+            record.update({k: v for k, v in metrics.items() if k not in ('beta',)})
+            for k, v in record.items():
+                if isinstance(v, Tensor):
+                    v = v.detach().float().cpu() if not v.is_complex() else v.detach().cpu()
+                history.setdefault(k, []).append(v)
+        return {'history': history, 'x': x, 'timer': timer}
