@@ -51,7 +51,7 @@ def parse():
     ap.add_argument('--beta', type=float, default=6.0)
     ap.add_argument('--mode', choices=['l2hmc', 'hmc'], default='l2hmc')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-chains', type=int, default=8)
+    ap.add_argument('--cpu-chains', type=int, default=32)
     return ap.parse_args()
 
 
@@ -169,13 +169,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU path)'
-    torch.cuda.set_device(local_rank)
+    # L2Q_BENCH_SHARE_GPU=1 + L2Q_BENCH_BACKEND=gloo: functional test of the N>1 path on a
+    # 1-GPU box (all ranks on device 0); the real runs use one GPU per rank and RCCL.
+    share = os.environ.get('L2Q_BENCH_SHARE_GPU') == '1'
+    torch.cuda.set_device(0 if share else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL over xGMI
+        dist.init_process_group(os.environ.get('L2Q_BENCH_BACKEND', 'nccl'), rank=rank,
+                                world_size=world)                      # nccl = RCCL over xGMI
     dyn, lat = build(args, seed=9992)
     x = hot_start(lat, args, seed=9992 * (rank + 1))
     beta = torch.tensor(args.beta)

@@ -176,6 +176,18 @@ int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const doub
                                double scale_q, void* v, const void* force, int is_complex,
                                double eps, int forward, double* logdet, void* ws,
                                size_t ws_bytes, void* stream);
+/* Two consecutive v-updates on the SAME x (closing update of leapfrog step k, opening update
+ * of step k+1; optionally the merged trajectory's momentum flip v -> -v in between,
+ * dynamics.py:1001) from ONE evaluation of the heads: update (eps1, forward1), [flip],
+ * update (eps2, forward2).  logdet receives the sum of both updates' log-Jacobians. */
+int l2q_vnet_heads_vupdate_pair_f64(const double* Z, int M, int K, long N, const double* Ws,
+                                    const double* bs, const double* cs, double scale_s,
+                                    const double* Wt, const double* bt, double scale_t,
+                                    const double* Wq, const double* bq, const double* cq,
+                                    double scale_q, void* v, const void* force, int is_complex,
+                                    double eps1, int forward1, int flip_between, double eps2,
+                                    int forward2, double* logdet, void* ws, size_t ws_bytes,
+                                    void* stream);
 size_t l2q_vnet_heads_ws_bytes(int M, long N);
 /* fp32 variant on v_mfma_f32_16x16x4_f32 (U(1) networks). */
 int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const float* A2,

@@ -265,13 +265,18 @@ struct HeadsArgs {
   const double* cq;       // per-column scale of q
   double ss, st, sq;      // scalar scales (used where the vector is null; st always)
   double eps;
+  double eps2;            // second update of a pair (PAIR kernels)
+  int fwd2, flip;         // its direction; v -> -v between the two updates
   double* v;              // [M][N] (x2 if complex), updated in place
   const double* F;        // [M][N] (x2 if complex)
   double* logdet_part;    // [M][ncols_part]
   int M, N, K, ncols_part;
 };
 
-template <bool CPLX, bool FWD>
+// PAIR: the closing v-update of one leapfrog step and the opening v-update of the next act on
+// the same x, hence the same (s, t, q): both are applied here from one evaluation of the heads
+// (optionally with the momentum flip of the merged trajectory in between).
+template <bool CPLX, bool FWD, bool PAIR>
 __global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_kernel(HeadsArgs a, int swz) {
   constexpr int BM = 64, BN = kHeadsBN, NJ = BN / 32;
   using T = double;
@@ -359,18 +364,31 @@ __global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_ker
         ld[i][r] += lj;
         const double es = exp(lj), eq = exp(eps * q);
         const long o = m * (long)a.N + n;
+        double vr, vi = 0.0, fr0, fi0 = 0.0;
         if (CPLX) {
           const double2 vv = reinterpret_cast<const double2*>(a.v)[o];
           const double2 ff = reinterpret_cast<const double2*>(a.F)[o];
-          const double fr = ff.x * eq + t, fi = ff.y * eq;
-          double2 out;
-          if (FWD) { out.x = es * vv.x - heps * fr; out.y = es * vv.y - heps * fi; }
-          else { out.x = es * (vv.x + heps * fr); out.y = es * (vv.y + heps * fi); }
-          reinterpret_cast<double2*>(a.v)[o] = out;
+          vr = vv.x; vi = vv.y; fr0 = ff.x; fi0 = ff.y;
         } else {
-          const double f = a.F[o] * eq + t;
-          a.v[o] = FWD ? (es * a.v[o] - heps * f) : (es * (a.v[o] + heps * f));
+          vr = a.v[o]; fr0 = a.F[o];
         }
+        {
+          const double fr = fr0 * eq + t, fi = fi0 * eq;
+          if (FWD) { vr = es * vr - heps * fr; vi = es * vi - heps * fi; }
+          else { vr = es * (vr + heps * fr); vi = es * (vi + heps * fi); }
+        }
+        if (PAIR) {
+          if (a.flip) { vr = -vr; vi = -vi; }
+          const double h2 = 0.5 * a.eps2;
+          const double lj2 = a.fwd2 ? h2 * s : -h2 * s;
+          ld[i][r] += lj2;
+          const double es2 = exp(lj2), eq2 = exp(a.eps2 * q);
+          const double fr = fr0 * eq2 + t, fi = fi0 * eq2;
+          if (a.fwd2) { vr = es2 * vr - h2 * fr; vi = es2 * vi - h2 * fi; }
+          else { vr = es2 * (vr + h2 * fr); vi = es2 * (vi + h2 * fi); }
+        }
+        if (CPLX) reinterpret_cast<double2*>(a.v)[o] = make_double2(vr, vi);
+        else a.v[o] = vr;
       }
   }
   // row partial of logdet over this wave's columns: butterfly over the 16 column lanes
@@ -481,13 +499,12 @@ size_t l2q_vnet_heads_ws_bytes(int M, long N) {
   return (size_t)M * (size_t)(cdiv(N, kHeadsBN) * 2) * sizeof(double) + 256;
 }
 
-int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const double* Ws,
-                               const double* bs, const double* cs, double scale_s,
-                               const double* Wt, const double* bt, double scale_t,
-                               const double* Wq, const double* bq, const double* cq,
-                               double scale_q, void* v, const void* force, int is_complex,
-                               double eps, int forward, double* logdet, void* ws, size_t ws_bytes,
-                               void* stream) {
+static int heads_launch(const double* Z, int M, int K, long N, const double* Ws, const double* bs,
+                        const double* cs, double scale_s, const double* Wt, const double* bt,
+                        double scale_t, const double* Wq, const double* bq, const double* cq,
+                        double scale_q, void* v, const void* force, int is_complex, double eps,
+                        int forward, int pair, double eps2, int forward2, int flip,
+                        double* logdet, void* ws, size_t ws_bytes, void* stream) {
   L2Q_REQUIRE(Z && Ws && bs && Wt && bt && Wq && bq && v && force && logdet && ws, L2Q_EINVAL,
               "null pointer");
   L2Q_REQUIRE(M > 0 && K > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
@@ -502,21 +519,49 @@ int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const doub
   HeadsArgs a;
   a.Z = Z; a.W[0] = Ws; a.W[1] = Wt; a.W[2] = Wq; a.b[0] = bs; a.b[1] = bt; a.b[2] = bq;
   a.cs = cs; a.cq = cq; a.ss = scale_s; a.st = scale_t; a.sq = scale_q; a.eps = eps;
+  a.eps2 = eps2; a.fwd2 = forward2; a.flip = flip;
   a.v = (double*)v; a.F = (const double*)force; a.logdet_part = (double*)ws;
   a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncols;
   const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
   const int swz = tuning().xcd_swizzle;
   // partial columns of wave tiles that fall entirely beyond N are never written: clear first
   (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * sizeof(double), st);
-  if (is_complex) {
-    if (forward) hipLaunchKernelGGL((fused_heads_vupdate_kernel<true, true>), grid, block, 0, st, a, swz);
-    else hipLaunchKernelGGL((fused_heads_vupdate_kernel<true, false>), grid, block, 0, st, a, swz);
+#define L2Q_HEADS(C, F, P) \
+  hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz)
+  if (pair) {
+    if (is_complex) { if (forward) L2Q_HEADS(true, true, true); else L2Q_HEADS(true, false, true); }
+    else { if (forward) L2Q_HEADS(false, true, true); else L2Q_HEADS(false, false, true); }
   } else {
-    if (forward) hipLaunchKernelGGL((fused_heads_vupdate_kernel<false, true>), grid, block, 0, st, a, swz);
-    else hipLaunchKernelGGL((fused_heads_vupdate_kernel<false, false>), grid, block, 0, st, a, swz);
+    if (is_complex) { if (forward) L2Q_HEADS(true, true, false); else L2Q_HEADS(true, false, false); }
+    else { if (forward) L2Q_HEADS(false, true, false); else L2Q_HEADS(false, false, false); }
   }
+#undef L2Q_HEADS
   launch_finalize((const double*)ws, logdet, M, ncols, 1, 1.0, 0.0, st);
   return check_launch("l2q_vnet_heads_vupdate_f64");
+}
+
+int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const double* Ws,
+                               const double* bs, const double* cs, double scale_s,
+                               const double* Wt, const double* bt, double scale_t,
+                               const double* Wq, const double* bq, const double* cq,
+                               double scale_q, void* v, const void* force, int is_complex,
+                               double eps, int forward, double* logdet, void* ws, size_t ws_bytes,
+                               void* stream) {
+  return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v,
+                      force, is_complex, eps, forward, 0, 0.0, 0, 0, logdet, ws, ws_bytes, stream);
+}
+
+int l2q_vnet_heads_vupdate_pair_f64(const double* Z, int M, int K, long N, const double* Ws,
+                                    const double* bs, const double* cs, double scale_s,
+                                    const double* Wt, const double* bt, double scale_t,
+                                    const double* Wq, const double* bq, const double* cq,
+                                    double scale_q, void* v, const void* force, int is_complex,
+                                    double eps1, int forward1, int flip_between, double eps2,
+                                    int forward2, double* logdet, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v,
+                      force, is_complex, eps1, forward1, 1, eps2, forward2, flip_between, logdet,
+                      ws, ws_bytes, stream);
 }
 
 }  // extern "C"

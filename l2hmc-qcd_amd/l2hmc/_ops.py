@@ -295,6 +295,25 @@ def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
     return logdet
 
 
+def vnet_heads_vupdate_pair_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
+                             force: torch.Tensor, eps1: float, forward1: bool, flip: bool,
+                             eps2: float, forward2: bool) -> torch.Tensor:
+    """Two consecutive v-updates on the same x from one evaluation of the heads (optionally
+    with v -> -v in between); returns the summed logdet [nb]."""
+    m, k = z.shape
+    ws_, bs, cs = heads['s']
+    wt, bt, _ = heads['t']
+    wq, bq, cq = heads['q']
+    n = ws_.shape[0]
+    logdet = torch.empty(m, dtype=torch.float64, device=z.device)
+    ws = N.workspace(int(N.load().l2q_vnet_heads_ws_bytes(m, n)), z.device)
+    N.call('l2q_vnet_heads_vupdate_pair_f64', z, m, k, n, ws_, bs, cs, float(scales[0]), wt, bt,
+           float(scales[1]), wq, bq, cq, float(scales[2]), v, force, int(v.is_complex()),
+           float(eps1), int(forward1), int(flip), float(eps2), int(forward2), logdet, ws,
+           ws.numel())
+    return logdet
+
+
 # ---------------------------------------------------------------------------- U(1)
 def u1_plaq_sums(x: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
     """[nb, 3]: sum cos(theta), sum sin(theta), sum project_angle(theta)."""

@@ -136,6 +136,7 @@ class Dynamics(nn.Module):
         self.fuse_heads = True      # SU3: fused heads + v-update kernel (same results)
         self.fuse_x_updates = True  # SU3: both x half-updates of a LF step in one kernel
         self.reuse_v_inputs = True  # force / vec8 / hidden activation once per distinct x
+        self.pair_v_updates = True  # adjacent v-updates on the same x in one heads kernel
         self._inject: Optional[dict] = None
         self._eps_cache: dict = {}
         self._masks_native: Optional[list] = None
@@ -405,45 +406,69 @@ class Dynamics(nn.Module):
         return xnet.forward_flat(xm.reshape(nb, -1), vn.reshape(nb, -1))
 
     # ---- sub-updates on native state (in place on xn / vn)
-    def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
-                    cache: Optional[dict] = None) -> Tensor:
-        """v-update in place; returns logdet.  `cache` (trajectory-local): the force, the
-        vec8 network inputs and the hidden activation depend only on x (and the network), and
-        x does not change between the closing v-update of one leapfrog step and the opening
-        v-update of the next (nor across the momentum flip), so they are computed once per
-        distinct x -- 9 instead of 16 evaluations in a merged nlf = 4 trajectory.  Same inputs,
-        same deterministic kernels: bitwise identical results."""
-        eps = self._eps('v', step)
+    def _can_fuse_heads(self, vnet) -> bool:
+        return (self.fuse_heads and self._networks_built and self.group == 'SU3'
+                and vnet.units[-1] % 2 == 0)
+
+    def _v_inputs_n(self, vnet, xn: Tensor, beta, cache: Optional[dict]):
+        """(force, hidden activation z, kernel weights) for the fused heads kernel.  `cache`
+        (trajectory-local): the force, the vec8 network inputs and z depend only on x (and the
+        network), and x does not change between the closing v-update of one leapfrog step and
+        the opening v-update of the next (nor across the momentum flip), so they are computed
+        once per distinct x -- 9 instead of 16 evaluations in a merged nlf = 4 trajectory.
+        Same inputs, same deterministic kernels: bitwise identical results."""
         nb = xn.shape[0]
-        vnet = self._get_vnet(step)
         hit = cache is not None and cache.get('valid', False)
         fn = cache['F'] if hit else self._force_n(xn, beta)
         if cache is not None and not hit:
             cache.clear()
             cache.update({'valid': True, 'F': fn})
-        if (self.fuse_heads and self._networks_built and self.group == 'SU3'
-                and vnet.units[-1] % 2 == 0):
+        if not self._can_fuse_heads(vnet):
+            return fn, None, None
+        p = self._perms()
+        w = vnet.kernel_weights(p['in'], p['out'])
+        zkey = ('z', id(vnet))
+        if cache is not None and zkey in cache:
+            return fn, cache[zkey], w
+        if cache is not None and 'xv' in cache:
+            xv, fv = cache['xv'], cache['fv']
+        else:
+            xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
+            fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
+            if cache is not None:
+                cache['xv'], cache['fv'] = xv, fv
+        z = vnet.hidden_flat(xv, fv, w)
+        if cache is not None:
+            cache[zkey] = z
+        return fn, z, w
+
+    def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
+                    cache: Optional[dict] = None) -> Tensor:
+        """v-update in place (dynamics.py:1266-1297); returns logdet [nb]."""
+        eps = self._eps('v', step)
+        nb = xn.shape[0]
+        vnet = self._get_vnet(step)
+        fn, z, w = self._v_inputs_n(vnet, xn, beta, cache)
+        if z is not None:
             # heads + momentum update in one kernel: s, t, q never reach HBM
-            p = self._perms()
-            w = vnet.kernel_weights(p['in'], p['out'])
-            zkey = ('z', id(vnet))
-            if cache is not None and zkey in cache:
-                z = cache[zkey]
-            else:
-                if cache is not None and 'xv' in cache:
-                    xv, fv = cache['xv'], cache['fv']
-                else:
-                    xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
-                    fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
-                    if cache is not None:
-                        cache['xv'], cache['fv'] = xv, fv
-                z = vnet.hidden_flat(xv, fv, w)
-                if cache is not None:
-                    cache[zkey] = z
             return ops.vnet_heads_vupdate_(z, w['heads_scaled'], (vnet.nw.s, vnet.nw.t, vnet.nw.q),
                                            vn.reshape(nb, -1), fn.reshape(nb, -1), eps, forward)
         s, t, q = self._vnet_n(step, xn, fn)
         return ops.v_update_(vn.reshape(nb, -1), fn.reshape(nb, -1), s, t, q, eps, forward)
+
+    def _update_v_pair_n(self, step0: int, forward0: bool, flip: bool, step1: int,
+                         forward1: bool, xn: Tensor, vn: Tensor, beta,
+                         cache: Optional[dict] = None) -> Tensor:
+        """The closing v-update of one leapfrog step and the opening v-update of the next (same
+        x, same network => same s, t, q), optionally with the merged trajectory's v -> -v in
+        between (dynamics.py:1001), from ONE evaluation of the heads.  Sum of both logdets."""
+        nb = xn.shape[0]
+        vnet = self._get_vnet(step1)
+        fn, z, w = self._v_inputs_n(vnet, xn, beta, cache)
+        return ops.vnet_heads_vupdate_pair_(
+            z, w['heads_scaled'], (vnet.nw.s, vnet.nw.t, vnet.nw.q), vn.reshape(nb, -1),
+            fn.reshape(nb, -1), self._eps('v', step0), forward0, flip, self._eps('v', step1),
+            forward1)
 
     def _update_x_n(self, step: int, xn: Tensor, vn: Tensor, mask: Tensor, complement: bool,
                     forward: bool, first: bool) -> Optional[Tensor]:
@@ -456,17 +481,37 @@ class Dynamics(nn.Module):
         return ops.u1_x_update_(xn.reshape(nb, -1), vn, s, t, q, mask, complement, eps,
                                 forward, self.config.use_ncp)
 
+    def _flip_v_n(self, vn: Tensor) -> Tensor:
+        if self.group == 'SU3':
+            return ops.scale(vn, -1.0, out=vn)
+        return vn.neg_()
+
     def _lf_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
-              cache: Optional[dict] = None) -> Tensor:
+              cache: Optional[dict] = None, pend: Optional[dict] = None) -> Tensor:
         """One generalised leapfrog step in place; returns logdet [nb]
-        (dynamics.py:1187-1228)."""
+        (dynamics.py:1187-1228).  `pend` (optional, trajectory-local) enables deferral of the
+        closing v-update: it is then executed together with the next step's opening v-update
+        (`_update_v_pair_n`), its logdet being returned by that next call; the caller flushes
+        a last pending update with `_flush_pending_n`."""
         if forward:
             st, order = step, ((False, True), (True, False))     # (complement, first)
         else:
             st = self.config.nleapfrog - step - 1
             order = ((True, False), (False, True))
         m = self._native_masks()[st]
-        ld = self._update_v_n(st, xn, vn, beta, forward, cache)
+        prev = pend.pop('p', None) if pend is not None else None
+        if prev is not None:
+            st0, f0, flip = prev
+            v0, v1 = self._get_vnet(st0), self._get_vnet(st)
+            if v0 is v1 and self._can_fuse_heads(v1):
+                ld = self._update_v_pair_n(st0, f0, flip, st, forward, xn, vn, beta, cache)
+            else:
+                ld = self._update_v_n(st0, xn, vn, beta, f0, cache)
+                if flip:
+                    self._flip_v_n(vn)
+                ld = ld + self._update_v_n(st, xn, vn, beta, forward, cache)
+        else:
+            ld = self._update_v_n(st, xn, vn, beta, forward, cache)
         if self.group == 'SU3' and self.fuse_x_updates:
             # both half-updates share expm(eps v): one kernel, one pass over x
             eps = self._eps('x', st)
@@ -478,7 +523,20 @@ class Dynamics(nn.Module):
                     ld = ld + l
         if cache is not None:
             cache['valid'] = False                     # x changed
+        if pend is not None:
+            pend['p'] = (st, forward, False)           # closing v-update deferred
+            return ld
         return ld + self._update_v_n(st, xn, vn, beta, forward, cache)
+
+    def _flush_pending_n(self, pend: Optional[dict], xn, vn, beta, cache) -> Optional[Tensor]:
+        prev = pend.pop('p', None) if pend is not None else None
+        if prev is None:
+            return None
+        st0, f0, flip = prev
+        ld = self._update_v_n(st0, xn, vn, beta, f0, cache)
+        if flip:
+            self._flip_v_n(vn)
+        return ld
 
     # ------------------------------------------------------------------ public sub-updates
     def group_to_vec(self, x: Tensor) -> Tensor:
@@ -678,20 +736,24 @@ class Dynamics(nn.Module):
             self.update_history(m, history)
         h = h_init
         cache = {} if self.reuse_v_inputs else None
+        # per-step metrics need v between the paired updates -> pairing only when not verbose
+        pend = {} if (self.pair_v_updates and not verbose and cache is not None
+                      and self.group == 'SU3' and self._networks_built) else None
         for step in range(self.config.nleapfrog):
-            logdet = self._lf_n(step, x_, v_, beta, True, cache)
+            logdet = self._lf_n(step, x_, v_, beta, True, cache, pend)
             sumlogdet = sumlogdet + logdet
             if verbose:
                 sldf = sldf + logdet
                 extras = {'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet}
                 self.update_history(self._metrics_n(x_, v_, beta, sumlogdet, step, extras),
                                     history)
-        if self.group == 'SU3':
-            ops.scale(v_, -1.0, out=v_)
+        if pend is not None and 'p' in pend:
+            st0, f0, _ = pend['p']
+            pend['p'] = (st0, f0, True)                # flip happens inside the paired kernel
         else:
-            v_ = -v_
+            v_ = self._flip_v_n(v_)
         for step in range(self.config.nleapfrog):
-            logdet = self._lf_n(step, x_, v_, beta, False, cache)
+            logdet = self._lf_n(step, x_, v_, beta, False, cache, pend)
             sumlogdet = sumlogdet + logdet
             if verbose:
                 sldb = sldb + logdet
@@ -700,6 +762,9 @@ class Dynamics(nn.Module):
                                      self.config.nleapfrog - step - 1, extras)
                 h = mt['energy']
                 self.update_history(mt, history)
+        last = self._flush_pending_n(pend, x_, v_, beta, cache)
+        if last is not None:
+            sumlogdet = sumlogdet + last
         if not verbose or self.config.nleapfrog == 0:
             h = self._hamiltonian_n(x_, v_, beta)
         acc = self._accept_prob_n(h_init, h, sumlogdet)

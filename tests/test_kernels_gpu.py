@@ -296,3 +296,14 @@ def test_fused_heads_vupdate(ops, cplx, shape):
         fn = host(f) * np.exp(0.07 * qn) + tn
         want = np.exp(lj) * host(v) - 0.035 * fn if fwd else np.exp(lj) * (host(v) + 0.035 * fn)
         assert err(host(v2), want) < 1e-12 and err(host(ld2), lj.sum(1)) < 1e-11
+        # paired updates (optionally with the momentum flip in between) == two single calls
+        for flip in (False, True):
+            for fwd2 in (True, False):
+                va = v.clone()
+                la = ops.vnet_heads_vupdate_(z, scaled, nw, va, f, 0.07, fwd)
+                if flip:
+                    va = -va
+                la = la + ops.vnet_heads_vupdate_(z, scaled, nw, va, f, 0.05, fwd2)
+                vb = v.clone()
+                lb = ops.vnet_heads_vupdate_pair_(z, scaled, nw, vb, f, 0.07, fwd, flip, 0.05, fwd2)
+                assert float((va - vb).abs().max()) < 1e-13 and err(host(la), host(lb)) < 1e-11
