@@ -114,17 +114,19 @@ class KernelTimer:
             e0.record()
             orig(name, *a)
             e1.record()
-            timer.records.append((name, a[2] if name.startswith('l2q_gemm') else None, e0, e1))
+            fl = 2.0 * a[2] * a[3] * (a[4] + a[7]) if name.startswith('l2q_gemm') else 0.0
+            timer.records.append((name, fl, e0, e1))
         native.call = timed_call
         import l2hmc._ops as ops
         ops.N.call = timed_call
 
     def summary(self):
         out = {}
-        for name, _, e0, e1 in self.records:
-            d = out.setdefault(name, [0, 0.0])
+        for name, fl, e0, e1 in self.records:
+            d = out.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += fl
         return out
 
 
@@ -223,47 +225,57 @@ def main():
         ks = timer.summary()
         total_k = sum(v[1] for v in ks.values())
         kernels = {}
-        for name, (cnt, tt) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
+        for name, (cnt, tt, fl) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
             ent = {'launches': cnt, 'avg_ms': round(tt / cnt * 1e3, 4),
                    'share': round(tt / total_k, 4)}
             if name in ALG_BYTES:
                 ent['GB/s'] = round(sites * ALG_BYTES[name] / (tt / cnt) / 1e9, 1)
             kernels[name] = ent
+        traffic_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+
+        def traffic(name):
+            t = pmc.get(name)
+            return (None, None) if t is None else (t['total_bytes'], t.get('source'))
 
         def hbm_roof(name):
-            cnt, tt = ks[name]
+            cnt, tt, _ = ks[name]
             ach = sites * ALG_BYTES[name] / (tt / cnt) / 1e9
+            tr, src = traffic(name)
             return {'kernel': name, 'bound': 'hbm', 'achieved': round(ach, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': None, 'avg_ms': round(tt / cnt * 1e3, 4), 'launches': cnt,
-                    'algorithmic_bytes_per_launch': sites * ALG_BYTES[name]}
+                    'traffic': tr, 'traffic_source': src, 'avg_ms': round(tt / cnt * 1e3, 4),
+                    'launches': cnt, 'algorithmic_bytes_per_launch': sites * ALG_BYTES[name],
+                    'time_s': tt}
+
+        def mfma_roof(names, label, flops):
+            cnt = sum(ks[n][0] for n in names)
+            tt = sum(ks[n][1] for n in names)
+            ach = flops / tt / 1e12
+            tr, src = traffic(names[0])
+            return {'kernel': label, 'bound': 'mfma', 'achieved': round(ach, 2),
+                    'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                    'frac': round(ach / FP64_MFMA_PEAK_TF, 4), 'traffic': tr,
+                    'traffic_source': src, 'avg_ms': round(tt / cnt * 1e3, 4), 'launches': cnt,
+                    'time_s': tt}
 
         rooflines = []
         force_name = 'l2q_su3_force' if 'l2q_su3_force' in ks else 'l2q_su3_force_kick'
         rooflines.append(hbm_roof(force_name))
         rooflines.append(hbm_roof('l2q_su3_plaq_reduce'))
+        heads = [n for n in ('l2q_vnet_heads_vupdate_pair_f64', 'l2q_vnet_heads_vupdate_f64')
+                 if n in ks]
+        if heads:
+            per = 3 * 2.0 * args.nchains * args.units[-1] * 36 * V       # s, t, q heads
+            rooflines.append(mfma_roof(heads, 'l2q_vnet_heads_vupdate[_pair]_f64 (3 heads + '
+                                       'v-update)', per * sum(ks[n][0] for n in heads)))
         if 'l2q_gemm_f64' in ks:
-            h = args.units[0]
-            cnt, tt = ks['l2q_gemm_f64']
-            # per vnet call: input layer 2*nb*h*(2*32V) + heads 3 * 2*nb*h*36V (+ hidden)
-            flops_call = 2.0 * args.nchains * h * (64 * V) + 3 * 2.0 * args.nchains * args.units[-1] * 36 * V
-            for a, b in zip(args.units[:-1], args.units[1:]):
-                flops_call += 2.0 * args.nchains * a * b
-            ncalls = cnt / (4 + len(args.units) - 1)
-            ach = flops_call * ncalls / tt / 1e12
-            rooflines.append({'kernel': 'l2q_gemm_f64 (vnet layers)', 'bound': 'mfma',
-                              'achieved': round(ach, 2), 'peak': FP64_MFMA_PEAK_TF,
-                              'unit': 'TFLOP/s', 'frac': round(ach / FP64_MFMA_PEAK_TF, 4),
-                              'traffic': None, 'launches': cnt})
-        # the dominant kernel by measured time among the roofline'd ones
-        def ktime(r):
-            return ks[r['kernel'].split(' ')[0]][1]
-        roofline = dict(max(rooflines, key=ktime))
-        traffic_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(traffic_file):
-            tr = json.load(open(traffic_file))
-            for r in rooflines + [roofline]:
-                r['traffic'] = tr.get(r['kernel'].split(' ')[0])
+            rooflines.append(mfma_roof(['l2q_gemm_f64'], 'l2q_gemm_f64 (input + hidden layers)',
+                                       ks['l2q_gemm_f64'][2]))
+        # `roofline` = the dominant kernel (largest share of the timed region) among those
+        roofline = dict(max(rooflines, key=lambda r: r['time_s']))
+        for r in rooflines + [roofline]:
+            r.pop('time_s', None)
         nchain_lf = world * args.nchains * nlf_exec * args.steps
         out = {
             'metric': 'chain*leapfrog-steps/sec, 4D SU(3) 8^4 fp64 '

@@ -277,7 +277,7 @@ struct HeadsArgs {
 // the same x, hence the same (s, t, q): both are applied here from one evaluation of the heads
 // (optionally with the momentum flip of the merged trajectory in between).
 template <bool CPLX, bool FWD, bool PAIR>
-__global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_kernel(HeadsArgs a, int swz) {
+__global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_kernel(HeadsArgs a, int swz, int stagger) {
   constexpr int BM = 64, BN = kHeadsBN, NJ = BN / 32;
   using T = double;
   using acc_t = v4f64;
@@ -288,6 +288,12 @@ __global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_ker
   // logical block order: m fastest, so the M/64 blocks that share a W tile are adjacent and
   // (after the XCD swizzle) on the same XCD's L2
   const long mt = (a.M + BM - 1) / BM;
+  // The two workgroups co-resident on a CU start together and would otherwise run their
+  // MFMA-free epilogues at the same time; delaying the second resident set once keeps one
+  // block's epilogue under the other's MFMA main loop for the rest of the launch.
+  if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
   const long m0 = (w % mt) * BM, n0 = (w / mt) * BN;
 
@@ -524,10 +530,11 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
   a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncols;
   const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
   const int swz = tuning().xcd_swizzle;
+  const int stg = tuning().heads_stagger;
   // partial columns of wave tiles that fall entirely beyond N are never written: clear first
   (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * sizeof(double), st);
 #define L2Q_HEADS(C, F, P) \
-  hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz)
+  hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz, stg)
   if (pair) {
     if (is_complex) { if (forward) L2Q_HEADS(true, true, true); else L2Q_HEADS(true, false, true); }
     else { if (forward) L2Q_HEADS(false, true, true); else L2Q_HEADS(false, false, true); }

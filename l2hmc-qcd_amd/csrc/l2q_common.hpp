@@ -15,6 +15,7 @@ struct Tuning {
   int force_occ = 2;
   int xcd_swizzle = 1;
   int plaq_sweep = 0;     // 1: t-sweep plaquette kernel (measured slower: L2 cannot hold the slices)
+  int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
   int force_tile = 1;     // LDS-tiled force kernel (0: flat thread-per-link grid)
 };
 Tuning& tuning();

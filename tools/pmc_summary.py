@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Collate rocprofv3 --pmc passes (one output dir per counter group, csv format) into a text
+summary and profiles/pmc_traffic.json (HBM/fabric bytes per launch, keyed by C-ABI entry point).
+usage: pmc_summary.py <glob of p_counter_collection.csv> <out.txt> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
+    'su3_plaq_kernel': 'l2q_su3_plaq_reduce', 'su3_plaq_sweep_kernel': None,
+    'su3_force_tile_kernel<false': 'l2q_su3_force', 'su3_force_kernel<false': None,
+    'fused_heads_vupdate_kernel<true, true, true>': 'l2q_vnet_heads_vupdate_pair_f64',
+    'fused_heads_vupdate_kernel<true, true, false>': 'l2q_vnet_heads_vupdate_f64',
+    'gemm_nt_kernel<double, false, true>': 'l2q_gemm_f64',
+    'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
+}
+
+
+def short(n):
+    return re.sub(r'\(.*', '', n).replace('void ', '')[:80]
+
+
+def main():
+    files = glob.glob(sys.argv[1])
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    lines = ['# rocprofv3 --pmc passes (separate runs per counter group) of tools/kprof.py:',
+             '# SU(3) 8^4, 256 chains, fp64.  FETCH_SIZE / WRITE_SIZE in KiB as reported; on gfx950',
+             '# FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM',
+             '# section) -> read bytes = 2 * FETCH_SIZE * 1024.  Means over the launches of a run.', '']
+    traffic = {}
+    for k, v in agg.items():
+        if 'l2q' not in k:
+            continue
+        lines.append(k)
+        for c, vals in sorted(v.items()):
+            lines.append(f'    {c:28s} launches={len(vals):3d} mean={sum(vals) / len(vals):.5g}')
+        if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            rd = 2 * sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']) * 1024
+            wr = sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE']) * 1024
+            lines.append(f'    -> HBM/fabric traffic per launch: read {rd / 1e6:.1f} MB (FETCH_SIZE x2) '
+                         f'+ write {wr / 1e6:.1f} MB = {(rd + wr) / 1e6:.1f} MB')
+            for frag, entry in ENTRY.items():
+                if entry and frag in k:
+                    traffic[entry] = {'read_bytes': rd, 'write_bytes': wr, 'total_bytes': rd + wr,
+                                      'source': f'{sys.argv[2]} ({k})'}
+        if 'TCC_HIT_sum' in v:
+            h, m = sum(v['TCC_HIT_sum']), sum(v['TCC_MISS_sum'])
+            lines.append(f'    -> L2 hit rate {h / (h + m):.3f}')
+    open(sys.argv[2], 'w').write('\n'.join(lines) + '\n')
+    json.dump(traffic, open(sys.argv[3], 'w'), indent=1)
+    print('\n'.join(l for l in lines if '->' in l or (l and not l.startswith(' '))))
+
+
+if __name__ == '__main__':
+    main()
