@@ -911,6 +911,14 @@ class Dynamics(nn.Module):
         return {'init': self._state_from_n(xn, vn, beta),
                 'proposed': self._state_from_n(x_, v_, beta), 'metrics': hist}
 
+    def make_graphed(self, x: Tensor, beta: float, mode: str = 'fb', eps: Optional[float] = None,
+                     nleapfrog: Optional[int] = None, warmup: int = 2) -> 'GraphedTransition':
+        """Capture one whole transition (momenta, 2N leapfrog steps, accept/select) into a HIP
+        graph.  The U(1) configs are launch-bound (~40 small kernels per leapfrog step on a
+        16 x 16 lattice); replaying a graph removes the per-launch host cost.  `beta` must be a
+        Python float (a tensor would need a host read inside the capture)."""
+        return GraphedTransition(self, x, float(beta), mode, eps, nleapfrog, warmup)
+
     def random_state(self, beta: float) -> State:
         x = self.g.random(list(self.xshape)).to(self.device)
         v = self.g.random_momentum(list(self.xshape)).to(x.device)
@@ -923,3 +931,42 @@ class Dynamics(nn.Module):
         dx = torch.abs(state.x - state_.x.reshape(state.x.shape))
         dv = torch.abs(state.v - state_.v.reshape(state.v.shape))
         return {'dx': dx.detach().cpu().numpy(), 'dv': dv.detach().cpu().numpy()}
+
+
+class GraphedTransition:
+    """A transition of `Dynamics` recorded once as a HIP graph and replayed with new inputs.
+
+        g = dyn.make_graphed(x, beta=4.0)          # 'fb' (Dynamics.forward) or 'hmc'
+        x_out, metrics = g(x)                      # same outputs as dyn((x, beta))
+
+    Outputs are views of the graph's static buffers: valid until the next call (clone to keep).
+    Random draws come from the device generator (graph-safe philox offsets), i.e. successive
+    replays draw fresh momenta / accept uniforms."""
+
+    def __init__(self, dyn: Dynamics, x: Tensor, beta: float, mode: str, eps, nleapfrog,
+                 warmup: int):
+        assert mode in ('fb', 'hmc')
+        if not torch.cuda.is_available():
+            raise RuntimeError('GraphedTransition needs a GPU')
+        self.dyn, self.beta, self.mode = dyn, beta, mode
+        self.static_x = x.to(DEVICE).clone()
+
+        def run():
+            if mode == 'fb':
+                return dyn.apply_transition_fb((self.static_x, beta))
+            return dyn.apply_transition_hmc((self.static_x, beta), eps=eps, nleapfrog=nleapfrog)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # warm-up: caches, workspaces, weight copies
+            for _ in range(max(1, warmup)):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out_x, self.out_metrics = run()
+
+    def __call__(self, x: Tensor):
+        self.static_x.copy_(x.reshape(self.static_x.shape))
+        self.graph.replay()
+        return self.out_x, self.out_metrics

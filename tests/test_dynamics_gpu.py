@@ -231,3 +231,45 @@ def test_state_dict_layout():
     assert dyn.xnet.input_layer.xlayer.weight.shape == (1, 2 * 36 * 16)
     m = dyn.masks[0]
     assert m.shape == (1, dyn.xdim) and m.dtype == torch.float32 and int(m.sum()) == dyn.xdim // 2
+
+
+@pytest.mark.parametrize('name', ['u1_c1'])
+def test_graphed_transition_u1(golden, name):
+    """a transition captured into a HIP graph replays to the same result as the eager path"""
+    torch.set_default_dtype(torch.float32)
+    g = golden(name)
+    dyn, lat = build_u1_dynamics(g, verbose=False)
+    x = dev(g['x'])
+    beta = float(g['beta'])
+    inj = {'normals': dev(g['normals']), 'u': dev(g['u'])}
+    dyn._inject = inj
+    xo_e, m_e = dyn((x, beta))
+    gt = dyn.make_graphed(x, beta)
+    xo_g, m_g = gt(x)
+    assert err(host(xo_g), host(xo_e)) == 0.0
+    assert np.array_equal(host(m_g['acc_mask']), g['acc_mask'])
+    assert err(host(m_g['acc']), host(m_e['acc'])) == 0.0
+    # replay with another input: equals the eager result for that input
+    x2 = dev(np.roll(g['x'], 1, axis=0))
+    xo_e2, _ = dyn((x2, beta))
+    xo_g2, _ = gt(x2)
+    assert err(host(xo_g2), host(xo_e2)) == 0.0
+    # HMC flavour
+    dyn._inject = {'normals': dev(g['hmc_normals']), 'u': dev(g['hmc_u'])}
+    gh = dyn.make_graphed(x, beta, mode='hmc', eps=float(g['hmc_eps']),
+                          nleapfrog=int(g['hmc_nleapfrog']))
+    xo_h, m_h = gh(x)
+    assert np.array_equal(host(m_h['acc_mask']), g['hmc_acc_mask'])
+
+
+def test_graphed_transition_su3(golden):
+    torch.set_default_dtype(torch.float64)
+    g = golden('su3_l2hmc')
+    dyn, lat = build_su3_dynamics(g, verbose=False)
+    x = dev(g['x'])
+    dyn._inject = {'normals': dev(g['normals']), 'u': dev(g['u'])}
+    xo_e, m_e = dyn((x, float(g['beta'])))
+    gt = dyn.make_graphed(x, float(g['beta']))
+    xo_g, m_g = gt(x)
+    assert err(host(xo_g), host(xo_e)) == 0.0
+    assert np.array_equal(host(m_g['acc_mask']), g['acc_mask'])

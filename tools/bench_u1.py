@@ -42,3 +42,15 @@ for name, fn, nlf in (('Dynamics.forward (L2HMC)', lambda x: dyn((x, beta)), 2 *
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     print(f'U(1) {a.L} nb={a.nb} nlf={a.nlf} conv={a.conv} {name}: {dt*1e3:.2f} ms/step '
           f'{a.nb * nlf / dt:.3e} chain*LF/s  acc={float(m["acc"].mean()):.3f}')
+for name, kw in (('graphed forward (L2HMC)', dict(mode='fb')),
+                 ('graphed hmc', dict(mode='hmc', eps=0.1, nleapfrog=2 * a.nlf))):
+    gt = dyn.make_graphed(x, a.beta, **kw)
+    for _ in range(2):
+        xo, m = gt(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        xo, m = gt(x)
+        x = dyn.g.compat_proj(xo.reshape(x.shape))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+    print(f'U(1) {a.L} nb={a.nb} nlf={a.nlf} conv={a.conv} {name}: {dt*1e3:.2f} ms/step '
+          f'{a.nb * 2 * a.nlf / dt:.3e} chain*LF/s  acc={float(m["acc"].mean()):.3f}')
