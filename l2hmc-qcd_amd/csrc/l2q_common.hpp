@@ -14,7 +14,7 @@ struct Tuning {
   int plaq_occ = 2;
   int force_occ = 2;
   int xcd_swizzle = 1;
-  int plaq_sweep = 0;     // 1: t-sweep plaquette kernel (measured slower: L2 cannot hold the slices)
+  int plaq_sweep = 2;     // 2: slice-resident kernel (LDS + register prefetch), 1: L2 t-sweep, 0: flat
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
   int force_tile = 1;     // LDS-tiled force kernel (0: flat thread-per-link grid)
 };

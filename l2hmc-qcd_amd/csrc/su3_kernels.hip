@@ -278,6 +278,166 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_plaq_sweep_kernel(
   }
 }
 
+// ------------------------------------------------------------------ plaquette, slice-resident
+// One workgroup = 128 spatial sites of one chain, sweeping t.  LDS holds the 4 links of the
+// CURRENT time slice for the tile ([4][9][128] complex = 72 KiB); the NEXT slice's links are
+// prefetched into registers while the current slice is being computed and become the LDS
+// tile of the next iteration.  Every link is therefore fetched from HBM exactly once per
+// sweep (plus the x-halo of the tile): own links, +y/+z(/+x) neighbours come from LDS, the
+// +t neighbours from the prefetch registers.  (The flat kernel moves 2.7x the algorithmic
+// bytes through the fabric and is bound by that.)
+constexpr int kSlice = 128;
+
+__device__ __forceinline__ void lds_store_link(double2* tile, int rho, int li, const M3& m) {
+#pragma unroll
+  for (int e = 0; e < 9; ++e) tile[(rho * 9 + e) * kSlice + li] = make_double2(m.re[e], m.im[e]);
+}
+
+// link rho through a (base, stride) pair that points either into the LDS tile (stride 128)
+// or into the global slice (stride V): one code path, flat addressing
+struct SliceRef {
+  const double2* base;   // entry e of link rho at base[(rho * 9 + e) * stride]
+  int stride;
+};
+
+// own-site link: always in the tile -> plain ds_read_b128
+__device__ __forceinline__ void slice_own(M3& m, const double2* tile, int rho, int li) {
+  const double2* l = tile + rho * 9 * kSlice + li;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double2 dd = l[e * kSlice];
+    m.re[e] = dd.x; m.im[e] = dd.y;
+  }
+}
+
+// neighbour link: LDS when the (wave-uniform, loop-invariant) direction is known in-tile
+template <bool LDS>
+__device__ __forceinline__ void slice_nbr(M3& m, const SliceRef& r, const double2* tile, int lnb,
+                                          int rho);
+template <>
+__device__ __forceinline__ void slice_nbr<true>(M3& m, const SliceRef&, const double2* tile,
+                                                int lnb, int rho) {
+  slice_own(m, tile, rho, lnb);
+}
+
+__device__ __forceinline__ void slice_link(M3& m, const SliceRef& r, int rho) {
+  const double2* p = r.base + rho * 9 * r.stride;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double2 dd = p[e * r.stride];
+    m.re[e] = dd.x; m.im[e] = dd.y;
+  }
+}
+
+template <>
+__device__ __forceinline__ void slice_nbr<false>(M3& m, const SliceRef& r, const double2*, int,
+                                                 int rho) {
+  slice_link(m, r, rho);
+}
+
+// YZ: +y and +z neighbours of every lane are inside the tile (e.g. the tile is a stack of
+// whole (y,z) planes) -> plain LDS reads for them; +x stays on the generic flat path.
+template <bool YZ>
+__global__ __launch_bounds__(kSlice, 1) void su3_plaq_slice_kernel(
+    const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz,
+    double* __restrict__ partial) {
+  __shared__ double2 tile[4 * 9 * kSlice];
+  __shared__ double red[8];
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const int per_chain = nsb * tsplit;
+  const long c = w / per_chain;
+  const int r = (int)(w % per_chain);
+  const int tc = r / nsb, sb = r % nsb;
+  const int Vs = d.X * d.Y * d.Z, V = d.V;
+  const int tile0 = sb * kSlice;
+  const int li = threadIdx.x;
+  const int sp = tile0 + li;                            // spatial site (Vs % 128 == 0)
+  const int tlen = (d.T + tsplit - 1) / tsplit;
+  const int t0 = tc * tlen, t1 = min(d.T, t0 + tlen);
+  const double2* xc = xn + c * 36L * V;
+  // periodic spatial neighbours (indices within a slice)
+  int sn[4];
+  {
+    int q = sp;
+    const int z = q % d.Z; q /= d.Z;
+    const int y = q % d.Y; q /= d.Y;
+    const int x = q;
+    sn[0] = sp;
+    sn[1] = (x + 1 == d.X) ? sp - (d.X - 1) * d.Y * d.Z : sp + d.Y * d.Z;
+    sn[2] = (y + 1 == d.Y) ? sp - (d.Y - 1) * d.Z : sp + d.Z;
+    sn[3] = (z + 1 == d.Z) ? sp - (d.Z - 1) : sp + 1;
+  }
+  bool in_tile[4];                                      // wave-uniform, loop-invariant
+#pragma unroll
+  for (int u = 0; u < 4; ++u) in_tile[u] = __all((unsigned)(sn[u] - tile0) < (unsigned)kSlice);
+  M3 nxt[4];
+#pragma unroll
+  for (int rho = 0; rho < 4; ++rho) load_link(nxt[rho], xc + rho * 9 * V, V, t0 * Vs + sp);
+  double sr = 0.0, si = 0.0;
+#pragma unroll 1
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();                                    // previous slice fully consumed
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) lds_store_link(tile, rho, li, nxt[rho]);
+    __syncthreads();
+    const int tn = (t + 1 == d.T) ? 0 : t + 1;
+    // prefetch the next slice: U_1..U_3 now (needed by the temporal planes below), U_0 after
+    // the spatial planes (only needed as next iteration's tile) to cap register pressure
+#pragma unroll
+    for (int rho = 1; rho < 4; ++rho) load_link(nxt[rho], xc + rho * 9 * V, V, tn * Vs + sp);
+    const double2* xs = xc + (long)t * Vs;              // base of slice t (index by spatial site)
+    SliceRef nb_[4];                                    // own site and +x, +y, +z neighbours
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      nb_[u].base = in_tile[u] ? (const double2*)(tile + (sn[u] - tile0)) : (xs + sn[u]);
+      nb_[u].stride = in_tile[u] ? kSlice : V;
+    }
+    // spatial-spatial planes (u, v) = (2,1), (3,1), (3,2): everything in the current slice
+    {
+      M3 a, b, yuv;
+      slice_own(a, tile, 2, li); slice_nbr<YZ>(b, nb_[2], tile, sn[2] - tile0, 1); m3_mul_nn(yuv, a, b);
+      slice_own(a, tile, 1, li); slice_link(b, nb_[1], 2); m3_trace_y_abh(sr, si, yuv, a, b);
+    }
+    {
+      M3 a, b, yuv;
+      slice_own(a, tile, 3, li); slice_nbr<YZ>(b, nb_[3], tile, sn[3] - tile0, 1); m3_mul_nn(yuv, a, b);
+      slice_own(a, tile, 1, li); slice_link(b, nb_[1], 3); m3_trace_y_abh(sr, si, yuv, a, b);
+    }
+    {
+      M3 a, b, yuv;
+      slice_own(a, tile, 3, li); slice_nbr<YZ>(b, nb_[3], tile, sn[3] - tile0, 2); m3_mul_nn(yuv, a, b);
+      slice_own(a, tile, 2, li); slice_nbr<YZ>(b, nb_[2], tile, sn[2] - tile0, 3); m3_trace_y_abh(sr, si, yuv, a, b);
+    }
+    // temporal planes (u, 0): U_u(s) U_0(s+u) (U_0(s) U_u(s+t))^H, U_u(s+t) = prefetched link
+    load_link(nxt[0], xc, V, tn * Vs + sp);
+    {
+      M3 a, b, yuv;
+      slice_own(a, tile, 1, li); slice_link(b, nb_[1], 0); m3_mul_nn(yuv, a, b);
+      slice_own(a, tile, 0, li); m3_trace_y_abh(sr, si, yuv, a, nxt[1]);
+    }
+    {
+      M3 a, b, yuv;
+      slice_own(a, tile, 2, li); slice_nbr<YZ>(b, nb_[2], tile, sn[2] - tile0, 0); m3_mul_nn(yuv, a, b);
+      slice_own(a, tile, 0, li); m3_trace_y_abh(sr, si, yuv, a, nxt[2]);
+    }
+    {
+      M3 a, b, yuv;
+      slice_own(a, tile, 3, li); slice_nbr<YZ>(b, nb_[3], tile, sn[3] - tile0, 0); m3_mul_nn(yuv, a, b);
+      slice_own(a, tile, 0, li); m3_trace_y_abh(sr, si, yuv, a, nxt[3]);
+    }
+  }
+  // block reduction (2 waves)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sr += __shfl_down(sr, off, 64); si += __shfl_down(si, off, 64); }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = sr; red[(threadIdx.x >> 6) * 2 + 1] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[(c * per_chain + r) * 2 + 0] = red[0] + red[2];
+    partial[(c * per_chain + r) * 2 + 1] = red[1] + red[3];
+  }
+}
+
 // ------------------------------------------------------------------ staple force, LDS tile
 // One workgroup = 64 consecutive sites x 4 directions (wavefront w <-> mu = w).  The 4 own
 // links of the 64 sites are staged once in LDS ([4][9][64] complex = 36 KiB); every operand
@@ -602,7 +762,27 @@ int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, doub
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)ws;
   const int swz = tuning().xcd_swizzle;
-  if (tuning().plaq_sweep) {
+  if (tuning().plaq_sweep == 2 && (X * Y * Z) % kSlice == 0) {
+    const int Vs = X * Y * Z;
+    const int nsb = Vs / kSlice;
+    int tsplit = (int)cdiv(1024, (long)nb * nsb);      // keep >= ~1024 workgroups
+    if (tsplit > T) tsplit = T;
+    if (tsplit < 1) tsplit = 1;
+    const int tlen = (int)cdiv(T, tsplit);
+    tsplit = (int)cdiv(T, tlen);
+    const long per_chain = (long)nsb * tsplit;
+    L2Q_REQUIRE(ws_bytes >= (size_t)nb * per_chain * 2 * sizeof(double), L2Q_ESHAPE,
+                "workspace too small");
+    // a 128-site tile made of whole (y,z) rows with Y*Z | 128 keeps +y, +z inside the tile
+    const bool yz = (kSlice % (Y * Z)) == 0;
+    if (yz) hipLaunchKernelGGL(su3_plaq_slice_kernel<true>, dim3((unsigned)(nb * per_chain)), dim3(kSlice), 0, st,
+                               (const double2*)xn, d, nsb, tsplit, swz, partial);
+    else hipLaunchKernelGGL(su3_plaq_slice_kernel<false>, dim3((unsigned)(nb * per_chain)), dim3(kSlice), 0, st,
+                            (const double2*)xn, d, nsb, tsplit, swz, partial);
+    launch_finalize(partial, out, nb, per_chain, 2, 1.0, 0.0, st);
+    return check_launch("l2q_su3_plaq_reduce");
+  }
+  if (tuning().plaq_sweep == 1) {
     const int Vs = X * Y * Z;
     const int nsb = (int)cdiv(Vs, kBlock);
     int tsplit = (int)cdiv(1024, (long)nb * nsb);      // keep >= ~1024 workgroups in flight

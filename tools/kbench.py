@@ -50,12 +50,13 @@ def main():
         print(f'{name:34s} {t*1e3:8.3f} ms  {gbs:8.1f} GB/s  ({gbs/8000*100:5.1f}% of 8 TB/s)'
               + (f'  {tf:6.2f} TFLOP/s' if flop_per_site else ''), flush=True)
 
-    for sweep in (0, 1):
+    for sweep in (0, 1, 2):
         native.set_tuning('plaq_sweep', sweep)
         for occ in (2, 3, 4):
             native.set_tuning('plaq_occ', occ)
             rec(f'su3_plaq_reduce sweep={sweep} occ={occ}', timeit(lambda: ops.su3_plaq_sums_n(xn, L)), 576, 2800)
     native.set_tuning('plaq_occ', 2)
+    native.set_tuning('plaq_sweep', 2)
     native.set_tuning('xcd_swizzle', 0)
     rec('su3_plaq_reduce occ=2 noswz', timeit(lambda: ops.su3_plaq_sums_n(xn, L)), 576, 2800)
     native.set_tuning('xcd_swizzle', 1)
