@@ -50,17 +50,46 @@ DynamicsInput = Tuple[Tensor, Tensor]
 DynamicsOutput = Tuple[Tensor, dict]
 
 
-@dataclass
 class State:
-    x: Tensor               # gauge links
-    v: Tensor               # conj. momenta
-    beta: Tensor            # inv. coupling const.
+    """(x, v, beta) container with the reference's interface (dynamics.py:45-67).  Inside a
+    transition the fields live in the kernels' native layout; ``x`` / ``v`` may therefore be
+    given as zero-argument callables that convert to the reference layout on first access
+    (most callers only ever read ``mc_states.proposed.x``)."""
 
-    def __post_init__(self):
-        self.nb = self.x.shape[0]
-        self.xshape = self.x.shape
+    def __init__(self, x, v, beta, xshape=None):
+        self._x, self._v, self.beta = x, v, beta
+        if xshape is None:
+            xshape = self.x.shape
+        self.xshape = xshape
+        self.nb = xshape[0]
 
-    def flatten(self) -> State:
+    @property
+    def x(self) -> Tensor:
+        if callable(self._x):
+            self._x = self._x()
+        return self._x
+
+    @x.setter
+    def x(self, value) -> None:
+        self._x = value
+
+    @property
+    def v(self) -> Tensor:
+        if callable(self._v):
+            self._v = self._v()
+        return self._v
+
+    @v.setter
+    def v(self, value) -> None:
+        self._v = value
+
+    def __iter__(self):
+        return iter((self.x, self.v, self.beta))
+
+    def __repr__(self) -> str:
+        return f'State(nb={self.nb}, xshape={tuple(self.xshape)}, beta={self.beta})'
+
+    def flatten(self) -> 'State':
         return State(x=self.x.flatten(1), v=self.v.flatten(1), beta=self.beta)
 
     def to_numpy(self):
@@ -804,7 +833,11 @@ class Dynamics(nn.Module):
             state.v.to(DEVICE).reshape(xn.shape[0], -1).contiguous()
         return xn, vn
 
-    def _state_from_n(self, xn, vn, beta) -> State:
+    def _state_from_n(self, xn, vn, beta, lazy: bool = False) -> State:
+        if lazy and self.group == 'SU3':
+            shape = (xn.shape[0], *self.xshape[1:])
+            return State(x=lambda: self._unpack(xn), v=lambda: self._unpack(vn), beta=beta,
+                         xshape=shape)
         v = self._unpack(vn) if self.group == 'SU3' else vn
         return State(x=self._unpack(xn), v=v, beta=beta)
 
@@ -849,12 +882,16 @@ class Dynamics(nn.Module):
         ma = (acc > u).to(torch.float32)
         xo_n = ops.select_rows(x_.reshape(nb, -1), xn.reshape(nb, -1), ma).reshape(xn.shape)
         vo_n = ops.select_rows(v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)
-        init = self._state_from_n(xn, vn, beta)
-        prop = self._state_from_n(x_, v_, beta)
+        # reference-layout copies of the init / proposed / out states are made on first access
+        init = self._state_from_n(xn, vn, beta, lazy=True)
+        prop = self._state_from_n(x_, v_, beta, lazy=True)
         xout = self._unpack(xo_n).reshape(nb, -1)
-        vout = (self._unpack(vo_n) if self.group == 'SU3' else vo_n).reshape(nb, -1)
-        mc_states = MonteCarloStates(init=init, proposed=prop,
-                                     out=State(x=xout, v=vout, beta=beta))
+        if self.group == 'SU3':
+            out = State(x=xout, v=lambda: self._unpack(vo_n).reshape(nb, -1), beta=beta,
+                        xshape=xout.shape)
+        else:
+            out = State(x=xout, v=vo_n.reshape(nb, -1), beta=beta)
+        mc_states = MonteCarloStates(init=init, proposed=prop, out=out)
         if with_sumlogdet:
             hist.update({'beta': beta, 'sumlogdet': ma * hist['sumlogdet']})
         hist.update({'acc_mask': ma, 'mc_states': mc_states})
