@@ -529,6 +529,216 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_tile_kernel(
   }
 }
 
+// ------------------------------------------------------------------ staple force, slice-resident
+// One workgroup = 128 spatial sites x 4 directions (512 threads, wavefront pairs <-> mu),
+// sweeping t.  LDS holds TWO time slices of the tile's links (current and next,
+// 2 x [4][9][128] complex = 144 KiB); each thread prefetches its own link of the slice after
+// next into registers.  The staples that reach back to slice t-1 (the down-staple of a
+// spatial link in the t direction, built from slice t-1 links only) are computed one
+// iteration early and carried in registers, so slice t-1 is never needed again.
+// Per site and sweep the links are read from HBM once (+ the x-halo of the tile); ~17 of the
+// 19 operands of a link come from LDS instead of L2 (the flat kernel issues 76 matrix loads
+// per site to L2 and leaves the SIMDs idle 53 % of the time waiting for them).
+constexpr int kFS = 128;
+// compiler-only fence: keeps hipcc from hoisting the next staple's operand loads above the
+// current staple's arithmetic (register budget is 256 at 2 waves/SIMD)
+#define L2Q_SCHED_FENCE() asm volatile("" ::: "memory")
+
+struct SPos {
+  int q, x, y, z;        // spatial site index and coordinates
+};
+
+// one periodic hop in spatial direction dir (1, 2, 3 = x, y, z); dir and sgn are wave-uniform
+__device__ __forceinline__ SPos sp_move(SPos p, int dir, int sgn, const Dims& d) {
+  const int n = dir == 1 ? d.X : dir == 2 ? d.Y : d.Z;
+  const int st = dir == 1 ? d.Y * d.Z : dir == 2 ? d.Z : 1;
+  int c = dir == 1 ? p.x : dir == 2 ? p.y : p.z;
+  if (sgn > 0) {
+    if (c + 1 == n) { p.q -= (n - 1) * st; c = 0; } else { p.q += st; c += 1; }
+  } else {
+    if (c == 0) { p.q += (n - 1) * st; c = n - 1; } else { p.q -= st; c -= 1; }
+  }
+  if (dir == 1) p.x = c; else if (dir == 2) p.y = c; else p.z = c;
+  return p;
+}
+
+// link rho of spatial site q in a slice: LDS copy if q is inside the tile (wave-uniform),
+// else the global slice; one code path through a flat pointer
+__device__ __forceinline__ void fs_get(M3& m, const double2* slot, const double2* __restrict__ gsl,
+                                       int rho, int q, int tile0, int V) {
+  const int li = q - tile0;
+  const bool in = __all((unsigned)li < (unsigned)kFS);
+  const double2* base = in ? (slot + rho * 9 * kFS + li) : (gsl + rho * 9 * V + q);
+  const int stride = in ? kFS : V;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double2 dd = base[e * stride];
+    m.re[e] = dd.x; m.im[e] = dd.y;
+  }
+}
+
+__device__ __forceinline__ void fs_own(M3& m, const double2* slot, int rho, int lt) {
+  const double2* l = slot + rho * 9 * kFS + lt;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double2 dd = l[e * kFS];
+    m.re[e] = dd.x; m.im[e] = dd.y;
+  }
+}
+
+__device__ __forceinline__ void fs_put(double2* slot, int rho, int lt, const M3& m) {
+#pragma unroll
+  for (int e = 0; e < 9; ++e) slot[(rho * 9 + e) * kFS + lt] = make_double2(m.re[e], m.im[e]);
+}
+
+template <bool KICK>
+__global__ __launch_bounds__(4 * kFS, 2) void su3_force_slice_kernel(
+    const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
+    double2* __restrict__ out) {
+  extern __shared__ double2 fs_lds[];                   // [2][4][9][kFS]
+  constexpr int kSlot = 4 * 9 * kFS;
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const int per_chain = nsb * tsplit;
+  const long c = w / per_chain;
+  const int r = (int)(w % per_chain);
+  const int tc = r / nsb, sb = r % nsb;
+  const int Vs = d.X * d.Y * d.Z, V = d.V, T = d.T;
+  const int tile0 = sb * kFS;
+  const int lt = threadIdx.x & (kFS - 1), mu = threadIdx.x >> 7;      // mu is wave-uniform
+  const int tlen = (T + tsplit - 1) / tsplit;
+  const int t0 = tc * tlen, t1 = min(T, t0 + tlen);
+  const double2* xc = xn + c * 36L * V;
+  double2* oc = out + (c * 4 + mu) * 9L * V;
+  SPos p;
+  p.q = tile0 + lt;
+  {
+    int q = p.q;
+    p.z = q % d.Z; q /= d.Z;
+    p.y = q % d.Y; q /= d.Y;
+    p.x = q;
+  }
+  const int sp = p.q;
+  // prologue: slices t0-1 and t0 of the tile -> slots 0, 1 (each thread its own link)
+  {
+    const int ta = (t0 - 1 + T) % T;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+      const int sl = (ta + k) % T;
+      M3 tmp;
+      load_link(tmp, xc + mu * 9 * V, V, sl * Vs + sp);
+      fs_put(fs_lds + k * kSlot, mu, lt, tmp);
+    }
+  }
+  __syncthreads();
+  int slot_cur = 0;
+  M3 dcarry;
+  m3_zero(dcarry);
+  const int niter = (t1 - t0) + 1;
+#pragma unroll 1
+  for (int it = 0; it < niter; ++it) {
+    const int tcur = (t0 - 1 + it + T) % T;
+    const int tnext = (tcur + 1) % T;
+    const double2* cur = fs_lds + slot_cur * kSlot;
+    const double2* nxt = fs_lds + (slot_cur ^ 1) * kSlot;
+    const double2* gcur = xc + (long)tcur * Vs;
+    const double2* gnxt = xc + (long)tnext * Vs;
+    const bool more = it + 1 < niter;
+    SPos pmu = p;
+    if (mu != 0) pmu = sp_move(p, mu, +1, d);
+    if (it > 0) {
+      M3 acc;
+      if (mu == 0) {
+        m3_zero(acc);
+#pragma unroll 1
+        for (int nu = 1; nu < 4; ++nu) {
+          const SPos pp = sp_move(p, nu, +1, d), pm = sp_move(p, nu, -1, d);
+          M3 a, b, t;
+          // up:   U_nu(s+t) U_t(s+nu)^H U_nu(s)^H
+          fs_own(a, nxt, nu, lt);
+          fs_get(b, cur, gcur, 0, pp.q, tile0, V);
+          m3_mul_na(t, a, b);
+          fs_own(a, cur, nu, lt);
+          m3_mac_na(acc, t, a);
+          L2Q_SCHED_FENCE();
+          // down: U_nu(s+t-nu)^H U_t(s-nu)^H U_nu(s-nu)
+          fs_get(a, nxt, gnxt, nu, pm.q, tile0, V);
+          fs_get(b, cur, gcur, 0, pm.q, tile0, V);
+          m3_mul_aa(t, a, b);
+          fs_get(a, cur, gcur, nu, pm.q, tile0, V);
+          m3_mac_nn(acc, t, a);
+          L2Q_SCHED_FENCE();
+        }
+      } else {
+        acc = dcarry;                                  // down staple in the t direction
+        {
+          M3 a, b, t;
+          // up (nu = t): U_t(s+mu) U_mu(s+t)^H U_t(s)^H
+          fs_get(a, cur, gcur, 0, pmu.q, tile0, V);
+          fs_own(b, nxt, mu, lt);
+          m3_mul_na(t, a, b);
+          fs_own(a, cur, 0, lt);
+          m3_mac_na(acc, t, a);
+          L2Q_SCHED_FENCE();
+        }
+#pragma unroll 1
+        for (int nu = 1; nu < 4; ++nu) {
+          if (nu == mu) continue;
+          const SPos pp = sp_move(p, nu, +1, d), pm = sp_move(p, nu, -1, d);
+          const SPos pmm = sp_move(pmu, nu, -1, d);
+          M3 a, b, t;
+          // up:   U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H
+          fs_get(a, cur, gcur, nu, pmu.q, tile0, V);
+          fs_get(b, cur, gcur, mu, pp.q, tile0, V);
+          m3_mul_na(t, a, b);
+          fs_own(a, cur, nu, lt);
+          m3_mac_na(acc, t, a);
+          L2Q_SCHED_FENCE();
+          // down: U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu)
+          fs_get(a, cur, gcur, nu, pmm.q, tile0, V);
+          fs_get(b, cur, gcur, mu, pm.q, tile0, V);
+          m3_mul_aa(t, a, b);
+          fs_get(a, cur, gcur, nu, pm.q, tile0, V);
+          m3_mac_nn(acc, t, a);
+          L2Q_SCHED_FENCE();
+        }
+      }
+      M3 u, ua, f;
+      fs_own(u, cur, mu, lt);
+      m3_mul_nn(ua, u, acc);
+      m3_tah(f, ua);
+      const int s = tcur * Vs + sp;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        double2 rr = make_double2(coef * f.re[e], coef * f.im[e]);
+        if (KICK) {
+          const double2 v = oc[e * V + s];
+          rr.x += v.x; rr.y += v.y;
+        }
+        oc[e * V + s] = rr;
+      }
+      L2Q_SCHED_FENCE();
+    }
+    // prefetch this thread's link of the slice after next (hidden behind the carry staple,
+    // the barrier and the partner wavefront's work)
+    M3 pre;
+    if (more) load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
+    if (mu != 0 && more) {
+      // next iteration's t-direction down staple of link (tnext, sp, mu), all from slice tcur:
+      //   U_t(tcur, sp+mu)^H U_mu(tcur, sp)^H U_t(tcur, sp)
+      M3 a, b, t;
+      fs_get(a, cur, gcur, 0, pmu.q, tile0, V);
+      fs_own(b, cur, mu, lt);
+      m3_mul_aa(t, a, b);
+      fs_own(a, cur, 0, lt);
+      m3_mul_nn(dcarry, t, a);
+    }
+    __syncthreads();                                    // slice tcur fully consumed
+    if (more) fs_put(fs_lds + slot_cur * kSlot, mu, lt, pre);
+    slot_cur ^= 1;
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ per-link kernels
 // out = keep (.) x + expm(eps v) @ ((1-keep) (.) x).  TWO: the two half-updates of one
 // leapfrog step (keep = mask then keep = 1 - mask, or the reverse order when `complement`)
@@ -722,6 +932,27 @@ using namespace l2q;
 template <bool KICK>
 static void launch_force(const double2* xn, Dims d, int nb, long nblk, double coef, double2* out,
                          hipStream_t st) {
+  const int Vs_ = d.X * d.Y * d.Z;
+  if (tuning().force_tile == 2 && Vs_ % kFS == 0) {
+    const int nsb = Vs_ / kFS;
+    int tsplit = (int)cdiv(512, (long)nb * nsb);       // >= ~2 resident rounds of 256 CUs
+    if (tsplit > d.T) tsplit = d.T;
+    if (tsplit < 1) tsplit = 1;
+    const int tlen = (int)cdiv(d.T, tsplit);
+    tsplit = (int)cdiv(d.T, tlen);
+    const size_t lds = 2ul * 4 * 9 * kFS * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((su3_force_slice_kernel<KICK>), dim3((unsigned)((long)nb * nsb * tsplit)),
+                       dim3(4 * kFS), lds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, out);
+    return;
+  }
   if (tuning().force_tile) {
     const long ntile = cdiv(d.V, 64);
     const dim3 grid((unsigned)(nb * ntile)), block(kBlock);
