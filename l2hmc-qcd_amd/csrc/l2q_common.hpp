@@ -16,7 +16,7 @@ struct Tuning {
   int xcd_swizzle = 1;
   int plaq_sweep = 2;     // 2: slice-resident kernel (LDS + register prefetch), 1: L2 t-sweep, 0: flat
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
-  int force_tile = 1;     // LDS-tiled force kernel (0: flat thread-per-link grid)
+  int force_tile = 2;     // 2: slice-resident kernel, 1: LDS-tiled (64 sites x 4 mu), 0: flat
 };
 Tuning& tuning();
 

@@ -540,6 +540,12 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_tile_kernel(
 // 19 operands of a link come from LDS instead of L2 (the flat kernel issues 76 matrix loads
 // per site to L2 and leaves the SIMDs idle 53 % of the time waiting for them).
 constexpr int kFS = 128;
+// 0: carried t-staple + register prefetch of the slice after next (143 spilled VGPRs, 0.97 ms)
+// 1: no prefetch (59 spills, 0.64 ms)   2: no prefetch, t-staple re-read from slice t-1 through
+// L2 (18 spills, 0.56 ms) -- measured on MI355X at cfg-4; the register budget decides.
+#ifndef L2Q_FS_VARIANT
+#define L2Q_FS_VARIANT 2
+#endif
 // compiler-only fence: keeps hipcc from hoisting the next staple's operand loads above the
 // current staple's arithmetic (register budget is 256 at 2 waves/SIMD)
 #define L2Q_SCHED_FENCE() asm volatile("" ::: "memory")
@@ -669,7 +675,20 @@ __global__ __launch_bounds__(4 * kFS, 2) void su3_force_slice_kernel(
           L2Q_SCHED_FENCE();
         }
       } else {
+#if L2Q_FS_VARIANT != 2
         acc = dcarry;                                  // down staple in the t direction
+#else
+        {                                              // t-direction down staple from slice t-1 (L2)
+          const double2* gprv = xc + (long)((tcur - 1 + T) % T) * Vs;
+          M3 a, b, t;
+          load_link(a, gprv, V, pmu.q);
+          load_link(b, gprv + mu * 9 * V, V, sp);
+          m3_mul_aa(t, a, b);
+          load_link(a, gprv, V, sp);
+          m3_mul_nn(acc, t, a);
+          L2Q_SCHED_FENCE();
+        }
+#endif
         {
           M3 a, b, t;
           // up (nu = t): U_t(s+mu) U_mu(s+t)^H U_t(s)^H
@@ -720,8 +739,11 @@ __global__ __launch_bounds__(4 * kFS, 2) void su3_force_slice_kernel(
     }
     // prefetch this thread's link of the slice after next (hidden behind the carry staple,
     // the barrier and the partner wavefront's work)
+#if L2Q_FS_VARIANT == 0
     M3 pre;
     if (more) load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
+#endif
+#if L2Q_FS_VARIANT != 2
     if (mu != 0 && more) {
       // next iteration's t-direction down staple of link (tnext, sp, mu), all from slice tcur:
       //   U_t(tcur, sp+mu)^H U_mu(tcur, sp)^H U_t(tcur, sp)
@@ -732,8 +754,17 @@ __global__ __launch_bounds__(4 * kFS, 2) void su3_force_slice_kernel(
       fs_own(a, cur, 0, lt);
       m3_mul_nn(dcarry, t, a);
     }
+#endif
     __syncthreads();                                    // slice tcur fully consumed
+#if L2Q_FS_VARIANT == 0
     if (more) fs_put(fs_lds + slot_cur * kSlot, mu, lt, pre);
+#else
+    if (more) {
+      M3 pre;
+      load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
+      fs_put(fs_lds + slot_cur * kSlot, mu, lt, pre);
+    }
+#endif
     slot_cur ^= 1;
     __syncthreads();
   }

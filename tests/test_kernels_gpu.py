@@ -114,14 +114,14 @@ def test_su3_stencils_vs_oracle(ops, L):
         for variant in (0, 1, 2):
             for swz in (0, 1):
                 native.set_tuning('force_occ', occ); native.set_tuning('plaq_occ', occ)
-                native.set_tuning('plaq_sweep', variant); native.set_tuning('force_tile', variant & 1)
+                native.set_tuning('plaq_sweep', variant); native.set_tuning('force_tile', variant)
                 native.set_tuning('xcd_swizzle', swz)
                 assert err(host(ops.su3_plaq_sums_n(xn, L)), s) < 1e-10
                 assert err(host(ops.su3_unpack(ops.su3_force_n(xn, 5.7, L), L)), f) < 1e-13
                 v = xn.clone()
                 ops.su3_force_kick_n(xn, 5.7, -0.3, v, L)
                 assert err(host(ops.su3_unpack(v, L)), x - 0.3 * f) < 1e-12
-    for k, val in (('force_occ', 2), ('plaq_occ', 2), ('plaq_sweep', 2), ('force_tile', 1),
+    for k, val in (('force_occ', 2), ('plaq_occ', 2), ('plaq_sweep', 2), ('force_tile', 2),
                    ('xcd_swizzle', 1)):
         native.set_tuning(k, val)
 

@@ -61,13 +61,14 @@ def main():
     rec('su3_plaq_reduce occ=2 noswz', timeit(lambda: ops.su3_plaq_sums_n(xn, L)), 576, 2800)
     native.set_tuning('xcd_swizzle', 1)
     f = torch.empty_like(xn)
-    for tile in (0, 1):
+    for tile in (0, 1, 2):
         native.set_tuning('force_tile', tile)
-        for occ in (2, 3):
+        for occ in ((2, 3) if tile < 2 else (2,)):
             native.set_tuning('force_occ', occ)
             rec(f'su3_force tile={tile} occ={occ}', timeit(lambda: native.call(
                 'l2q_su3_force', xn, 6.0, f, nb, *L)), 1152, 11200)
     native.set_tuning('force_occ', 2)
+    native.set_tuning('force_tile', 1)
     native.set_tuning('xcd_swizzle', 0)
     rec('su3_force occ=2 noswz', timeit(lambda: native.call(
         'l2q_su3_force', xn, 6.0, f, nb, *L)), 1152, 11200)
