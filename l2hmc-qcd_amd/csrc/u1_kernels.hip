@@ -68,20 +68,36 @@ __global__ __launch_bounds__(kBlock) void u1_plaq_kernel(const T* __restrict__ x
   if (threadIdx.x == 0) { out[c * 3 + 0] = (T)a; out[c * 3 + 1] = (T)b; out[c * 3 + 2] = (T)p; }
 }
 
-// force written and/or fused kick v += coef * F
+// force written and/or fused kick v += coef * F.  One workgroup per chain: sin(theta) of every
+// plaquette is computed ONCE into LDS (each one enters 4 force components), then the force
+// is two differences of LDS values.  Lattices beyond kU1MaxLds sites recompute instead.
+constexpr int kU1MaxLds = 8192;
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void u1_force_kernel(const T* __restrict__ x, T beta,
                                                           T* __restrict__ force, T* v, T coef,
                                                           int Tn, int Xn) {
+  __shared__ T sth[kU1MaxLds];
   const int c = blockIdx.x, V = Tn * Xn;
   const T* xc = x + (long)c * 2 * V;
+  const bool cached = V <= kU1MaxLds;
+  if (cached) {
+    for (int s = threadIdx.x; s < V; s += kBlock)
+      sth[s] = Math<T>::sin(plaq_angle(xc, s / Xn, s % Xn, Tn, Xn));
+    __syncthreads();
+  }
   for (int s = threadIdx.x; s < V; s += kBlock) {
     const int t = s / Xn, xx = s % Xn;
     const int tm = (t == 0) ? Tn - 1 : t - 1;
     const int xm = (xx == 0) ? Xn - 1 : xx - 1;
-    const T s0 = Math<T>::sin(plaq_angle(xc, t, xx, Tn, Xn));
-    const T sxm = Math<T>::sin(plaq_angle(xc, t, xm, Tn, Xn));
-    const T stm = Math<T>::sin(plaq_angle(xc, tm, xx, Tn, Xn));
+    T s0, sxm, stm;
+    if (cached) {
+      s0 = sth[s]; sxm = sth[t * Xn + xm]; stm = sth[tm * Xn + xx];
+    } else {
+      s0 = Math<T>::sin(plaq_angle(xc, t, xx, Tn, Xn));
+      sxm = Math<T>::sin(plaq_angle(xc, t, xm, Tn, Xn));
+      stm = Math<T>::sin(plaq_angle(xc, tm, xx, Tn, Xn));
+    }
     const T f0 = beta * (s0 - sxm);
     const T f1 = beta * (-s0 + stm);
     const long o = (long)c * 2 * V;

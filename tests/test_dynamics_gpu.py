@@ -273,3 +273,24 @@ def test_graphed_transition_su3(golden):
     xo_g, m_g = gt(x)
     assert err(host(xo_g), host(xo_e)) == 0.0
     assert np.array_equal(host(m_g['acc_mask']), g['acc_mask'])
+
+
+def test_u1_large_lattice_vs_oracle():
+    """BASELINE cfg-3 lattice (64 x 64) at a small chain count: kernels vs the numpy oracle"""
+    torch.set_default_dtype(torch.float32)
+    from oracle import u1 as ou1
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc import _ops as ops
+    rng = np.random.default_rng(4)
+    L = (64, 64)
+    x = ou1.compat_proj((2 * np.pi * rng.random((5, 2, *L))).astype(np.float32))
+    lat = LatticeU1(5, list(L))
+    xd = dev(x)
+    assert err(host(lat.action(xd, torch.tensor(6.0))), ou1.action(x, 6.0)) < 5e-2     # |S| ~ 2.4e4
+    assert err(host(lat.grad_action(xd, torch.tensor(6.0))), ou1.grad_action(x, 6.0)) < 2e-5
+    assert err(host(lat.plaqs(xd)), ou1.plaqs(x)) < 1e-6
+    assert err(host(lat.int_charges(xd)), ou1.int_charges(x)) < 1e-3
+    v = rng.normal(size=(5, 2 * 64 * 64)).astype(np.float32)
+    vd = dev(v)
+    ops.u1_force_kick_(xd, 6.0, -0.05, vd, L)
+    assert err(host(vd), v - 0.05 * ou1.grad_action(x, 6.0).reshape(5, -1)) < 2e-5

@@ -10,8 +10,9 @@ import re
 import sys
 
 ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
-    'su3_plaq_kernel': 'l2q_su3_plaq_reduce', 'su3_plaq_sweep_kernel': None,
-    'su3_force_tile_kernel<false': 'l2q_su3_force', 'su3_force_kernel<false': None,
+    'su3_plaq_slice_kernel': 'l2q_su3_plaq_reduce', 'su3_plaq_kernel': None, 'su3_plaq_sweep_kernel': None,
+    'su3_force_slice_kernel<false': 'l2q_su3_force', 'su3_force_tile_kernel<false': None,
+    'su3_force_kernel<false': None,
     'fused_heads_vupdate_kernel<true, true, true>': 'l2q_vnet_heads_vupdate_pair_f64',
     'fused_heads_vupdate_kernel<true, true, false>': 'l2q_vnet_heads_vupdate_f64',
     'gemm_nt_kernel<double, false, true>': 'l2q_gemm_f64',
