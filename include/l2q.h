@@ -243,6 +243,84 @@ int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw,
 int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int pool, int act,
                              float* out, void* stream);
 
+/* ================================================================ training-gradient path
+ * Reverse-mode (VJP) counterparts of the U(1) sub-updates and network layers, the train-mode
+ * BatchNorm1d, and the optimiser step.  The reference gets these from torch.autograd
+ * (`loss.backward()`, trainers/pytorch/trainer.py:1284-1314) and torch.optim.Adam (:206-209).
+ * Conventions: "g*" / "d*" arguments are cotangents with the shape of the quantity they
+ * belong to; arguments documented "+=" are accumulated into, all others are overwritten. */
+
+/* dx = dy * act'(z) from the activation OUTPUT y = act(z) (tanh, relu, leaky_relu, elu, none);
+ * dx may alias dy.  (network.py:447-451, 536-538) */
+int l2q_act_bwd(const void* dy, const void* y, int act, long n, int elem_bytes, void* dx,
+                void* stream);
+/* out = alpha * a * b element-wise (nn.Dropout mask, network.py:540-541); out may alias a */
+int l2q_mul(const void* a, const void* b, double alpha, long n, int elem_bytes, void* out,
+            void* stream);
+/* y[c][:] += a[c] * x[c][:]  (cotangent of the kinetic energy 1/2 sum v^2, dynamics.py:1485) */
+int l2q_axpy_rows(const void* x, const void* a, int nb, long n, int elem_bytes, void* y,
+                  void* stream);
+/* out[n] (+)= alpha * sum_m a[m][n] * (b ? b[m][n] : 1), fixed summation order
+ * (bias gradients; ScaledTanh.coeff gradient with b = the head's output) */
+int l2q_colsum(const void* a, const void* b, int M, int N, double alpha, int accumulate,
+               int elem_bytes, void* out, void* stream);
+/* head s = scale * exp(coeff[n]) * tanh(pre) (ScaledTanh, network.py:175-206):
+ * dpre = ds * scale e^coeff (1 - tanh^2), tanh recovered from s.  coeff == NULL: linear head
+ * t = scale * pre, dpre = scale * ds. */
+int l2q_scaled_tanh_bwd(const void* ds, const void* s, const void* coeff, double scale, int M,
+                        int N, int elem_bytes, void* dpre, void* stream);
+/* nn.BatchNorm1d in train mode over x[M][N] (network.py:543-544): batch mean / biased
+ * variance, y = (x - mean) invstd gamma + beta; running stats (may be NULL) updated with
+ * `momentum` and the unbiased variance like torch. */
+int l2q_bn_train_fwd(const void* x, const void* gamma, const void* beta, double eps,
+                     double momentum, void* running_mean, void* running_var, int M, int N,
+                     int elem_bytes, void* y, void* save_mean, void* save_invstd, void* stream);
+/* dx overwritten; dgamma, dbeta += */
+int l2q_bn_bwd(const void* dy, const void* x, const void* save_mean, const void* save_invstd,
+               const void* gamma, int M, int N, int elem_bytes, void* dx, void* dgamma,
+               void* dbeta, void* stream);
+/* adjoint of l2q_im2col_periodic_f32 (gather form, no atomics): dx (strides sn, sc, sh, sw)
+ * overwritten with the sum of the dcol entries that read each input pixel */
+int l2q_col2im_periodic_f32(const float* dcol, long sn, long sc, long sh, long sw, int nb, int C,
+                            int H, int W, int k, float* dx, void* stream);
+/* adjoint of l2q_maxpool_act_nhwc_f32: din[nb][H][W][C] overwritten (first maximum of each
+ * window receives dout * act'(out)) */
+int l2q_maxpool_act_nhwc_bwd_f32(const float* dout, const float* out, const float* in, int nb,
+                                 int H, int W, int C, int pool, int act, float* din,
+                                 void* stream);
+/* VJP of the U(1) force (the reference differentiates through autograd.grad(create_graph=True),
+ * lattice/u1/pytorch/lattice.py:102-117):  dx += D^T [cos(theta) beta (D dF)] */
+int l2q_u1_force_bwd(const void* x, const void* dF, double beta, int nb, int T, int X,
+                     int elem_bytes, void* dx, void* stream);
+/* VJP of the per-chain plaquette sums (action, sin-charge; lattice.py:80-86, 221-224):
+ * dx += D^T [-gcos[c] sin(theta) + gsin[c] cos(theta)];  gcos / gsin [nb], either may be NULL */
+int l2q_u1_plaq_bwd(const void* x, const void* gcos, const void* gsin, int nb, int T, int X,
+                    int elem_bytes, void* dx, void* stream);
+/* VJP of l2q_u1_x_update.  x: the field BEFORE the update; gx [nb][n]: cotangent of the
+ * updated field; gl [nb] (may be NULL): cotangent of logdet.  dx, ds, dt, dq overwritten,
+ * dv +=, deps[c] = per-chain d/d eps (sum over chains on the host side). */
+int l2q_u1_x_update_bwd(const void* x, const void* v, const void* s, const void* t, const void* q,
+                        const float* mask, int complement, double eps, int forward, int use_ncp,
+                        const void* gx, const void* gl, int elem_bytes, int nb, long n, void* dx,
+                        void* dv, void* ds, void* dt, void* dq, void* deps, void* stream);
+/* VJP of l2q_v_update (real fields).  v: momentum BEFORE the update.  All outputs overwritten. */
+int l2q_v_update_bwd(const void* v, const void* force, const void* s, const void* t,
+                     const void* q, double eps, int forward, const void* gv, const void* gl,
+                     int elem_bytes, int nb, long n, void* dv, void* dF, void* ds, void* dt,
+                     void* dq, void* deps, void* stream);
+/* VJP of l2q_u1_masked_cos_sin: dx += m (-sin(m x) dout[:, 0:2] + cos(m x) dout[:, 2:4]) */
+int l2q_u1_masked_cos_sin_bwd(const void* x, const float* mask, int complement, const void* dout,
+                              int nb, long n, int elem_bytes, void* dx, void* stream);
+/* torch.optim.Adam step (no weight decay / amsgrad) over one flat parameter arena; the
+ * gradient is multiplied by grad_scale first (1/world_size, gradient clipping). step >= 1. */
+int l2q_adam(void* p, const void* g, void* m, void* v, long n, double lr, double beta1,
+             double beta2, double eps, long step, double grad_scale, int elem_bytes,
+             void* stream);
+/* out[0] = sum a^2 (gradient norm for clip_grad_norm, trainer.py:1297-1301), order-stable */
+int l2q_sumsq(const void* a, long n, int elem_bytes, double* out, void* ws, size_t ws_bytes,
+              void* stream);
+size_t l2q_sumsq_ws_bytes(long n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,10 @@ from . import native as N
 
 C128 = torch.complex128
 
+# bumped whenever parameters are modified by a kernel behind PyTorch's back (the fused Adam
+# step on the flat arena does not touch Tensor._version): invalidates cached weight copies
+PARAM_GENERATION = [0]
+
 
 def _vol(lat: Sequence[int]) -> int:
     v = 1
@@ -35,6 +39,12 @@ def transpose(a: torch.Tensor, batch: int, rows: int, cols: int) -> torch.Tensor
     out = torch.empty_like(a)
     N.call('l2q_transpose', a, out, batch, rows, cols, a.element_size())
     return out
+
+
+def t2d(a: torch.Tensor) -> torch.Tensor:
+    """[rows, cols] -> contiguous [cols, rows]."""
+    r, c = a.shape
+    return transpose(a, 1, r, c).reshape(c, r)
 
 
 def su3_pack(x: torch.Tensor) -> torch.Tensor:
@@ -409,4 +419,179 @@ def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch
         return y.reshape(nb, Ho, Wo, cout)
     out = torch.empty((nb, Ho // pool, Wo // pool, cout), dtype=torch.float32, device=x.device)
     N.call('l2q_maxpool_act_nhwc_f32', y, nb, Ho, Wo, cout, pool, N.ACT[act], out)
+    return out
+
+
+# ---------------------------------------------------------------------------- training (VJPs)
+def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: Optional[str]) -> torch.Tensor:
+    """dy * act'(z) from the activation output y (in place on dy)."""
+    if N.ACT[act] == 0:
+        return dy
+    N.call('l2q_act_bwd', dy, y, N.ACT[act], dy.numel(), dy.element_size(), dy)
+    return dy
+
+
+def mul(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0,
+        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(a) if out is None else out
+    N.call('l2q_mul', a, b, float(alpha), a.numel(), a.element_size(), out)
+    return out
+
+
+def axpy_rows_(y: torch.Tensor, a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """y[c] += a[c] * x[c]"""
+    nb = y.shape[0]
+    N.call('l2q_axpy_rows', x, a.to(x.dtype).contiguous(), nb, y.numel() // nb, y.element_size(), y)
+    return y
+
+
+def add_(y: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """y += alpha * x (float32 / float64, any shape)."""
+    N.call('l2q_axpy', x, float(alpha), y, y.numel(), y.element_size())
+    return y
+
+
+def colsum_(out: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor] = None,
+            alpha: float = 1.0, accumulate: bool = True) -> torch.Tensor:
+    """out[n] (+)= alpha * sum_m a[m, n] * (b[m, n] | 1)"""
+    m, n = a.shape
+    N.call('l2q_colsum', a, b, m, n, float(alpha), int(accumulate), a.element_size(), out)
+    return out
+
+
+def scaled_tanh_bwd(ds: torch.Tensor, s: Optional[torch.Tensor], coeff: Optional[torch.Tensor],
+                    scale: float) -> torch.Tensor:
+    m, n = ds.shape
+    dpre = torch.empty_like(ds)
+    N.call('l2q_scaled_tanh_bwd', ds, s, coeff, float(scale), m, n, ds.element_size(), dpre)
+    return dpre
+
+
+def bn_train_fwd(x: torch.Tensor, gamma, beta, eps: float, momentum: float, running_mean,
+                 running_var):
+    m, n = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(n, dtype=x.dtype, device=x.device)
+    invstd = torch.empty(n, dtype=x.dtype, device=x.device)
+    N.call('l2q_bn_train_fwd', x, gamma, beta, float(eps), float(momentum), running_mean,
+           running_var, m, n, x.element_size(), y, mean, invstd)
+    return y, mean, invstd
+
+
+def bn_bwd(dy, x, mean, invstd, gamma, dgamma, dbeta) -> torch.Tensor:
+    m, n = x.shape
+    dx = torch.empty_like(x)
+    N.call('l2q_bn_bwd', dy, x, mean, invstd, gamma, m, n, x.element_size(), dx, dgamma, dbeta)
+    return dx
+
+
+def u1_force_bwd_(dx: torch.Tensor, x: torch.Tensor, dF: torch.Tensor, beta: float,
+                  lat: Sequence[int]) -> torch.Tensor:
+    T, X = (int(i) for i in lat)
+    N.call('l2q_u1_force_bwd', x, dF, float(beta), x.shape[0], T, X, x.element_size(), dx)
+    return dx
+
+
+def u1_plaq_bwd_(dx: torch.Tensor, x: torch.Tensor, gcos: Optional[torch.Tensor],
+                 gsin: Optional[torch.Tensor], lat: Sequence[int]) -> torch.Tensor:
+    T, X = (int(i) for i in lat)
+    gcos = None if gcos is None else gcos.to(x.dtype).contiguous()
+    gsin = None if gsin is None else gsin.to(x.dtype).contiguous()
+    N.call('l2q_u1_plaq_bwd', x, gcos, gsin, x.shape[0], T, X, x.element_size(), dx)
+    return dx
+
+
+def u1_x_update_bwd(x, v, s, t, q, mask, complement: bool, eps: float, forward: bool,
+                    use_ncp: bool, gx, gl, dv):
+    """-> (dx, ds, dt, dq, deps[nb]); dv accumulated in place."""
+    nb = x.shape[0]
+    n = x.numel() // nb
+    dx, ds, dt, dq = (torch.empty_like(s) for _ in range(4))
+    deps = torch.empty(nb, dtype=x.dtype, device=x.device)
+    N.call('l2q_u1_x_update_bwd', x, v, s, t, q, mask, int(complement), float(eps), int(forward),
+           int(use_ncp), gx, gl, x.element_size(), nb, n, dx, dv, ds, dt, dq, deps)
+    return dx, ds, dt, dq, deps
+
+
+def v_update_bwd(v, force, s, t, q, eps: float, forward: bool, gv, gl):
+    """-> (dv, dF, ds, dt, dq, deps[nb])"""
+    nb = v.shape[0]
+    n = v.numel() // nb
+    dv, dF, ds, dt, dq = (torch.empty_like(s) for _ in range(5))
+    deps = torch.empty(nb, dtype=v.dtype, device=v.device)
+    N.call('l2q_v_update_bwd', v, force, s, t, q, float(eps), int(forward), gv, gl,
+           v.element_size(), nb, n, dv, dF, ds, dt, dq, deps)
+    return dv, dF, ds, dt, dq, deps
+
+
+def u1_masked_cos_sin_bwd_(dx, x, mask, complement: bool, dout) -> torch.Tensor:
+    nb = x.shape[0]
+    N.call('l2q_u1_masked_cos_sin_bwd', x, mask, int(complement), dout, nb, x.numel() // nb,
+           x.element_size(), dx)
+    return dx
+
+
+def conv2d_periodic_gemm_train(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch.Tensor,
+                               pool: int = 1, act: Optional[str] = None):
+    """conv2d_periodic_gemm that also returns what the backward pass needs."""
+    x = x.contiguous()
+    if layout == 'nchw':
+        nb, C, H, W = x.shape
+        strides = (C * H * W, H * W, W, 1)
+    else:
+        nb, H, W, C = x.shape
+        strides = (H * W * C, 1, W * C, C)
+    cout, cin, k, _ = w.shape
+    Ho, Wo, Kc = H + k - 1, W + k - 1, C * k * k
+    col = torch.empty((nb * Ho * Wo, Kc), dtype=torch.float32, device=x.device)
+    N.call('l2q_im2col_periodic_f32', x, *strides, nb, C, H, W, k, col)
+    pool = max(int(pool), 1)
+    y = gemm(col, w.reshape(cout, Kc).contiguous(), b.contiguous(), act=None if pool > 1 else act)
+    ctx = {'col': col, 'strides': strides, 'dims': (nb, C, H, W, k, cout), 'pool': pool,
+           'act': act, 'y': y}
+    if pool == 1:
+        out = y.reshape(nb, Ho, Wo, cout)
+    else:
+        out = torch.empty((nb, Ho // pool, Wo // pool, cout), dtype=torch.float32, device=x.device)
+        N.call('l2q_maxpool_act_nhwc_f32', y, nb, Ho, Wo, cout, pool, N.ACT[act], out)
+    ctx['out'] = out
+    return out, ctx
+
+
+def conv2d_periodic_gemm_bwd(ctx: dict, dout: torch.Tensor, w: torch.Tensor, dw: torch.Tensor,
+                             db: torch.Tensor, need_dx: bool = True):
+    """dw, db accumulated (+=); returns dx in the layout / strides of the forward input."""
+    nb, C, H, W, k, cout = ctx['dims']
+    Ho, Wo, Kc = H + k - 1, W + k - 1, C * k * k
+    pool, act = ctx['pool'], ctx['act']
+    dout = dout.contiguous()
+    if pool > 1:
+        dy = torch.empty_like(ctx['y'])
+        N.call('l2q_maxpool_act_nhwc_bwd_f32', dout, ctx['out'], ctx['y'], nb, Ho, Wo, cout, pool,
+               N.ACT[act], dy)
+    else:
+        dy = act_bwd(dout.reshape(nb * Ho * Wo, cout).clone(), ctx['y'], act)
+    dy = dy.reshape(nb * Ho * Wo, cout)
+    colsum_(db, dy)
+    add_(dw, gemm(t2d(dy), t2d(ctx['col'])).reshape(dw.shape))      # dW = dy^T col
+    if not need_dx:
+        return None
+    dcol = gemm(dy, t2d(w.reshape(cout, Kc)))                        # [M, Kc]
+    sn, sc, sh, sw = ctx['strides']
+    shape = (nb, C, H, W) if sw == 1 else (nb, H, W, C)
+    dx = torch.empty(shape, dtype=torch.float32, device=dout.device)
+    N.call('l2q_col2im_periodic_f32', dcol, sn, sc, sh, sw, nb, C, H, W, k, dx)
+    return dx
+
+
+def adam_step_(p, g, m, v, lr: float, beta1: float, beta2: float, eps: float, step: int,
+               grad_scale: float = 1.0) -> None:
+    N.call('l2q_adam', p, g, m, v, p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+           int(step), float(grad_scale), p.element_size())
+
+
+def sumsq(a: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.float64, device=a.device)
+    ws = N.workspace(int(N.load().l2q_sumsq_ws_bytes(a.numel())), a.device)
+    N.call('l2q_sumsq', a, a.numel(), a.element_size(), out, ws, ws.numel())
     return out

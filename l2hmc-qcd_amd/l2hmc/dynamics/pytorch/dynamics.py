@@ -288,12 +288,19 @@ class Dynamics(nn.Module):
         (dynamics.py:82-83, 1270, 1394); cached per parameter version (no per-step sync)."""
         p = (self.xeps if which == 'x' else self.veps)[step]
         key = (which, step)
+        ver = (p._version, ops.PARAM_GENERATION[0])
         hit = self._eps_cache.get(key)
-        if hit is not None and hit[0] == p._version and hit[2] is p:
+        if hit is not None and hit[0] == ver and hit[2] is p:
             return hit[1]
-        val = float(sigmoid(p.detach().cpu().log()))
-        self._eps_cache[key] = (p._version, val, p)
-        return val
+        # refresh every step size with one device -> host copy
+        ps = list(self.xeps) + list(self.veps)
+        vals = torch.stack([q.detach().reshape(()) for q in ps]).cpu()
+        n = len(self.xeps)
+        for i, q in enumerate(ps):
+            k = ('x', i) if i < n else ('v', i - n)
+            self._eps_cache[k] = ((q._version, ops.PARAM_GENERATION[0]),
+                                  float(sigmoid(vals[i].log())), q)
+        return self._eps_cache[key][1]
 
     def _get_vnet(self, step: int):
         if not self._networks_built:

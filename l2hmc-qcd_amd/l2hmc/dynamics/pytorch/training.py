@@ -1,0 +1,294 @@
+"""Training-gradient path of the U(1) L2HMC sampler: one merged forward/backward trajectory
+recorded on a tape, the loss, and the reverse sweep that turns the loss cotangents into
+parameter gradients -- what ``loss.backward()`` does in the reference's
+``Trainer.train_step`` (trainers/pytorch/trainer.py:1284-1367) through torch.autograd.
+
+There is no autograd graph here.  Each sub-update of the integrator (dynamics.py:1187-1477)
+has a hand-written cotangent kernel in ``csrc/train_kernels.hip`` (``l2q_v_update_bwd``,
+``l2q_u1_x_update_bwd``, ``l2q_u1_force_bwd`` -- the reference differentiates *through* the
+force, ``create_graph=True`` -- ``l2q_u1_masked_cos_sin_bwd``, ``l2q_u1_plaq_bwd``) and the
+networks have explicit backward passes (network.py ``LeapfrogLayer.backward``).  The host keeps
+the tape: per sub-update the states it started from and the network activations
+(HBM is 288 GB; a 64 x 64 / 8192-chain trajectory tape is ~30 GB).  Only the per-chain scalars
+of the loss / acceptance probability ([nb] vectors) go through torch.autograd.
+
+Parameters and gradients live in one flat arena per dtype (``ParamArena``): the optimiser is a
+single fused Adam launch and the data-parallel gradient exchange a single all-reduce.
+
+SU(3): not built (needs the expm / projectSU / staple cotangents).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from l2hmc import DEVICE
+from l2hmc import _ops as ops
+
+Tensor = torch.Tensor
+
+
+# ------------------------------------------------------------------------------ arena
+class ParamArena:
+    """All trainable parameters of a module re-homed into ONE contiguous buffer per dtype,
+    with a matching flat gradient buffer (each ``p.grad`` is a view of it) and flat Adam
+    moments.  MI355X-first replacement of per-tensor optimiser loops and bucketed DDP:
+    one `l2q_adam` launch, one RCCL all-reduce."""
+
+    def __init__(self, module: nn.Module):
+        self.groups: dict = {}
+        params = [p for p in module.parameters() if p.requires_grad]
+        by_dtype: dict = {}
+        for p in params:
+            by_dtype.setdefault(p.dtype, []).append(p)
+        for dt, ps in by_dtype.items():
+            n = sum(p.numel() for p in ps)
+            flat = torch.empty(n, dtype=dt, device=DEVICE)
+            grad = torch.zeros(n, dtype=dt, device=DEVICE)
+            off = 0
+            with torch.no_grad():
+                for p in ps:
+                    k = p.numel()
+                    flat[off:off + k].copy_(p.detach().reshape(-1).to(DEVICE))
+                    p.data = flat[off:off + k].view(p.shape)
+                    p.grad = grad[off:off + k].view(p.shape)
+                    off += k
+            self.groups[dt] = {'params': ps, 'flat': flat, 'grad': grad,
+                               'm': torch.zeros_like(flat), 'v': torch.zeros_like(flat)}
+        self.step_count = 0
+        ops.PARAM_GENERATION[0] += 1
+
+    def zero_grad(self) -> None:
+        for g in self.groups.values():
+            g['grad'].zero_()
+
+    def numel(self) -> int:
+        return sum(g['flat'].numel() for g in self.groups.values())
+
+    def all_reduce(self) -> float:
+        """Sum the flat gradients over ranks (RCCL over xGMI: one collective per dtype);
+        returns the 1/world factor to fold into the optimiser step (DDP averages)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return 1.0
+        for g in self.groups.values():
+            dist.all_reduce(g['grad'], op=dist.ReduceOp.SUM)
+        return 1.0 / dist.get_world_size()
+
+    def grad_norm(self, scale: float = 1.0) -> float:
+        tot = 0.0
+        for g in self.groups.values():
+            tot += float(ops.sumsq(g['grad']).item())
+        return scale * tot ** 0.5
+
+    def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                  grad_scale: float = 1.0) -> None:
+        self.step_count += 1
+        for g in self.groups.values():
+            ops.adam_step_(g['flat'], g['grad'], g['m'], g['v'], lr, betas[0], betas[1], eps,
+                           self.step_count, grad_scale)
+        ops.PARAM_GENERATION[0] += 1
+
+
+# ------------------------------------------------------------------------------ forward (tape)
+def _eps_and_slope(p: Tensor) -> tuple[float, float]:
+    """eps = sigmoid(log p) = p / (1 + p) and d eps / d p = 1 / (1 + p)^2 (dynamics.py:82-83)"""
+    pv = float(p.detach().cpu())
+    return pv / (1.0 + pv), 1.0 / (1.0 + pv) ** 2
+
+
+class Tape:
+    def __init__(self):
+        self.entries: list = []
+        self.eps_grads: dict = {}          # ('x'|'v', step) -> list of [nb] tensors
+
+
+def _v_step(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, forward: bool):
+    nb = x.shape[0]
+    eps = dyn._eps('v', st)
+    vnet = dyn._get_vnet(st)
+    F = ops.u1_force(x, beta, dyn.latvolume)
+    s, t, q, ctx = vnet.forward_train(x, F)
+    v_new = v.clone()
+    ld = ops.v_update_(v_new, F.reshape(nb, -1), s, t, q, eps, forward)
+    tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
+                         's': s, 't': t, 'q': q, 'ctx': ctx, 'net': vnet, 'eps': eps})
+    return v_new, ld
+
+
+def _x_step(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, mask: Tensor, complement: bool,
+            forward: bool, first: bool):
+    nb = x.shape[0]
+    eps = dyn._eps('x', st)
+    xnet = dyn._get_xnet(st, first)
+    xm = ops.u1_masked_cos_sin(x, mask, complement, dyn.latvolume)
+    s, t, q, ctx = xnet.forward_train(xm, v)
+    x_new = x.clone()
+    ld = ops.u1_x_update_(x_new.reshape(nb, -1), v, s, t, q, mask, complement, eps, forward,
+                          dyn.config.use_ncp)
+    tape.entries.append({'kind': 'x', 'step': st, 'forward': forward, 'x': x, 'v': v, 's': s,
+                         't': t, 'q': q, 'ctx': ctx, 'net': xnet, 'mask': mask,
+                         'complement': complement, 'eps': eps})
+    return x_new, ld
+
+
+def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool):
+    """One generalised leapfrog step (dynamics.py:1187-1228), functional (new tensors)."""
+    if forward:
+        st, order = step, ((False, True), (True, False))         # (complement, first)
+    else:
+        st = dyn.config.nleapfrog - step - 1
+        order = ((True, False), (False, True))
+    m = dyn._native_masks()[st]
+    v, ld = _v_step(dyn, tape, st, x, v, beta, forward)
+    for comp, first in order:
+        x, l = _x_step(dyn, tape, st, x, v, m, comp, forward, first)
+        ld = ld + l
+    v, l = _v_step(dyn, tape, st, x, v, beta, forward)
+    return x, v, ld + l
+
+
+def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
+    """Merged forward + backward trajectory (dynamics.py:956-1029) recording the tape.
+    Returns (x_prop, v_prop, history, tape)."""
+    if dyn.group != 'U1':
+        raise NotImplementedError('the training-gradient path is built for U(1) only '
+                                  '(SU(3): SURVEY.md 8(f) item 1, next round)')
+    if not dyn._networks_built:
+        raise RuntimeError('training needs networks (Dynamics(network_factory=...))')
+    tape = Tape()
+    nb = xn.shape[0]
+    x, v = xn, vn
+    sumlogdet = dyn._zeros_nb(nb)
+    h_init = dyn._hamiltonian_n(xn, vn, beta)
+    history: dict = {}
+    verbose = dyn.config.verbose
+    sldf = torch.zeros_like(sumlogdet)
+    sldb = torch.zeros_like(sumlogdet)
+    if verbose:
+        dyn.update_history({'energy': h_init, 'logprob': h_init - sumlogdet, 'logdet': sumlogdet,
+                            'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet,
+                            'xeps': dyn.xeps[0], 'veps': dyn.veps[0]}, history)
+    nlf = dyn.config.nleapfrog
+    for step in range(nlf):
+        x, v, ld = _lf_train(dyn, tape, step, x, v, beta, True)
+        sumlogdet = sumlogdet + ld
+        if verbose:
+            sldf = sldf + ld
+            dyn.update_history(dyn._metrics_n(x, v, beta, sumlogdet, step,
+                                              {'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet}),
+                               history)
+    v = -v
+    tape.entries.append({'kind': 'flip'})
+    for step in range(nlf):
+        x, v, ld = _lf_train(dyn, tape, step, x, v, beta, False)
+        sumlogdet = sumlogdet + ld
+        if verbose:
+            sldb = sldb + ld
+            dyn.update_history(dyn._metrics_n(x, v, beta, sumlogdet, nlf - step - 1,
+                                              {'sldf': torch.zeros_like(sldb), 'sldb': sldb,
+                                               'sld': sumlogdet}), history)
+    h_prop = dyn._hamiltonian_n(x, v, beta)
+    acc = dyn._accept_prob_n(h_init, h_prop, sumlogdet)
+    history.update({'acc': acc, 'sumlogdet': sumlogdet})
+    if verbose:
+        history = dyn._stack_history(history)
+    tape.h_init = h_init
+    return x, v, history, tape
+
+
+# ------------------------------------------------------------------------------ loss + seeds
+def loss_and_seeds(dyn, loss_fn, xn_init: Tensor, x_prop: Tensor, v_prop: Tensor, tape: Tape,
+                   sumlogdet: Tensor, beta: float):
+    """Loss value (reference: LatticeLoss.calc_loss on (x_init, x_prop, acc)) and the
+    cotangents it sends into the trajectory: (loss, gx_prop, gv_prop, g_sumlogdet).
+    The lattice-sized reductions are the l2q kernels; only [nb]-vectors see autograd."""
+    lat = dyn.latvolume
+    V = dyn.volume
+    sp = ops.u1_plaq_sums(x_prop, lat)
+    si = ops.u1_plaq_sums(xn_init, lat)
+    ke = ops.u1_kinetic(v_prop)
+    cos_p = sp[:, 0].clone().requires_grad_(True)
+    sin_p = sp[:, 1].clone().requires_grad_(True)
+    ke_p = ke.clone().requires_grad_(True)
+    sld = sumlogdet.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        h_prop = ke_p + beta * (V - cos_p)
+        dh = tape.h_init.detach() - h_prop + sld
+        acc = torch.exp(torch.minimum(dh, torch.zeros_like(dh)))
+        loss = loss_fn.loss_from_sums(si[:, 0], si[:, 1], cos_p, sin_p, acc)
+        g_cos, g_sin, g_ke, g_sld = torch.autograd.grad(loss, [cos_p, sin_p, ke_p, sld],
+                                                        allow_unused=True)
+    nb = x_prop.shape[0]
+    gx = torch.zeros_like(x_prop)
+    z = torch.zeros(nb, dtype=x_prop.dtype, device=x_prop.device)
+    ops.u1_plaq_bwd_(gx, x_prop, z if g_cos is None else g_cos, z if g_sin is None else g_sin, lat)
+    gv = torch.zeros_like(v_prop)
+    if g_ke is not None:
+        ops.axpy_rows_(gv, g_ke, v_prop)
+    gl = (z if g_sld is None else g_sld).to(x_prop.dtype).contiguous()
+    return loss.detach(), gx, gv, gl
+
+
+# ------------------------------------------------------------------------------ reverse sweep
+def backward(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float) -> None:
+    """Replay the tape in reverse, accumulating every parameter's .grad (networks, xeps, veps).
+    gx / gv: cotangents of the proposed state; gl [nb]: cotangent of sum logdet (every
+    sub-update's logdet enters the sum with weight 1)."""
+    lat = dyn.latvolume
+    nb = gx.shape[0]
+    gx = gx.reshape(nb, -1).contiguous()
+    gv = gv.reshape(nb, -1).contiguous()
+    eps_acc: dict = {}
+    for e in reversed(tape.entries):
+        kind = e['kind']
+        if kind == 'flip':
+            gv = -gv
+            continue
+        if kind == 'v':
+            x, v, F = e['x'], e['v'], e['F']
+            dv, dF, ds, dt, dq, deps = ops.v_update_bwd(v, F.reshape(nb, -1), e['s'], e['t'],
+                                                        e['q'], e['eps'], e['forward'], gv, gl)
+            dx_net, dF_net = e['net'].backward(e['ctx'], ds, dt, dq)
+            ops.add_(dF, dF_net.reshape(nb, -1))
+            ops.add_(gx, dx_net.reshape(nb, -1))
+            ops.u1_force_bwd_(gx, x, dF, beta, lat)
+            gv = dv
+            eps_acc.setdefault(('v', e['step']), []).append(deps)
+        else:
+            x, v = e['x'], e['v']
+            dx, ds, dt, dq, deps = ops.u1_x_update_bwd(
+                x.reshape(nb, -1), v, e['s'], e['t'], e['q'], e['mask'], e['complement'],
+                e['eps'], e['forward'], dyn.config.use_ncp, gx, gl, gv)
+            dxm, dv_net = e['net'].backward(e['ctx'], ds, dt, dq)
+            ops.add_(gv, dv_net.reshape(nb, -1))
+            ops.u1_masked_cos_sin_bwd_(dx, x, e['mask'], e['complement'], dxm.contiguous())
+            gx = dx
+            eps_acc.setdefault(('x', e['step']), []).append(deps)
+    # d loss / d (x|v)eps[step] = sum over chains and sub-updates of deps, times d eps / d p
+    for (which, st), lst in eps_acc.items():
+        p = (dyn.xeps if which == 'x' else dyn.veps)[st]
+        if not p.requires_grad or p.grad is None:
+            continue
+        _, slope = _eps_and_slope(p)
+        tot = torch.stack(lst).sum()
+        p.grad.add_((slope * tot).to(p.dtype).reshape(p.shape))
+
+
+def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1.0):
+    """forward_step + calc_loss + loss.backward() of the reference's train_step for one input
+    batch: returns (x_out [nb, xdim], metrics, loss).  Gradients are ACCUMULATED into the
+    parameters' .grad (zero them first)."""
+    from l2hmc.dynamics.pytorch.dynamics import _beta
+    b = _beta(beta)
+    xn = dyn._pack(x)
+    vn = dyn._momentum_n(xn.shape[0])
+    x_, v_, hist, tape = trajectory_fb_train(dyn, xn, vn, b)
+    loss, gx, gv, gl = loss_and_seeds(dyn, loss_fn, xn, x_, v_, tape, hist['sumlogdet'], b)
+    if loss_weight != 1.0:
+        gx, gv, gl = gx * loss_weight, gv * loss_weight, gl * loss_weight
+    backward(dyn, tape, gx, gv, gl, b)
+    xout, metrics = dyn._finish(xn, vn, x_, v_, beta, hist, with_sumlogdet=True)
+    return xout, metrics, loss

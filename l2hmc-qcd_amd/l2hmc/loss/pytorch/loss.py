@@ -88,6 +88,26 @@ class LatticeLoss:
         return self._mixed(acc.to(DEVICE) * (d2 / nelem).to(acc.dtype), self.rmse_weight,
                            use_mixed_loss)
 
+    def loss_from_sums(self, cos_init: Tensor, sin_init: Tensor, cos_prop: Tensor,
+                       sin_prop: Tensor, acc: Tensor) -> Tensor:
+        """U(1) training loss from the per-chain plaquette sums (sum cos theta, sum sin theta)
+        of the initial / proposed configurations: the same value as `calc_loss`, written with
+        differentiable torch ops on [nb] vectors only (dynamics/pytorch/training.py seeds the
+        lattice-sized cotangent kernels with its gradient).  loss.py:100-148, 194-210."""
+        if not isinstance(self.lattice, LatticeU1):
+            raise NotImplementedError('training loss from sums: U(1) only')
+        if self.plaq_weight > 0:
+            raise NotImplementedError('U(1) plaq_loss is ill-formed in the reference '
+                                      '(loss.py:64-66) and unused (plaq_weight = 0)')
+        if self.rmse_weight > 0:
+            raise RuntimeError('imag is not implemented for tensors with non-complex dtypes.')
+        total = torch.zeros((), dtype=acc.dtype, device=acc.device)
+        if self.charge_weight > 0:
+            two_pi = 2.0 * torch.pi
+            dq = sin_prop / two_pi - sin_init / two_pi
+            total = total + self._mixed(acc * dq ** 2, self.charge_weight, None)
+        return total
+
     def lattice_metrics(self, xinit: Tensor, xout: Optional[Tensor] = None) -> dict[str, Tensor]:
         metrics = self.lattice.calc_metrics(x=xinit)
         if xout is not None:

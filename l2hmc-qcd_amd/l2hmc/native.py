@@ -63,6 +63,23 @@ SIGNATURES = {
     'l2q_conv2d_periodic_f32': (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     'l2q_im2col_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, P]),
     'l2q_maxpool_act_nhwc_f32': (I, [P, I, I, I, I, I, I, P, P]),
+    'l2q_act_bwd': (I, [P, P, I, L, I, P, P]),
+    'l2q_mul': (I, [P, P, D, L, I, P, P]),
+    'l2q_axpy_rows': (I, [P, P, I, L, I, P, P]),
+    'l2q_colsum': (I, [P, P, I, I, D, I, I, P, P]),
+    'l2q_scaled_tanh_bwd': (I, [P, P, P, D, I, I, I, P, P]),
+    'l2q_bn_train_fwd': (I, [P, P, P, D, D, P, P, I, I, I, P, P, P, P]),
+    'l2q_bn_bwd': (I, [P, P, P, P, P, I, I, I, P, P, P, P]),
+    'l2q_col2im_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, P]),
+    'l2q_maxpool_act_nhwc_bwd_f32': (I, [P, P, P, I, I, I, I, I, I, P, P]),
+    'l2q_u1_force_bwd': (I, [P, P, D, I, I, I, I, P, P]),
+    'l2q_u1_plaq_bwd': (I, [P, P, P, I, I, I, I, P, P]),
+    'l2q_u1_x_update_bwd': (I, [P, P, P, P, P, P, I, D, I, I, P, P, I, I, L, P, P, P, P, P, P, P]),
+    'l2q_v_update_bwd': (I, [P, P, P, P, P, D, I, P, P, I, I, L, P, P, P, P, P, P, P]),
+    'l2q_u1_masked_cos_sin_bwd': (I, [P, P, I, P, I, L, I, P, P]),
+    'l2q_adam': (I, [P, P, P, P, L, D, D, D, D, L, D, I, P]),
+    'l2q_sumsq': (I, [P, L, I, P, P, Z, P]),
+    'l2q_sumsq_ws_bytes': (Z, [L]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -63,6 +63,21 @@ def zero_weights(m):
             nn.init.constant_(m.bias.data, 0)
 
 
+def _linear_bwd(dpre: Tensor, x: Tensor, weight: nn.Parameter, bias: Optional[nn.Parameter],
+                need_dx: bool = True, xT: Optional[Tensor] = None) -> Optional[Tensor]:
+    """Backward of y = x W^T + b given dpre = dL/dy: W.grad += dpre^T x, b.grad += colsum(dpre),
+    returns dL/dx = dpre W (MFMA GEMMs on transposed operands; accumulation into the flat
+    gradient arena the parameters' .grad are views of)."""
+    if xT is None:
+        xT = ops.t2d(x)
+    ops.add_(weight.grad, ops.gemm(ops.t2d(dpre), xT))
+    if bias is not None:
+        ops.colsum_(bias.grad, dpre)
+    if not need_dx:
+        return None
+    return ops.gemm(dpre, ops.t2d(weight.detach()))
+
+
 class PeriodicPadding(nn.Module):
     """Parameter-free; kept so that ConvStack.layers has the reference's numbering.  Inside
     ConvStack the padding is fused into the conv kernel (index arithmetic, no copy)."""
@@ -158,6 +173,45 @@ class ConvStack(nn.Module):
         return ops.gemm(x.reshape(x.shape[0], -1).contiguous(), lin.weight.detach(),
                         lin.bias.detach(), act=self.act)
 
+    # ---- training path: forward keeping what the backward needs, and the backward itself
+    def forward_train(self, x: Tensor) -> tuple[Tensor, dict]:
+        x = x.to(DEVICE)
+        nb = x.shape[0]
+        x = x.reshape(nb, self.in_channels, self.nt, self.nx).contiguous()
+        if x.dtype != torch.float32:
+            raise NotImplementedError('the conv kernels are fp32 (the U(1) configs)')
+        layout, ctxs = 'nchw', []
+        for ci, k, pool, act in self.plan:
+            conv = self.layers[ci]
+            x, c = ops.conv2d_periodic_gemm_train(x, layout, conv.weight.detach(),
+                                                  conv.bias.detach(), pool, act)
+            ctxs.append(c)
+            layout = 'nhwc'
+        nhwc_shape = None
+        if layout == 'nhwc':
+            nhwc_shape = tuple(x.shape)
+            _, H, W, C = x.shape
+            x = ops.transpose(x.reshape(nb, H * W, C), nb, H * W, C)
+        flat = x.reshape(nb, -1).contiguous()
+        lin = self.layers[self.linear_index]
+        y = ops.gemm(flat, lin.weight.detach(), lin.bias.detach(), act=self.act)
+        return y, {'convs': ctxs, 'nhwc_shape': nhwc_shape, 'flat': flat, 'y': y}
+
+    def backward(self, ctx: dict, dy: Tensor) -> Tensor:
+        """Accumulates the layers' .grad; returns dL/dx [nb, C, T, X]."""
+        lin = self.layers[self.linear_index]
+        dpre = ops.act_bwd(dy.contiguous().clone(), ctx['y'], self.act)
+        d = _linear_bwd(dpre, ctx['flat'], lin.weight, lin.bias)
+        nb = d.shape[0]
+        if ctx['nhwc_shape'] is not None:
+            _, H, W, C = ctx['nhwc_shape']
+            d = ops.transpose(d.reshape(nb, C, H * W), nb, C, H * W).reshape(nb, H, W, C)
+        for (ci, k, pool, act), c in zip(reversed(self.plan), reversed(ctx['convs'])):
+            conv = self.layers[ci]
+            d = ops.conv2d_periodic_gemm_bwd(c, d, conv.weight.detach(), conv.weight.grad,
+                                             conv.bias.grad)
+        return d
+
 
 class InputLayer(nn.Module):
     def __init__(self, xshape: Sequence[int], network_config: NetworkConfig,
@@ -246,7 +300,7 @@ class LeapfrogLayer(nn.Module):
     def _versions(self):
         vs = [p._version for p in self.parameters()]
         vs += [b._version for b in self.buffers()]
-        return tuple(vs) + (self.nw.s, self.nw.t, self.nw.q)
+        return tuple(vs) + (self.nw.s, self.nw.t, self.nw.q, ops.PARAM_GENERATION[0])
 
     def kernel_weights(self, in_perm: Optional[Tensor] = None,
                        out_perm: Optional[Tensor] = None) -> dict:
@@ -330,6 +384,90 @@ class LeapfrogLayer(nn.Module):
         for hw, hb in w['hidden']:
             z = ops.gemm(z, hw, hb, act=self.act)
         return z
+
+
+    # ---- training path (train-mode semantics: dropout active, BatchNorm batch statistics)
+    def forward_train(self, x: Tensor, v: Tensor) -> tuple[Tensor, Tensor, Tensor, dict]:
+        """(s, t, q, ctx).  x: the network's x input ([nb, C, T, X] when there is a conv stack,
+        otherwise anything flattenable to [nb, Kx]); v likewise.  reference: network.py:522-551
+        under autograd."""
+        il = self.input_layer
+        nb = x.shape[0]
+        conv_ctx = None
+        if isinstance(il.conv_stack, ConvStack):
+            xf, conv_ctx = il.conv_stack.forward_train(x)
+        else:
+            xf = x.reshape(nb, -1).contiguous()
+        vf = v.reshape(nb, -1).contiguous()
+        z = ops.gemm(xf, il.xlayer.weight.detach(), il.xlayer.bias.detach(), a2=vf,
+                     w2=il.vlayer.weight.detach(), bias2=il.vlayer.bias.detach(), act=self.act)
+        acts = [z]
+        for h in self.hidden_layers:
+            z = ops.gemm(z, h.weight.detach(), h.bias.detach(), act=self.act)
+            acts.append(z)
+        ctx: dict = {'xf': xf, 'vf': vf, 'acts': acts, 'conv': conv_ctx, 'xshape': tuple(x.shape),
+                     'vshape': tuple(v.shape)}
+        p = float(self.net_config.dropout_prob)
+        if p > 0 and self.training:
+            keep = torch.bernoulli(torch.full_like(z, 1.0 - p))
+            z = ops.mul(z, keep, 1.0 / (1.0 - p))
+            ctx['drop'] = keep
+        if self.net_config.use_batch_norm:
+            bn = self.batch_norm
+            ctx['bn_in'] = z
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            z, ctx['bn_mean'], ctx['bn_invstd'] = ops.bn_train_fwd(
+                z, bn.weight.detach(), bn.bias.detach(), bn.eps, mom, bn.running_mean,
+                bn.running_var)
+            bn.num_batches_tracked += 1
+        ctx['z'] = z
+        s = ops.gemm(z, self.scale.layer.weight.detach(), self.scale.layer.bias.detach(),
+                     coeff=self.scale.coeff.detach().reshape(-1), scale=self.nw.s, act='tanh')
+        t = ops.gemm(z, self.transl.weight.detach(), self.transl.bias.detach(), scale=self.nw.t)
+        q = ops.gemm(z, self.transf.layer.weight.detach(), self.transf.layer.bias.detach(),
+                     coeff=self.transf.coeff.detach().reshape(-1), scale=self.nw.q, act='tanh')
+        ctx['s'], ctx['q'] = s, q
+        return s, t, q, ctx
+
+    def backward(self, ctx: dict, ds: Tensor, dt: Tensor, dq: Tensor) -> tuple[Tensor, Tensor]:
+        """Accumulates every parameter's .grad; returns (dL/dx_in, dL/dv_in) shaped like the
+        inputs of forward_train."""
+        z = ctx['z']
+        zT = ops.t2d(z)
+        dz = None
+        for head, cot, out in ((self.scale, ds, ctx['s']), (self.transl, dt, None),
+                               (self.transf, dq, ctx['q'])):
+            if isinstance(head, ScaledTanh):
+                nw = self.nw.s if head is self.scale else self.nw.q
+                co = head.coeff.detach().reshape(-1)
+                ops.colsum_(head.coeff.grad.reshape(-1), cot, out)      # d s / d coeff = s
+                dpre = ops.scaled_tanh_bwd(cot, out, co, nw)
+                lin = head.layer
+            else:
+                dpre = ops.scaled_tanh_bwd(cot, None, None, self.nw.t)
+                lin = head
+            d = _linear_bwd(dpre, z, lin.weight, lin.bias, xT=zT)
+            dz = d if dz is None else ops.add_(dz, d)
+        if self.net_config.use_batch_norm:
+            bn = self.batch_norm
+            dz = ops.bn_bwd(dz, ctx['bn_in'], ctx['bn_mean'], ctx['bn_invstd'], bn.weight.detach(),
+                            bn.weight.grad, bn.bias.grad)
+        if 'drop' in ctx:
+            dz = ops.mul(dz, ctx['drop'], 1.0 / (1.0 - float(self.net_config.dropout_prob)))
+        acts = ctx['acts']
+        for i in range(len(self.hidden_layers) - 1, -1, -1):
+            h = self.hidden_layers[i]
+            dpre = ops.act_bwd(dz, acts[i + 1], self.act)
+            dz = _linear_bwd(dpre, acts[i], h.weight, h.bias)
+        il = self.input_layer
+        dpre = ops.act_bwd(dz, acts[0], self.act)
+        dxf = _linear_bwd(dpre, ctx['xf'], il.xlayer.weight, il.xlayer.bias)
+        dvf = _linear_bwd(dpre, ctx['vf'], il.vlayer.weight, il.vlayer.bias)
+        if ctx['conv'] is not None:
+            dx = il.conv_stack.backward(ctx['conv'], dxf)
+        else:
+            dx = dxf
+        return dx.reshape(ctx['xshape']), dvf.reshape(ctx['vshape'])
 
     def forward(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, Tensor, Tensor]:
         x, v = inputs

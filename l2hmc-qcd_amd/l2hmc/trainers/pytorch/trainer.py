@@ -2,9 +2,10 @@
 ``eval`` / ``warmup`` with the reference's step sequence (per-step ``compat_proj``, loss and
 lattice metrics, ``trainers/pytorch/trainer.py:904-956, 1085-1252, 1699-1744``).
 
-Out of scope here: optimizers / DDP wrappers / wandb / aim /
-rich live displays / checkpoint directories.  ``train_step`` needs the training-gradient
-path and raises until that is built.
+``train_step`` (U(1)): hand-written reverse sweep + fused Adam over a flat parameter arena +
+one RCCL all-reduce of the flat gradient (dynamics/pytorch/training.py) in place of
+autograd / torch.optim / DDP.  Out of scope here: wandb /
+aim / rich live displays / checkpoint directories.
 """
 from __future__ import annotations
 
@@ -41,7 +42,8 @@ class Trainer:
         evals = 2 * cfg.dynamics.nleapfrog if cfg.dynamics.merge_directions \
             else cfg.dynamics.nleapfrog
         self.timers = {k: StepTimer(evals_per_step=evals) for k in ('train', 'eval', 'hmc')}
-        self._estep = self._hstep = 0
+        self._estep = self._hstep = self._gstep = 0
+        self.arena = None                 # flat parameter / gradient arena (built on first train_step)
 
     # -- construction (trainer.py:490-562, trainers/trainer.py:292-309)
     def build_lattice(self):
@@ -103,10 +105,63 @@ class Trainer:
         self._estep += 1
         return self._finish(xinit, xout, metrics, 'eval')
 
-    def train_step(self, inputs):
-        raise NotImplementedError(
-            'train_step needs the training-gradient path (backward kernels + Adam), '
-            'SURVEY.md section 8(f) item 1 -- not built yet')
+    def train_step(self, inputs) -> tuple[Tensor, dict]:
+        """One optimisation step (trainer.py:1316-1367): compat_proj -> trajectory in train mode
+        -> LatticeLoss(x_init, x_prop, acc) -> gradients (hand-written reverse sweep,
+        dynamics/pytorch/training.py) -> data-parallel all-reduce of the flat gradient ->
+        clip_grad_norm -> fused Adam.  U(1) only in this round."""
+        from l2hmc.dynamics.pytorch import training as T
+        if self.arena is None:
+            self.arena = T.ParamArena(self.dynamics)
+        self.dynamics.train()
+        xinit, beta = inputs
+        beta = torch.as_tensor(beta, dtype=torch.get_default_dtype())
+        xinit = self._prep(xinit)
+        self.arena.zero_grad()
+        xout, metrics, loss = T.train_forward_backward(self.dynamics, self.loss_fn, xinit, beta)
+        loss_tot = loss
+        if (aw := self.config.loss.aux_weight) > 0:
+            # the reference's `aux_loss += aw * aux_loss` (trainer.py:1343-1353)
+            yinit = self.g.random(list(xinit.shape)).to(self.device)
+            _, _m, aux = T.train_forward_backward(self.dynamics, self.loss_fn, yinit, beta,
+                                                  loss_weight=1.0 + aw)
+            loss_tot = loss + (1.0 + aw) * aux
+        scale = self.arena.all_reduce()
+        clip = float(self.config.learning_rate.clip_norm)
+        if clip > 0.0:
+            coef = clip / (self.arena.grad_norm(scale) + 1e-6)
+            if coef < 1.0:
+                scale *= coef
+        self.arena.adam_step(lr=float(self.config.learning_rate.lr_init), grad_scale=scale)
+        metrics.pop('mc_states', None)
+        metrics['loss'] = float(loss_tot)
+        if self.config.dynamics.verbose:
+            metrics.update(self.loss_fn.lattice_metrics(xinit=xinit, xout=xout))
+        self._gstep += 1
+        return xout.detach(), metrics
+
+    def train(self, x: Optional[Tensor] = None, beta: Optional[float] = None,
+              nsteps: Optional[int] = None) -> dict:
+        """`nsteps` train steps at fixed beta (one era of trainer.py:1369-1470, without the
+        logging / checkpoint side effects)."""
+        beta = self.config.annealing_schedule.beta_init if beta is None else beta
+        nsteps = self.config.steps.nepoch if nsteps is None else nsteps
+        x = self.lattice.random() if x is None else x
+        timer = self.timers['train']
+        history: dict[str, list] = {}
+        for step in range(nsteps):
+            timer.start()
+            x, metrics = self.train_step((x, beta))
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            dt = timer.stop()
+            record = {'step': step, 'dt': dt, 'beta': beta}
+            record.update({k: v for k, v in metrics.items() if k not in ('beta',)})
+            for k, v in record.items():
+                if isinstance(v, Tensor):
+                    v = v.detach().float().cpu() if not v.is_complex() else v.detach().cpu()
+                history.setdefault(k, []).append(v)
+        return {'history': history, 'x': x, 'timer': timer}
 
     def warmup(self, beta: float, nsteps: int = 100, tol: float = 1e-5,
                x: Optional[Tensor] = None) -> Tensor:

@@ -1,0 +1,352 @@
+"""TEST INFRASTRUCTURE ONLY -- a torch-CPU stand-in for the libl2q.so entry points used by the
+U(1) sampling + training path.
+
+Purpose: (1) run the *host orchestration* of the training step (tape, reverse sweep, arena,
+Adam) on the CPU-only build container against the reference's gradient fixtures, and
+(2) serve as the checker for each backward kernel on the GPU (``tests/test_train_gpu.py``).
+Forward entry points are restated with plain torch ops; every backward entry point is obtained
+by ``torch.autograd`` of that restatement -- nothing here shares code or derivations with the
+HIP kernels.  The product never imports this module (``native.call`` raises on CPU tensors);
+tests install it with ``emu_native.install(monkeypatch)``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+ACT = {0: None, 1: 'tanh', 2: 'relu', 3: 'leaky_relu', 4: 'elu', 5: 'swish'}
+
+
+def _act(z, act):
+    a = ACT[act] if isinstance(act, int) else act
+    if a is None:
+        return z
+    if a == 'tanh':
+        return torch.tanh(z)
+    if a == 'relu':
+        return torch.relu(z)
+    if a == 'leaky_relu':
+        return torch.nn.functional.leaky_relu(z, 0.01)
+    if a == 'elu':
+        return torch.nn.functional.elu(z)
+    if a == 'swish':
+        return torch.nn.functional.silu(z)
+    raise ValueError(a)
+
+
+def _wrap(x):
+    return torch.remainder(x + math.pi, 2 * math.pi) - math.pi
+
+
+def _theta(x):                                   # x [nb, 2, T, X]
+    return x[:, 0] + torch.roll(x[:, 1], -1, 1) - torch.roll(x[:, 0], -1, 2) - x[:, 1]
+
+
+def _force(x, beta):
+    s = torch.sin(_theta(x))
+    return torch.stack([beta * (s - torch.roll(s, 1, 2)), beta * (-s + torch.roll(s, 1, 1))], 1)
+
+
+def _keep(mask, complement, like):
+    k = mask.to(like.dtype).reshape(1, -1)
+    return (1 - k) if complement else k
+
+
+def _x_update(x, v, s, t, q, mask, complement, eps, forward, ncp):
+    """x, v, s, t, q: [nb, n] -> (x', logdet)"""
+    keep = _keep(mask, complement, x)
+    mb = 1 - keep
+    S = eps * s if forward else -eps * s
+    es, eq = torch.exp(S), torch.exp(eps * q)
+    tr = v * eq + t
+    if ncp:
+        h = x / 2
+        x1 = 2 * torch.atan(torch.tan(h) * es)
+        xp = x1 + eps * tr if forward else x1 - es * eps * tr
+        ld = torch.log(es / (torch.cos(h) ** 2 + (es * torch.sin(h)) ** 2))
+    else:
+        xp = x * es + eps * tr if forward else es * (x - eps * tr)
+        ld = S
+    return _wrap(keep * x + mb * xp), (mb * ld).sum(1)
+
+
+def _v_update(v, f, s, t, q, eps, forward):
+    S = 0.5 * eps * s if forward else -0.5 * eps * s
+    es, eq = torch.exp(S), torch.exp(eps * q)
+    fq = f * eq + t
+    vn = es * v - 0.5 * eps * fq if forward else es * (v + 0.5 * eps * fq)
+    return vn, S.sum(1)
+
+
+def _im2col(x4, k):
+    """x4 [nb, C, H, W] -> col [nb*Ho*Wo, C*k*k] with periodic padding k-1 on both sides."""
+    nb, C, H, W = x4.shape
+    p = k - 1
+    xp = torch.cat([x4[:, :, -p:, :], x4, x4[:, :, :p, :]], 2) if p > 0 else x4
+    xp = torch.cat([xp[:, :, :, -p:], xp, xp[:, :, :, :p]], 3) if p > 0 else xp
+    cols = torch.nn.functional.unfold(xp, k)                   # [nb, C*k*k, Ho*Wo]
+    return cols.transpose(1, 2).reshape(-1, C * k * k)
+
+
+def _as_nchw(x, sn, sc, sh, sw, nb, C, H, W):
+    if sw == 1:
+        return x.reshape(nb, C, H, W)
+    return x.reshape(nb, H, W, C).permute(0, 3, 1, 2)
+
+
+def _maxpool_act(y, nb, H, W, C, pool, act):
+    y4 = y.reshape(nb, H, W, C).permute(0, 3, 1, 2)
+    o = torch.nn.functional.max_pool2d(y4, pool)
+    return _act(o, act).permute(0, 2, 3, 1).contiguous()
+
+
+def _vjp(fn, inputs, cotangents):
+    """fn(*inputs) -> tuple of outputs; returns grads wrt inputs (zeros where unused)."""
+    ins = [i.detach().clone().requires_grad_(True) for i in inputs]
+    with torch.enable_grad():
+        outs = fn(*ins)
+    if isinstance(outs, torch.Tensor):
+        outs = (outs,)
+    pairs = [(o, c) for o, c in zip(outs, cotangents) if c is not None]
+    grads = torch.autograd.grad([o for o, _ in pairs], ins, [c.reshape(o.shape) for o, c in pairs],
+                                allow_unused=True)
+    return [torch.zeros_like(i) if g is None else g for g, i in zip(grads, ins)]
+
+
+# ---------------------------------------------------------------------------- entry points
+def l2q_transpose(a, out, batch, rows, cols, esz):
+    out.copy_(a.reshape(batch, rows, cols).transpose(1, 2).reshape(out.shape))
+
+
+def _gemm(A, W, M, N, K, A2, W2, K2, bias, bias2, coeff, scale, act, C, ws, wsn):
+    z = A.reshape(M, K) @ W.reshape(N, K).T
+    if A2 is not None:
+        z = z + A2.reshape(M, K2) @ W2.reshape(N, K2).T
+    if bias is not None:
+        z = z + bias
+    if bias2 is not None:
+        z = z + bias2
+    y = _act(z, act)
+    y = scale * torch.exp(coeff) * y if coeff is not None else scale * y
+    C.copy_(y.reshape(C.shape))
+
+
+l2q_gemm_f32 = _gemm
+l2q_gemm_f64 = _gemm
+
+
+def l2q_u1_plaq_reduce(x, nb, T, X, esz, out):
+    th = _theta(x.reshape(nb, 2, T, X))
+    out[:, 0] = torch.cos(th).sum((1, 2))
+    out[:, 1] = torch.sin(th).sum((1, 2))
+    out[:, 2] = (th - 2 * math.pi * torch.floor((th + math.pi) / (2 * math.pi))).sum((1, 2))
+
+
+def l2q_u1_force(x, beta, force, v, coef, nb, T, X, esz):
+    f = _force(x.reshape(nb, 2, T, X), beta)
+    if force is not None:
+        force.copy_(f.reshape(force.shape))
+    if v is not None:
+        v.add_(coef * f.reshape(v.shape))
+
+
+def l2q_u1_x_update(x, v, s, t, q, mask, complement, eps, forward, ncp, esz, nb, n, logdet):
+    xn, ld = _x_update(x.reshape(nb, n), v.reshape(nb, n), s, t, q, mask, complement, eps,
+                       bool(forward), bool(ncp))
+    x.copy_(xn.reshape(x.shape))
+    logdet.copy_(ld)
+
+
+def l2q_v_update(v, force, s, t, q, eps, forward, cplx, esz, nb, n, logdet, ws, wsn):
+    assert not cplx
+    vn, ld = _v_update(v.reshape(nb, n), force.reshape(nb, n), s, t, q, eps, bool(forward))
+    v.copy_(vn.reshape(v.shape))
+    logdet.copy_(ld)
+
+
+def l2q_u1_wrap(x, y, n, esz):
+    y.copy_(_wrap(x))
+
+
+def l2q_u1_kinetic_reduce(v, nb, n, esz, out):
+    out.copy_(0.5 * (v.reshape(nb, n) ** 2).sum(1))
+
+
+def l2q_axpy(p, alpha, x, n, esz):
+    x.add_(alpha * p.reshape(x.shape))
+
+
+def l2q_u1_masked_cos_sin(x, mask, complement, out, nb, n, esz):
+    a = _keep(mask, complement, x) * x.reshape(nb, n)
+    out.copy_(torch.cat([torch.cos(a), torch.sin(a)], 1).reshape(out.shape))
+
+
+def l2q_accept(h_init, h_prop, sld, u, acc, mask, nb, esz):
+    a = torch.exp(torch.minimum(h_init - h_prop + sld, torch.zeros_like(h_init)))
+    acc.copy_(a)
+    mask.copy_((a > u).float())
+
+
+def l2q_select_rows(a, b, mask, out, nb, row_bytes):
+    m = mask.reshape(nb, *([1] * (a.dim() - 1))).bool()
+    out.copy_(torch.where(m, a, b))
+
+
+def l2q_im2col_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, col):
+    col.copy_(_im2col(_as_nchw(x, sn, sc, sh, sw, nb, C, H, W), k))
+
+
+def l2q_maxpool_act_nhwc_f32(y, nb, H, W, C, pool, act, out):
+    out.copy_(_maxpool_act(y, nb, H, W, C, pool, act))
+
+
+# ---- training entry points (VJPs by autograd of the restatements above)
+def l2q_act_bwd(dy, y, act, n, esz, dx):
+    a = ACT[act]
+    if a == 'tanh':
+        d = 1 - y * y
+    elif a == 'relu':
+        d = (y > 0).to(y.dtype)
+    elif a == 'leaky_relu':
+        d = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01))
+    elif a == 'elu':
+        d = torch.where(y > 0, torch.ones_like(y), y + 1)
+    else:
+        d = torch.ones_like(y)
+    dx.copy_(dy * d)
+
+
+def l2q_mul(a, b, alpha, n, esz, out):
+    out.copy_(alpha * a * b)
+
+
+def l2q_axpy_rows(x, a, nb, n, esz, y):
+    y.add_((a.reshape(nb, 1) * x.reshape(nb, n)).reshape(y.shape))
+
+
+def l2q_colsum(a, b, M, N, alpha, accumulate, esz, out):
+    r = alpha * ((a * b) if b is not None else a).reshape(M, N).double().sum(0).to(a.dtype)
+    if accumulate:
+        out.add_(r.reshape(out.shape))
+    else:
+        out.copy_(r.reshape(out.shape))
+
+
+def l2q_scaled_tanh_bwd(ds, s, coeff, scale, M, N, esz, dpre):
+    if coeff is None:
+        dpre.copy_(scale * ds)
+        return
+    g = scale * torch.exp(coeff).reshape(1, N)
+    th = torch.where(g != 0, s / g, torch.zeros_like(s))
+    dpre.copy_(ds * g * (1 - th * th))
+
+
+def l2q_bn_train_fwd(x, gamma, beta, eps, momentum, rm, rv, M, N, esz, y, mean, invstd):
+    mu = x.mean(0)
+    var = x.var(0, unbiased=False)
+    mean.copy_(mu)
+    invstd.copy_(1 / torch.sqrt(var + eps))
+    y.copy_((x - mu) * invstd * gamma + beta)
+    if rm is not None:
+        rm.mul_(1 - momentum).add_(momentum * mu)
+        rv.mul_(1 - momentum).add_(momentum * x.var(0, unbiased=True))
+
+
+def l2q_bn_bwd(dy, x, mean, invstd, gamma, M, N, esz, dx, dgamma, dbeta):
+    eps_vec = (1 / invstd ** 2 - x.var(0, unbiased=False)).detach()
+
+    def f(x_, g_, b_):
+        mu = x_.mean(0)
+        return (x_ - mu) / torch.sqrt(x_.var(0, unbiased=False) + eps_vec) * g_ + b_
+    gx, gg, gb = _vjp(f, [x, gamma, torch.zeros_like(gamma)], [dy])
+    dx.copy_(gx)
+    dgamma.add_(gg)
+    dbeta.add_(gb)
+
+
+def l2q_col2im_periodic_f32(dcol, sn, sc, sh, sw, nb, C, H, W, k, dx):
+    (g,) = _vjp(lambda a: _im2col(a, k), [torch.zeros(nb, C, H, W, dtype=dcol.dtype)], [dcol])
+    if sw == 1:
+        dx.copy_(g.reshape(dx.shape))
+    else:
+        dx.copy_(g.permute(0, 2, 3, 1).reshape(dx.shape))
+
+
+def l2q_maxpool_act_nhwc_bwd_f32(dout, out, y, nb, H, W, C, pool, act, din):
+    (g,) = _vjp(lambda a: _maxpool_act(a, nb, H, W, C, pool, act), [y.reshape(nb, H, W, C)], [dout])
+    din.copy_(g.reshape(din.shape))
+
+
+def l2q_u1_force_bwd(x, dF, beta, nb, T, X, esz, dx):
+    (g,) = _vjp(lambda a: _force(a, beta), [x.reshape(nb, 2, T, X)], [dF])
+    dx.add_(g.reshape(dx.shape))
+
+
+def l2q_u1_plaq_bwd(x, gcos, gsin, nb, T, X, esz, dx):
+    def f(a):
+        th = _theta(a)
+        return torch.cos(th).sum((1, 2)), torch.sin(th).sum((1, 2))
+    (g,) = _vjp(f, [x.reshape(nb, 2, T, X)], [gcos, gsin])
+    dx.add_(g.reshape(dx.shape))
+
+
+def l2q_u1_x_update_bwd(x, v, s, t, q, mask, complement, eps, forward, ncp, gx, gl, esz, nb, n,
+                        dx, dv, ds, dt, dq, deps):
+    e = torch.tensor(float(eps), dtype=x.dtype).expand(nb).clone()
+
+    def f(x_, v_, s_, t_, q_, e_):
+        return _x_update(x_, v_, s_, t_, q_, mask, complement, e_.reshape(nb, 1), bool(forward),
+                         bool(ncp))
+    g = _vjp(f, [x.reshape(nb, n), v.reshape(nb, n), s, t, q, e], [gx.reshape(nb, n), gl])
+    dx.copy_(g[0].reshape(dx.shape))
+    dv.add_(g[1].reshape(dv.shape))
+    ds.copy_(g[2]); dt.copy_(g[3]); dq.copy_(g[4]); deps.copy_(g[5])
+
+
+def l2q_v_update_bwd(v, force, s, t, q, eps, forward, gv, gl, esz, nb, n, dv, dF, ds, dt, dq,
+                     deps):
+    e = torch.tensor(float(eps), dtype=v.dtype).expand(nb).clone()
+
+    def f(v_, f_, s_, t_, q_, e_):
+        return _v_update(v_, f_, s_, t_, q_, e_.reshape(nb, 1), bool(forward))
+    g = _vjp(f, [v.reshape(nb, n), force.reshape(nb, n), s, t, q, e], [gv.reshape(nb, n), gl])
+    dv.copy_(g[0].reshape(dv.shape)); dF.copy_(g[1].reshape(dF.shape))
+    ds.copy_(g[2]); dt.copy_(g[3]); dq.copy_(g[4]); deps.copy_(g[5])
+
+
+def l2q_u1_masked_cos_sin_bwd(x, mask, complement, dout, nb, n, esz, dx):
+    def f(a):
+        m = _keep(mask, complement, a) * a
+        return torch.cat([torch.cos(m), torch.sin(m)], 1)
+    (g,) = _vjp(f, [x.reshape(nb, n)], [dout.reshape(nb, 2 * n)])
+    dx.add_(g.reshape(dx.shape))
+
+
+def l2q_adam(p, g, m, v, n, lr, b1, b2, eps, step, gscale, esz):
+    gi = g * gscale
+    m.mul_(b1).add_((1 - b1) * gi)
+    v.mul_(b2).add_((1 - b2) * gi * gi)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.sub_((lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps))
+
+
+def l2q_sumsq(a, n, esz, out, ws, wsn):
+    out[0] = (a.double() ** 2).sum()
+
+
+_TABLE = {k: v for k, v in globals().items() if k.startswith('l2q_')}
+
+
+def call(name, *args):
+    fn = _TABLE.get(name)
+    if fn is None:
+        raise NotImplementedError(f'emu_native: {name} is not emulated')
+    with torch.no_grad():
+        fn(*args)
+
+
+def install(monkeypatch):
+    """Route l2hmc.native.call to the emulation (CPU tensors)."""
+    from l2hmc import native
+    monkeypatch.setattr(native, 'call', call)

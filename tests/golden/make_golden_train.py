@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Golden *training-step* vectors (loss, per-parameter gradients, BatchNorm running statistics,
+parameters after one Adam step) from the REAL reference in train mode.
+
+    bash tests/golden/setup_reference_env.sh
+    PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py f64
+    PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py f32
+
+`f64`: U(1) 4x4, dense networks, float64 default dtype (tight tolerance); `f32`: U(1) 4x6 with
+the conv stack (a pooling layer), float32.  Sequence = Trainer.train_step of the reference
+(trainers/pytorch/trainer.py:1316-1367): compat_proj -> dynamics((x, beta)) in train mode ->
+LatticeLoss(x_init, x_prop, acc) -> loss.backward() -> Adam(lr_init).step().
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+WHICH = sys.argv[1]
+if WHICH == 'f64':
+    torch.set_default_dtype(torch.float64)
+sys.argv = [sys.argv[0], 'su3' if WHICH == 'f64' else 'u1']
+sys.path.insert(0, OUT)
+import make_golden as mg  # noqa: E402  (imports the reference, sets nothing else)
+import l2hmc.configs as cfgs  # noqa: E402
+from l2hmc.loss.pytorch.loss import LatticeLoss  # noqa: E402
+
+npy = mg.npy
+
+
+def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps=0.1, lr=1e-3):
+    dyn, lat = mg.build_dynamics('U1', L, nb, nlf=nlf, eps=eps, units=units, act=act, conv=conv,
+                                 sep=True, split=True, bn=bn, dropout=0.0, seed=seed)
+    mg.perturb(dyn, seed + 1)
+    bt = torch.tensor(beta)
+    mg.seed_all(seed + 2)
+    x = lat.random()
+    for _ in range(40):
+        x, _m = dyn.apply_transition_hmc((x, bt), eps=0.2, nleapfrog=5)
+        x = dyn.g.compat_proj(dyn.unflatten(x)).detach()
+    # .copy(): Tensor.numpy() aliases the live parameters, which Adam then updates in place
+    sd0 = {k: a.copy() for k, a in mg.state_dict_np(dyn).items()
+           if not k.startswith('networks.')}
+    dyn.train()
+    loss_fn = LatticeLoss(lat, loss_cfg)
+    opt = torch.optim.Adam(dyn.parameters(), lr=lr)
+    mg.seed_all(seed + 3)
+    nrm = torch.randn(nb, 2, *L)
+    u = torch.rand(nb)
+    mg.seed_all(seed + 3)
+    xinit = dyn.g.compat_proj(x.reshape(dyn.xshape))
+    xinit.requires_grad_(True)
+    opt.zero_grad()
+    xout, m = dyn((xinit, bt))
+    mc = m['mc_states']
+    assert torch.equal(mc.init.v.detach(), nrm.reshape(nb, -1))
+    loss = loss_fn(xinit, mc.proposed.x, m['acc'])
+    loss.backward()
+    grads = {}
+    for n, p in dyn.named_parameters():
+        grads['grad.' + n] = (npy(p.grad).copy() if p.grad is not None
+                              else np.zeros(tuple(p.shape)))
+    opt.step()
+    sd1 = {k: a for k, a in mg.state_dict_np(dyn).items() if not k.startswith('networks.')}
+    mg.save(name, latvolume=np.array(L), beta=beta, nleapfrog=nlf, x=npy(x), normals=npy(nrm),
+            u=npy(u), masks=np.stack([npy(mm)[0] for mm in dyn.masks]),
+            x_prop=npy(mc.proposed.x), x_out=npy(xout), acc=npy(m['acc']),
+            acc_mask=npy(m['acc_mask']), sumlogdet=npy(m['sumlogdet']), loss=npy(loss),
+            lr=lr, charge_weight=loss_cfg.charge_weight, use_mixed_loss=loss_cfg.use_mixed_loss,
+            units=np.array(units), activation=act, use_batch_norm=bn,
+            conv_filters=np.array(conv['filters'] if conv else []),
+            conv_sizes=np.array(conv['sizes'] if conv else []),
+            conv_pool=np.array(conv['pool'] if conv else []),
+            **{'sd.' + k: a for k, a in sd0.items()}, **{'sd1.' + k: a for k, a in sd1.items()},
+            **grads)
+    gn = np.sqrt(sum(float((g ** 2).sum()) for g in grads.values()))
+    print(f'  {name}: loss {float(loss):.6g} acc {npy(m["acc"])[:6]} |grad| {gn:.4g}')
+
+
+if __name__ == '__main__':
+    if WHICH == 'f64':
+        train_case('u1_train_f64', (4, 4), 6, 2, [8, 6], 'leaky_relu', None, beta=2.0, seed=300,
+                   bn=True, loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.01))
+        train_case('u1_train_f64_plain', (4, 6), 5, 3, [8], 'tanh', None, beta=3.0, seed=320,
+                   bn=False, loss_cfg=cfgs.LossConfig(use_mixed_loss=False, charge_weight=0.5))
+    else:
+        train_case('u1_train_conv', (4, 6), 5, 2, [8, 6], 'leaky_relu',
+                   {'filters': [2, 3, 4], 'sizes': [3, 2, 2], 'pool': [2, 2, 2]}, beta=2.5,
+                   seed=340, bn=True,
+                   loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.01))

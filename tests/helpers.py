@@ -115,3 +115,101 @@ def build_u1_dynamics(g, verbose=True):
     dyn.set_masks(g['masks'])
     dyn.eval()
     return dyn, lat
+
+
+def build_u1_train_dynamics(g, dropout=0.0):
+    """Product Dynamics + LatticeLoss configured like a u1_train_* golden file (train mode).
+    Call under the default dtype the fixture was generated with."""
+    import torch
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.loss.pytorch.loss import LatticeLoss
+    from l2hmc.network.pytorch.network import NetworkFactory
+    L = [int(i) for i in g['latvolume']]
+    nb = int(g['x'].shape[0])
+    nlf = int(g['nleapfrog'])
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=nlf, eps=0.1,
+                             eps_hmc=0.1, use_ncp=True, verbose=False, use_split_xnets=True,
+                             use_separate_networks=True, merge_directions=True)
+    kw = u1_net_kwargs(g)
+    nc = cfgs.NetworkConfig(units=[int(i) for i in g['units']], activation_fn=kw['activation'],
+                            dropout_prob=dropout, use_batch_norm=kw['use_batch_norm'])
+    cc = cfgs.ConvolutionConfig(**kw['conv']) if kw['conv'] else cfgs.ConvolutionConfig()
+    xdim = dc.xdim
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [xdim, 2], 'v': [xdim]},
+                          vnet={'x': [xdim], 'v': [xdim]})
+    lat = LatticeU1(nb, L)
+    nf = NetworkFactory(input_spec=spec, network_config=nc, conv_config=cc)
+    dyn = Dynamics(potential_fn=lat.action, config=dc, network_factory=nf)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(g, 'sd.').items()}
+    res = dyn.load_state_dict(sd, strict=False)
+    assert all(k.startswith('networks.') for k in res.missing_keys), res.missing_keys
+    assert not res.unexpected_keys, res.unexpected_keys
+    dyn._eps_cache = {}
+    dyn.set_masks(g['masks'])
+    dyn.train()
+    loss_fn = LatticeLoss(lat, cfgs.LossConfig(use_mixed_loss=bool(g['use_mixed_loss']),
+                                               charge_weight=float(g['charge_weight'])))
+    return dyn, lat, loss_fn
+
+
+def check_train_step(g, dyn, loss_fn, rtol, atol_rel, adam_min_grad=0.0):
+    """Run the product's forward + reverse sweep + Adam on the fixture's inputs and compare with
+    the reference's loss / gradients / updated parameters.  Returns the worst relative errors."""
+    import torch
+    from l2hmc.dynamics.pytorch import training as T
+    arena = T.ParamArena(dyn)
+    arena.zero_grad()
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    x = torch.from_numpy(g['x'])
+    beta = torch.tensor(float(g['beta']))
+    xin = dyn.g.compat_proj(dyn.unflatten(x.to(dyn.device)))
+    xout, metrics, loss = T.train_forward_backward(dyn, loss_fn, xin, beta)
+    dyn._inject = None
+    out = {}
+    acc = metrics['acc'].detach().cpu().numpy()
+    np.testing.assert_allclose(acc, g['acc'], rtol=rtol, atol=rtol)
+    xp = metrics['mc_states'].proposed.x.detach().cpu().numpy().reshape(g['x_prop'].shape)
+    d = np.abs(np.angle(np.exp(1j * (xp - g['x_prop'])))).max()
+    assert d < 50 * rtol, f'x_prop differs by {d}'
+    assert np.array_equal(metrics['acc_mask'].cpu().numpy(), g['acc_mask'])
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=20 * rtol)
+    worst = 0.0
+    gn = np.sqrt(sum(float((g[k] ** 2).sum()) for k in list(g) if k.startswith('grad.')))
+    names = dict(dyn.named_parameters())
+    for k in list(g):
+        if not k.startswith('grad.'):
+            continue
+        ref = g[k]
+        got = names[k[5:]].grad.detach().cpu().numpy()
+        err = np.abs(got - ref).max()
+        scale = max(np.abs(ref).max(), atol_rel * gn)
+        worst = max(worst, err / scale)
+        assert err <= rtol * 100 * scale, f'{k}: err {err:.3e} vs scale {scale:.3e}'
+    out['grad_rel'] = worst
+    arena.adam_step(lr=float(g['lr']))
+    sd = dyn.state_dict()
+    wp = 0.0
+    for k in list(g):
+        if not k.startswith('sd1.'):
+            continue
+        name = k[4:]
+        if name.endswith('num_batches_tracked'):
+            assert int(sd[name]) == int(g[k]), name
+            continue
+        got = sd[name].detach().cpu().numpy()
+        ref = g[k]
+        before = g['sd.' + name]
+        # Adam's first step moves every touched weight by ~lr: compare the *update*
+        diff = np.abs((got - before) - (ref - before))
+        gk = 'grad.' + name if ('grad.' + name) in g else 'grad.networks.' + name
+        if adam_min_grad > 0 and gk in g:
+            # Adam's first update is lr * g / (|g| + 1e-8): where the gradient is rounding noise
+            # the sign of the step is noise too -- compare where the gradient is resolved
+            diff = np.where(np.abs(g[gk]) > adam_min_grad, diff, 0.0)
+        err = diff.max() if diff.size else 0.0
+        if err > wp:
+            wp, out['param_worst'] = err, name
+    out['param_abs'] = wp
+    return out

@@ -1,0 +1,81 @@
+"""CPU tests of the training-gradient path's HOST side (tape, reverse sweep, loss seeds,
+network backward sequencing, flat arena, Adam bookkeeping) against the reference's gradient
+fixtures, with the libl2q.so entry points replaced by the torch restatement in
+tests/emu_native.py (test infrastructure; the product has no CPU path).  The kernels
+themselves are checked against the same restatement on the GPU (test_train_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+import emu_native
+import helpers
+
+
+@pytest.fixture
+def f64():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('name', ['u1_train_f64', 'u1_train_f64_plain'])
+def test_train_step_host_logic_f64(name, golden, monkeypatch, f64):
+    g = golden(name)
+    emu_native.install(monkeypatch)
+    dyn, lat, loss_fn = helpers.build_u1_train_dynamics(g)
+    out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-9, atol_rel=1e-6)
+    assert out['grad_rel'] < 1e-7, out
+    assert out['param_abs'] < 1e-7, out      # Adam's g / (|g| + 1e-8) amplifies rounding of tiny g
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+def test_train_step_host_logic_conv_f32(golden, monkeypatch):
+    g = golden('u1_train_conv')
+    emu_native.install(monkeypatch)
+    dyn, lat, loss_fn = helpers.build_u1_train_dynamics(g)
+    out = helpers.check_train_step(g, dyn, loss_fn, rtol=2e-4, atol_rel=1e-3,
+                                   adam_min_grad=1e-3)
+    assert out['grad_rel'] < 2e-2, out
+    assert out['param_abs'] < 2e-5, out
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('conv', [False, True])
+def test_trainer_train_loop_host_logic(conv, monkeypatch):
+    """Trainer.train_step bookkeeping with dropout + BatchNorm (+ conv stack): arena views,
+    Adam step counter, cache invalidation after the fused update, eval after training."""
+    import l2hmc.configs as cfgs
+    from l2hmc.trainers.pytorch.trainer import Trainer
+    emu_native.install(monkeypatch)
+    old = torch.get_default_dtype()
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = cfgs.get_config(['dynamics.group=U1', 'dynamics.latvolume=[4,4]',
+                               'dynamics.nchains=8', 'dynamics.nleapfrog=2',
+                               'dynamics.verbose=false', 'network.units=[8,8]',
+                               'network.dropout_prob=0.2', 'network.use_batch_norm=true',
+                               'learning_rate.clip_norm=1.0']
+                              + ([] if conv else ['conv=none']))
+        tr = Trainer(cfg)
+        x = tr.warmup(beta=2.0, nsteps=3)
+        before = {k: v.detach().clone() for k, v in tr.dynamics.named_parameters()}
+        eps0 = tr.dynamics._eps('x', 0)
+        out = tr.train(x=x, beta=2.0, nsteps=3)
+        assert all(np.isfinite(l) for l in out['history']['loss'])
+        moved = sum(int(not torch.equal(p.detach(), before[k]))
+                    for k, p in tr.dynamics.named_parameters())
+        assert moved >= 0.9 * len(before), (moved, len(before))
+        assert tr.arena.step_count == 3
+        assert tr.dynamics._eps('x', 0) != eps0          # step-size cache saw the fused update
+        # every parameter is a view of the flat arena, every grad a view of the flat gradient
+        for grp in tr.arena.groups.values():
+            lo, hi = grp['flat'].data_ptr(), grp['flat'].data_ptr() + grp['flat'].numel() * 8
+            for p in grp['params']:
+                assert lo <= p.data_ptr() < hi
+        _, m = tr.eval_step((out['x'], 2.0))
+        assert torch.isfinite(m['acc']).all()
+    finally:
+        torch.set_default_dtype(old)
