@@ -262,8 +262,9 @@ int l2q_axpy_rows(const void* x, const void* a, int nb, long n, int elem_bytes, 
                   void* stream);
 /* out[n] (+)= alpha * sum_m a[m][n] * (b ? b[m][n] : 1), fixed summation order
  * (bias gradients; ScaledTanh.coeff gradient with b = the head's output) */
-int l2q_colsum(const void* a, const void* b, int M, int N, double alpha, int accumulate,
-               int elem_bytes, void* out, void* stream);
+int l2q_colsum(const void* a, const void* b, long M, int N, double alpha, int accumulate,
+               int elem_bytes, void* out, void* ws, size_t ws_bytes, void* stream);
+size_t l2q_colsum_ws_bytes(long M, int N);
 /* head s = scale * exp(coeff[n]) * tanh(pre) (ScaledTanh, network.py:175-206):
  * dpre = ds * scale e^coeff (1 - tanh^2), tanh recovered from s.  coeff == NULL: linear head
  * t = scale * pre, dpre = scale * ds. */

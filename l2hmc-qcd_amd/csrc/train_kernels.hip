@@ -44,30 +44,51 @@ __global__ void axpy_rows_kernel(const T* __restrict__ x, const T* __restrict__ 
   if (j < n) y[c * n + j] += a[c] * x[c * n + j];
 }
 
-// out[n] (+)= alpha * sum_m a[m][n] * (b ? b[m][n] : 1).  Block = 64 columns x 16 row groups;
-// each thread walks its rows in order, the 16 partials are added in a fixed order.
+// out[n] (+)= alpha * sum_m a[m][n] * (b ? b[m][n] : 1), two order-stable stages.
+// Stage 1: a block of CX columns x (1024 / CX) row lanes reduces `rpb` consecutive rows into
+// partial[r][n] (CX = 8..64 by N so that a wavefront still reads contiguous memory when N is
+// small: conv bias gradients have N = 8 and M ~ 10^6 rows).  Stage 2 sums the partials.
 template <typename T>
-__global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ a,
-                                                      const T* __restrict__ b, int M, int N,
-                                                      double alpha, int accumulate,
-                                                      T* __restrict__ out) {
-  __shared__ double part[16][64];
+__global__ __launch_bounds__(1024) void colsum_partial_kernel(const T* __restrict__ a,
+                                                              const T* __restrict__ b, long M,
+                                                              int N, long rpb,
+                                                              double* __restrict__ partial) {
+  __shared__ double part[1024];
+  const int CX = blockDim.x, RY = blockDim.y;
   const int cx = threadIdx.x, ry = threadIdx.y;
-  const long col = (long)blockIdx.x * 64 + cx;
+  const long col = (long)blockIdx.x * CX + cx;
+  const long r0 = (long)blockIdx.y * rpb;
+  long r1 = r0 + rpb; if (r1 > M) r1 = M;
   double s = 0.0;
   if (col < N) {
-    for (long m = ry; m < M; m += 16) {
+    for (long m = r0 + ry; m < r1; m += RY) {
       const double av = (double)a[m * N + col];
       s += b ? av * (double)b[m * N + col] : av;
     }
   }
-  part[ry][cx] = s;
+  part[ry * CX + cx] = s;
   __syncthreads();
   if (ry == 0 && col < N) {
     double r = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) r += part[k][cx];
-    r *= alpha;
+    for (int k = 0; k < RY; ++k) r += part[k * CX + cx];
+    partial[(long)blockIdx.y * N + col] = r;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void colsum_final_kernel(const double* __restrict__ partial,
+                                                              long R, int N, double alpha,
+                                                              int accumulate, T* __restrict__ out) {
+  __shared__ double part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 64 + cx;
+  double s = 0.0;
+  if (col < N)
+    for (long r = ry; r < R; r += 4) s += partial[r * N + col];
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) {
+    const double r = alpha * (part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
     out[col] = accumulate ? (T)((double)out[col] + r) : (T)r;
   }
 }
@@ -443,14 +464,34 @@ int l2q_axpy_rows(const void* x, const void* a, int nb, long n, int elem_bytes, 
   return check_launch("l2q_axpy_rows");
 }
 
-int l2q_colsum(const void* a, const void* b, int M, int N, double alpha, int accumulate,
-               int elem_bytes, void* out, void* stream) {
-  L2Q_REQUIRE(a && out, L2Q_EINVAL, "null pointer");
+static long colsum_rows_per_block(long M) {
+  long rpb = M >= 4096 ? 256 : 64;
+  if (cdiv(M, rpb) > 4096) rpb = cdiv(M, 4096);
+  return rpb;
+}
+
+size_t l2q_colsum_ws_bytes(long M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)cdiv(M, colsum_rows_per_block(M)) * (size_t)N * sizeof(double);
+}
+
+int l2q_colsum(const void* a, const void* b, long M, int N, double alpha, int accumulate,
+               int elem_bytes, void* out, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(a && out && ws, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(M > 0 && N > 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(ws_bytes >= l2q_colsum_ws_bytes(M, N), L2Q_EINVAL, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  L2Q_DISPATCH_T(elem_bytes,
-                 hipLaunchKernelGGL(colsum_kernel<T>, dim3(grid1(N, 64)), dim3(64, 16), 0, st,
-                                    (const T*)a, (const T*)b, M, N, alpha, accumulate, (T*)out));
+  const long rpb = colsum_rows_per_block(M);
+  const long R = cdiv(M, rpb);
+  int cx = 64;
+  while (cx > 8 && cx / 2 >= N) cx /= 2;
+  const dim3 blk(cx, 1024 / cx), grid((unsigned)cdiv(N, cx), (unsigned)R);
+  L2Q_DISPATCH_T(elem_bytes, {
+    hipLaunchKernelGGL(colsum_partial_kernel<T>, grid, blk, 0, st, (const T*)a, (const T*)b, M, N,
+                       rpb, (double*)ws);
+    hipLaunchKernelGGL(colsum_final_kernel<T>, dim3(grid1(N, 64)), dim3(kBlock), 0, st,
+                       (const double*)ws, R, N, alpha, accumulate, (T*)out);
+  });
   return check_launch("l2q_colsum");
 }
 

@@ -455,7 +455,9 @@ def colsum_(out: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor] = None
             alpha: float = 1.0, accumulate: bool = True) -> torch.Tensor:
     """out[n] (+)= alpha * sum_m a[m, n] * (b[m, n] | 1)"""
     m, n = a.shape
-    N.call('l2q_colsum', a, b, m, n, float(alpha), int(accumulate), a.element_size(), out)
+    ws = N.workspace(int(N.load().l2q_colsum_ws_bytes(m, n)), a.device)
+    N.call('l2q_colsum', a, b, m, n, float(alpha), int(accumulate), a.element_size(), out, ws,
+           ws.numel())
     return out
 
 

@@ -66,7 +66,8 @@ SIGNATURES = {
     'l2q_act_bwd': (I, [P, P, I, L, I, P, P]),
     'l2q_mul': (I, [P, P, D, L, I, P, P]),
     'l2q_axpy_rows': (I, [P, P, I, L, I, P, P]),
-    'l2q_colsum': (I, [P, P, I, I, D, I, I, P, P]),
+    'l2q_colsum': (I, [P, P, L, I, D, I, I, P, P, Z, P]),
+    'l2q_colsum_ws_bytes': (Z, [L, I]),
     'l2q_scaled_tanh_bwd': (I, [P, P, P, D, I, I, I, P, P]),
     'l2q_bn_train_fwd': (I, [P, P, P, D, D, P, P, I, I, I, P, P, P, P]),
     'l2q_bn_bwd': (I, [P, P, P, P, P, I, I, I, P, P, P, P]),

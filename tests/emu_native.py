@@ -225,7 +225,7 @@ def l2q_axpy_rows(x, a, nb, n, esz, y):
     y.add_((a.reshape(nb, 1) * x.reshape(nb, n)).reshape(y.shape))
 
 
-def l2q_colsum(a, b, M, N, alpha, accumulate, esz, out):
+def l2q_colsum(a, b, M, N, alpha, accumulate, esz, out, ws=None, wsn=0):
     r = alpha * ((a * b) if b is not None else a).reshape(M, N).double().sum(0).to(a.dtype)
     if accumulate:
         out.add_(r.reshape(out.shape))

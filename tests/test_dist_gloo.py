@@ -73,3 +73,66 @@ def test_shard_chains_errors():
     assert D.shard_chains(2048, rank=3, world_size=8) == (768, 1024)
     with pytest.raises(ValueError):
         D.shard_chains(10, rank=0, world_size=4)
+
+
+# ------------------------------------------------------------------ data-parallel train step
+def _train_worker(rank, world, port, out):
+    """Each rank: the same Dynamics (base seed), its shard of the chains, one train step through
+    ParamArena.all_reduce (the path bench / Trainer use under torchrun).  Kernels are replaced
+    by tests/emu_native.py -- this container has no GPU; the collective is real (gloo)."""
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import numpy as np
+    torch.set_default_dtype(torch.float64)
+    import emu_native
+    import helpers
+    from l2hmc import native
+    from l2hmc.dynamics.pytorch import training as T
+    from l2hmc.utils import dist as D
+    native.call = emu_native.call
+    if world > 1:
+        assert D.setup_torch(seed=1234, backend='gloo') == rank
+    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'u1_train_f64_plain.npz')))
+    nb = g['x'].shape[0] - 1                               # 5 chains in the file -> use 4
+    lo, hi = (rank * nb // world, (rank + 1) * nb // world)
+    gs = dict(g)
+    for k in ('x', 'normals', 'u'):
+        gs[k] = g[k][lo:hi]
+    dyn, lat, loss_fn = helpers.build_u1_train_dynamics(gs)
+    arena = T.ParamArena(dyn)
+    arena.zero_grad()
+    dyn._inject = {'normals': gs['normals'], 'u': gs['u']}
+    x = dyn.g.compat_proj(dyn.unflatten(torch.from_numpy(gs['x'])))
+    _, m, loss = T.train_forward_backward(dyn, loss_fn, x, torch.tensor(float(g['beta'])))
+    scale = arena.all_reduce()
+    grp = arena.groups[torch.float64]
+    grads = (grp['grad'] * scale).clone()
+    arena.adam_step(lr=1e-3, grad_scale=scale)
+    torch.save({'grads': grads, 'params': grp['flat'].clone(), 'loss': float(loss), 'scale': scale},
+               os.path.join(out, f't{world}_{rank}.pt'))
+    if world > 1:
+        D.cleanup()
+
+
+def test_two_rank_train_step_equals_single_process(tmp_path):
+    """2 ranks x 2 chains == 1 process x 4 chains: averaged flat gradient and the parameters
+    after the fused Adam step (no BatchNorm in this fixture, so shard statistics don't enter)."""
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    old = torch.get_default_dtype()
+    try:
+        _train_worker(0, 1, port, str(tmp_path))
+    finally:
+        torch.set_default_dtype(old)
+    r0, r1 = (torch.load(tmp_path / f't2_{i}.pt') for i in range(2))
+    one = torch.load(tmp_path / 't1_0.pt')
+    assert r0['scale'] == 0.5 and one['scale'] == 1.0
+    assert torch.equal(r0['grads'], r1['grads'])
+    assert torch.equal(r0['params'], r1['params'])                 # replicas stay in lock-step
+    gn = float(one['grads'].abs().max())
+    assert float((r0['grads'] - one['grads']).abs().max()) < 1e-12 * max(gn, 1.0)
+    assert abs(0.5 * (r0['loss'] + r1['loss']) - one['loss']) < 1e-12 * max(abs(one['loss']), 1.0)
+    assert float((r0['params'] - one['params']).abs().max()) < 1e-7

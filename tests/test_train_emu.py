@@ -11,6 +11,14 @@ import emu_native
 import helpers
 
 
+@pytest.fixture(autouse=True)
+def _f32_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)
+    yield
+    torch.set_default_dtype(old)
+
+
 @pytest.fixture
 def f64():
     old = torch.get_default_dtype()
