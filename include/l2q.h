@@ -322,6 +322,41 @@ int l2q_sumsq(const void* a, long n, int elem_bytes, double* out, void* ws, size
               void* stream);
 size_t l2q_sumsq_ws_bytes(long n);
 
+/* ---- SU(3) cotangents (fp64 / complex128, native layout xn[nb][4][9][V]).  Cotangent
+ * convention of torch for complex tensors: g_z = dL/dRe z + i dL/dIm z. */
+
+/* VJP of l2q_su3_expm_mul (one masked half-update, dynamics.py:1420-1425 / 1468-1474; eps is
+ * the signed step the forward was called with).  gx overwritten, gv +=, deps[c] = per-chain
+ * dL/d eps.  Uses the Frechet derivative of the matrix exponential (scaling & squaring). */
+int l2q_su3_expm_mul_bwd(const void* xn, const void* vn, double eps, const float* mask_n,
+                         int complement, const void* gxnew, void* gx, void* gv, double* deps,
+                         int nb, long V, void* ws, size_t ws_bytes, void* stream);
+/* VJP of l2q_su3_projsu_vec8 (su3_to_vec(projectSU(.)), group.py:138-147): gm += .  `in` are
+ * the matrices the forward projected; gvec [nfields][8][V]. */
+int l2q_su3_projsu_vec8_bwd(const void* in, const double* gvec, void* gm, long nfields, long V,
+                            void* stream);
+/* VJP of the force as the reference differentiates it: F = TAH(D x^H) with D = dS/dx held
+ * constant (lattice/su3/pytorch/lattice.py:299-308, no create_graph):
+ * gx += (beta/3) TAH(gf) (staple sum)^H */
+int l2q_su3_force_bwd(const void* xn, const void* gf, double beta, void* gx, int nb, int T, int X,
+                      int Y, int Z, void* stream);
+/* VJP of the per-plane plaquette sums (action, plaq / charge loss terms, loss.py:56-148):
+ * L = sum_planes Re(conj(w[c][p]) sum_sites tr P_p), w [nb][6] complex (re, im), planes ordered
+ * as l2q_su3_plaq_planes.  gx += dL/dx. */
+int l2q_su3_plaq_bwd(const void* xn, const double* w, void* gx, int nb, int T, int X, int Y, int Z,
+                     void* stream);
+/* l2q_v_update_bwd for complex128 momenta (SU3): v, force, gv, dv, dF complex [nb][n];
+ * s, t, q, ds, dt, dq real [nb][n].  All outputs overwritten. */
+int l2q_v_update_bwd_c128(const void* v, const void* force, const double* s, const double* t,
+                          const double* q, double eps, int forward, const void* gv,
+                          const double* gl, int nb, long n, void* dv, void* dF, double* ds,
+                          double* dt, double* dq, double* deps, void* ws, size_t ws_bytes,
+                          void* stream);
+/* gx[c][:] += 2 a[c] (x[c][:] - y[c][:]) over n doubles per chain (cotangent of
+ * l2q_diff_norm2_reduce, the rmse term of LatticeLoss, loss.py:119-148) */
+int l2q_diff_bwd_f64(const double* x, const double* y, const double* a, int nb, long n, double* gx,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,524 @@
+// su3_train_kernels.hip -- reverse-mode (VJP) kernels of the SU(3) L2HMC training step, gfx950.
+//
+// Cotangent convention (the one torch uses for complex tensors): for a real loss L and a
+// complex quantity z, g_z = dL/dRe z + i dL/dIm z, i.e. dL = Re tr(g_z^H dz).  With it
+//   W = A B      =>  g_A = g_W B^H,  g_B = A^H g_W
+//   E = expm(A)  =>  g_A = L_exp(A^H)[g_E]            (Frechet derivative at A^H)
+//   F = TAH(M)   =>  g_M = TAH(g_F)                   (orthogonal projector, self-adjoint)
+// The reference obtains all of these from torch.autograd over torch.matrix_exp, the closed-form
+// projectSU (group/su3/pytorch/utils.py:227-346) and autograd.grad(action) (lattice.py:299-308).
+#include "l2q_common.hpp"
+#include "su3_links.hpp"
+
+namespace l2q {
+
+__device__ __forceinline__ void m3_adjoint(M3& r, const M3& a) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { r.re[3 * i + j] = a.re[3 * j + i]; r.im[3 * i + j] = -a.im[3 * j + i]; }
+}
+
+// sum_ij Re(conj(a_ij) b_ij)
+__device__ __forceinline__ double m3_inner(const M3& a, const M3& b) {
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s += a.re[i] * b.re[i] + a.im[i] * b.im[i];
+  return s;
+}
+
+// E = exp(B) and L = L_exp(B)[G] (Frechet derivative of the exponential at B in direction G):
+// scaling & squaring on the Taylor series, M_n = M_{n-1} X + X^{n-1} G,
+// L_0 = sum M_n / n!, then L <- E L + L E, E <- E E per squaring.
+__device__ __forceinline__ void m3_expm_frechet(M3& E, M3& L, const M3& B, const M3& G) {
+  double n2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) n2 += B.re[i] * B.re[i] + B.im[i] * B.im[i];
+  const double nrm = sqrt(n2);
+  int s = 0;
+  double scale = 1.0;
+  if (nrm > 0.25) {
+    int ex;
+    (void)frexp(nrm, &ex);
+    s = ex + 2;                                      // nrm / 2^s in [0.125, 0.25)
+    if (s > 60) s = 60;
+    scale = ldexp(1.0, -s);
+  }
+  M3 X, Gs, P, M;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    X.re[i] = B.re[i] * scale; X.im[i] = B.im[i] * scale;
+    Gs.re[i] = G.re[i] * scale; Gs.im[i] = G.im[i] * scale;
+  }
+  m3_identity(E);
+  m3_zero(L);
+  m3_identity(P);
+  m3_zero(M);
+  double f = 1.0;
+#pragma unroll 1
+  for (int n = 1; n <= 13; ++n) {
+    M3 t;
+    m3_mul_nn(t, M, X);
+    m3_mac_nn(t, P, Gs);
+    M = t;
+    m3_mul_nn(t, P, X);
+    P = t;
+    f /= (double)n;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      E.re[i] = fma(f, P.re[i], E.re[i]); E.im[i] = fma(f, P.im[i], E.im[i]);
+      L.re[i] = fma(f, M.re[i], L.re[i]); L.im[i] = fma(f, M.im[i], L.im[i]);
+    }
+  }
+#pragma unroll 1
+  for (int k = 0; k < s; ++k) {
+    M3 t;
+    m3_mul_nn(t, E, L);
+    m3_mac_nn(t, L, E);
+    L = t;
+    m3_mul_nn(t, E, E);
+    E = t;
+  }
+}
+
+// ------------------------------------------------------------------ x half-update (expm) VJP
+// forward (l2q_su3_expm_mul): x' = keep (.) x + expm(eps v) @ ((1 - keep) (.) x)
+//   g_x = keep (.) g + (1 - keep) (.) (E^H g);   g_E = g y^H,  y = (1 - keep) (.) x
+//   g_A = L_exp((eps v)^H)[g_E];  g_v += eps g_A;  d eps = sum Re tr(g_A^H v)
+__global__ __launch_bounds__(kBlock) void su3_expm_mul_bwd_kernel(
+    const double2* __restrict__ xn, const double2* __restrict__ vn, double eps,
+    const float* __restrict__ mask, int complement, const double2* __restrict__ gxn, double2* gx,
+    double2* gv, int V, long nblk, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;     // f = chain*4 + mu
+  const int s = (int)blk * kBlock + threadIdx.x;
+  const int mu = (int)(f & 3);
+  double de = 0.0;
+  if (s < V) {
+    M3 x, v, g;
+    load_link(x, xn + f * 9L * V, V, s);
+    load_link(v, vn + f * 9L * V, V, s);
+    load_link(g, gxn + f * 9L * V, V, s);
+    double keep[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      double k = 0.0;
+      if (mask != nullptr) {
+        k = (double)mask[(mu * 9 + i) * (long)V + s];
+        if (complement) k = 1.0 - k;
+      }
+      keep[i] = k;
+    }
+    M3 y, gE, B;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      y.re[i] = (1.0 - keep[i]) * x.re[i]; y.im[i] = (1.0 - keep[i]) * x.im[i];
+    }
+    m3_mul_na(gE, g, y);                               // g y^H
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {                    // B = (eps v)^H
+        B.re[3 * i + j] = eps * v.re[3 * j + i]; B.im[3 * i + j] = -eps * v.im[3 * j + i];
+      }
+    M3 EB, gA;
+    m3_expm_frechet(EB, gA, B, gE);                    // EB = expm(eps v)^H
+    M3 gy;
+    m3_mul_nn(gy, EB, g);                              // E^H g
+    M3 out;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      out.re[i] = keep[i] * g.re[i] + (1.0 - keep[i]) * gy.re[i];
+      out.im[i] = keep[i] * g.im[i] + (1.0 - keep[i]) * gy.im[i];
+    }
+    store_link(gx + f * 9L * V, V, s, out);
+    de = m3_inner(gA, v);
+    double2* gvf = gv + f * 9L * V;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      double2 o = gvf[e * (long)V + s];
+      o.x = fma(eps, gA.re[e], o.x); o.y = fma(eps, gA.im[e], o.y);
+      gvf[e * (long)V + s] = o;
+    }
+  }
+  const double r = block_sum(de, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// ------------------------------------------------------------------ projectSU -> vec8 VJP
+// J^H A J and V J for the complex Jacobi rotation in the (P, Q) plane:
+//   J_PP = cs, J_PQ = sn, J_QP = -sn ph, J_QQ = cs ph   (ph = e^{-i arg h_PQ})
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(M3& H, M3& Vm) {
+  const double cr = H.re[3 * P + Q], ci = H.im[3 * P + Q];
+  const double ac = sqrt(cr * cr + ci * ci);
+  if (!(ac > 1e-300)) return;
+  const double a = H.re[3 * P + P], b = H.re[3 * Q + Q];
+  const double tau = (b - a) / (2.0 * ac);
+  const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+  const double pr = cr / ac, pi = -ci / ac;            // ph = conj(c) / |c|
+  // right-multiply by J: columns P, Q of H and of V
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    {
+      const double xr = H.re[3 * r + P], xi = H.im[3 * r + P], yr = H.re[3 * r + Q], yi = H.im[3 * r + Q];
+      const double zr = yr * pr - yi * pi, zi = yr * pi + yi * pr;     // y * ph
+      H.re[3 * r + P] = cs * xr - sn * zr; H.im[3 * r + P] = cs * xi - sn * zi;
+      H.re[3 * r + Q] = sn * xr + cs * zr; H.im[3 * r + Q] = sn * xi + cs * zi;
+    }
+    {
+      const double xr = Vm.re[3 * r + P], xi = Vm.im[3 * r + P], yr = Vm.re[3 * r + Q], yi = Vm.im[3 * r + Q];
+      const double zr = yr * pr - yi * pi, zi = yr * pi + yi * pr;
+      Vm.re[3 * r + P] = cs * xr - sn * zr; Vm.im[3 * r + P] = cs * xi - sn * zi;
+      Vm.re[3 * r + Q] = sn * xr + cs * zr; Vm.im[3 * r + Q] = sn * xi + cs * zi;
+    }
+  }
+  // left-multiply by J^H: rows P, Q of H
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double xr = H.re[3 * P + k], xi = H.im[3 * P + k], yr = H.re[3 * Q + k], yi = H.im[3 * Q + k];
+    const double zr = yr * pr + yi * pi, zi = -yr * pi + yi * pr;      // y * conj(ph)
+    H.re[3 * P + k] = cs * xr - sn * zr; H.im[3 * P + k] = cs * xi - sn * zi;
+    // row Q: sn * x + cs * conj(ph) * y
+    H.re[3 * Q + k] = sn * xr + cs * zr; H.im[3 * Q + k] = sn * xi + cs * zi;
+  }
+  H.re[3 * P + Q] = 0.0; H.im[3 * P + Q] = 0.0;
+  H.re[3 * Q + P] = 0.0; H.im[3 * Q + P] = 0.0;
+  H.im[3 * P + P] = 0.0; H.im[3 * Q + Q] = 0.0;
+}
+
+// y = su3_to_vec(projectSU(M)):  g_M += VJP(g_y).  projectSU(M) = U e^{i theta},
+// U = M (M^H M)^{-1/2} (polar factor), theta = -arg(det U) / 3.
+//   g_W from g_y (adjoint of the linear 8-component map), c = Re tr(g_W^H i W),
+//   g_U = e^{-i theta} g_W - (c / 3) i U;   Z = U^H g_U;  H K + K H = Z with H = U^H M;
+//   g_M = U (K - K^H).
+// The Sylvester equation is solved in the eigenbasis of H (cyclic complex Jacobi, 6 sweeps):
+// robust for the degenerate H ~ 1 of a link that is already unitary, where a polynomial-in-H
+// solution (and the reference's closed-form eigenvalue derivative) breaks down.
+__global__ __launch_bounds__(kBlock) void su3_projsu_vec8_bwd_kernel(
+    const double2* __restrict__ in, const double* __restrict__ gvec, double2* gm, int V,
+    long nblk) {
+  const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  if (s >= V) return;
+  M3 m, u;
+  load_link(m, in + f * 9L * V, V, s);
+  m3_project_u(u, m);
+  double dr, di;
+  m3_det(dr, di, u);
+  const double theta = -atan2(di, dr) / 3.0;
+  const double pr = cos(theta), pi = sin(theta);
+  double gy[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) gy[a] = gvec[(f * 8 + a) * (long)V + s];
+  // g_W: adjoint of m3_to_vec8
+  M3 gw;
+  m3_zero(gw);
+  const double s3 = 0.57735026918962584;
+  gw.re[1] = -2.0 * gy[1]; gw.im[1] = -2.0 * gy[0];
+  gw.re[2] = -2.0 * gy[4]; gw.im[2] = -2.0 * gy[3];
+  gw.re[5] = -2.0 * gy[6]; gw.im[5] = -2.0 * gy[5];
+  gw.im[0] = -gy[2] - s3 * gy[7];
+  gw.im[4] = gy[2] - s3 * gy[7];
+  gw.im[8] = 2.0 * s3 * gy[7];
+  // c = Re tr(g_W^H i W), W = u * phi
+  double c = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double wr = u.re[i] * pr - u.im[i] * pi, wi = u.re[i] * pi + u.im[i] * pr;
+    c += gw.re[i] * (-wi) + gw.im[i] * wr;            // i W = (-wi, wr)
+  }
+  M3 gu;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    // conj(phi) g_W - (c/3) i U
+    gu.re[i] = gw.re[i] * pr + gw.im[i] * pi + (c / 3.0) * u.im[i];
+    gu.im[i] = -gw.re[i] * pi + gw.im[i] * pr - (c / 3.0) * u.re[i];
+  }
+  M3 h, z;
+  m3_mul_an(h, u, m);                                  // H = U^H M
+  m3_mul_an(z, u, gu);                                 // Z = U^H g_U
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 3; ++j) {                      // Hermitian part
+      const double ar = 0.5 * (h.re[3 * i + j] + h.re[3 * j + i]);
+      const double ai = 0.5 * (h.im[3 * i + j] - h.im[3 * j + i]);
+      h.re[3 * i + j] = ar; h.im[3 * i + j] = ai;
+      h.re[3 * j + i] = ar; h.im[3 * j + i] = -ai;
+    }
+  M3 vm;
+  m3_identity(vm);
+#pragma unroll 1
+  for (int sweep = 0; sweep < 6; ++sweep) {
+    jacobi_rotate<0, 1>(h, vm);
+    jacobi_rotate<0, 2>(h, vm);
+    jacobi_rotate<1, 2>(h, vm);
+  }
+  const double e0 = h.re[0], e1 = h.re[4], e2 = h.re[8];
+  M3 t, zt;
+  m3_mul_an(t, vm, z);                                 // V^H Z
+  m3_mul_nn(zt, t, vm);                                // V^H Z V
+  const double ev[3] = {e0, e1, e2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double inv = 1.0 / (ev[i] + ev[j]);
+      zt.re[3 * i + j] *= inv; zt.im[3 * i + j] *= inv;
+    }
+  M3 k;
+  m3_mul_nn(t, vm, zt);
+  m3_mul_na(k, t, vm);                                 // K = V Kt V^H
+  M3 ka;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                      // K - K^H
+      ka.re[3 * i + j] = k.re[3 * i + j] - k.re[3 * j + i];
+      ka.im[3 * i + j] = k.im[3 * i + j] + k.im[3 * j + i];
+    }
+  M3 g;
+  m3_mul_nn(g, u, ka);
+  double2* o = gm + f * 9L * V;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    double2 r = o[e * (long)V + s];
+    r.x += g.re[e]; r.y += g.im[e];
+    o[e * (long)V + s] = r;
+  }
+}
+
+// ------------------------------------------------------------------ staple-type VJPs
+// Both use the up / down staples of link (s, mu) in direction nu
+//   S_up = U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H,  S_dn = U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu).
+// MODE 0 (force VJP; the reference's force is TAH(D x^H) with D = dS/dx held constant,
+//   lattice/su3/pytorch/lattice.py:299-308):  g_x += coef TAH(g_F) (sum S)^H
+// MODE 1 (plaquette-sum VJP, L = sum_p Re(conj(w_p) tr P_p), planes p = (u > v) in the order
+//   (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)):
+//   mu > nu: g_x += w_p S_up^H + conj(w_p) S_dn^H;   mu < nu: g_x += conj(w_p) S_up^H + w_p S_dn^H
+__device__ __forceinline__ int plane_index(int u, int v) { return u * (u - 1) / 2 + v; }
+
+__device__ __forceinline__ void mac_scaled_adjoint(M3& acc, double wr, double wi, const M3& sm) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double ar = sm.re[3 * j + i], ai = -sm.im[3 * j + i];     // (S^H)_ij
+      acc.re[3 * i + j] += wr * ar - wi * ai;
+      acc.im[3 * i + j] += wr * ai + wi * ar;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 2) void su3_staple_bwd_kernel(
+    const double2* __restrict__ xn, Dims d, long nblk, int swz, double coef,
+    const double2* __restrict__ gf, const double* __restrict__ w, double2* gx) {
+  const long total = (long)gridDim.x;
+  const long wk = xcd_swizzle(blockIdx.x, total, swz);
+  const int mu = (int)(wk & 3);
+  const long cb = wk >> 2;
+  const long c = cb / nblk, blk = cb % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  if (s >= d.V) return;
+  const int V = d.V;
+  const double2* xc = xn + c * 36L * V;
+  const double2* fm = xc + mu * 9 * V;
+  const Site p = site_coords(s, d);
+  const int cmu = coord_of(p, mu);
+  const int s_pmu = fwd(s, cmu, d, mu);
+  M3 acc;
+  m3_zero(acc);
+#pragma unroll 1
+  for (int nu = 0; nu < 4; ++nu) {
+    if (nu == mu) continue;
+    const double2* fn = xc + nu * 9 * V;
+    const int cnu = coord_of(p, nu);
+    const int s_pnu = fwd(s, cnu, d, nu);
+    const int s_mnu = bwd(s, cnu, d, nu);
+    const int s_pmu_mnu = bwd(s_pmu, cnu, d, nu);
+    double wr = 1.0, wi = 0.0;
+    if (MODE == 1) {
+      const int pl = mu > nu ? plane_index(mu, nu) : plane_index(nu, mu);
+      wr = w[(c * 6 + pl) * 2 + 0];
+      wi = w[(c * 6 + pl) * 2 + 1];
+      if (mu < nu) wi = -wi;                           // conj(w) multiplies S_up^H when mu < nu
+    }
+    M3 a, b, t, st;
+    load_link(a, fn, V, s_pmu);
+    load_link(b, fm, V, s_pnu);
+    m3_mul_na(t, a, b);
+    load_link(a, fn, V, s);
+    m3_mul_na(st, t, a);                               // S_up
+    mac_scaled_adjoint(acc, wr, wi, st);
+    load_link(a, fn, V, s_pmu_mnu);
+    load_link(b, fm, V, s_mnu);
+    m3_mul_aa(t, a, b);
+    load_link(a, fn, V, s_mnu);
+    m3_mul_nn(st, t, a);                               // S_dn
+    mac_scaled_adjoint(acc, wr, -wi, st);
+  }
+  M3 g;
+  if (MODE == 0) {
+    M3 gfl, tg;
+    load_link(gfl, gf + (c * 4 + mu) * 9L * V, V, s);
+    m3_tah(tg, gfl);
+    m3_mul_nn(g, tg, acc);                             // TAH(g_F) (sum S)^H  (acc holds the adjoint sum)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { g.re[i] *= coef; g.im[i] *= coef; }
+  } else {
+    g = acc;
+  }
+  double2* o = gx + (c * 4 + mu) * 9L * V;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    double2 r = o[e * (long)V + s];
+    r.x += g.re[e]; r.y += g.im[e];
+    o[e * (long)V + s] = r;
+  }
+}
+
+// ------------------------------------------------------------------ complex v-update VJP
+// v, F, g_v complex [nb][n]; s, t, q real [nb][n] (dynamics.py:1266-1297 on complex momenta)
+template <bool FWD>
+__global__ __launch_bounds__(kBlock) void v_update_bwd_cplx_kernel(
+    const double2* __restrict__ v, const double2* __restrict__ force, const double* __restrict__ s,
+    const double* __restrict__ t, const double* __restrict__ q, double eps,
+    const double2* __restrict__ gv, const double* __restrict__ gl, long n, long nblk,
+    double2* __restrict__ dv, double2* __restrict__ dF, double* __restrict__ ds,
+    double* __restrict__ dt, double* __restrict__ dq, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const long j = blk * kBlock + threadIdx.x;
+  double de = 0.0;
+  if (j < n) {
+    const long o = c * n + j;
+    const double glc = gl ? gl[c] : 0.0;
+    const double2 vj = v[o], fj = force[o], g = gv[o];
+    const double sj = s[o], tj = t[o], qj = q[o];
+    const double S = FWD ? 0.5 * eps * sj : -0.5 * eps * sj;
+    const double es = exp(S), eq = exp(eps * qj);
+    const double fqr = fj.x * eq + tj, fqi = fj.y * eq;
+    double dS, dBr, dBi;
+    if (FWD) {
+      dS = es * (g.x * vj.x + g.y * vj.y) + glc;
+      dBr = -g.x; dBi = -g.y;
+    } else {
+      const double wr = vj.x + 0.5 * eps * fqr, wi = vj.y + 0.5 * eps * fqi;
+      dS = es * (g.x * wr + g.y * wi) + glc;
+      dBr = g.x * es; dBi = g.y * es;
+    }
+    dv[o] = make_double2(g.x * es, g.y * es);
+    dF[o] = make_double2(dBr * 0.5 * eps * eq, dBi * 0.5 * eps * eq);
+    dt[o] = 0.5 * eps * dBr;
+    const double dQ = 0.5 * eps * eq * (dBr * fj.x + dBi * fj.y);
+    ds[o] = FWD ? 0.5 * eps * dS : -0.5 * eps * dS;
+    dq[o] = eps * dQ;
+    de = 0.5 * (dBr * fqr + dBi * fqi) + (FWD ? 0.5 * sj * dS : -0.5 * sj * dS) + qj * dQ;
+  }
+  const double r = block_sum(de, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// g_x += 2 a[c] (x - y)  (cotangent of sum |x - y|^2, the rmse term of LatticeLoss)
+__global__ void diff_bwd_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                const double* __restrict__ a, long n, double* gx) {
+  const long c = blockIdx.y;
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) gx[c * n + j] += 2.0 * a[c] * (x[c * n + j] - y[c * n + j]);
+}
+
+}  // namespace l2q
+
+using namespace l2q;
+
+static bool dims_ok4(int nb, int T, int X, int Y, int Z) {
+  return nb > 0 && T > 0 && X > 0 && Y > 0 && Z > 0 && (double)T * X * Y * Z * 36.0 < 2.0e9;
+}
+
+extern "C" {
+
+int l2q_su3_expm_mul_bwd(const void* xn, const void* vn, double eps, const float* mask_n,
+                         int complement, const void* gxnew, void* gx, void* gv, double* deps,
+                         int nb, long V, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(xn && vn && gxnew && gx && gv && deps && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * 4 * nblk * sizeof(double), L2Q_EINVAL, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(su3_expm_mul_bwd_kernel, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock), 0, st,
+                     (const double2*)xn, (const double2*)vn, eps, mask_n, complement,
+                     (const double2*)gxnew, (double2*)gx, (double2*)gv, (int)V, nblk, (double*)ws);
+  launch_finalize((const double*)ws, deps, nb, 4 * nblk, 1, 1.0, 0.0, st);
+  return check_launch("l2q_su3_expm_mul_bwd");
+}
+
+int l2q_su3_projsu_vec8_bwd(const void* in, const double* gvec, void* gm, long nfields, long V,
+                            void* stream) {
+  L2Q_REQUIRE(in && gvec && gm, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL(su3_projsu_vec8_bwd_kernel, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)in, gvec, (double2*)gm, (int)V, nblk);
+  return check_launch("l2q_su3_projsu_vec8_bwd");
+}
+
+int l2q_su3_force_bwd(const void* xn, const void* gf, double beta, void* gx, int nb, int T, int X,
+                      int Y, int Z, void* stream) {
+  L2Q_REQUIRE(xn && gf && gx, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok4(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  hipLaunchKernelGGL(su3_staple_bwd_kernel<0>, dim3((unsigned)(nb * nblk * 4)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)xn, d, nblk, tuning().xcd_swizzle,
+                     beta / 3.0, (const double2*)gf, (const double*)nullptr, (double2*)gx);
+  return check_launch("l2q_su3_force_bwd");
+}
+
+int l2q_su3_plaq_bwd(const void* xn, const double* w, void* gx, int nb, int T, int X, int Y, int Z,
+                     void* stream) {
+  L2Q_REQUIRE(xn && w && gx, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok4(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  hipLaunchKernelGGL(su3_staple_bwd_kernel<1>, dim3((unsigned)(nb * nblk * 4)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)xn, d, nblk, tuning().xcd_swizzle, 1.0,
+                     (const double2*)nullptr, w, (double2*)gx);
+  return check_launch("l2q_su3_plaq_bwd");
+}
+
+int l2q_v_update_bwd_c128(const void* v, const void* force, const double* s, const double* t,
+                          const double* q, double eps, int forward, const void* gv,
+                          const double* gl, int nb, long n, void* dv, void* dF, double* ds,
+                          double* dt, double* dq, double* deps, void* ws, size_t ws_bytes,
+                          void* stream) {
+  L2Q_REQUIRE(v && force && s && t && q && gv && dv && dF && ds && dt && dq && deps && ws,
+              L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
+  const long nblk = cdiv(n, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * sizeof(double), L2Q_EINVAL, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(nb * nblk)), block(kBlock);
+  if (forward)
+    hipLaunchKernelGGL(v_update_bwd_cplx_kernel<true>, grid, block, 0, st, (const double2*)v,
+                       (const double2*)force, s, t, q, eps, (const double2*)gv, gl, n, nblk,
+                       (double2*)dv, (double2*)dF, ds, dt, dq, (double*)ws);
+  else
+    hipLaunchKernelGGL(v_update_bwd_cplx_kernel<false>, grid, block, 0, st, (const double2*)v,
+                       (const double2*)force, s, t, q, eps, (const double2*)gv, gl, n, nblk,
+                       (double2*)dv, (double2*)dF, ds, dt, dq, (double*)ws);
+  launch_finalize((const double*)ws, deps, nb, nblk, 1, 1.0, 0.0, st);
+  return check_launch("l2q_v_update_bwd_c128");
+}
+
+int l2q_diff_bwd_f64(const double* x, const double* y, const double* a, int nb, long n, double* gx,
+                     void* stream) {
+  L2Q_REQUIRE(x && y && a && gx, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
+  hipLaunchKernelGGL(diff_bwd_kernel, dim3((unsigned)cdiv(n, kBlock), (unsigned)nb), dim3(kBlock), 0,
+                     (hipStream_t)stream, x, y, a, n, gx);
+  return check_launch("l2q_diff_bwd_f64");
+}
+
+}  // extern "C"

@@ -597,3 +597,59 @@ def sumsq(a: torch.Tensor) -> torch.Tensor:
     ws = N.workspace(int(N.load().l2q_sumsq_ws_bytes(a.numel())), a.device)
     N.call('l2q_sumsq', a, a.numel(), a.element_size(), out, ws, ws.numel())
     return out
+
+
+# ---------------------------------------------------------------------------- SU(3) training (VJPs)
+def su3_expm_mul_bwd_n(xn, vn, eps: float, mask_n, complement: bool, gxnew, gv):
+    """-> (gx, deps[nb]); gv accumulated in place.  eps: the signed step of the forward call."""
+    nb, _, _, V = xn.shape
+    gx = torch.empty_like(xn)
+    deps = torch.empty(nb, dtype=torch.float64, device=xn.device)
+    ws = N.workspace(nb * 4 * ((V + 255) // 256) * 8, xn.device)
+    N.call('l2q_su3_expm_mul_bwd', xn, vn, float(eps), mask_n, int(complement), gxnew, gx, gv, deps,
+           nb, V, ws, ws.numel())
+    return gx, deps
+
+
+def su3_projsu_vec8_bwd_(gm: torch.Tensor, mn: torch.Tensor, gvec: torch.Tensor) -> torch.Tensor:
+    """gm += VJP of su3_projsu_vec8_n at mn for the cotangent gvec [..., 8, V]."""
+    V = mn.shape[-1]
+    nf = mn.numel() // (9 * V)
+    N.call('l2q_su3_projsu_vec8_bwd', mn, gvec.contiguous(), gm, nf, V)
+    return gm
+
+
+def su3_force_bwd_(gx: torch.Tensor, xn: torch.Tensor, gf: torch.Tensor, beta: float,
+                   lat: Sequence[int]) -> torch.Tensor:
+    T, X, Y, Z = (int(i) for i in lat)
+    N.call('l2q_su3_force_bwd', xn, gf, float(beta), gx, xn.shape[0], T, X, Y, Z)
+    return gx
+
+
+def su3_plaq_bwd_(gx: torch.Tensor, xn: torch.Tensor, w: torch.Tensor,
+                  lat: Sequence[int]) -> torch.Tensor:
+    """w [nb, 6, 2] float64: complex plane weights (re, im)."""
+    T, X, Y, Z = (int(i) for i in lat)
+    N.call('l2q_su3_plaq_bwd', xn, w.to(torch.float64).contiguous(), gx, xn.shape[0], T, X, Y, Z)
+    return gx
+
+
+def v_update_bwd_c128(v, force, s, t, q, eps: float, forward: bool, gv, gl):
+    """complex momenta: -> (dv, dF, ds, dt, dq, deps[nb])"""
+    nb = v.shape[0]
+    n = v.numel() // nb
+    dv, dF = torch.empty_like(v), torch.empty_like(v)
+    ds, dt, dq = (torch.empty_like(s) for _ in range(3))
+    deps = torch.empty(nb, dtype=torch.float64, device=v.device)
+    ws = N.workspace(nb * ((n + 255) // 256) * 8, v.device)
+    N.call('l2q_v_update_bwd_c128', v, force, s, t, q, float(eps), int(forward), gv, gl, nb, n, dv,
+           dF, ds, dt, dq, deps, ws, ws.numel())
+    return dv, dF, ds, dt, dq, deps
+
+
+def diff_bwd_(gx: torch.Tensor, x: torch.Tensor, y: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    """gx += 2 a[c] (x - y) over float64 / complex128 tensors of equal shape."""
+    nb = x.shape[0]
+    n = x.numel() // nb * (2 if x.is_complex() else 1)
+    N.call('l2q_diff_bwd_f64', x, y, a.to(torch.float64).contiguous(), nb, n, gx)
+    return gx

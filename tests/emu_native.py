@@ -335,6 +335,226 @@ def l2q_sumsq(a, n, esz, out, ws, wsn):
     out[0] = (a.double() ** 2).sum()
 
 
+
+# ============================================================================ SU(3) (native layout)
+C128 = torch.complex128
+
+
+def _adj(a):
+    return a.conj().transpose(-1, -2)
+
+
+def _mats(xn):
+    """xn[..., 9, V] -> [..., V, 3, 3]"""
+    V = xn.shape[-1]
+    return xn.transpose(-1, -2).reshape(*xn.shape[:-2], V, 3, 3)
+
+
+def _native(m):
+    """[..., V, 3, 3] -> [..., 9, V]"""
+    V = m.shape[-3]
+    return m.reshape(*m.shape[:-3], V, 9).transpose(-1, -2).contiguous()
+
+
+def _roll(a, mu, sh):                      # a [nb, T, X, Y, Z, 3, 3]; value at s + sh * mu
+    return torch.roll(a, -sh, dims=1 + mu)
+
+
+def _su3_planes(x):
+    """x [nb, 4, T, X, Y, Z, 3, 3] -> per-plane sums of tr P, [nb, 6] complex
+    (lattice/su3/pytorch/lattice.py:157-199, planes (u > v) in loop order)"""
+    out = []
+    for u in range(1, 4):
+        for v in range(u):
+            P = x[:, u] @ _roll(x[:, v], u, 1) @ _adj(x[:, v] @ _roll(x[:, u], v, 1))
+            out.append(torch.diagonal(P, dim1=-2, dim2=-1).sum(-1).sum((1, 2, 3, 4)))
+    return torch.stack(out, 1)
+
+
+def _tah(m):
+    r = 0.5 * (m - _adj(m))
+    tr = torch.diagonal(r, dim1=-2, dim2=-1).sum(-1) / 3
+    return r - tr[..., None, None] * torch.eye(3, dtype=m.dtype)
+
+
+def _su3_force(x, beta):
+    """TAH(D x^H) with D = d action / dx held constant (lattice.py:299-308)."""
+    xd = x.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        S = -(beta / 3.0) * _su3_planes(xd).real.sum()
+        (D,) = torch.autograd.grad(S, xd)
+    return _tah(D.detach() @ _adj(x))
+
+
+def _proj_su(M):
+    """polar factor with the determinant phase removed (utils.py:332-346), via eigh"""
+    w, V = torch.linalg.eigh(_adj(M) @ M)
+    U = M @ ((V * (1 / torch.sqrt(w))[..., None, :]) @ _adj(V))
+    d = torch.linalg.det(U)
+    th = -torch.atan2(d.imag, d.real) / 3
+    return U * torch.complex(torch.cos(th), torch.sin(th))[..., None, None]
+
+
+def _to_vec8(x):
+    s3 = 1 / math.sqrt(3.0)
+    x00, x01, x02 = x[..., 0, 0], x[..., 0, 1], x[..., 0, 2]
+    x11, x12, x22 = x[..., 1, 1], x[..., 1, 2], x[..., 2, 2]
+    return torch.stack([-2 * x01.imag, -2 * x01.real, x11.imag - x00.imag, -2 * x02.imag,
+                        -2 * x02.real, -2 * x12.imag, -2 * x12.real,
+                        s3 * (2 * x22.imag - x11.imag - x00.imag)], -1)
+
+
+def _keep_n(mask_n, complement, nb, V):
+    if mask_n is None:
+        return None
+    k = mask_n.reshape(1, 4, 9, V).double()
+    return (1 - k) if complement else k
+
+
+def _expm_mul(xn, vn, eps, keep):
+    """native in / native out"""
+    E = torch.matrix_exp(eps * _mats(vn))
+    if keep is None:
+        return _native(E @ _mats(xn))
+    return keep * xn + _native(E @ _mats((1 - keep) * xn))
+
+
+def l2q_su3_pack(x, out, nb, V):
+    out.copy_(_native(x.reshape(nb, 4, V, 3, 3)))
+
+
+def l2q_su3_unpack(xn, out, nb, V):
+    out.copy_(_mats(xn.reshape(nb, 4, 9, V)).reshape(out.shape))
+
+
+def l2q_su3_plaq_reduce(xn, nb, T, X, Y, Z, out, ws, wsn):
+    p = _su3_planes(_mats(xn.reshape(nb, 4, 9, -1)).reshape(nb, 4, T, X, Y, Z, 3, 3)).sum(1)
+    out[:, 0] = p.real
+    out[:, 1] = p.imag
+
+
+def l2q_su3_plaq_planes(xn, nb, T, X, Y, Z, out, ws, wsn):
+    p = _su3_planes(_mats(xn.reshape(nb, 4, 9, -1)).reshape(nb, 4, T, X, Y, Z, 3, 3))
+    out[:, :, 0] = p.real
+    out[:, :, 1] = p.imag
+
+
+def l2q_su3_force(xn, beta, f, nb, T, X, Y, Z):
+    x = _mats(xn.reshape(nb, 4, 9, -1)).reshape(nb, 4, T, X, Y, Z, 3, 3)
+    f.copy_(_native(_su3_force(x, beta).reshape(nb, 4, -1, 3, 3)).reshape(f.shape))
+
+
+def l2q_su3_force_kick(xn, beta, coef, vn, nb, T, X, Y, Z):
+    x = _mats(xn.reshape(nb, 4, 9, -1)).reshape(nb, 4, T, X, Y, Z, 3, 3)
+    vn.add_(coef * _native(_su3_force(x, beta).reshape(nb, 4, -1, 3, 3)).reshape(vn.shape))
+
+
+def l2q_su3_expm_mul(xn, vn, eps, mask_n, complement, out, nb, V):
+    keep = _keep_n(mask_n, complement, nb, V)
+    out.copy_(_expm_mul(xn.reshape(nb, 4, 9, V), vn.reshape(nb, 4, 9, V), eps, keep).reshape(out.shape))
+
+
+def l2q_su3_expm_mul2(xn, vn, eps, mask_n, complement_first, out, nb, V):
+    k1 = _keep_n(mask_n, complement_first, nb, V)
+    x1 = _expm_mul(xn.reshape(nb, 4, 9, V), vn.reshape(nb, 4, 9, V), eps, k1)
+    out.copy_(_expm_mul(x1, vn.reshape(nb, 4, 9, V), eps, 1 - k1).reshape(out.shape))
+
+
+def l2q_su3_project_su(xn, out, nf, V):
+    out.copy_(_native(_proj_su(_mats(xn.reshape(nf, 9, V)))).reshape(out.shape))
+
+
+def l2q_su3_projsu_vec8(xn, out, nf, V):
+    v = _to_vec8(_proj_su(_mats(xn.reshape(nf, 9, V))))            # [nf, V, 8]
+    out.copy_(v.transpose(-1, -2).reshape(out.shape))
+
+
+def l2q_su3_kinetic_reduce(vn, nb, V, out, ws, wsn):
+    out.copy_(0.5 * ((vn.reshape(nb, -1).abs() ** 2).sum(1) - 8.0 * 4 * V))
+
+
+def l2q_su3_assemble_tah(normals, out, nf, V):
+    n = normals.reshape(8, nf, V)
+    h = math.sqrt(0.5)
+    r3, r8 = h * n[0], h * n[1] / math.sqrt(3.0)
+    r01, r02, r12, i01, i02, i12 = (h * n[k] for k in range(2, 8))
+    m = torch.zeros(nf, V, 3, 3, dtype=C128)
+    m[..., 0, 0] = 1j * (r8 + r3); m[..., 1, 1] = 1j * (r8 - r3); m[..., 2, 2] = 1j * (-2 * r8)
+    m[..., 0, 1] = torch.complex(r01, i01); m[..., 1, 0] = torch.complex(-r01, i01)
+    m[..., 0, 2] = torch.complex(r02, i02); m[..., 2, 0] = torch.complex(-r02, i02)
+    m[..., 1, 2] = torch.complex(r12, i12); m[..., 2, 1] = torch.complex(-r12, i12)
+    out.copy_(_native(m).reshape(out.shape))
+
+
+def l2q_diff_norm2_reduce(a, b, nb, n, out, ws, wsn):
+    out.copy_(((a - b).reshape(nb, -1).abs() ** 2).sum(1))
+
+
+def l2q_scale_f64(x, alpha, y, n):
+    y.copy_(alpha * x)
+
+
+_v_update_real = l2q_v_update
+
+
+def l2q_v_update(v, force, s, t, q, eps, forward, cplx, esz, nb, n, logdet, ws, wsn):   # noqa: F811
+    if not cplx:
+        return _v_update_real(v, force, s, t, q, eps, forward, cplx, esz, nb, n, logdet, ws, wsn)
+    vn, ld = _v_update(v.reshape(nb, n), force.reshape(nb, n), s, t, q, eps, bool(forward))
+    v.copy_(vn.reshape(v.shape))
+    logdet.copy_(ld)
+
+
+# ---- SU(3) training entry points
+def l2q_su3_expm_mul_bwd(xn, vn, eps, mask_n, complement, gxnew, gx, gv, deps, nb, V, ws, wsn):
+    keep = _keep_n(mask_n, complement, nb, V)
+    e = torch.full((nb,), float(eps), dtype=torch.float64)
+    g = _vjp(lambda x_, v_, e_: _expm_mul(x_, e_.reshape(nb, 1, 1, 1) * v_, 1.0, keep),
+             [xn.reshape(nb, 4, 9, V), vn.reshape(nb, 4, 9, V), e], [gxnew.reshape(nb, 4, 9, V)])
+    gx.copy_(g[0].reshape(gx.shape))
+    gv.add_(g[1].reshape(gv.shape))
+    deps.copy_(g[2])
+
+
+def l2q_su3_projsu_vec8_bwd(xn, gvec, gm, nf, V):
+    (g,) = _vjp(lambda a: _to_vec8(_proj_su(_mats(a))).transpose(-1, -2),
+                [xn.reshape(nf, 9, V)], [gvec.reshape(nf, 8, V)])
+    gm.add_(g.reshape(gm.shape))
+
+
+def l2q_su3_force_bwd(xn, gf, beta, gx, nb, T, X, Y, Z):
+    def f(a):
+        x = _mats(a).reshape(nb, 4, T, X, Y, Z, 3, 3)
+        return _native(_su3_force(x, beta).reshape(nb, 4, -1, 3, 3))
+    (g,) = _vjp(f, [xn.reshape(nb, 4, 9, -1)], [gf.reshape(nb, 4, 9, -1)])
+    gx.add_(g.reshape(gx.shape))
+
+
+def l2q_su3_plaq_bwd(xn, w, gx, nb, T, X, Y, Z):
+    wc = torch.complex(w.reshape(nb, 6, 2)[..., 0], w.reshape(nb, 6, 2)[..., 1])
+
+    def f(a):
+        x = _mats(a).reshape(nb, 4, T, X, Y, Z, 3, 3)
+        return (wc.conj() * _su3_planes(x)).real.sum()
+    (g,) = _vjp(f, [xn.reshape(nb, 4, 9, -1)], [torch.ones(())])
+    gx.add_(g.reshape(gx.shape))
+
+
+def l2q_v_update_bwd_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, dv, dF, ds, dt, dq,
+                          deps, ws, wsn):
+    e = torch.full((nb,), float(eps), dtype=torch.float64)
+
+    def f(v_, f_, s_, t_, q_, e_):
+        return _v_update(v_, f_, s_, t_, q_, e_.reshape(nb, 1), bool(forward))
+    g = _vjp(f, [v.reshape(nb, n), force.reshape(nb, n), s, t, q, e], [gv.reshape(nb, n), gl])
+    dv.copy_(g[0].reshape(dv.shape)); dF.copy_(g[1].reshape(dF.shape))
+    ds.copy_(g[2]); dt.copy_(g[3]); dq.copy_(g[4]); deps.copy_(g[5])
+
+
+def l2q_diff_bwd_f64(x, y, a, nb, n, gx):
+    gx.add_((2.0 * a.reshape(nb, 1) * (x.reshape(nb, n) - y.reshape(nb, n))).reshape(gx.shape))
+
+
 _TABLE = {k: v for k, v in globals().items() if k.startswith('l2q_')}
 
 
