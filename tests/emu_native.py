@@ -347,7 +347,7 @@ def _adj(a):
 def _mats(xn):
     """xn[..., 9, V] -> [..., V, 3, 3]"""
     V = xn.shape[-1]
-    return xn.transpose(-1, -2).reshape(*xn.shape[:-2], V, 3, 3)
+    return xn.transpose(-1, -2).reshape(*xn.shape[:-2], V, 3, 3).contiguous()
 
 
 def _native(m):
