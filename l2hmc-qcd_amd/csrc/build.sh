@@ -7,10 +7,11 @@ mkdir -p "$out" "$here/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
+newest_hdr="$(ls -t "$here"/*.hpp "$here/../../include/l2q.h" | head -1)"
 for f in common su3_kernels u1_kernels gemm train_kernels su3_train_kernels; do
+  # rebuild when the source or ANY header is newer than the object
   if [ ! -f "$here/obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/obj/$f.o" ] \
-     || [ "$here/l2q_common.hpp" -nt "$here/obj/$f.o" ] || [ "$here/su3_math.hpp" -nt "$here/obj/$f.o" ] || [ "$here/u1_math.hpp" -nt "$here/obj/$f.o" ] || [ "$here/su3_links.hpp" -nt "$here/obj/$f.o" ] \
-     || [ "$here/../../include/l2q.h" -nt "$here/obj/$f.o" ]; then
+     || [ "$newest_hdr" -nt "$here/obj/$f.o" ]; then
     $HIPCC $FLAGS -c "$here/$f.hip" -o "$here/obj/$f.o" &
     pids+=($!)
   fi

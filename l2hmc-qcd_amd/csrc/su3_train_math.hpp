@@ -83,16 +83,15 @@ __device__ __forceinline__ void jacobi_rotate(M3& H, M3& Vm) {
   const double ac = sqrt(cr * cr + ci * ci);
   const double a = H.re[3 * P + P], b = H.re[3 * Q + Q];
   // converged (relative to the diagonal) or so small that cr^2 + ci^2 is denormal and the
-  // phase conj(c)/|c| would no longer have unit modulus: drop the element
-  if (!(ac > 1e-19 * (fabs(a) + fabs(b))) || !(ac > 1e-140)) {
-    H.re[3 * P + Q] = 0.0; H.im[3 * P + Q] = 0.0;
-    H.re[3 * Q + P] = 0.0; H.im[3 * Q + P] = 0.0;
-    return;
-  }
-  const double tau = (b - a) / (2.0 * ac);
+  // phase conj(c)/|c| would no longer have unit modulus: identity rotation (branch-free, the
+  // lanes of a wavefront converge at different sweeps)
+  const bool live = (ac > 1e-19 * (fabs(a) + fabs(b))) && (ac > 1e-140);
+  const double acs = live ? ac : 1.0;
+  const double tau = (b - a) / (2.0 * acs);
   const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-  const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
-  const double pr = cr / ac, pi = -ci / ac;            // ph = conj(c) / |c|
+  const double cs = live ? 1.0 / sqrt(1.0 + t * t) : 1.0;
+  const double sn = live ? t * cs : 0.0;
+  const double pr = live ? cr / acs : 1.0, pi = live ? -ci / acs : 0.0;   // ph = conj(c) / |c|
   // right-multiply by J: columns P, Q of H and of V
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
