@@ -15,7 +15,13 @@ of the loss / acceptance probability ([nb] vectors) go through torch.autograd.
 Parameters and gradients live in one flat arena per dtype (``ParamArena``): the optimiser is a
 single fused Adam launch and the data-parallel gradient exchange a single all-reduce.
 
-SU(3): not built (needs the expm / projectSU / staple cotangents).
+SU(3) uses the same tape with the cotangent kernels of ``csrc/su3_train_kernels.hip``:
+``l2q_su3_expm_mul_bwd`` (Frechet derivative of the matrix exponential), ``l2q_su3_projsu_vec8_bwd``
+(polar-projection derivative solved in a Jacobi eigenbasis), ``l2q_su3_force_bwd`` (the reference
+differentiates the force only through the ``x^H`` factor of ``TAH(dS/dx x^H)``,
+lattice/su3/pytorch/lattice.py:299-308), ``l2q_su3_plaq_bwd`` and ``l2q_v_update_bwd_c128``.
+The vnet runs on reference-ordered 8-component inputs (transposes at its boundary) so that the
+ordinary ``LeapfrogLayer.backward`` accumulates into the checkpoint-ordered parameters.
 """
 from __future__ import annotations
 
@@ -134,6 +140,36 @@ def _x_step(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, mask: Tensor, comple
     return x_new, ld
 
 
+def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, forward: bool):
+    """x, v native [nb, 4, 9, V] complex128."""
+    nb, _, _, V = x.shape
+    eps = dyn._eps('v', st)
+    vnet = dyn._get_vnet(st)
+    F = ops.su3_force_n(x, beta, dyn.latvolume)
+    xv = ops.su3_projsu_vec8_n(x).reshape(nb, -1)
+    fv = ops.su3_projsu_vec8_n(F).reshape(nb, -1)
+    # the network sees the reference's entry order (mu, site, component)
+    s, t, q, ctx = vnet.forward_train(ops.unpack_entries(xv, V, 8), ops.unpack_entries(fv, V, 8))
+    sn, tn, qn = (ops.pack_entries(a, V, 9) for a in (s, t, q))
+    v_new = v.clone()
+    ld = ops.v_update_(v_new.reshape(nb, -1), F.reshape(nb, -1), sn, tn, qn, eps, forward)
+    tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
+                         's': sn, 't': tn, 'q': qn, 'ctx': ctx, 'net': vnet, 'eps': eps})
+    return v_new, ld
+
+
+def _x_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, mask: Tensor, complement: bool,
+                forward: bool):
+    """x' = keep (.) x + expm(+-eps v) @ ((1 - keep) (.) x); no network, logdet = 0
+    (dynamics.py:1420-1425, 1468-1474)."""
+    eps = dyn._eps('x', st)
+    seps = eps if forward else -eps
+    x_new = ops.su3_expm_mul_n(x, v, seps, mask, complement)
+    tape.entries.append({'kind': 'x', 'step': st, 'forward': forward, 'x': x, 'v': v,
+                         'mask': mask, 'complement': complement, 'eps': seps})
+    return x_new
+
+
 def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool):
     """One generalised leapfrog step (dynamics.py:1187-1228), functional (new tensors)."""
     if forward:
@@ -142,6 +178,12 @@ def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool):
         st = dyn.config.nleapfrog - step - 1
         order = ((True, False), (False, True))
     m = dyn._native_masks()[st]
+    if dyn.group == 'SU3':
+        v, ld = _v_step_su3(dyn, tape, st, x, v, beta, forward)
+        for comp, _first in order:
+            x = _x_step_su3(dyn, tape, st, x, v, m, comp, forward)
+        v, l = _v_step_su3(dyn, tape, st, x, v, beta, forward)
+        return x, v, ld + l
     v, ld = _v_step(dyn, tape, st, x, v, beta, forward)
     for comp, first in order:
         x, l = _x_step(dyn, tape, st, x, v, m, comp, forward, first)
@@ -153,9 +195,6 @@ def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool):
 def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
     """Merged forward + backward trajectory (dynamics.py:956-1029) recording the tape.
     Returns (x_prop, v_prop, history, tape)."""
-    if dyn.group != 'U1':
-        raise NotImplementedError('the training-gradient path is built for U(1) only '
-                                  '(SU(3): SURVEY.md 8(f) item 1, next round)')
     if not dyn._networks_built:
         raise RuntimeError('training needs networks (Dynamics(network_factory=...))')
     tape = Tape()
@@ -180,7 +219,7 @@ def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
             dyn.update_history(dyn._metrics_n(x, v, beta, sumlogdet, step,
                                               {'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet}),
                                history)
-    v = -v
+    v = ops.scale(v, -1.0) if dyn.group == 'SU3' else -v
     tape.entries.append({'kind': 'flip'})
     for step in range(nlf):
         x, v, ld = _lf_train(dyn, tape, step, x, v, beta, False)
@@ -205,6 +244,8 @@ def loss_and_seeds(dyn, loss_fn, xn_init: Tensor, x_prop: Tensor, v_prop: Tensor
     """Loss value (reference: LatticeLoss.calc_loss on (x_init, x_prop, acc)) and the
     cotangents it sends into the trajectory: (loss, gx_prop, gv_prop, g_sumlogdet).
     The lattice-sized reductions are the l2q kernels; only [nb]-vectors see autograd."""
+    if dyn.group == 'SU3':
+        return _loss_and_seeds_su3(dyn, loss_fn, xn_init, x_prop, v_prop, tape, sumlogdet, beta)
     lat = dyn.latvolume
     V = dyn.volume
     sp = ops.u1_plaq_sums(x_prop, lat)
@@ -232,11 +273,42 @@ def loss_and_seeds(dyn, loss_fn, xn_init: Tensor, x_prop: Tensor, v_prop: Tensor
     return loss.detach(), gx, gv, gl
 
 
+def _loss_and_seeds_su3(dyn, loss_fn, xn_init, x_prop, v_prop, tape, sumlogdet, beta):
+    """SU(3): per-plane plaquette sums (l2q_su3_plaq_planes), |x' - x|^2 (l2q_diff_norm2_reduce)
+    and the kinetic energy are the only lattice-sized reductions the loss / acceptance need."""
+    lat = dyn.latvolume
+    nb = x_prop.shape[0]
+    pl_i = ops.su3_plaq_planes_n(xn_init, lat)                       # [nb, 6, 2]
+    pl_p = ops.su3_plaq_planes_n(x_prop, lat).clone().requires_grad_(True)
+    ke_p = ops.su3_kinetic_n(v_prop).clone().requires_grad_(True)
+    d2 = ops.diff_norm2(x_prop, xn_init).clone().requires_grad_(True)
+    sld = sumlogdet.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        h_prop = ke_p + (-beta / 3.0) * pl_p[:, :, 0].sum(1)
+        dh = tape.h_init.detach() - h_prop + sld
+        acc = torch.exp(torch.minimum(dh, torch.zeros_like(dh)))
+        loss = loss_fn.loss_from_sums_su3(pl_i, pl_p, d2, acc, nelem=x_prop[0].numel())
+        g_pl, g_ke, g_d2, g_sld = torch.autograd.grad(loss, [pl_p, ke_p, d2, sld], allow_unused=True)
+    gx = torch.zeros_like(x_prop)
+    if g_pl is not None:
+        ops.su3_plaq_bwd_(gx, x_prop, g_pl, lat)
+    if g_d2 is not None:
+        ops.diff_bwd_(gx, x_prop, xn_init, g_d2)
+    gv = torch.zeros_like(v_prop)
+    if g_ke is not None:                                             # KE = 1/2 sum (|v|^2 - 8)
+        ops.axpy_rows_(torch.view_as_real(gv), g_ke, torch.view_as_real(v_prop))
+    z = torch.zeros(nb, dtype=torch.float64, device=x_prop.device)
+    gl = (z if g_sld is None else g_sld).to(torch.float64).contiguous()
+    return loss.detach(), gx, gv, gl
+
+
 # ------------------------------------------------------------------------------ reverse sweep
 def backward(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float) -> None:
     """Replay the tape in reverse, accumulating every parameter's .grad (networks, xeps, veps).
     gx / gv: cotangents of the proposed state; gl [nb]: cotangent of sum logdet (every
     sub-update's logdet enters the sum with weight 1)."""
+    if dyn.group == 'SU3':
+        return _backward_su3(dyn, tape, gx, gv, gl, beta)
     lat = dyn.latvolume
     nb = gx.shape[0]
     gx = gx.reshape(nb, -1).contiguous()
@@ -267,7 +339,42 @@ def backward(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float) -
             ops.u1_masked_cos_sin_bwd_(dx, x, e['mask'], e['complement'], dxm.contiguous())
             gx = dx
             eps_acc.setdefault(('x', e['step']), []).append(deps)
-    # d loss / d (x|v)eps[step] = sum over chains and sub-updates of deps, times d eps / d p
+    _accumulate_eps_grads(dyn, eps_acc)
+
+
+def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float) -> None:
+    lat = dyn.latvolume
+    nb, _, _, V = gx.shape
+    gx, gv = gx.contiguous(), gv.contiguous()
+    eps_acc: dict = {}
+    for e in reversed(tape.entries):
+        kind = e['kind']
+        if kind == 'flip':
+            gv = ops.scale(gv, -1.0)
+            continue
+        if kind == 'v':
+            x, v, F = e['x'], e['v'], e['F']
+            dv, dF, dsn, dtn, dqn, deps = ops.v_update_bwd_c128(
+                v.reshape(nb, -1), F.reshape(nb, -1), e['s'], e['t'], e['q'], e['eps'],
+                e['forward'], gv.reshape(nb, -1), gl)
+            ds, dt, dq = (ops.unpack_entries(a, V, 9) for a in (dsn, dtn, dqn))
+            dxr, dfr = e['net'].backward(e['ctx'], ds, dt, dq)
+            dF = dF.reshape(F.shape)
+            ops.su3_projsu_vec8_bwd_(dF, F, ops.pack_entries(dfr.reshape(nb, -1), V, 8))
+            ops.su3_projsu_vec8_bwd_(gx, x, ops.pack_entries(dxr.reshape(nb, -1), V, 8))
+            ops.su3_force_bwd_(gx, x, dF, beta, lat)
+            gv = dv.reshape(v.shape)
+            eps_acc.setdefault(('v', e['step']), []).append(deps)
+        else:
+            gx, deps = ops.su3_expm_mul_bwd_n(e['x'], e['v'], e['eps'], e['mask'], e['complement'],
+                                              gx, gv)
+            # the kernel differentiates w.r.t. the signed step it was called with
+            eps_acc.setdefault(('x', e['step']), []).append(deps if e['forward'] else -deps)
+    _accumulate_eps_grads(dyn, eps_acc)
+
+
+def _accumulate_eps_grads(dyn, eps_acc: dict) -> None:
+    """d loss / d (x|v)eps[step] = sum over chains and sub-updates of deps, times d eps / d p"""
     for (which, st), lst in eps_acc.items():
         p = (dyn.xeps if which == 'x' else dyn.veps)[st]
         if not p.requires_grad or p.grad is None:

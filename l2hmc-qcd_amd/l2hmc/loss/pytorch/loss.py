@@ -108,6 +108,26 @@ class LatticeLoss:
             total = total + self._mixed(acc * dq ** 2, self.charge_weight, None)
         return total
 
+    def loss_from_sums_su3(self, planes_init: Tensor, planes_prop: Tensor, d2: Tensor, acc: Tensor,
+                           nelem: int) -> Tensor:
+        """SU(3) training loss from per-chain reductions: planes_* [nb, 6, 2] = per-plane
+        (sum Re tr P, sum Im tr P), d2 [nb] = sum |x' - x|^2.  Same value as `calc_loss`
+        (loss.py:56-148, 194-210), differentiable torch ops on small tensors only."""
+        assert isinstance(self.lattice, LatticeSU3)
+        total = torch.zeros((), dtype=acc.dtype, device=acc.device)
+        if self.rmse_weight > 0:
+            total = total + self._mixed(acc * (d2 / nelem).to(acc.dtype), self.rmse_weight, None)
+        if self.plaq_weight > 0:
+            p1, p2 = planes_init[:, :, 0].transpose(0, 1), planes_prop[:, :, 0].transpose(0, 1)
+            ploss = acc * (p2 - p1) ** 2                                 # [6, nb]
+            # the reference's _plaq_loss takes use_mixed_loss=None literally -> not mixed
+            total = total + (-ploss / self.plaq_weight.to(acc.device)).mean()
+        if self.charge_weight > 0:
+            norm = 6 * 3 * self.lattice.volume
+            q1, q2 = planes_init[:, :, 1].sum(1) / norm, planes_prop[:, :, 1].sum(1) / norm
+            total = total + self._mixed(acc * (q2 - q1) ** 2, self.charge_weight, None)
+        return total
+
     def lattice_metrics(self, xinit: Tensor, xout: Optional[Tensor] = None) -> dict[str, Tensor]:
         metrics = self.lattice.calc_metrics(x=xinit)
         if xout is not None:

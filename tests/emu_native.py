@@ -552,6 +552,8 @@ def l2q_v_update_bwd_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, dv, dF
 
 
 def l2q_diff_bwd_f64(x, y, a, nb, n, gx):
+    if x.is_complex():                       # n counts doubles
+        x, y, gx = torch.view_as_real(x), torch.view_as_real(y), torch.view_as_real(gx)
     gx.add_((2.0 * a.reshape(nb, 1) * (x.reshape(nb, n) - y.reshape(nb, n))).reshape(gx.shape))
 
 

@@ -5,6 +5,7 @@ parameters after one Adam step) from the REAL reference in train mode.
     bash tests/golden/setup_reference_env.sh
     PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py f64
     PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py f32
+    PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py su3
 
 `f64`: U(1) 4x4, dense networks, float64 default dtype (tight tolerance); `f32`: U(1) 4x6 with
 the conv stack (a pooling layer), float32.  Sequence = Trainer.train_step of the reference
@@ -19,9 +20,9 @@ import torch
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 WHICH = sys.argv[1]
-if WHICH == 'f64':
+if WHICH in ('f64', 'su3'):
     torch.set_default_dtype(torch.float64)
-sys.argv = [sys.argv[0], 'su3' if WHICH == 'f64' else 'u1']
+sys.argv = [sys.argv[0], 'su3' if WHICH in ('f64', 'su3') else 'u1']
 sys.path.insert(0, OUT)
 import make_golden as mg  # noqa: E402  (imports the reference, sets nothing else)
 import l2hmc.configs as cfgs  # noqa: E402
@@ -79,8 +80,74 @@ def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps
     print(f'  {name}: loss {float(loss):.6g} acc {npy(m["acc"])[:6]} |grad| {gn:.4g}')
 
 
+def su3_train_case(name, L, nb, nlf, units, act, beta, seed, bn, loss_cfg, eps=0.006, lr=1e-3):
+    """SU(3): vnet only (the xnet is never called, dynamics.py:1420-1425).  Start near
+    equilibrium and pick a draw whose acceptance is not saturated so that the gradient also
+    flows through acc.  The reference's train_step begins with compat_proj (projectSU)."""
+    from l2hmc.group.su3.pytorch import utils as U
+    dyn, lat = mg.build_dynamics('SU3', L, nb, nlf=nlf, eps=eps, units=units, act=act, bn=bn,
+                                 dropout=0.0, seed=seed)
+    mg.perturb(dyn, seed + 1)
+    bt = torch.tensor(beta)
+    mg.seed_all(seed + 2)
+    x = torch.matrix_exp(0.3 * U.randTAH3((nb, 4, *L)))
+    shape = tuple(x.shape[:-2])
+    sd0 = {k: a.copy() for k, a in mg.state_dict_np(dyn).items()
+           if not k.startswith('networks.')}
+    dyn.train()
+    loss_fn = LatticeLoss(lat, loss_cfg)
+    opt = torch.optim.Adam(dyn.parameters(), lr=lr)
+    best = None
+    for sd in range(seed + 3, seed + 60):
+        mg.seed_all(sd)
+        xo, m = dyn((dyn.g.compat_proj(x.reshape(dyn.xshape)), bt))
+        a = npy(m['acc'])
+        inside = int(((a > 0.02) & (a < 0.98)).sum())
+        if best is None or inside > best[0]:
+            best = (inside, sd)
+        if inside == nb:
+            break
+    sd = best[1]
+    mg.seed_all(sd)
+    nrm = torch.stack([torch.randn(shape) for _ in range(8)])
+    u = torch.rand(nb)
+    mg.seed_all(sd)
+    xinit = dyn.g.compat_proj(x.reshape(dyn.xshape)).detach()
+    xinit.requires_grad_(True)
+    opt.zero_grad()
+    xout, m = dyn((xinit, bt))
+    mc = m['mc_states']
+    assert np.array_equal(npy((m['acc'] > u).float()), npy(m['acc_mask'])), 'uniform replay'
+    loss = loss_fn(xinit, mc.proposed.x, m['acc'])
+    loss.backward()
+    grads = {}
+    for n, p in dyn.named_parameters():
+        grads['grad.' + n] = (npy(p.grad).copy() if p.grad is not None
+                              else np.zeros(tuple(p.shape)))
+    opt.step()
+    sd1 = {k: a for k, a in mg.state_dict_np(dyn).items() if not k.startswith('networks.')}
+    mg.save(name, latvolume=np.array(L), beta=beta, nleapfrog=nlf, x=npy(x), normals=npy(nrm),
+            u=npy(u), masks=np.stack([npy(mm)[0] for mm in dyn.masks]),
+            x_prop=npy(mc.proposed.x), x_out=npy(xout), acc=npy(m['acc']),
+            acc_mask=npy(m['acc_mask']), sumlogdet=npy(m['sumlogdet']), loss=npy(loss), lr=lr,
+            charge_weight=loss_cfg.charge_weight, plaq_weight=loss_cfg.plaq_weight,
+            rmse_weight=loss_cfg.rmse_weight, use_mixed_loss=loss_cfg.use_mixed_loss,
+            units=np.array(units), activation=act, use_batch_norm=bn,
+            # the SU(3) xnet is never called: no gradient, no update -- not stored
+            **{'sd.' + k: a for k, a in sd0.items() if 'xnet' not in k},
+            **{'sd1.' + k: a for k, a in sd1.items() if 'xnet' not in k},
+            **{k: a for k, a in grads.items() if 'xnet' not in k})
+    assert all(float(np.abs(a).max()) == 0.0 for k, a in grads.items() if 'xnet' in k)
+    gn = np.sqrt(sum(float((g ** 2).sum()) for g in grads.values()))
+    print(f'  {name}: loss {float(loss):.6g} acc {npy(m["acc"])} |grad| {gn:.4g}')
+
+
 if __name__ == '__main__':
-    if WHICH == 'f64':
+    if WHICH == 'su3':
+        su3_train_case('su3_train', (2, 3, 2, 4), 3, 2, [6], 'tanh', beta=6.0, seed=400, bn=False,
+                       loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.05,
+                                                rmse_weight=0.1, plaq_weight=0.1))
+    elif WHICH == 'f64':
         train_case('u1_train_f64', (4, 4), 6, 2, [8, 6], 'leaky_relu', None, beta=2.0, seed=300,
                    bn=True, loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.01))
         train_case('u1_train_f64_plain', (4, 6), 5, 3, [8], 'tanh', None, beta=3.0, seed=320,

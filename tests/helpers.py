@@ -213,3 +213,39 @@ def check_train_step(g, dyn, loss_fn, rtol, atol_rel, adam_min_grad=0.0):
             wp, out['param_worst'] = err, name
     out['param_abs'] = wp
     return out
+
+
+def build_su3_train_dynamics(g):
+    """Product Dynamics + LatticeLoss configured like tests/golden/su3_train.npz (train mode,
+    float64 default dtype)."""
+    import torch
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.loss.pytorch.loss import LatticeLoss
+    from l2hmc.network.pytorch.network import NetworkFactory
+    L = [int(i) for i in g['latvolume']]
+    nb = int(g['x'].shape[0])
+    nlf = int(g['nleapfrog'])
+    dc = cfgs.DynamicsConfig(nchains=nb, group='SU3', latvolume=L, nleapfrog=nlf, eps=0.006,
+                             eps_hmc=0.006, verbose=False, use_split_xnets=False,
+                             use_separate_networks=False, merge_directions=True)
+    nc = cfgs.NetworkConfig(units=[int(i) for i in g['units']], activation_fn=str(g['activation']),
+                            dropout_prob=0.0, use_batch_norm=bool(g['use_batch_norm']))
+    V = int(np.prod(L))
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [32 * V], 'v': [32 * V]},
+                          vnet={'x': [32 * V], 'v': [32 * V]})
+    lat = LatticeSU3(nb, L)
+    nf = NetworkFactory(input_spec=spec, network_config=nc, conv_config=cfgs.ConvolutionConfig())
+    dyn = Dynamics(potential_fn=lat.action, config=dc, network_factory=nf)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(g, 'sd.').items()}
+    res = dyn.load_state_dict(sd, strict=False)
+    assert all('xnet' in k or k.startswith('networks.') for k in res.missing_keys), res.missing_keys
+    assert not res.unexpected_keys, res.unexpected_keys
+    dyn._eps_cache = {}
+    dyn.set_masks(g['masks'])
+    dyn.train()
+    loss_fn = LatticeLoss(lat, cfgs.LossConfig(
+        use_mixed_loss=bool(g['use_mixed_loss']), charge_weight=float(g['charge_weight']),
+        plaq_weight=float(g['plaq_weight']), rmse_weight=float(g['rmse_weight'])))
+    return dyn, lat, loss_fn

@@ -87,3 +87,14 @@ def test_trainer_train_loop_host_logic(conv, monkeypatch):
         assert torch.isfinite(m['acc']).all()
     finally:
         torch.set_default_dtype(old)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+def test_su3_train_step_host_logic(golden, monkeypatch, f64):
+    """SU(3) tape / reverse sweep / loss seeds against the reference's autograd gradients."""
+    g = golden('su3_train')
+    emu_native.install(monkeypatch)
+    dyn, lat, loss_fn = helpers.build_su3_train_dynamics(g)
+    out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-7, atol_rel=1e-6, adam_min_grad=1e-6)
+    assert out['grad_rel'] < 1e-5, out
+    assert out['param_abs'] < 1e-6, out
