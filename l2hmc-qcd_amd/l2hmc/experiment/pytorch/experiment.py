@@ -24,8 +24,11 @@ class Experiment:
     def build_trainer(self, **kw) -> Trainer:
         return self.trainer
 
-    def train(self, *a, **kw):
-        return self.trainer.train_step(None)
+    def train(self, x: Optional[torch.Tensor] = None, nera: Optional[int] = None,
+              nepoch: Optional[int] = None, beta: Optional[float] = None,
+              nsteps: Optional[int] = None) -> dict:
+        """experiment.py:380-417: the trainer's era / epoch loop with the annealed beta."""
+        return self.trainer.train(x=x, beta=beta, nsteps=nsteps, nera=nera, nepoch=nepoch)
 
     def evaluate(self, job_type: str, beta: Optional[float] = None, nsteps: Optional[int] = None,
                  eps: Optional[float] = None, nleapfrog: Optional[int] = None,

@@ -109,7 +109,7 @@ class Trainer:
         """One optimisation step (trainer.py:1316-1367): compat_proj -> trajectory in train mode
         -> LatticeLoss(x_init, x_prop, acc) -> gradients (hand-written reverse sweep,
         dynamics/pytorch/training.py) -> data-parallel all-reduce of the flat gradient ->
-        clip_grad_norm -> fused Adam.  U(1) only in this round."""
+        clip_grad_norm -> fused Adam.  U(1) and SU(3)."""
         from l2hmc.dynamics.pytorch import training as T
         if self.arena is None:
             self.arena = T.ParamArena(self.dynamics)
@@ -141,9 +141,24 @@ class Trainer:
         return xout.detach(), metrics
 
     def train(self, x: Optional[Tensor] = None, beta: Optional[float] = None,
-              nsteps: Optional[int] = None) -> dict:
-        """`nsteps` train steps at fixed beta (one era of trainer.py:1369-1470, without the
-        logging / checkpoint side effects)."""
+              nsteps: Optional[int] = None, nera: Optional[int] = None,
+              nepoch: Optional[int] = None) -> dict:
+        """Training loop (trainer.py:1369-1697 without logging / checkpoint side effects).
+        With `beta` / `nsteps`: that many steps at fixed beta.  Otherwise `nera` eras of `nepoch`
+        steps with beta annealed linearly from beta_init to beta_final over the eras
+        (configs.py:840-873)."""
+        if beta is None and nsteps is None:
+            nera = self.config.steps.nera if nera is None else nera
+            nepoch = self.config.steps.nepoch if nepoch is None else nepoch
+            betas = self.config.annealing_schedule.setup(nera=nera, nepoch=nepoch)
+            out: dict = {'history': {}, 'x': x}
+            for era in range(nera):
+                res = self.train(x=out['x'], beta=float(betas[str(era)]), nsteps=nepoch)
+                for k, v in res['history'].items():
+                    out['history'].setdefault(k, []).extend(v)
+                out['history'].setdefault('era', []).extend([era] * nepoch)
+                out['x'], out['timer'] = res['x'], res['timer']
+            return out
         beta = self.config.annealing_schedule.beta_init if beta is None else beta
         nsteps = self.config.steps.nepoch if nsteps is None else nsteps
         x = self.lattice.random() if x is None else x

@@ -98,3 +98,20 @@ def test_su3_train_step_host_logic(golden, monkeypatch, f64):
     out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-7, atol_rel=1e-6, adam_min_grad=1e-6)
     assert out['grad_rel'] < 1e-5, out
     assert out['param_abs'] < 1e-6, out
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+def test_experiment_train_eras_host_logic(monkeypatch):
+    """Experiment.train: eras x epochs with the linearly annealed beta."""
+    import l2hmc.configs as cfgs
+    from l2hmc.experiment.pytorch.experiment import Experiment
+    emu_native.install(monkeypatch)
+    cfg = cfgs.get_config(['dynamics.group=U1', 'dynamics.latvolume=[4,4]', 'dynamics.nchains=4',
+                           'dynamics.nleapfrog=2', 'dynamics.verbose=false', 'network.units=[4]',
+                           'conv=none', 'steps.nera=3', 'steps.nepoch=2',
+                           'annealing_schedule.beta_init=1.0', 'annealing_schedule.beta_final=3.0'])
+    ex = Experiment(cfg)
+    out = ex.train()
+    assert out['history']['beta'] == [1.0, 1.0, 2.0, 2.0, 3.0, 3.0]
+    assert out['history']['era'] == [0, 0, 1, 1, 2, 2]
+    assert ex.trainer.arena.step_count == 6

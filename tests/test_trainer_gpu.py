@@ -81,8 +81,8 @@ def test_experiment_from_config_su3():
     assert len(res['history']['acc']) == 2
     rate = res['timer'].get_eval_rate()
     assert rate['num_steps'] == 2 and rate['eval_rate'] > 0
-    with pytest.raises(NotImplementedError):
-        tr.train_step((res['x'], 6.0))
+    xt, mt = tr.train_step((res['x'], 6.0))                 # SU(3) training step
+    assert np.isfinite(mt['loss']) and xt.shape == res['x'].shape
 
 
 def test_cli_u1(capsys):
