@@ -165,6 +165,33 @@ def cpu_baseline(dyn, args):
                       'single-threaded numpy'}
 
 
+def secondary(dyn, x, beta, args, nlf_exec):
+    """Untimed-region extras SURVEY.md 8(d) asks to report beside the headline: the same
+    trajectory with per-step metrics (verbose=True, the YAML default) and the plain-HMC
+    baseline sampler (apply_transition_hmc), each over 2 steps after 1 warm-up."""
+    res = {}
+
+    def rate(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        return round(args.nchains * nlf_exec * 2 / (time.perf_counter() - t0), 1)
+    old = dyn.config.verbose
+    try:
+        dyn.config.verbose = True
+        res['l2hmc_verbose_true'] = rate(lambda: dyn((x, beta)))
+        dyn.config.verbose = False
+        res['hmc'] = rate(lambda: dyn.apply_transition_hmc((x, beta), eps=0.01,
+                                                           nleapfrog=nlf_exec))
+    finally:
+        dyn.config.verbose = old
+    res['unit'] = 'chain*leapfrog-steps/s'
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -299,6 +326,7 @@ def main():
             'accept_prob_mean': round(float(acc.mean()), 4),
         }
         if world == 1 and not args.no_cpu_baseline:
+            out['secondary'] = secondary(dyn, x, beta, args, nlf_exec)
             out['cpu_baseline'] = cpu_baseline(dyn, args)
         print(json.dumps(out), flush=True)
     if dist is not None:
