@@ -89,6 +89,50 @@ class ParamArena:
             tot += float(ops.sumsq(g['grad']).item())
         return scale * tot ** 0.5
 
+    # ---- torch.optim.Adam-compatible (de)serialisation (`optimizer_state_dict` of the
+    # reference's checkpoints, trainers/pytorch/trainer.py:573-614)
+    def _param_slices(self):
+        for g in self.groups.values():
+            base = g['flat'].data_ptr()
+            for p in g['params']:
+                off = (p.data_ptr() - base) // g['flat'].element_size()
+                yield p, g, off, p.numel()
+
+    def state_dict(self, params_in_order, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> dict:
+        """Layout of torch.optim.Adam(params_in_order).state_dict() after `step_count` steps."""
+        index = {id(p): i for i, p in enumerate(params_in_order)}
+        state = {}
+        if self.step_count > 0:
+            for p, g, off, n in self._param_slices():
+                if id(p) not in index:
+                    continue
+                state[index[id(p)]] = {
+                    'step': torch.tensor(float(self.step_count)),
+                    'exp_avg': g['m'][off:off + n].view(p.shape).clone(),
+                    'exp_avg_sq': g['v'][off:off + n].view(p.shape).clone()}
+        group = {'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
+                 'fused': None, 'decoupled_weight_decay': False,
+                 'params': list(range(len(params_in_order)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd: dict, params_in_order) -> None:
+        """Accepts a torch.optim.Adam state_dict over the same parameter order (parameters the
+        optimiser never stepped, e.g. the SU(3) xnet, have no entry and keep zero moments)."""
+        steps = {int(float(v['step'])) for v in sd['state'].values()}
+        if len(steps) > 1:
+            raise ValueError(f'per-parameter step counts differ: {sorted(steps)}')
+        self.step_count = steps.pop() if steps else 0
+        where = {id(p): (g, off, n) for p, g, off, n in self._param_slices()}
+        for g in self.groups.values():
+            g['m'].zero_()
+            g['v'].zero_()
+        for i, st in sd['state'].items():
+            p = params_in_order[int(i)]
+            g, off, n = where[id(p)]
+            g['m'][off:off + n].copy_(st['exp_avg'].reshape(-1).to(g['m']))
+            g['v'][off:off + n].copy_(st['exp_avg_sq'].reshape(-1).to(g['v']))
+
     def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
                   grad_scale: float = 1.0) -> None:
         self.step_count += 1

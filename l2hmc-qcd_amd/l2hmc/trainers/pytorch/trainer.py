@@ -140,6 +140,54 @@ class Trainer:
         self._gstep += 1
         return xout.detach(), metrics
 
+    # -- checkpoints (trainer.py:573-680): same keys / file names as the reference
+    def save_ckpt(self, era: int, epoch: int, outdir, metrics: Optional[dict] = None):
+        """`ckpt-{era}-{epoch}-{step}.tar` with era / epoch / gstep / xeps / veps /
+        model_state_dict / optimizer_state_dict (torch.optim.Adam layout) and
+        `model-{era}-{epoch}-{step}.pth` (the bare state_dict).  Rank 0 only."""
+        from pathlib import Path
+        from l2hmc.dynamics.pytorch import training as T
+        from l2hmc import RANK
+        if RANK != 0:
+            return None
+        outdir = Path(outdir)
+        outdir.mkdir(parents=True, exist_ok=True)
+        if self.arena is None:
+            self.arena = T.ParamArena(self.dynamics)
+        params = list(self.dynamics.parameters())
+        ckpt = {'era': era, 'epoch': epoch, 'gstep': self._gstep,
+                'xeps': [e.detach().cpu().numpy() for e in self.dynamics.xeps],
+                'veps': [e.detach().cpu().numpy() for e in self.dynamics.veps],
+                'model_state_dict': {k: v.detach().cpu().clone()
+                                     for k, v in self.dynamics.state_dict().items()},
+                'optimizer_state_dict': self.arena.state_dict(
+                    params, lr=float(self.config.learning_rate.lr_init))}
+        if metrics is not None:
+            ckpt.update(metrics)
+        f = outdir.joinpath(f'ckpt-{era}-{epoch}-{self._gstep}.tar')
+        torch.save(ckpt, f)
+        torch.save(ckpt['model_state_dict'], outdir.joinpath(f'model-{era}-{epoch}-{self._gstep}.pth'))
+        return f
+
+    def load_ckpt(self, path) -> dict:
+        """Restore parameters, step sizes, optimiser moments and the global step from a
+        checkpoint written by `save_ckpt` (or by the reference's trainer for the same model)."""
+        from l2hmc.dynamics.pytorch import training as T
+        from l2hmc import _ops as ops
+        ckpt = torch.load(path, map_location='cpu', weights_only=False)
+        if self.arena is None:
+            self.arena = T.ParamArena(self.dynamics)
+        sd = ckpt['model_state_dict']
+        with torch.no_grad():                       # copy INTO the arena views (keep the aliasing)
+            own = self.dynamics.state_dict()
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v.to(own[k].device))
+        ops.PARAM_GENERATION[0] += 1
+        self.arena.load_state_dict(ckpt['optimizer_state_dict'], list(self.dynamics.parameters()))
+        self._gstep = int(ckpt.get('gstep', ckpt.get('step', 0)))
+        return ckpt
+
     def train(self, x: Optional[Tensor] = None, beta: Optional[float] = None,
               nsteps: Optional[int] = None, nera: Optional[int] = None,
               nepoch: Optional[int] = None) -> dict:

@@ -115,3 +115,51 @@ def test_experiment_train_eras_host_logic(monkeypatch):
     assert out['history']['beta'] == [1.0, 1.0, 2.0, 2.0, 3.0, 3.0]
     assert out['history']['era'] == [0, 0, 1, 1, 2, 2]
     assert ex.trainer.arena.step_count == 6
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+def test_checkpoint_roundtrip_and_torch_adam_layout(monkeypatch, tmp_path):
+    """save_ckpt / load_ckpt: parameters, Adam moments and step survive; the optimizer_state_dict
+    loads into a real torch.optim.Adam over the same parameters (the reference's format), and a
+    state_dict produced by torch.optim.Adam loads into the arena."""
+    import l2hmc.configs as cfgs
+    from l2hmc.trainers.pytorch.trainer import Trainer
+    emu_native.install(monkeypatch)
+    ov = ['dynamics.group=U1', 'dynamics.latvolume=[4,4]', 'dynamics.nchains=4',
+          'dynamics.nleapfrog=2', 'dynamics.verbose=false', 'network.units=[4]', 'conv=none']
+    torch.manual_seed(1); np.random.seed(1)
+    tr = Trainer(cfgs.get_config(ov))
+    out = tr.train(beta=2.0, nsteps=3)
+    f = tr.save_ckpt(era=0, epoch=3, outdir=tmp_path)
+    ck = torch.load(f, weights_only=False)
+    assert set(ck) >= {'era', 'epoch', 'gstep', 'xeps', 'veps', 'model_state_dict', 'optimizer_state_dict'}
+    assert ck['gstep'] == 3 and len(ck['xeps']) == 2
+    # (a) our optimizer_state_dict is a valid torch.optim.Adam state
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in tr.dynamics.parameters()]
+    opt = torch.optim.Adam(ref_params, lr=1e-3)
+    opt.load_state_dict(ck['optimizer_state_dict'])
+    st = opt.state_dict()['state']
+    assert len(st) == len(ref_params) and float(st[0]['step']) == 3.0
+    # (b) round trip into a fresh trainer built from another seed
+    torch.manual_seed(2); np.random.seed(2)
+    tr2 = Trainer(cfgs.get_config(ov))
+    tr2.dynamics.set_masks([m.numpy() for m in tr.dynamics.masks])
+    tr2.load_ckpt(f)
+    for (k, a), (_, b) in zip(tr.dynamics.state_dict().items(), tr2.dynamics.state_dict().items()):
+        assert torch.equal(a, b), k
+    g1, g2 = tr.arena.groups[torch.float32], tr2.arena.groups[torch.float32]
+    assert torch.equal(g1['m'], g2['m']) and torch.equal(g1['v'], g2['v'])
+    assert tr2.arena.step_count == 3 and tr2._gstep == 3
+    # identical continuation: one more step from the same state and the same draws
+    x = out['x']
+    for t in (tr, tr2):
+        torch.manual_seed(5)
+        t.dynamics.rng_device = 'cpu'
+        t.train_step((x, 2.0))
+    assert torch.equal(g1['flat'], g2['flat'])
+    # (c) a state produced by torch.optim.Adam loads into the arena
+    for p in ref_params:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    tr2.arena.load_state_dict(opt.state_dict(), list(tr2.dynamics.parameters()))
+    assert tr2.arena.step_count == 4
