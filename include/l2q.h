@@ -243,6 +243,33 @@ int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw,
 int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int pool, int act,
                              float* out, void* stream);
 
+/* ---------------------------------------------------------------- fused U(1) sub-updates (fp32)
+ * One launch per L2HMC sub-update on small 2D lattices (n = 2 T X <= l2q_u1_fused_max_n()):
+ * the force (v-step) or the masked cos/sin inputs (x-step), the whole dense LeapfrogLayer in
+ * eval mode (network.py:430-451, 522-551; BatchNorm folded into the heads by the caller) and
+ * the update with its log-det (dynamics.py:1266-1297 / 1386-1477).  s, t, q never reach memory.
+ * Network description (device pointers unless noted):
+ *   wxT [Kx][U0], wvT [Kv][U0]   transposed xlayer / vlayer weights, b0 [U0] = sum of their biases
+ *   hidden                       for l = 1..nl-1: W_l [U_l][U_{l-1}] then b_l [U_l], packed
+ *   units (HOST pointer) [nl]    widths U_0..U_{nl-1} (each <= 64, nl <= 8)
+ *   ws, wt, wq [n][U_last], bs, bt, bq [n]; cs, cq [n] per-entry scale (nw * exp(coeff));
+ *   scale_t; act: L2Q_ACT_* of the dense layers.
+ * v-step: Kx = Kv = n (inputs x and force(x)); v updated in place, x untouched.
+ * x-step: Kx = 2 n ([cos(m x), sin(m x)]), Kv = n (v); x updated in place (+ compat_proj). */
+int l2q_u1_fused_max_n(void);
+int l2q_u1_vstep_f32(const float* x, float* v, double beta, double eps, int forward, int nb, int T,
+                     int X, const float* wxT, const float* wvT, const float* b0,
+                     const float* hidden, const int* units, int nl, const float* ws,
+                     const float* bs, const float* cs, const float* wt, const float* bt,
+                     double scale_t, const float* wq, const float* bq, const float* cq, int act,
+                     float* logdet, void* stream);
+int l2q_u1_xstep_f32(float* x, const float* v, const float* mask, int complement, double eps,
+                     int forward, int use_ncp, int nb, int n, const float* wxT, const float* wvT,
+                     const float* b0, const float* hidden, const int* units, int nl,
+                     const float* ws, const float* bs, const float* cs, const float* wt,
+                     const float* bt, double scale_t, const float* wq, const float* bq,
+                     const float* cq, int act, float* logdet, void* stream);
+
 /* ================================================================ training-gradient path
  * Reverse-mode (VJP) counterparts of the U(1) sub-updates and network layers, the train-mode
  * BatchNorm1d, and the optimiser step.  The reference gets these from torch.autograd

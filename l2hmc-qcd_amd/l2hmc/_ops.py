@@ -422,6 +422,40 @@ def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch
     return out
 
 
+def _fused_net_args(fw: dict):
+    hs = fw['heads']
+    return (fw['wxT'], fw['wvT'], fw['b0'], fw['hidden'], fw['units_c'], fw['nl'],
+            hs['s'][0], hs['s'][1], hs['s'][2], hs['t'][0], hs['t'][1], float(fw['scale_t']),
+            hs['q'][0], hs['q'][1], hs['q'][2], N.ACT[fw['act']])
+
+
+def u1_vstep_(x: torch.Tensor, v: torch.Tensor, beta: float, eps: float, forward: bool,
+              lat: Sequence[int], fw: dict) -> torch.Tensor:
+    """Fused force + vnet + momentum update (v in place); returns logdet [nb].  fw: the
+    'fused_u1' entry of LeapfrogLayer.kernel_weights()."""
+    T, X = (int(i) for i in lat)
+    nb = x.shape[0]
+    logdet = torch.empty(nb, dtype=torch.float32, device=x.device)
+    N.call('l2q_u1_vstep_f32', x, v, float(beta), float(eps), int(forward), nb, T, X,
+           *_fused_net_args(fw), logdet)
+    return logdet
+
+
+def u1_xstep_(x: torch.Tensor, v: torch.Tensor, mask: torch.Tensor, complement: bool, eps: float,
+              forward: bool, use_ncp: bool, fw: dict) -> torch.Tensor:
+    """Fused masked cos/sin + xnet + position update (x in place); returns logdet [nb]."""
+    nb = x.shape[0]
+    n = x.numel() // nb
+    logdet = torch.empty(nb, dtype=torch.float32, device=x.device)
+    N.call('l2q_u1_xstep_f32', x, v, mask, int(complement), float(eps), int(forward),
+           int(use_ncp), nb, n, *_fused_net_args(fw), logdet)
+    return logdet
+
+
+def u1_fused_max_n() -> int:
+    return int(N.load().l2q_u1_fused_max_n())
+
+
 # ---------------------------------------------------------------------------- training (VJPs)
 def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: Optional[str]) -> torch.Tensor:
     """dy * act'(z) from the activation output y (in place on dy)."""

@@ -166,6 +166,7 @@ class Dynamics(nn.Module):
         self.fuse_x_updates = True  # SU3: both x half-updates of a LF step in one kernel
         self.reuse_v_inputs = True  # force / vec8 / hidden activation once per distinct x
         self.pair_v_updates = True  # adjacent v-updates on the same x in one heads kernel
+        self.fuse_u1_steps = True   # U1 (small lattices, dense nets): one kernel per sub-update
         self._inject: Optional[dict] = None
         self._eps_cache: dict = {}
         self._masks_native: Optional[list] = None
@@ -478,12 +479,24 @@ class Dynamics(nn.Module):
             cache[zkey] = z
         return fn, z, w
 
+    def _fused_u1(self, net) -> Optional[dict]:
+        """Weights in the layout of the fused U(1) sub-update kernels, or None when the fused
+        path does not apply (SU3, fp64, conv stack, wide layers, large lattice)."""
+        if not (self.fuse_u1_steps and self.group == 'U1' and self._networks_built
+                and self._dtype == torch.float32 and self.xdim <= ops.u1_fused_max_n()):
+            return None
+        net._check_mode()
+        return net.kernel_weights().get('fused_u1')
+
     def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
                     cache: Optional[dict] = None) -> Tensor:
         """v-update in place (dynamics.py:1266-1297); returns logdet [nb]."""
         eps = self._eps('v', step)
         nb = xn.shape[0]
         vnet = self._get_vnet(step)
+        fw = self._fused_u1(vnet)
+        if fw is not None:            # force + vnet + update in one launch
+            return ops.u1_vstep_(xn, vn, _beta(beta), eps, forward, self.latvolume, fw)
         fn, z, w = self._v_inputs_n(vnet, xn, beta, cache)
         if z is not None:
             # heads + momentum update in one kernel: s, t, q never reach HBM
@@ -512,8 +525,12 @@ class Dynamics(nn.Module):
         if self.group == 'SU3':
             ops.su3_expm_mul_n(xn, vn, eps if forward else -eps, mask, complement, out=xn)
             return None
-        s, t, q = self._xnet_n(step, first, xn, vn, mask, complement)
         nb = xn.shape[0]
+        fw = self._fused_u1(self._get_xnet(step, first))
+        if fw is not None:            # masked cos/sin + xnet + update in one launch
+            return ops.u1_xstep_(xn.reshape(nb, -1), vn, mask, complement, eps, forward,
+                                 self.config.use_ncp, fw)
+        s, t, q = self._xnet_n(step, first, xn, vn, mask, complement)
         return ops.u1_x_update_(xn.reshape(nb, -1), vn, s, t, q, mask, complement, eps,
                                 forward, self.config.use_ncp)
 

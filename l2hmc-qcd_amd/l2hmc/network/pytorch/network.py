@@ -351,6 +351,24 @@ class LeapfrogLayer(nn.Module):
                 't': (heads['t'][0], heads['t'][1], None),
                 'q': (heads['q'][0], heads['q'][1], (self.nw.q * heads['q'][2].exp()).contiguous()),
             }
+            if in_perm is None and out_perm is None and wx.dtype == torch.float32 \
+                    and not isinstance(il.conv_stack, ConvStack) \
+                    and max(self.units) <= 64 and len(self.units) <= 8:
+                # layout of the fused U(1) sub-update kernels (l2q_u1_vstep_f32 / _xstep_f32)
+                import ctypes
+                hidden = [torch.cat([h.weight.reshape(-1), h.bias.reshape(-1)])
+                          for h in self.hidden_layers]
+                hs = out['heads_scaled']
+                ones = torch.ones_like(hs['t'][1])
+                out['fused_u1'] = {
+                    'wxT': wx.t().contiguous(), 'wvT': wv.t().contiguous(),
+                    'b0': (il.xlayer.bias + il.vlayer.bias).contiguous(),
+                    'hidden': torch.cat(hidden).contiguous() if hidden else None,
+                    'units_c': (ctypes.c_int * len(self.units))(*[int(u) for u in self.units]),
+                    'nl': len(self.units), 'act': self.act, 'scale_t': float(self.nw.t),
+                    'heads': {'s': (hs['s'][0], hs['s'][1], hs['s'][2]),
+                              't': (hs['t'][0], hs['t'][1], ones),
+                              'q': (hs['q'][0], hs['q'][1], hs['q'][2])}}
         self._head_cache[key] = out
         return out
 

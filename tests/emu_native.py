@@ -201,6 +201,42 @@ def l2q_maxpool_act_nhwc_f32(y, nb, H, W, C, pool, act, out):
     out.copy_(_maxpool_act(y, nb, H, W, C, pool, act))
 
 
+def _fused_net(xin, vin, wxT, wvT, b0, hidden, units, nl, ws, bs, cs, wt, bt, scale_t, wq, bq, cq,
+               act):
+    units = [int(units[i]) for i in range(nl)]
+    z = _act(xin @ wxT + vin @ wvT + b0, act)
+    off = 0
+    for l in range(1, nl):
+        ui, uo = units[l - 1], units[l]
+        W = hidden[off:off + uo * ui].reshape(uo, ui); off += uo * ui
+        b = hidden[off:off + uo]; off += uo
+        z = _act(z @ W.T + b, act)
+    s = cs * torch.tanh(z @ ws.T + bs)
+    t = scale_t * (z @ wt.T + bt)
+    q = cq * torch.tanh(z @ wq.T + bq)
+    return s, t, q
+
+
+def l2q_u1_vstep_f32(x, v, beta, eps, forward, nb, T, X, *net_and_out):
+    *net, logdet = net_and_out
+    n = 2 * T * X
+    f = _force(x.reshape(nb, 2, T, X), beta).reshape(nb, n)
+    s, t, q = _fused_net(x.reshape(nb, n), f, *net)
+    vn, ld = _v_update(v.reshape(nb, n), f, s, t, q, eps, bool(forward))
+    v.copy_(vn.reshape(v.shape))
+    logdet.copy_(ld)
+
+
+def l2q_u1_xstep_f32(x, v, mask, complement, eps, forward, ncp, nb, n, *net_and_out):
+    *net, logdet = net_and_out
+    a = _keep(mask, complement, x) * x.reshape(nb, n)
+    s, t, q = _fused_net(torch.cat([torch.cos(a), torch.sin(a)], 1), v.reshape(nb, n), *net)
+    xn, ld = _x_update(x.reshape(nb, n), v.reshape(nb, n), s, t, q, mask, complement, eps,
+                       bool(forward), bool(ncp))
+    x.copy_(xn.reshape(x.shape))
+    logdet.copy_(ld)
+
+
 # ---- training entry points (VJPs by autograd of the restatements above)
 def l2q_act_bwd(dy, y, act, n, esz, dx):
     a = ACT[act]

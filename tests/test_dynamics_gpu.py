@@ -294,3 +294,57 @@ def test_u1_large_lattice_vs_oracle():
     vd = dev(v)
     ops.u1_force_kick_(xd, 6.0, -0.05, vd, L)
     assert err(host(vd), v - 0.05 * ou1.grad_action(x, 6.0).reshape(5, -1)) < 2e-5
+
+
+@pytest.mark.parametrize('lat,nb,units,act,bn', [((8, 8), 128, [16, 16, 16, 16], 'leaky_relu', True),
+                                                 ((4, 6), 5, [8, 6], 'tanh', False),
+                                                 ((16, 16), 37, [16, 16], 'relu', True),
+                                                 ((32, 32), 9, [64], 'elu', False),
+                                                 ((8, 8), 3, [5, 7, 3], 'swish', True)])
+def test_u1_fused_substeps_equal_unfused(lat, nb, units, act, bn):
+    """The one-launch U(1) sub-updates (l2q_u1_vstep_f32 / l2q_u1_xstep_f32: force or cos/sin +
+    whole LeapfrogLayer + update) against the multi-kernel path (force, GEMMs, update kernels)
+    on the same state: every sub-update of a leapfrog step in both directions, ragged chain
+    counts, 1-3 hidden layers, all activations, folded BatchNorm."""
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=list(lat), nleapfrog=2, eps=0.1,
+                             eps_hmc=0.1, verbose=False)
+    nc = cfgs.NetworkConfig(units=units, activation_fn=act, dropout_prob=0.0, use_batch_norm=bn)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                          vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+    latt = LatticeU1(nb, list(lat))
+    dyn = Dynamics(latt.action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig())).eval()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n_, p in dyn.named_parameters():
+            if n_.endswith('coeff'):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g).to(p.device))
+        for n_, b in dyn.named_buffers():
+            if n_.endswith('running_mean'):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g).to(b.device))
+            if n_.endswith('running_var'):
+                b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g).to(b.device))
+    x0 = latt.random().to(dyn.device)
+    v0 = torch.randn(nb, dc.xdim, generator=g).to(dyn.device)
+    for forward in (True, False):
+        res = {}
+        for fused in (True, False):
+            dyn.fuse_u1_steps = fused
+            xn, vn = dyn._pack(x0), v0.clone()
+            ld = dyn._lf_n(1, xn, vn, 2.5, forward)
+            res[fused] = (xn.clone(), vn.clone(), ld.clone())
+        assert dyn._fused_u1(dyn._get_vnet(0)) is None      # switch is honoured
+        dyn.fuse_u1_steps = True
+        assert dyn._fused_u1(dyn._get_vnet(0)) is not None
+        dx = torch.remainder(res[True][0] - res[False][0] + np.pi, 2 * np.pi) - np.pi
+        assert float(dx.abs().max()) < 2e-4, float(dx.abs().max())
+        scale = max(1.0, float(res[False][1].abs().max()))
+        assert float((res[True][1] - res[False][1]).abs().max()) < 2e-4 * scale
+        lscale = max(1.0, float(res[False][2].abs().max()))
+        assert float((res[True][2] - res[False][2]).abs().max()) < 5e-4 * lscale
