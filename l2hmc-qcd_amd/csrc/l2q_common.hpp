@@ -17,6 +17,7 @@ struct Tuning {
   int plaq_sweep = 2;     // 2: slice-resident kernel (LDS + register prefetch), 1: L2 t-sweep, 0: flat
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
   int force_tile = 2;     // 2: slice-resident kernel, 1: LDS-tiled (64 sites x 4 mu), 0: flat
+  int u1_fused_ch = 0;    // chains per workgroup of the fused U(1) kernels (0: auto; 1, 2, 4, 8)
 };
 Tuning& tuning();
 

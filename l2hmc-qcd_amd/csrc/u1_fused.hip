@@ -271,11 +271,16 @@ static int fill_net(U1Net& net, const float* wxT, const float* wvT, const float*
   return L2Q_OK;
 }
 
-static int chains_per_block(long floats_per_chain) {
-  // LDS: inputs + first-layer partials + activations; keep two workgroups per CU resident
+static int chains_per_block(long floats_per_chain, int nb) {
+  // More chains per workgroup amortise the weight stream from L2, fewer give more workgroups
+  // per CU to hide the barriers between the layers: take the largest CH that fits LDS
+  // (two workgroups per CU) and still leaves >= 4 workgroups per CU.
+  const int forced = tuning().u1_fused_ch;
   for (int ch = 8; ch >= 1; ch >>= 1) {
     const long bytes = (long)ch * (floats_per_chain + kBlock + 2 * kMaxWidth) * 4;
-    if (bytes <= 72 * 1024) return ch;
+    if (bytes > 72 * 1024) continue;
+    if (forced) { if (ch <= forced) return ch; continue; }
+    if (ch == 1 || cdiv(nb, ch) >= 4 * 256) return ch;
   }
   return 0;
 }
@@ -298,7 +303,7 @@ int l2q_u1_vstep_f32(const float* x, float* v, double beta, double eps, int forw
   const int rc = fill_net(net, wxT, wvT, b0, hidden, units, nl, ws, bs, cs, wt, bt, scale_t, wq,
                           bq, cq, act);
   if (rc != L2Q_OK) return rc;
-  const int ch = chains_per_block(2L * n + n / 2);
+  const int ch = chains_per_block(2L * n + n / 2, nb);
   L2Q_REQUIRE(ch > 0, L2Q_ESHAPE, "does not fit LDS");
   const size_t lds = (size_t)ch * (2L * n + n / 2 + kBlock + 2 * kMaxWidth) * 4;
   hipStream_t st = (hipStream_t)stream;
@@ -333,7 +338,7 @@ int l2q_u1_xstep_f32(float* x, const float* v, const float* mask, int complement
   const int rc = fill_net(net, wxT, wvT, b0, hidden, units, nl, ws, bs, cs, wt, bt, scale_t, wq,
                           bq, cq, act);
   if (rc != L2Q_OK) return rc;
-  const int ch = chains_per_block(3L * n);
+  const int ch = chains_per_block(3L * n, nb);
   L2Q_REQUIRE(ch > 0, L2Q_ESHAPE, "does not fit LDS");
   const size_t lds = (size_t)ch * (3L * n + kBlock + 2 * kMaxWidth) * 4;
   hipStream_t st = (hipStream_t)stream;

@@ -17,6 +17,8 @@ ap.add_argument('--nlf', type=int, default=8)
 ap.add_argument('--beta', type=float, default=4.0)
 ap.add_argument('--conv', action='store_true')
 ap.add_argument('--steps', type=int, default=5)
+ap.add_argument('--ch', type=int, default=0, help='chains per workgroup of the fused U(1) kernels (0: auto)')
+ap.add_argument('--unfused', action='store_true', help='multi-kernel sub-updates instead of the fused U(1) kernels')
 a = ap.parse_args()
 torch.manual_seed(9992); np.random.seed(9992)
 dc = cfgs.DynamicsConfig(nchains=a.nb, group='U1', latvolume=a.L, nleapfrog=a.nlf, eps=0.1,
@@ -29,6 +31,9 @@ spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc
                       vnet={'x': [dc.xdim], 'v': [dc.xdim]})
 lat = LatticeU1(a.nb, a.L)
 dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cc)).eval()
+dyn.fuse_u1_steps = not a.unfused
+from l2hmc import native  # noqa: E402
+native.set_tuning('u1_fused_ch', a.ch)
 x = lat.random()
 beta = torch.tensor(a.beta)
 for name, fn, nlf in (('Dynamics.forward (L2HMC)', lambda x: dyn((x, beta)), 2 * a.nlf),
