@@ -255,20 +255,21 @@ int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int p
  *   ws, wt, wq [n][U_last], bs, bt, bq [n]; cs, cq [n] per-entry scale (nw * exp(coeff));
  *   scale_t; act: L2Q_ACT_* of the dense layers.
  * v-step: Kx = Kv = n (inputs x and force(x)); v updated in place, x untouched.
- * x-step: Kx = 2 n ([cos(m x), sin(m x)]), Kv = n (v); x updated in place (+ compat_proj). */
+ * x-step: Kx = 2 n ([cos(m x), sin(m x)]), Kv = n (v); x updated in place (+ compat_proj).
+ * accumulate != 0: logdet[c] += the sub-update's log-det (running sum of a leapfrog step). */
 int l2q_u1_fused_max_n(void);
 int l2q_u1_vstep_f32(const float* x, float* v, double beta, double eps, int forward, int nb, int T,
                      int X, const float* wxT, const float* wvT, const float* b0,
                      const float* hidden, const int* units, int nl, const float* ws,
                      const float* bs, const float* cs, const float* wt, const float* bt,
                      double scale_t, const float* wq, const float* bq, const float* cq, int act,
-                     float* logdet, void* stream);
+                     int accumulate, float* logdet, void* stream);
 int l2q_u1_xstep_f32(float* x, const float* v, const float* mask, int complement, double eps,
                      int forward, int use_ncp, int nb, int n, const float* wxT, const float* wvT,
                      const float* b0, const float* hidden, const int* units, int nl,
                      const float* ws, const float* bs, const float* cs, const float* wt,
                      const float* bt, double scale_t, const float* wq, const float* bq,
-                     const float* cq, int act, float* logdet, void* stream);
+                     const float* cq, int act, int accumulate, float* logdet, void* stream);
 
 /* ================================================================ training-gradient path
  * Reverse-mode (VJP) counterparts of the U(1) sub-updates and network layers, the train-mode

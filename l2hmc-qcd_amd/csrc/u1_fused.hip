@@ -114,7 +114,7 @@ template <int CH, bool FWD>
 __global__ __launch_bounds__(kBlock) void u1_vstep_kernel(const float* __restrict__ x,
                                                           float* v, U1Net net, float beta,
                                                           float eps, int Tn, int Xn, int nb,
-                                                          float* __restrict__ logdet) {
+                                                          int accumulate, float* logdet) {
   extern __shared__ float sm[];
   const int V = Tn * Xn, n = 2 * V;
   float* xin = sm;                     // [CH][n]
@@ -170,7 +170,8 @@ __global__ __launch_bounds__(kBlock) void u1_vstep_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const double r = block_sum(ld[c], red);
-    if (threadIdx.x == 0 && c0 + c < nb) logdet[c0 + c] = (float)r;
+    if (threadIdx.x == 0 && c0 + c < nb)
+      logdet[c0 + c] = accumulate ? logdet[c0 + c] + (float)r : (float)r;
   }
 }
 
@@ -179,7 +180,7 @@ template <int CH, bool FWD, bool NCP>
 __global__ __launch_bounds__(kBlock) void u1_xstep_kernel(float* x, const float* __restrict__ v,
                                                           U1Net net, const float* __restrict__ mask,
                                                           int complement, float eps, int n, int nb,
-                                                          float* __restrict__ logdet) {
+                                                          int accumulate, float* logdet) {
   extern __shared__ float sm[];
   float* xin = sm;                     // [CH][2n]: cos then sin of the kept entries
   float* vin = xin + CH * 2 * n;       // [CH][n]
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(kBlock) void u1_xstep_kernel(float* x, const float*
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const double r = block_sum(ld[c], red);
-    if (threadIdx.x == 0 && c0 + c < nb) logdet[c0 + c] = (float)r;
+    if (threadIdx.x == 0 && c0 + c < nb)
+      logdet[c0 + c] = accumulate ? logdet[c0 + c] + (float)r : (float)r;
   }
 }
 
@@ -294,7 +296,7 @@ int l2q_u1_vstep_f32(const float* x, float* v, double beta, double eps, int forw
                      const float* hidden, const int* units, int nl, const float* ws,
                      const float* bs, const float* cs, const float* wt, const float* bt,
                      double scale_t, const float* wq, const float* bq, const float* cq, int act,
-                     float* logdet, void* stream) {
+                     int accumulate, float* logdet, void* stream) {
   L2Q_REQUIRE(x && v && logdet, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && T_ > 0 && X_ > 0, L2Q_EINVAL, "non-positive size");
   const int n = 2 * T_ * X_;
@@ -311,9 +313,9 @@ int l2q_u1_vstep_f32(const float* x, float* v, double beta, double eps, int forw
 #define L2Q_VS(CHN)                                                                            \
   do {                                                                                         \
     if (forward) hipLaunchKernelGGL((u1_vstep_kernel<CHN, true>), grid, block, lds, st, x, v,  \
-                                    net, (float)beta, (float)eps, T_, X_, nb, logdet);         \
+                                    net, (float)beta, (float)eps, T_, X_, nb, accumulate, logdet); \
     else hipLaunchKernelGGL((u1_vstep_kernel<CHN, false>), grid, block, lds, st, x, v, net,    \
-                            (float)beta, (float)eps, T_, X_, nb, logdet);                      \
+                            (float)beta, (float)eps, T_, X_, nb, accumulate, logdet);          \
   } while (0)
   switch (ch) {
     case 8: L2Q_VS(8); break;
@@ -330,7 +332,7 @@ int l2q_u1_xstep_f32(float* x, const float* v, const float* mask, int complement
                      const float* b0, const float* hidden, const int* units, int nl,
                      const float* ws, const float* bs, const float* cs, const float* wt,
                      const float* bt, double scale_t, const float* wq, const float* bq,
-                     const float* cq, int act, float* logdet, void* stream) {
+                     const float* cq, int act, int accumulate, float* logdet, void* stream) {
   L2Q_REQUIRE(x && v && mask && logdet, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
   L2Q_REQUIRE(n <= l2q_u1_fused_max_n(), L2Q_ESHAPE, "lattice too large for the fused kernel");
@@ -345,7 +347,7 @@ int l2q_u1_xstep_f32(float* x, const float* v, const float* mask, int complement
   const dim3 grid((unsigned)cdiv(nb, ch)), block(kBlock);
 #define L2Q_XS(CHN, F, N)                                                                      \
   hipLaunchKernelGGL((u1_xstep_kernel<CHN, F, N>), grid, block, lds, st, x, v, net, mask,      \
-                     complement, (float)eps, n, nb, logdet)
+                     complement, (float)eps, n, nb, accumulate, logdet)
 #define L2Q_XS4(CHN)                                                                           \
   do {                                                                                         \
     if (forward) { if (use_ncp) L2Q_XS(CHN, true, true); else L2Q_XS(CHN, true, false); }      \

@@ -430,25 +430,27 @@ def _fused_net_args(fw: dict):
 
 
 def u1_vstep_(x: torch.Tensor, v: torch.Tensor, beta: float, eps: float, forward: bool,
-              lat: Sequence[int], fw: dict) -> torch.Tensor:
-    """Fused force + vnet + momentum update (v in place); returns logdet [nb].  fw: the
-    'fused_u1' entry of LeapfrogLayer.kernel_weights()."""
+              lat: Sequence[int], fw: dict, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused force + vnet + momentum update (v in place); returns logdet [nb] (added into
+    `acc` when given).  fw: the 'fused_u1' entry of LeapfrogLayer.kernel_weights()."""
     T, X = (int(i) for i in lat)
     nb = x.shape[0]
-    logdet = torch.empty(nb, dtype=torch.float32, device=x.device)
+    logdet = torch.empty(nb, dtype=torch.float32, device=x.device) if acc is None else acc
     N.call('l2q_u1_vstep_f32', x, v, float(beta), float(eps), int(forward), nb, T, X,
-           *_fused_net_args(fw), logdet)
+           *_fused_net_args(fw), int(acc is not None), logdet)
     return logdet
 
 
 def u1_xstep_(x: torch.Tensor, v: torch.Tensor, mask: torch.Tensor, complement: bool, eps: float,
-              forward: bool, use_ncp: bool, fw: dict) -> torch.Tensor:
-    """Fused masked cos/sin + xnet + position update (x in place); returns logdet [nb]."""
+              forward: bool, use_ncp: bool, fw: dict,
+              acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused masked cos/sin + xnet + position update (x in place); returns logdet [nb] (added
+    into `acc` when given)."""
     nb = x.shape[0]
     n = x.numel() // nb
-    logdet = torch.empty(nb, dtype=torch.float32, device=x.device)
+    logdet = torch.empty(nb, dtype=torch.float32, device=x.device) if acc is None else acc
     N.call('l2q_u1_xstep_f32', x, v, mask, int(complement), float(eps), int(forward),
-           int(use_ncp), nb, n, *_fused_net_args(fw), logdet)
+           int(use_ncp), nb, n, *_fused_net_args(fw), int(acc is not None), logdet)
     return logdet
 
 

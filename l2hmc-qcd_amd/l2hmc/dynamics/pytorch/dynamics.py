@@ -489,14 +489,15 @@ class Dynamics(nn.Module):
         return net.kernel_weights().get('fused_u1')
 
     def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
-                    cache: Optional[dict] = None) -> Tensor:
-        """v-update in place (dynamics.py:1266-1297); returns logdet [nb]."""
+                    cache: Optional[dict] = None, acc: Optional[Tensor] = None) -> Tensor:
+        """v-update in place (dynamics.py:1266-1297); returns logdet [nb] (the fused U(1) kernel
+        adds it into `acc` when given)."""
         eps = self._eps('v', step)
         nb = xn.shape[0]
         vnet = self._get_vnet(step)
         fw = self._fused_u1(vnet)
         if fw is not None:            # force + vnet + update in one launch
-            return ops.u1_vstep_(xn, vn, _beta(beta), eps, forward, self.latvolume, fw)
+            return ops.u1_vstep_(xn, vn, _beta(beta), eps, forward, self.latvolume, fw, acc)
         fn, z, w = self._v_inputs_n(vnet, xn, beta, cache)
         if z is not None:
             # heads + momentum update in one kernel: s, t, q never reach HBM
@@ -520,7 +521,7 @@ class Dynamics(nn.Module):
             forward1)
 
     def _update_x_n(self, step: int, xn: Tensor, vn: Tensor, mask: Tensor, complement: bool,
-                    forward: bool, first: bool) -> Optional[Tensor]:
+                    forward: bool, first: bool, acc: Optional[Tensor] = None) -> Optional[Tensor]:
         eps = self._eps('x', step)
         if self.group == 'SU3':
             ops.su3_expm_mul_n(xn, vn, eps if forward else -eps, mask, complement, out=xn)
@@ -529,7 +530,7 @@ class Dynamics(nn.Module):
         fw = self._fused_u1(self._get_xnet(step, first))
         if fw is not None:            # masked cos/sin + xnet + update in one launch
             return ops.u1_xstep_(xn.reshape(nb, -1), vn, mask, complement, eps, forward,
-                                 self.config.use_ncp, fw)
+                                 self.config.use_ncp, fw, acc)
         s, t, q = self._xnet_n(step, first, xn, vn, mask, complement)
         return ops.u1_x_update_(xn.reshape(nb, -1), vn, s, t, q, mask, complement, eps,
                                 forward, self.config.use_ncp)
@@ -552,6 +553,20 @@ class Dynamics(nn.Module):
             st = self.config.nleapfrog - step - 1
             order = ((True, False), (False, True))
         m = self._native_masks()[st]
+        if self.group == 'U1' and self.fuse_u1_steps:
+            fv = self._fused_u1(self._get_vnet(st))
+            fx = {True: self._fused_u1(self._get_xnet(st, True)),
+                  False: self._fused_u1(self._get_xnet(st, False))} if fv is not None else None
+            if fv is not None and fx[True] is not None and fx[False] is not None:
+                # four one-launch sub-updates, the log-det summed inside the kernels
+                nb, b = xn.shape[0], _beta(beta)
+                ev, ex = self._eps('v', st), self._eps('x', st)
+                ld = ops.u1_vstep_(xn, vn, b, ev, forward, self.latvolume, fv)
+                for comp, first in order:
+                    ops.u1_xstep_(xn.reshape(nb, -1), vn, m, comp, ex, forward,
+                                  self.config.use_ncp, fx[first], ld)
+                ops.u1_vstep_(xn, vn, b, ev, forward, self.latvolume, fv, ld)
+                return ld
         prev = pend.pop('p', None) if pend is not None else None
         if prev is not None:
             st0, f0, flip = prev

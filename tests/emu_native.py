@@ -218,23 +218,23 @@ def _fused_net(xin, vin, wxT, wvT, b0, hidden, units, nl, ws, bs, cs, wt, bt, sc
 
 
 def l2q_u1_vstep_f32(x, v, beta, eps, forward, nb, T, X, *net_and_out):
-    *net, logdet = net_and_out
+    *net, accumulate, logdet = net_and_out
     n = 2 * T * X
     f = _force(x.reshape(nb, 2, T, X), beta).reshape(nb, n)
     s, t, q = _fused_net(x.reshape(nb, n), f, *net)
     vn, ld = _v_update(v.reshape(nb, n), f, s, t, q, eps, bool(forward))
     v.copy_(vn.reshape(v.shape))
-    logdet.copy_(ld)
+    logdet.copy_(logdet + ld if accumulate else ld)
 
 
 def l2q_u1_xstep_f32(x, v, mask, complement, eps, forward, ncp, nb, n, *net_and_out):
-    *net, logdet = net_and_out
+    *net, accumulate, logdet = net_and_out
     a = _keep(mask, complement, x) * x.reshape(nb, n)
     s, t, q = _fused_net(torch.cat([torch.cos(a), torch.sin(a)], 1), v.reshape(nb, n), *net)
     xn, ld = _x_update(x.reshape(nb, n), v.reshape(nb, n), s, t, q, mask, complement, eps,
                        bool(forward), bool(ncp))
     x.copy_(xn.reshape(x.shape))
-    logdet.copy_(ld)
+    logdet.copy_(logdet + ld if accumulate else ld)
 
 
 # ---- training entry points (VJPs by autograd of the restatements above)
