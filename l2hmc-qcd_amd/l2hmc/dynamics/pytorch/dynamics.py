@@ -963,6 +963,93 @@ class Dynamics(nn.Module):
         x_, v_, hist = self._kernel_n(xn, vn, beta, forward)
         return self._finish(xn, vn, x_, v_, beta, hist, with_sumlogdet=True)
 
+    def apply_transition_both(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
+        """Forward and backward single-direction proposals from the same x (two momentum draws),
+        mixed per chain by a random direction mask, then accept / reject
+        (dynamics.py:744-803, including its per-key masking of the metrics)."""
+        x, beta = inputs
+        nb = x.shape[0]
+        xn = self._pack(x)
+        vf0 = self._momentum_n(nb)
+        xf, vf, mf_hist = self._kernel_n(xn, vf0, beta, True)
+        vb0 = self._momentum_n(nb)
+        xb, vb, mb_hist = self._kernel_n(xn, vb0, beta, False)
+        mf_, mb_ = self._get_direction_masks(batch_size=nb)
+
+        def mix(a, b):
+            flat = ops.select_rows(a.reshape(nb, -1), b.reshape(nb, -1), mf_)
+            return flat.reshape(a.shape)
+        v_init, xp, vp = mix(vf0, vb0), mix(xf, xb), mix(vf, vb)
+        logdetp = mf_ * mf_hist['sumlogdet'] + mb_ * mb_hist['sumlogdet']
+        acc = mf_ * mf_hist['acc'] + mb_ * mb_hist['acc']
+        ma_, mr_ = self._get_accept_masks(acc)
+        xo_n = ops.select_rows(xp.reshape(nb, -1), xn.reshape(nb, -1), ma_).reshape(xn.shape)
+        vo_n = ops.select_rows(vp.reshape(nb, -1), v_init.reshape(nb, -1), ma_).reshape(vp.shape)
+        metrics = {}
+        for (key, valf), (_, valb) in zip(mf_hist.items(), mb_hist.items()):
+            if isinstance(valf, Tensor) and valf.shape[-1:] == (nb,):
+                metrics[key] = ma_ * (mf_ * valf + mb_ * valb)
+        mc_states = MonteCarloStates(init=self._state_from_n(xn, v_init, beta, lazy=True),
+                                     proposed=self._state_from_n(xp, vp, beta, lazy=True),
+                                     out=self._state_from_n(xo_n, vo_n, beta, lazy=True))
+        metrics.update({'acc': acc, 'acc_mask': ma_, 'sumlogdet': ma_ * logdetp,
+                        'mc_states': mc_states})
+        return self._unpack(xo_n).reshape(nb, -1), metrics
+
+    def get_metrics(self, state: State, logdet: Tensor, step: Optional[int] = None,
+                    extras: Optional[dict] = None) -> dict:
+        """energy / logprob / logdet (+ step sizes) of a reference-layout state (:865-886)."""
+        xn, vn = self._state_n(state)
+        return self._metrics_n(xn, vn, state.beta, logdet.to(DEVICE), step, extras)
+
+    # plain-HMC pieces with the *trainable* step sizes (dynamics.py:1244-1264)
+    def _update_v_fwd_hmc(self, step: int, state: State) -> Tensor:
+        xn, vn = self._state_n(state)
+        vn = vn.clone()
+        self._kick_n(xn, vn, state.beta, -0.5 * self._eps('v', step))
+        return self._unpack(vn) if self.group == 'SU3' else vn.reshape(state.v.shape)
+
+    def _update_v_bwd_hmc(self, step: int, state: State) -> Tensor:
+        xn, vn = self._state_n(state)
+        vn = vn.clone()
+        self._kick_n(xn, vn, state.beta, 0.5 * self._eps('v', step))
+        return self._unpack(vn) if self.group == 'SU3' else vn.reshape(state.v.shape)
+
+    def _update_x_hmc(self, step: int, state: State, sign: float) -> Tensor:
+        xn, vn = self._state_n(state)
+        eps = sign * self._eps('x', step)
+        if self.group == 'SU3':
+            return self._unpack(ops.su3_expm_mul_n(xn, vn, eps))
+        xn = xn.clone()
+        ops.axpy_(xn.reshape(xn.shape[0], -1), vn, eps)
+        return self._unpack(xn)
+
+    def _update_x_fwd_hmc(self, step: int, state: State) -> Tensor:
+        return self._update_x_hmc(step, state, +1.0)
+
+    def _update_x_bwd_hmc(self, step: int, state: State) -> Tensor:
+        return self._update_x_hmc(step, state, -1.0)
+
+    def _stack_as_xy(self, x: Tensor) -> Tensor:
+        """[cos(x), sin(x)] stacked on a new last axis (dynamics.py:1137-1140); U(1) fields."""
+        x = x.to(DEVICE).contiguous()
+        nb, n = x.shape[0], x[0].numel()
+        ones = torch.ones(n, dtype=torch.float32, device=DEVICE)
+        cs = ops.u1_masked_cos_sin(x.reshape(nb, n), ones, False, (n // 2,)).reshape(nb, 2, n)
+        return torch.stack([cs[:, 0].reshape(x.shape), cs[:, 1].reshape(x.shape)], dim=-1)
+
+    @staticmethod
+    def complexify(x: Tensor, dim: int = 1) -> Tensor:
+        """real pairs along `dim` -> complex (dynamics.py:1501-1535)"""
+        assert len(x.shape) >= 2
+        assert x.shape[dim] == 2
+        if dim != 1:
+            xr, xi = x.transpose(0, dim)
+            return torch.complex(xr.transpose(0, dim - 1), xi.transpose(0, dim - 1))
+        if len(x.shape) == 2:
+            return torch.complex(x[:, 0], x[:, 1])
+        return torch.complex(x[:, 0, ...], x[:, 1, ...])
+
     def generate_proposal_hmc(self, inputs, eps=None, nleapfrog=None) -> dict:
         x, beta = inputs
         xn = self._pack(x)

@@ -348,3 +348,103 @@ def test_u1_fused_substeps_equal_unfused(lat, nb, units, act, bn):
         assert float((res[True][1] - res[False][1]).abs().max()) < 2e-4 * scale
         lscale = max(1.0, float(res[False][2].abs().max()))
         assert float((res[True][2] - res[False][2]).abs().max()) < 5e-4 * lscale
+
+
+@pytest.mark.parametrize('group', ['U1', 'SU3'])
+def test_apply_transition_both_and_hmc_helpers(group, golden):
+    """apply_transition_both (dynamics.py:744-803) against the oracle's two single-direction
+    kernels mixed with the same direction / accept masks; get_metrics; the *_hmc sub-update
+    helpers; complexify / _stack_as_xy."""
+    import oracle.su3 as osu3
+    import oracle.u1 as ou1
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics, State
+    if group == 'SU3':
+        torch.set_default_dtype(torch.float64)
+        g = golden('su3_l2hmc')
+        dyn, lat = helpers.build_su3_dynamics(g, verbose=False)
+        orc = helpers.su3_oracle(g)
+        tol = 1e-9
+    else:
+        torch.set_default_dtype(torch.float32)
+        g = golden('u1_c1')
+        dyn, lat = helpers.build_u1_dynamics(g, verbose=False)
+        orc = helpers.u1_oracle(g)
+        tol = 5e-3
+    orc.merge_directions = False
+    x = torch.from_numpy(g['x'])
+    nb = x.shape[0]
+    beta = float(g['beta'])
+    gen = np.random.default_rng(3)
+    shape = (8, nb, 4, *[int(i) for i in g['latvolume']]) if group == 'SU3' else \\
+        (nb, 2, *[int(i) for i in g['latvolume']])
+    nf, nbk = gen.standard_normal(shape), gen.standard_normal(shape)
+    if group == 'U1':
+        nf, nbk = nf.astype(np.float32), nbk.astype(np.float32)
+    dirmask = (gen.random(nb) > 0.5).astype(np.float32)
+    u = gen.random(nb).astype(np.float64 if group == 'SU3' else np.float32)
+    draws = iter([nf, nbk])
+    real_mom = dyn._momentum_n
+
+    def momentum(n):
+        dyn._inject = {'normals': next(draws)}
+        try:
+            return real_mom(n)
+        finally:
+            dyn._inject = None
+    dyn._momentum_n = momentum
+    dyn._get_direction_masks = lambda batch_size: (torch.from_numpy(dirmask).to(dyn.device),
+                                                   torch.from_numpy(1 - dirmask).to(dyn.device))
+    dyn._uniform = lambda acc: torch.from_numpy(u).to(acc)
+    xo, m = dyn.apply_transition_both((x, torch.tensor(beta)))
+    # oracle: the two single-direction kernels (dynamics.py:1031-1063 incl. its swapped accept args)
+    xin = ou1.compat_proj(g['x']) if False else g['x']
+    res = {}
+    for name, nrm, fwd in (('f', nf, True), ('b', nbk, False)):
+        v0 = orc.random_momentum(nrm)
+        xx, vv = xin.reshape(nb, -1) if group == 'U1' else xin, v0
+        sld = np.zeros(nb)
+        for step in range(orc.nlf):
+            xx, vv, ld = (orc.forward_lf if fwd else orc.backward_lf)(step, xx, vv, beta)
+            sld = sld + ld
+        h0 = orc.hamiltonian(xin.reshape(nb, -1) if group == 'U1' else xin, v0, beta)
+        h1 = orc.hamiltonian(xx, vv, beta)
+        res[name] = (xx.reshape(nb, -1), orc.accept_prob(h1, h0, sld), sld)
+    mf = dirmask
+    acc = mf * res['f'][1] + (1 - mf) * res['b'][1]
+    xp = mf[:, None] * res['f'][0] + (1 - mf)[:, None] * res['b'][0]
+    ma = (acc > u).astype(np.float32)
+    xo_ref = ma[:, None] * xp + (1 - ma)[:, None] * g['x'].reshape(nb, -1)
+    np.testing.assert_allclose(m['acc'].cpu().numpy(), acc, rtol=tol, atol=tol)
+    assert np.array_equal(m['acc_mask'].cpu().numpy(), ma)
+    got = xo.cpu().numpy()
+    if group == 'U1':
+        d = np.abs(np.angle(np.exp(1j * (got - xo_ref)))).max()
+    else:
+        d = np.abs(got - xo_ref).max()
+    assert d < 10 * tol, d
+    # get_metrics on a reference-layout state == hamiltonian pieces
+    st = State(x=x.to(dyn.device), v=dyn.g.random_momentum(list(x.shape)).to(dyn.device)
+               if group == 'SU3' else torch.randn(nb, dyn.xdim).to(dyn.device), beta=torch.tensor(beta))
+    ld = torch.zeros(nb, dtype=torch.get_default_dtype(), device=dyn.device)
+    mt = dyn.get_metrics(st, ld, step=0)
+    assert torch.allclose(mt['energy'], dyn.hamiltonian(st), rtol=1e-5)
+    # trainable-step HMC helpers: v -/+ eps/2 F and update_gauge(x, +-eps v)
+    ev, ex = dyn._eps('v', 0), dyn._eps('x', 0)
+    F = dyn.grad_potential(st.x, st.beta).reshape(st.v.shape)
+    assert torch.allclose(dyn._update_v_fwd_hmc(0, st), st.v - 0.5 * ev * F, atol=1e-5)
+    assert torch.allclose(dyn._update_v_bwd_hmc(0, st), st.v + 0.5 * ev * F, atol=1e-5)
+    xf = dyn._update_x_fwd_hmc(0, st)
+    xb = dyn._update_x_bwd_hmc(0, State(xf, st.v, st.beta))
+    dxx = (xb.reshape(st.x.shape) - st.x)
+    if group == 'U1':
+        dxx = torch.remainder(dxx + np.pi, 2 * np.pi) - np.pi
+    assert float(dxx.abs().max()) < 1e-5                      # x -> x' -> x
+    # complexify / _stack_as_xy
+    r = torch.randn(3, 2, 4, 5)
+    assert torch.equal(Dynamics.complexify(r, 1), torch.complex(r[:, 0], r[:, 1]))
+    r2 = torch.randn(3, 4, 5, 2)
+    assert torch.equal(Dynamics.complexify(r2, 3), torch.complex(r2[..., 0], r2[..., 1]))
+    if group == 'U1':
+        xy = dyn._stack_as_xy(x)
+        assert torch.allclose(xy[..., 0].cpu(), x.cos(), atol=1e-6)
+        assert torch.allclose(xy[..., 1].cpu(), x.sin(), atol=1e-6)
