@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import helpers
 from helpers import build_su3_dynamics, build_u1_dynamics, su3_oracle
 
 pytestmark = pytest.mark.gpu
@@ -375,7 +376,7 @@ def test_apply_transition_both_and_hmc_helpers(group, golden):
     nb = x.shape[0]
     beta = float(g['beta'])
     gen = np.random.default_rng(3)
-    shape = (8, nb, 4, *[int(i) for i in g['latvolume']]) if group == 'SU3' else \\
+    shape = (8, nb, 4, *[int(i) for i in g['latvolume']]) if group == 'SU3' else \
         (nb, 2, *[int(i) for i in g['latvolume']])
     nf, nbk = gen.standard_normal(shape), gen.standard_normal(shape)
     if group == 'U1':
@@ -443,7 +444,9 @@ def test_apply_transition_both_and_hmc_helpers(group, golden):
     r = torch.randn(3, 2, 4, 5)
     assert torch.equal(Dynamics.complexify(r, 1), torch.complex(r[:, 0], r[:, 1]))
     r2 = torch.randn(3, 4, 5, 2)
-    assert torch.equal(Dynamics.complexify(r2, 3), torch.complex(r2[..., 0], r2[..., 1]))
+    # dim != 1: the reference's two transposes leave the middle axes swapped (dynamics.py:1525-1531)
+    assert torch.equal(Dynamics.complexify(r2, 3),
+                       torch.complex(r2[..., 0], r2[..., 1]).transpose(1, 2))
     if group == 'U1':
         xy = dyn._stack_as_xy(x)
         assert torch.allclose(xy[..., 0].cpu(), x.cos(), atol=1e-6)
