@@ -1,6 +1,7 @@
 """``SU3`` group object -- API of src/l2hmc/group/su3/pytorch/group.py:33-227 on HIP kernels."""
 from __future__ import annotations
 
+import logging
 from typing import Optional, Sequence
 
 import torch
@@ -10,9 +11,10 @@ from l2hmc import _ops as ops
 from l2hmc.group.group import Group
 from l2hmc.group.su3.pytorch.utils import (
     _native, _reference, checkSU, checkU, eyeOf, norm2, projectSU, projectTAH, projectU,
-    randTAH3, su3_to_vec, vec_to_su3,
+    randTAH3, rsqrtPHM3, rsqrtPHM3f, su3_to_vec, vec_to_su3,
 )
 
+log = logging.getLogger(__name__)
 Tensor = torch.Tensor
 C128 = torch.complex128
 
@@ -49,8 +51,35 @@ class SU3(Group):
         eye[..., (0, 4, 8), :] = 1.0
         return _reference(ops.su3_expm_mul_n(eye, xn, 1.0), x.shape)
 
+    def diff_trace(self, x: Tensor) -> Tensor:
+        log.error('TODO')                       # stubs in the reference too (group.py:80-86)
+        return x
+
+    def diff2trace(self, x: Tensor) -> Tensor:
+        log.error('TODO')
+        return x
+
     def projectTAH(self, x: Tensor) -> Tensor:
         return projectTAH(x)
+
+    def compat_proju(self, u: Tensor, x: Tensor) -> Tensor:
+        """group.py:149-166 verbatim in behaviour: project solve(u, x)[0] to the traceless
+        anti-Hermitian algebra and return u @ B (small-batch utility, plain tensor ops)."""
+        _, n, _ = x.shape
+        algebra_elem = torch.linalg.solve(u, x)[0]
+        B = (algebra_elem - algebra_elem.conj().transpose(-2, -1)) / 2.
+        trace = torch.einsum('bii->b', B)
+        B = B - ((1 / n) * trace.unsqueeze(-1).unsqueeze(-1)
+                 * torch.eye(n).repeat(x.shape[0], 1, 1))
+        assert torch.abs(torch.mean(torch.einsum('bii->b', B))) < 1e-6
+        return B
+
+    @staticmethod
+    def rsqrtPHM3f(tr: Tensor, p2: Tensor, det: Tensor):
+        return rsqrtPHM3f(tr, p2, det)
+
+    def rsqrtPHM3(self, x: Tensor) -> Tensor:
+        return rsqrtPHM3(x)
 
     def projectSU(self, x: Tensor) -> Tensor:
         return projectSU(x)

@@ -66,6 +66,42 @@ def randTAH3(shape: Sequence[int]) -> Tensor:
     return _reference(vn.reshape(1, 1, 9, n), (*shape, 3, 3))
 
 
+def eigs3x3(tr: Tensor, p2: Tensor, det: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """Eigenvalues of a 3x3 positive Hermitian matrix from tr X, tr X^2 and det X by the
+    trigonometric (Cardano) form -- the function the reference exports as utils.py:227-283,
+    including its clamp of the acos argument to +-(1 - 1e-12).  Host-side utility: the kernels
+    have their own device version (csrc/su3_math.hpp m3_eigs)."""
+    tr3, p23 = tr / 3.0, p2 / 3.0
+    q = (0.5 * (p23 - tr3 * tr3)).abs()
+    r = 0.25 * tr3 * (5.0 * tr3 * tr3 - p2) - 0.5 * det
+    sq = torch.sqrt(q)
+    ratio = (r / (q * sq).clamp(min=1e-300)).clamp(-3e38, 3e38)
+    t = torch.acos(ratio.real.clamp(-1.0 + 1e-12, 1.0 - 1e-12)) / 3.0
+    sqc, sqs = sq * torch.cos(t), (3.0 ** 0.5) * sq * torch.sin(t)
+    ll = tr3 + sqc
+    return tr3 - 2.0 * sqc, ll + sqs, ll - sqs
+
+
+def rsqrtPHM3f(tr: Tensor, p2: Tensor, det: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """Coefficients c0, c1, c2 with X^{-1/2} = c0 + c1 X + c2 X^2 (utils.py:286-317)."""
+    e0, e1, e2 = eigs3x3(tr, p2, det)
+    s0, s1, s2 = e0.abs().sqrt(), e1.abs().sqrt(), e2.abs().sqrt()
+    u, w = s0 + s1 + s2, s0 * s1 * s2
+    di = 1.0 / (w * (s0 + s1) * (s0 + s2) * (s1 + s2))
+    c0 = di * (w * u * u + e0 * s0 * (e1 + e2) + e1 * s1 * (e0 + e2) + e2 * s2 * (e0 + e1))
+    return c0, -(tr * u + w) * di, u * di
+
+
+def rsqrtPHM3(x: Tensor) -> Tensor:
+    """X^{-1/2} of a positive Hermitian 3x3 X (utils.py:320-329)."""
+    tr = torch.diagonal(x, dim1=-2, dim2=-1).sum(-1).real
+    x2 = x @ x
+    p2 = torch.diagonal(x2, dim1=-2, dim2=-1).sum(-1).real
+    c0, c1, c2 = (c.reshape(c.shape + (1, 1)).to(x.dtype)
+                  for c in rsqrtPHM3f(tr, p2, torch.linalg.det(x).real))
+    return c0 * torch.eye(3, dtype=x.dtype, device=x.device) + c1 * x + c2 * x2
+
+
 def projectU(x: Tensor) -> Tensor:
     """x (x^H x)^{-1/2}"""
     return _reference(ops.su3_project_u_n(_native(x)), x.shape)

@@ -14,6 +14,14 @@ TWO_PI = torch.pi * 2.
 Tensor = torch.Tensor
 
 
+def eyeOf(x: Tensor) -> Tensor:
+    """identity broadcastable against x's trailing matrix axes (group.py:50-57)"""
+    batch_dims = [1] * (len(x.shape) - 1)
+    eye = torch.zeros(batch_dims + [*x.shape[-1:]]).to(x.device)
+    eye[-1:] = torch.eye(x.shape[-1])
+    return eye
+
+
 def rand_unif(shape: Sequence[int], a: float, b: float, requires_grad: bool = True):
     """x ~ U(a, b) with shape `shape` (group.py:23-38)"""
     rand = (a - b) * torch.rand(tuple(shape)) + b
@@ -27,6 +35,9 @@ def random_angle(shape: Sequence[int], requires_grad: bool = True) -> Tensor:
 class U1Phase(Group):
     def __init__(self) -> None:
         super().__init__(dim=2, shape=[1], dtype=torch.get_default_dtype())
+
+    def floormod(self, x: Tensor | float, y: Tensor | float) -> Tensor:
+        return (x - torch.floor_divide(x, y) * y)
 
     def phase_to_coords(self, phi: Tensor) -> Tensor:
         return torch.cat([phi.cos(), phi.sin()], -1)

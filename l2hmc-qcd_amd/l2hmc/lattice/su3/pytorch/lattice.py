@@ -8,6 +8,7 @@ the DBW2 rectangle term (lattice.py:96-112, 180-196) is SURVEY.md 8(f) item 4.
 """
 from __future__ import annotations
 
+import logging
 from typing import Optional
 
 import numpy as np
@@ -19,6 +20,7 @@ from l2hmc import _ops as ops
 from l2hmc.configs import Charges
 from l2hmc.lattice.lattice import Lattice
 
+log = logging.getLogger(__name__)
 Tensor = torch.Tensor
 PI = np.pi
 TWO_PI = 2. * np.pi
@@ -26,6 +28,14 @@ TWO_PI = 2. * np.pi
 
 def _beta(beta) -> float:
     return float(beta.item()) if isinstance(beta, torch.Tensor) else float(beta)
+
+
+def pbc(tup: tuple[int], shape: tuple[int]) -> list:
+    return np.mod(tup, shape).tolist()
+
+
+def mat_adj(mat: np.ndarray) -> np.ndarray:
+    return mat.conj().T
 
 
 class PlaqSums:
@@ -94,6 +104,42 @@ class LatticeSU3(Lattice):
 
     def kinetic_energy(self, v: Tensor) -> Tensor:
         return self.g.kinetic_energy(v)
+
+    # ---- per-site plaquette matrices (observables / debugging helpers, lattice.py:93-155);
+    # the sampler itself only ever needs the reductions above
+    def _link_staple_op(self, link: Tensor, staple: Tensor) -> Tensor:
+        return self.g.mul(link, staple)
+
+    def _plaquette(self, x: Tensor, u: int, v: int) -> Tensor:
+        """U_u(x) U_v(x+u) U_u(x+v)^H U_v(x)^H as a matrix field [nb, T, X, Y, Z, 3, 3]"""
+        x = x.to(DEVICE).reshape(x.shape[0], *self._shape[1:])
+        xu, xv = x[:, u], x[:, v]
+        xuv = self.g.mul(xu, xv.roll(shifts=-1, dims=(u + 1)))
+        xvu = self.g.mul(xv, xu.roll(shifts=-1, dims=(v + 1)))
+        return self.g.mul(xuv, xvu, adjoint_b=True)
+
+    def _trace_plaquette(self, x: Tensor, u: int, v: int) -> Tensor:
+        return self.g.trace(self._plaquette(x, u, v))
+
+    def _plaquette_field(self, x: Tensor, needs_rect: bool = False):
+        if needs_rect:
+            raise NotImplementedError('DBW2 rectangles (c1 != 0) are not built')
+        plaqs = [self._plaquette(x, u, v) for u in range(1, self.dim) for v in range(u)]
+        return torch.stack(plaqs), None
+
+    def _rectangles(self, x: Tensor, u: int, v: int):
+        raise NotImplementedError('DBW2 rectangles (c1 != 0) are not built')
+
+    def _action(self, wloops, beta: Tensor) -> Tensor:
+        """The reference's unused opposite-sign variant (lattice.py:271-285): +coeff sum Re tr P / 3."""
+        ps = wloops[0] if isinstance(wloops, tuple) else wloops
+        return self.coeffs(torch.as_tensor(_beta(beta)))['plaq'] * ps.re / 3.0
+
+    def plaq_loss(self, acc: Tensor, x1=None, x2=None, wloops1=None, wloops2=None):
+        log.error('TODO')                       # a stub in the reference as well (lattice.py:351-359)
+
+    def charge_loss(self, acc: Tensor, x1=None, x2=None, wloops1=None, wloops2=None):
+        log.error('TODO')                       # (lattice.py:361-369)
 
     def action(self, x: Tensor, beta: Tensor) -> Tensor:
         """-(beta/3) sum Re tr P (lattice.py:252-269)"""

@@ -65,6 +65,10 @@ class LatticeU1(Lattice):
             raise ValueError('One of `x` or `wloops` must be specified.')
         return self.wilson_loops(x)
 
+    def draw_uniform_batch(self, requires_grad: bool = True) -> Tensor:
+        """uniform in (-pi, pi) (lattice.py:67-71)"""
+        return TWOPI * torch.rand(self._shape, requires_grad=requires_grad) - PI
+
     def kinetic_energy(self, v: Tensor) -> Tensor:
         return 0.5 * v.flatten(1) ** 2
 
@@ -130,7 +134,31 @@ class LatticeU1(Lattice):
             if x is None:
                 raise ValueError('One of `x` or `wloops` must be specified.')
             wloops4x4 = self.wilson_loops4x4(x)
+        return self._plaqs4x4(wloops4x4)
+
+    def _plaqs4x4(self, wloops4x4: Tensor) -> Tensor:
         return wloops4x4.cos().mean((1, 2))
+
+    def plaq_loss(self, acc: Tensor, x1: Optional[Tensor] = None, x2: Optional[Tensor] = None,
+                  wl1=None, wl2=None) -> Tensor:
+        """-(acc * sum 2 (1 - cos(theta_2 - theta_1)) + 1e-4).mean()  (lattice.py:278-292).  The
+        plaquette angle is linear in the links, so theta_2 - theta_1 = theta(x2 - x1) and one
+        reduction over the difference field gives the sum."""
+        if x1 is None or x2 is None:
+            raise ValueError('plaq_loss needs the configurations x1, x2 (the per-chain sums '
+                             'this build keeps instead of the plaquette field do not suffice)')
+        d = self._x(x2) - self._x(x1)
+        cosd = ops.u1_plaq_sums(d.contiguous(), self._lattice_shape)[:, 0]
+        ploss = acc.to(cosd.device) * (2. * (self.volume - cosd)) + 1e-4
+        return -ploss.mean(0)
+
+    def charge_loss(self, acc: Tensor, x1: Optional[Tensor] = None, x2: Optional[Tensor] = None,
+                    wl1: Optional[PlaqSumsU1] = None, wl2: Optional[PlaqSumsU1] = None) -> Tensor:
+        """-(acc * (sinQ_2 - sinQ_1)^2 + 1e-4).mean()  (lattice.py:294-308)"""
+        w1 = self._get_wloops(x1) if wl1 is None else wl1
+        w2 = self._get_wloops(x2) if wl2 is None else wl2
+        dq = (self._sin_charges(w2) - self._sin_charges(w1)) ** 2
+        return -(acc.to(dq.device) * dq + 1e-4).mean(0)
 
     def _sin_charges(self, wloops: PlaqSumsU1) -> Tensor:
         return wloops.sin / TWOPI

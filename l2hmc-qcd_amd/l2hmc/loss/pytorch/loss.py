@@ -88,6 +88,28 @@ class LatticeLoss:
         return self._mixed(acc.to(DEVICE) * (d2 / nelem).to(acc.dtype), self.rmse_weight,
                            use_mixed_loss)
 
+    # ---- the reference's wloops-based helpers (loss.py:57-92, 166-192) on this build's per-chain
+    # reductions (PlaqSums / PlaqSumsU1 objects returned by lattice.wilson_loops)
+    def _plaq_loss(self, w1, w2, acc: Tensor, use_mixed_loss: Optional[bool] = None) -> Tensor:
+        raise NotImplementedError('_plaq_loss needs per-plane (SU3) / per-row (U1) sums, not the '
+                                  'per-chain wloops reductions: use plaq_loss(x_init, x_prop, acc)')
+
+    def _charge_loss(self, w1, w2, acc: Tensor, use_mixed_loss: Optional[bool] = None) -> Tensor:
+        dq = (self.lattice._sin_charges(w2) - self.lattice._sin_charges(w1)) ** 2
+        return self._mixed(acc.to(dq.device) * dq, self.charge_weight, use_mixed_loss)
+
+    def general_loss(self, x_init: Tensor, x_prop: Tensor, acc: Tensor,
+                     plaq_weight: Optional[float] = None, charge_weight: Optional[float] = None,
+                     use_mixed_loss: Optional[bool] = None):
+        pw = self.plaq_weight if plaq_weight is None else plaq_weight
+        qw = self.charge_weight if charge_weight is None else charge_weight
+        loss = 0.0
+        if pw > 0:
+            loss = loss + pw * self.plaq_loss(x_init, x_prop, acc, use_mixed_loss=use_mixed_loss)
+        if qw > 0:
+            loss = loss + qw * self.charge_loss(x_init, x_prop, acc, use_mixed_loss=use_mixed_loss)
+        return loss
+
     def loss_from_sums(self, cos_init: Tensor, sin_init: Tensor, cos_prop: Tensor,
                        sin_prop: Tensor, acc: Tensor) -> Tensor:
         """U(1) training loss from the per-chain plaquette sums (sum cos theta, sum sin theta)

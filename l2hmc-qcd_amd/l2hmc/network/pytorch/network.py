@@ -51,6 +51,61 @@ def flatten(x: Tensor) -> Tensor:
     return x.reshape(x.shape[0], -1)
 
 
+def nested_children(m: nn.Module) -> dict:
+    """{name: nested dict of children | leaf module} (network.py:49-57)"""
+    children = dict(m.named_children())
+    if not children:
+        return {m._get_name(): m}
+    return {name: nested_children(child) if isinstance(child, nn.Module) else child
+            for name, child in children.items()}
+
+
+def xy_repr(x: Tensor) -> Tensor:
+    return torch.stack((torch.cos(x), torch.sin(x)), dim=1)
+
+
+def init_all(model: nn.Module, init_func: Callable, *params, **kwargs) -> None:
+    """init_func(p, *params, **kwargs) on every parameter (network.py:80-90)"""
+    for p in model.parameters():
+        init_func(p, *params, **kwargs)
+
+
+def init_all_by_shape(model: nn.Module, init_funcs: dict) -> None:
+    """Pick the initialiser by tensor rank: init_funcs[str(rank)] or init_funcs['default']
+    (network.py:93-118)."""
+    assert 'default' in init_funcs, 'init_funcs must have `default` entry'
+    for p in model.parameters():
+        if hasattr(p, 'shape'):
+            init_funcs.get(str(len(p.shape)), init_funcs['default'])(p)
+
+
+def init_weights(m: nn.Module, method: str = 'xavier_uniform') -> None:
+    """`model.apply(init_weights)` helper for nn.Linear layers (network.py:121-141)."""
+    if not isinstance(m, nn.Linear):
+        return
+    if method == 'zeros':
+        nn.init.zeros_(m.weight)
+        nn.init.zeros_(m.bias)
+        return
+    name = method if method.endswith('_') else method + '_'
+    fn = getattr(nn.init, name, None) or getattr(nn.init, method, None)
+    if callable(fn):
+        fn(m.weight)
+    else:
+        log.warning(f'Unable to initialize weights with {method}; keeping the default')
+
+
+def calc_output_size(hw: tuple[int, int], kernel_size, stride: int = 1, pad: int = 0,
+                     dilation: int = 1) -> tuple[int, int]:
+    """Conv2d output extent (network.py:209-236)"""
+    from math import floor
+    if isinstance(kernel_size, int):
+        kernel_size = (kernel_size, kernel_size)
+    h = floor(1 + (hw[0] + 2 * pad - dilation * (kernel_size[0] - 1) - 1) / stride)
+    w = floor(1 + (hw[1] + 2 * pad - dilation * (kernel_size[1] - 1) - 1) / stride)
+    return h, w
+
+
 def dummy_network(inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, Tensor, Tensor]:
     x, _ = inputs
     return torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)

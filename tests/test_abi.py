@@ -62,3 +62,59 @@ def test_configs_surface():
     a.setup(nera=3, nepoch=10)
     assert list(a.betas) == [2.0, 3.0, 4.0]
     assert c.dict_to_list_of_overrides({'dynamics': {'nchains': 4}}) == ['dynamics.nchains=4']
+
+
+def test_reference_api_surface_present():
+    """Every public member of the reference modules this build replaces exists here (names
+    collected from the reference once: `def` statements of dynamics / lattice / group /
+    network / loss; deprecated `_*_deprecated` variants and `_build_networks1` excluded)."""
+    import torch  # noqa: F401
+    import l2hmc.network.pytorch.network as net
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.group.su3.pytorch import utils as su3u
+    from l2hmc.group.su3.pytorch.group import SU3
+    from l2hmc.group.u1.pytorch import group as u1g
+    from l2hmc.lattice.su3.pytorch import lattice as lsu3
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.loss.pytorch.loss import LatticeLoss
+    want = {
+        Dynamics: 'apply_transition apply_transition_both apply_transition_fb apply_transition_hmc '
+                  'generate_proposal generate_proposal_fb generate_proposal_hmc transition_kernel '
+                  'transition_kernel_fb transition_kernel_hmc leapfrog_hmc _forward_lf _backward_lf '
+                  '_update_v_fwd _update_v_bwd _update_x_fwd _update_x_bwd _update_v_fwd_hmc '
+                  '_update_v_bwd_hmc _update_x_fwd_hmc _update_x_bwd_hmc _call_vnet _call_xnet '
+                  '_get_vnet _get_xnet _get_mask _build_masks _build_networks _get_accept_masks '
+                  '_get_direction_masks compute_accept_prob get_metrics update_history hamiltonian '
+                  'kinetic_energy potential_energy grad_potential random_state test_reversibility '
+                  'flatten unflatten group_to_vec vec_to_group complexify _stack_as_xy save load '
+                  'save_eps load_eps restore_eps assign_eps init_weights get_models',
+        lsu3.LatticeSU3: 'action _action grad_action action_with_grad wilson_loops _wilson_loops '
+                         '_plaquette _plaquette_field _trace_plaquette _rectangles _link_staple_op '
+                         '_plaquettes plaqs _plaqs charges _charges int_charges _int_charges '
+                         'sin_charges _sin_charges calc_metrics coeffs kinetic_energy '
+                         'potential_energy random random_momentum update_link plaq_loss charge_loss',
+        LatticeU1: 'action _action grad_action action_with_grad wilson_loops wilson_loops4x4 plaqs '
+                   '_plaqs plaqs4x4 _plaqs4x4 plaqs_diff charges _charges int_charges _int_charges '
+                   'sin_charges _sin_charges calc_metrics observables kinetic_energy '
+                   'potential_energy random random_momentum update_link draw_uniform_batch '
+                   'plaq_loss charge_loss _get_wloops',
+        SU3: 'update_gauge checkSU checkU mul adjoint trace exp projectTAH projectSU projectU '
+             'compat_proj compat_proju random random_momentum kinetic_energy vec_to_group '
+             'group_to_vec norm2 diff_trace diff2trace rsqrtPHM3 rsqrtPHM3f',
+        u1g.U1Phase: 'phase_to_coords coords_to_phase group_to_vec exp update_gauge mul adjoint '
+                     'trace diff_trace diff2trace floormod compat_proj projectTAH random '
+                     'random_momentum kinetic_energy',
+        LatticeLoss: 'mixed_loss plaq_loss charge_loss rmse_loss _plaq_loss _charge_loss general_loss '
+                     'lattice_metrics calc_loss',
+    }
+    missing = [f'{cls.__name__}.{n}' for cls, names in want.items() for n in names.split()
+               if not hasattr(cls, n)]
+    for mod, names in ((su3u, 'eyeOf norm2 randTAH3 projectU projectSU projectTAH checkSU checkU '
+                              'su3_to_vec vec_to_su3 eigs3x3 rsqrtPHM3 rsqrtPHM3f'),
+                       (u1g, 'eyeOf rand_unif random_angle'), (lsu3, 'pbc mat_adj'),
+                       (net, 'nested_children flatten xy_repr dummy_network init_all init_all_by_shape '
+                             'init_weights zero_weights calc_output_size get_network '
+                             'get_and_call_network PeriodicPadding ScaledTanh ConvStack InputLayer '
+                             'LeapfrogLayer NetworkFactory')):
+        missing += [f'{mod.__name__}.{n}' for n in names.split() if not hasattr(mod, n)]
+    assert not missing, missing

@@ -92,3 +92,43 @@ def test_cli_u1(capsys):
                 'steps.test=2', 'seed=3'])
     assert set(out) == {'eval', 'hmc'} and out['eval']['steps'] == 2
     assert out['hmc']['chain_LF_per_s'] > 0
+
+
+def test_minor_lattice_group_helpers():
+    """Small API members outside the sampler's path: U(1) lattice plaq_loss / charge_loss,
+    SU(3) per-site plaquette matrices, rsqrtPHM3, eigs3x3."""
+    torch.set_default_dtype(torch.float64)
+    from l2hmc.group.su3.pytorch import utils as U
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    g = torch.Generator().manual_seed(1)
+    # U(1)
+    lat = LatticeU1(5, [6, 4])
+    x1 = (2 * np.pi * torch.rand(5, 2, 6, 4, generator=g) - np.pi).cuda()
+    x2 = (2 * np.pi * torch.rand(5, 2, 6, 4, generator=g) - np.pi).cuda()
+    acc = torch.rand(5, generator=g).cuda()
+
+    def theta(x):
+        return x[:, 0] + torch.roll(x[:, 1], -1, 1) - torch.roll(x[:, 0], -1, 2) - x[:, 1]
+    want = -(acc * (2 * (1 - torch.cos(theta(x2) - theta(x1)))).sum((1, 2)) + 1e-4).mean(0)
+    assert abs(float(lat.plaq_loss(acc, x1, x2) - want)) < 1e-10
+    dq = (torch.sin(theta(x2)).sum((1, 2)) - torch.sin(theta(x1)).sum((1, 2))) / (2 * np.pi)
+    assert abs(float(lat.charge_loss(acc, x1, x2) - (-(acc * dq ** 2 + 1e-4).mean(0)))) < 1e-10
+    # SU(3): plaquette matrices and their traces against the reduction kernel
+    L = [2, 3, 2, 4]
+    ls = LatticeSU3(2, L)
+    x = ls.random().cuda()
+    tot = sum(ls._trace_plaquette(x, u, v).sum((1, 2, 3, 4)) for u in range(1, 4) for v in range(u))
+    w = ls.wilson_loops(x)
+    assert float((tot.real - w.re).abs().max()) < 1e-9 and float((tot.imag - w.im).abs().max()) < 1e-9
+    field, rect = ls._plaquette_field(x)
+    assert field.shape == (6, 2, *L, 3, 3) and rect is None
+    # X^{-1/2} of a positive Hermitian matrix
+    a = torch.complex(torch.randn(7, 3, 3, generator=g), torch.randn(7, 3, 3, generator=g))
+    h = a.adjoint() @ a + 0.5 * torch.eye(3)
+    r = U.rsqrtPHM3(h)
+    assert float((r @ h @ r - torch.eye(3)).abs().max()) < 1e-9
+    ev = torch.stack(U.eigs3x3(torch.diagonal(h, dim1=-2, dim2=-1).sum(-1).real,
+                               torch.diagonal(h @ h, dim1=-2, dim2=-1).sum(-1).real,
+                               torch.linalg.det(h).real), -1)
+    assert float((ev.sort(-1).values - torch.linalg.eigvalsh(h)).abs().max()) < 1e-8
