@@ -1,15 +1,31 @@
-"""``python -m l2hmc key=value ...`` -- thin counterpart of the reference's hydra entry point
-(src/l2hmc/__main__.py:55-274): compose the config tree with dotted overrides, build the
-Experiment, run the evaluation and the HMC baseline, print the eval rates as JSON.
+"""``python -m l2hmc key=value ...`` -- counterpart of the reference's hydra entry point
+(src/l2hmc/__main__.py:100-195): compose the config tree with dotted overrides, build the
+Experiment, train if ``steps.nera > 0 and steps.nepoch > 0``, evaluate the trained sampler and
+the plain-HMC baseline for ``steps.test`` steps, and report the model improvement
+(``<|dQint|>_trained / <|dQint|>_HMC``, utils/plot_helpers.py:189-263) -- as one JSON object
+instead of plots / wandb artefacts.
 
-    python -m l2hmc +experiment=su3 dynamics.nchains=16 steps.test=10
+    python -m l2hmc dynamics.group=SU3 dynamics.latvolume=[4,4,4,4] steps.nera=1 steps.nepoch=5
 """
 from __future__ import annotations
 
 import json
 import sys
+import time
 
 import l2hmc.configs as cfgs
+
+
+def _summary(res: dict, nb: int) -> dict:
+    rate = res['timer'].get_eval_rate()
+    h = res['history']
+    out = {'steps': rate['num_steps'], 'LF_per_s': rate['eval_rate'],
+           'chain_LF_per_s': rate['eval_rate'] * nb,
+           'acc_mean': float(sum(a.mean() for a in h['acc']) / len(h['acc'])),
+           'loss_last': h['loss'][-1]}
+    if 'dQint' in h and len(h['dQint']) > 1:
+        out['dQint_mean'] = float(sum(d.mean() for d in h['dQint'][1:]) / (len(h['dQint']) - 1))
+    return out
 
 
 def main(argv=None) -> dict:
@@ -17,18 +33,24 @@ def main(argv=None) -> dict:
     cfg = cfgs.get_config(overrides)
     from l2hmc.experiment.pytorch.experiment import Experiment
     ex = Experiment(cfg)
-    out = {}
+    out: dict = {}
     nb = ex.config.dynamics.nchains
-    for job in ('eval', 'hmc'):
-        res = ex.evaluate(job_type=job)
-        if res is None:
-            continue
-        rate = res['timer'].get_eval_rate()
-        h = res['history']
-        out[job] = {'steps': rate['num_steps'], 'LF_per_s': rate['eval_rate'],
-                    'chain_LF_per_s': rate['eval_rate'] * nb,
-                    'acc_mean': float(sum(a.mean() for a in h['acc']) / len(h['acc'])),
-                    'loss_last': h['loss'][-1]}
+    x = None
+    if ex.config.steps.nera > 0 and ex.config.steps.nepoch > 0:
+        t0 = time.time()
+        res = ex.train()
+        x = res['x']
+        out['train'] = {'steps': len(res['history']['loss']), 'seconds': time.time() - t0,
+                        'loss_first': res['history']['loss'][0],
+                        'loss_last': res['history']['loss'][-1],
+                        'beta_last': res['history']['beta'][-1]}
+    if ex.config.steps.test > 0:
+        for job in ('eval', 'hmc'):
+            res = ex.evaluate(job_type=job, x=x)
+            if res is not None:
+                out[job] = _summary(res, nb)
+        if 'dQint_mean' in out.get('eval', {}) and out.get('hmc', {}).get('dQint_mean', 0) > 0:
+            out['model_improvement'] = out['eval']['dQint_mean'] / out['hmc']['dQint_mean']
     print(json.dumps(out))
     return out
 

@@ -89,9 +89,13 @@ def test_cli_u1(capsys):
     torch.set_default_dtype(torch.float32)
     from l2hmc.__main__ import main
     out = main(['mode=test', 'dynamics.nchains=16', 'dynamics.latvolume=[8,8]', 'conv=none',
-                'steps.test=2', 'seed=3'])
-    assert set(out) == {'eval', 'hmc'} and out['eval']['steps'] == 2
+                'steps.nera=2', 'steps.nepoch=3', 'steps.test=2', 'seed=3'])
+    assert {'train', 'eval', 'hmc'} <= set(out) and out['eval']['steps'] == 2
+    assert out['train']['steps'] == 6 and np.isfinite(out['train']['loss_last'])
     assert out['hmc']['chain_LF_per_s'] > 0
+    out = main(['mode=test', 'dynamics.nchains=16', 'dynamics.latvolume=[8,8]', 'conv=none',
+                'steps.nera=0', 'steps.test=2', 'seed=3'])
+    assert 'train' not in out and {'eval', 'hmc'} <= set(out)
 
 
 def test_minor_lattice_group_helpers():
