@@ -46,12 +46,32 @@ __device__ __forceinline__ void u1_dense_stack(const U1Net& net, const float* xi
 #pragma unroll
   for (int c = 0; c < CH; ++c) acc[c] = 0.0f;
   if (u < U0) {
-    for (int k = sl; k < Kx; k += S) {
+    int k = sl;
+    for (; k + 3 * S < Kx; k += 4 * S) {             // four weight loads in flight
+      const float w0 = net.wxT[(long)k * U0 + u], w1 = net.wxT[(long)(k + S) * U0 + u];
+      const float w2 = net.wxT[(long)(k + 2 * S) * U0 + u], w3 = net.wxT[(long)(k + 3 * S) * U0 + u];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float* xc = xin + c * Kx + k;
+        acc[c] = fmaf(w0, xc[0], fmaf(w1, xc[S], fmaf(w2, xc[2 * S], fmaf(w3, xc[3 * S], acc[c]))));
+      }
+    }
+    for (; k < Kx; k += S) {
       const float w = net.wxT[(long)k * U0 + u];
 #pragma unroll
       for (int c = 0; c < CH; ++c) acc[c] = fmaf(w, xin[c * Kx + k], acc[c]);
     }
-    for (int k = sl; k < Kv; k += S) {
+    k = sl;
+    for (; k + 3 * S < Kv; k += 4 * S) {
+      const float w0 = net.wvT[(long)k * U0 + u], w1 = net.wvT[(long)(k + S) * U0 + u];
+      const float w2 = net.wvT[(long)(k + 2 * S) * U0 + u], w3 = net.wvT[(long)(k + 3 * S) * U0 + u];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float* vc = vin + c * Kv + k;
+        acc[c] = fmaf(w0, vc[0], fmaf(w1, vc[S], fmaf(w2, vc[2 * S], fmaf(w3, vc[3 * S], acc[c]))));
+      }
+    }
+    for (; k < Kv; k += S) {
       const float w = net.wvT[(long)k * U0 + u];
 #pragma unroll
       for (int c = 0; c < CH; ++c) acc[c] = fmaf(w, vin[c * Kv + k], acc[c]);
@@ -99,6 +119,21 @@ __device__ __forceinline__ void u1_head_pre(const U1Net& net, int UL, const floa
   const float* rs = net.ws + (long)j * UL;
   const float* rt = net.wt + (long)j * UL;
   const float* rq = net.wq + (long)j * UL;
+  if ((UL & 3) == 0) {                               // rows are 16-byte aligned: 128-bit loads
+    for (int k = 0; k < UL; k += 4) {
+      const float4 w_s = *reinterpret_cast<const float4*>(rs + k);
+      const float4 w_t = *reinterpret_cast<const float4*>(rt + k);
+      const float4 w_q = *reinterpret_cast<const float4*>(rq + k);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float4 zz = *reinterpret_cast<const float4*>(z0 + c * kMaxWidth + k);
+        as[c] = fmaf(w_s.x, zz.x, fmaf(w_s.y, zz.y, fmaf(w_s.z, zz.z, fmaf(w_s.w, zz.w, as[c]))));
+        at[c] = fmaf(w_t.x, zz.x, fmaf(w_t.y, zz.y, fmaf(w_t.z, zz.z, fmaf(w_t.w, zz.w, at[c]))));
+        aq[c] = fmaf(w_q.x, zz.x, fmaf(w_q.y, zz.y, fmaf(w_q.z, zz.z, fmaf(w_q.w, zz.w, aq[c]))));
+      }
+    }
+    return;
+  }
   for (int k = 0; k < UL; ++k) {
     const float w_s = rs[k], w_t = rt[k], w_q = rq[k];
 #pragma unroll

@@ -423,10 +423,20 @@ def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch
 
 
 def _fused_net_args(fw: dict):
-    hs = fw['heads']
-    return (fw['wxT'], fw['wvT'], fw['b0'], fw['hidden'], fw['units_c'], fw['nl'],
-            hs['s'][0], hs['s'][1], hs['s'][2], hs['t'][0], hs['t'][1], float(fw['scale_t']),
-            hs['q'][0], hs['q'][1], hs['q'][2], N.ACT[fw['act']])
+    """Network part of the fused-kernel argument list, marshalled once per weight version (the
+    tensors stay referenced by `fw`; device pointers are passed as plain ints)."""
+    args = fw.get('_args')
+    if args is None:
+        hs = fw['heads']
+        # pre-convert to device pointers (plain ints) on the GPU; tensors otherwise, so that the
+        # missing-GPU error still comes from native.call
+        p = N.ptr if fw['wxT'].is_cuda else (lambda t: t)
+        args = (p(fw['wxT']), p(fw['wvT']), p(fw['b0']), p(fw['hidden']), fw['units_c'], fw['nl'],
+                p(hs['s'][0]), p(hs['s'][1]), p(hs['s'][2]), p(hs['t'][0]), p(hs['t'][1]),
+                float(fw['scale_t']), p(hs['q'][0]), p(hs['q'][1]), p(hs['q'][2]),
+                N.ACT[fw['act']])
+        fw['_args'] = args
+    return args
 
 
 def u1_vstep_(x: torch.Tensor, v: torch.Tensor, beta: float, eps: float, forward: bool,
