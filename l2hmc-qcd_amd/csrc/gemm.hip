@@ -233,6 +233,125 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Periodic conv layer as an implicit GEMM: the im2col matrix is never materialised.  Row m of
+// the virtual A operand is output pixel (b, ho, wo), column kk = (ci*k + i)*k + j reads
+// in[b, ci, (ho+i-(k-1)) mod H, (wo+j-(k-1)) mod W] through generic element strides (NCHW for
+// the first layer, the previous layer's NHWC output afterwards).  The (b, ho, wo) decomposition
+// of the tile's 128 rows is done once per workgroup (LDS), the (ci, i, j) decomposition of a
+// thread's K column once per slab and divides by the compile-time kernel size only.
+// Materialised, the five col matrices of the default U(1) conv stack are 2.1 GB per call at
+// cfg-2 (written, then read again by the GEMM).
+struct ConvGeom {
+  long sn, sc, sh, sw;
+  int C, H, W, k, Ho, Wo, Kc;
+  long M;
+};
+
+template <int KS>
+__global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __restrict__ in,
+                                                              ConvGeom g,
+                                                              const float* __restrict__ Wt, int N,
+                                                              Epilogue<float> epi,
+                                                              float* __restrict__ C) {
+  using T = float;
+  constexpr int BM = 128, BN = 128;
+  using acc_t = Mfma<T>::acc_t;
+  __shared__ T As[BM][LDP];
+  __shared__ T Ws[BN][LDP];
+  __shared__ long rbase[BM];
+  __shared__ int rr0[BM], rc0[BM];
+  const int k = KS > 0 ? KS : g.k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+  for (int r = tid; r < BM; r += kBlock) {
+    const long m = m0 + r;
+    long base = -1;
+    int r0 = 0, c0 = 0;
+    if (m < g.M) {
+      const int wo = (int)(m % g.Wo);
+      const long t = m / g.Wo;
+      const int ho = (int)(t % g.Ho);
+      base = (t / g.Ho) * g.sn;
+      r0 = (ho - (k - 1)) % g.H; if (r0 < 0) r0 += g.H;
+      c0 = (wo - (k - 1)) % g.W; if (c0 < 0) c0 += g.W;
+    }
+    rbase[r] = base; rr0[r] = r0; rc0[r] = c0;
+  }
+  __syncthreads();
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
+
+  constexpr int SRPP = kBlock / BK, SNP = BM / SRPP;       // rows per pass, passes
+  const int kq = tid % BK, rq = tid / BK;
+  T areg[SNP];
+// gather this thread's K column (kk = K0 + kq) for its SNP rows of the tile
+#define L2Q_CONV_FETCH_A(K0)                                                            \
+  do {                                                                                  \
+    const long kk_ = (K0) + kq;                                                         \
+    const bool kin_ = kk_ < g.Kc;                                                       \
+    const int j_ = (int)(kk_ % k), ij_ = (int)(kk_ / k), i_ = ij_ % k, ci_ = ij_ / k;   \
+    const long coff_ = (long)ci_ * g.sc;                                                \
+    _Pragma("unroll") for (int p = 0; p < SNP; ++p) {                                   \
+      const int row_ = rq + p * SRPP;                                                   \
+      const long base_ = rbase[row_];                                                   \
+      T v_ = (T)0;                                                                      \
+      if (kin_ && base_ >= 0) {                                                         \
+        int r_ = rr0[row_] + i_; if (r_ >= g.H) r_ -= g.H; if (r_ >= g.H) r_ %= g.H;    \
+        int c_ = rc0[row_] + j_; if (c_ >= g.W) c_ -= g.W; if (c_ >= g.W) c_ %= g.W;    \
+        v_ = in[base_ + coff_ + r_ * g.sh + c_ * g.sw];                                 \
+      }                                                                                 \
+      areg[p] = v_;                                                                     \
+    }                                                                                   \
+  } while (0)
+  TileLoader<T, BN, false> lw;
+  L2Q_CONV_FETCH_A(0);
+  lw.fetch(Wt, Wt, n0, N, 0, g.Kc, 0, g.Kc);      // (p2 unused: K2 = 0; a literal nullptr crashes hipcc 7.2 at -O2+)
+  for (long k0 = 0; k0 < g.Kc; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < SNP; ++p) As[rq + p * SRPP][kq] = areg[p];
+    lw.store(Ws);
+    __syncthreads();
+    if (k0 + BK < g.Kc) {
+      L2Q_CONV_FETCH_A(k0 + BK);
+      lw.fetch(Wt, Wt, n0, N, k0 + BK, g.Kc, 0, g.Kc);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      T fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = As[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
+        fb[i] = Ws[wn + 16 * i + (lane & 15)][ks + (lane >> 4)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long n = n0 + wn + 16 * j + (lane & 15);
+    if (n >= N) continue;
+    const T cs = epi.colscale((int)n), cb = epi.colbias((int)n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+        if (m < g.M) C[m * N + n] = cs * apply_act<T>(acc[i][j][r] + cb, epi.act);
+      }
+  }
+#undef L2Q_CONV_FETCH_A
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const T* __restrict__ part,
                                                                int splits, long MN, int N,
@@ -498,6 +617,34 @@ int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const flo
   L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
   return gemm_launch<float>(A, W, M, N, K, A2, W2, K2, bias, bias2, coeff, scale, act, C, ws,
                             ws_bytes, (hipStream_t)stream);
+}
+
+int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
+                               int H, int W, int k, const float* weight, const float* bias,
+                               int cout, int act, float* out, void* stream) {
+  L2Q_REQUIRE(in && weight && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0 && cout > 0, L2Q_EINVAL,
+              "non-positive size");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  ConvGeom g;
+  g.sn = sn; g.sc = sc; g.sh = sh; g.sw = sw; g.C = C; g.H = H; g.W = W; g.k = k;
+  g.Ho = H + k - 1; g.Wo = W + k - 1; g.Kc = C * k * k;
+  g.M = (long)nb * g.Ho * g.Wo;
+  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16, L2Q_ESHAPE, "too many output pixels");
+  Epilogue<float> epi{bias, nullptr, nullptr, 1.0f, act};
+  const dim3 grid((unsigned)cdiv(cout, 128), (unsigned)cdiv(g.M, 128)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define L2Q_CG(KS) hipLaunchKernelGGL(conv_gemm_kernel<KS>, grid, block, 0, st, in, g, weight, cout, epi, out)
+  switch (k) {
+    case 1: L2Q_CG(1); break;
+    case 2: L2Q_CG(2); break;
+    case 3: L2Q_CG(3); break;
+    case 4: L2Q_CG(4); break;
+    case 5: L2Q_CG(5); break;
+    default: L2Q_CG(0); break;
+  }
+#undef L2Q_CG
+  return check_launch("l2q_conv_gemm_periodic_f32");
 }
 
 size_t l2q_vnet_heads_ws_bytes(int M, long N) {

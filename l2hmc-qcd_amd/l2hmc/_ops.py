@@ -410,11 +410,12 @@ def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch
     cout, cin, k, _ = w.shape
     assert cin == C
     Ho, Wo, Kc = H + k - 1, W + k - 1, C * k * k
-    col = torch.empty((nb * Ho * Wo, Kc), dtype=torch.float32, device=x.device)
-    N.call('l2q_im2col_periodic_f32', x, sn, sc, sh, sw, nb, C, H, W, k, col)
     pool = max(int(pool), 1)
-    y = gemm(col, w.reshape(cout, Kc).contiguous(), b.contiguous(),
-             act=None if pool > 1 else act)
+    y = torch.empty((nb * Ho * Wo, cout), dtype=torch.float32, device=x.device)
+    # im2col inside the GEMM's A-tile loader: no col matrix in HBM
+    N.call('l2q_conv_gemm_periodic_f32', x, sn, sc, sh, sw, nb, C, H, W, k,
+           w.reshape(cout, Kc).contiguous(), b.contiguous(), cout,
+           N.ACT[None if pool > 1 else act], y)
     if pool == 1:
         return y.reshape(nb, Ho, Wo, cout)
     out = torch.empty((nb, Ho // pool, Wo // pool, cout), dtype=torch.float32, device=x.device)

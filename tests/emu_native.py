@@ -197,6 +197,11 @@ def l2q_im2col_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, col):
     col.copy_(_im2col(_as_nchw(x, sn, sc, sh, sw, nb, C, H, W), k))
 
 
+def l2q_conv_gemm_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, w, b, cout, act, out):
+    col = _im2col(_as_nchw(x, sn, sc, sh, sw, nb, C, H, W), k)
+    out.copy_(_act(col @ w.reshape(cout, -1).T + b, act).reshape(out.shape))
+
+
 def l2q_maxpool_act_nhwc_f32(y, nb, H, W, C, pool, act, out):
     out.copy_(_maxpool_act(y, nb, H, W, C, pool, act))
 

@@ -307,3 +307,30 @@ def test_fused_heads_vupdate(ops, cplx, shape):
                 vb = v.clone()
                 lb = ops.vnet_heads_vupdate_pair_(z, scaled, nw, vb, f, 0.07, fwd, flip, 0.05, fwd2)
                 assert float((va - vb).abs().max()) < 1e-13 and err(host(la), host(lb)) < 1e-11
+
+
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+@pytest.mark.parametrize('dims', [(3, 2, 4, 6, 5, 8), (2, 8, 6, 6, 3, 16), (5, 16, 7, 5, 3, 32),
+                                  (2, 64, 4, 4, 2, 128), (130, 4, 8, 8, 3, 3), (1, 3, 2, 3, 3, 5)])
+def test_conv_gemm_periodic_equals_im2col_gemm(layout, dims):
+    """l2q_conv_gemm_periodic_f32 (im2col inside the GEMM's A-tile loader) against the
+    materialised im2col + GEMM and against torch's Conv2d on the periodically padded input."""
+    from l2hmc import _ops as ops
+    from l2hmc import native as N
+    nb, C, H, W, k, cout = dims
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(nb, C, H, W, generator=g)
+    w = torch.randn(cout, C, k, k, generator=g) / (C * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    p = k - 1
+    xp = torch.cat([x[:, :, -p:, :], x, x[:, :, :p, :]], 2) if p else x
+    xp = torch.cat([xp[:, :, :, -p:], xp, xp[:, :, :, :p]], 3) if p else xp
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xp, w, b), 0.01)
+    want = want.permute(0, 2, 3, 1).contiguous()
+    xin = x.cuda() if layout == 'nchw' else x.permute(0, 2, 3, 1).contiguous().cuda()
+    got = ops.conv2d_periodic_gemm(xin, layout, w.cuda(), b.cuda(), 1, 'leaky_relu')
+    assert got.shape == want.shape
+    assert float((got.cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    # materialised path (the one the training tape uses)
+    got2, _ = ops.conv2d_periodic_gemm_train(xin, layout, w.cuda(), b.cuda(), 1, 'leaky_relu')
+    assert float((got2 - got).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
