@@ -244,11 +244,13 @@ int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int p
                              float* out, void* stream);
 /* The conv layer without the col matrix: im2col happens inside the A-tile loader of the f32
  * MFMA GEMM.  out[(b*Ho + ho)*Wo + wo][cout] = act(conv + bias) (NHWC); weight [cout][C k k] in
- * nn.Conv2d's flatten order; input strides as for l2q_im2col_periodic_f32.  (The eval path uses
+ * nn.Conv2d's flatten order (ci, i, j), or -- channels_last_cols != 0 -- permuted to (i, j, ci) so
+ * that consecutive K columns of an NHWC input are contiguous in memory; input strides as for
+ * l2q_im2col_periodic_f32.  (The eval path uses
  * this; the training path keeps the materialised col matrix because the weight gradient needs it.) */
 int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
-                               int H, int W, int k, const float* weight, const float* bias,
-                               int cout, int act, float* out, void* stream);
+                               int H, int W, int k, const float* weight, int channels_last_cols,
+                               const float* bias, int cout, int act, float* out, void* stream);
 
 /* ---------------------------------------------------------------- fused U(1) sub-updates (fp32)
  * One launch per L2HMC sub-update on small 2D lattices (n = 2 T X <= l2q_u1_fused_max_n()):

@@ -245,17 +245,22 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
 struct ConvGeom {
   long sn, sc, sh, sw;
   int C, H, W, k, Ho, Wo, Kc;
+  int clast;            // column order of the virtual A / the weight rows: 0: (ci, i, j), 1: (i, j, ci)
   long M;
 };
 
-template <int KS>
+// BN = 32 / 64 / 128 output-channel tile: the conv layers have 8..128 channels, a fixed 128-wide
+// tile would spend most MFMAs on padding.
+template <int KS, int BN>
 __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __restrict__ in,
                                                               ConvGeom g,
                                                               const float* __restrict__ Wt, int N,
                                                               Epilogue<float> epi,
                                                               float* __restrict__ C) {
   using T = float;
-  constexpr int BM = 128, BN = 128;
+  constexpr int BM = 128;
+  constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;       // wavefront grid over the tile
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
   using acc_t = Mfma<T>::acc_t;
   __shared__ T As[BM][LDP];
   __shared__ T Ws[BN][LDP];
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __res
   __shared__ int rr0[BM], rc0[BM];
   const int k = KS > 0 ? KS : g.k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
   const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
   for (int r = tid; r < BM; r += kBlock) {
     const long m = m0 + r;
@@ -281,11 +286,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __res
   }
   __syncthreads();
 
-  acc_t acc[4][4];
+  acc_t acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
+    for (int j = 0; j < NI; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
 
   constexpr int SRPP = kBlock / BK, SNP = BM / SRPP;       // rows per pass, passes
   const int kq = tid % BK, rq = tid / BK;
@@ -295,7 +300,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __res
   do {                                                                                  \
     const long kk_ = (K0) + kq;                                                         \
     const bool kin_ = kk_ < g.Kc;                                                       \
-    const int j_ = (int)(kk_ % k), ij_ = (int)(kk_ / k), i_ = ij_ % k, ci_ = ij_ / k;   \
+    int j_, i_, ci_;                                                                    \
+    if (g.clast) { ci_ = (int)(kk_ % g.C); const int ij_ = (int)(kk_ / g.C); j_ = ij_ % k; i_ = ij_ / k; } \
+    else { j_ = (int)(kk_ % k); const int ij_ = (int)(kk_ / k); i_ = ij_ % k; ci_ = ij_ / k; }   \
     const long coff_ = (long)ci_ * g.sc;                                                \
     _Pragma("unroll") for (int p = 0; p < SNP; ++p) {                                   \
       const int row_ = rq + p * SRPP;                                                   \
@@ -324,25 +331,24 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __res
     }
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      T fa[4], fb[4];
+      T fa[MI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = As[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
-        fb[i] = Ws[wn + 16 * i + (lane & 15)][ks + (lane >> 4)];
-      }
+      for (int i = 0; i < MI; ++i) fa[i] = As[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < NI; ++j) fb[j] = Ws[wn + 16 * j + (lane & 15)][ks + (lane >> 4)];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NI; ++j) {
     const long n = n0 + wn + 16 * j + (lane & 15);
     if (n >= N) continue;
     const T cs = epi.colscale((int)n), cb = epi.colbias((int)n);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
@@ -620,8 +626,8 @@ int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const flo
 }
 
 int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
-                               int H, int W, int k, const float* weight, const float* bias,
-                               int cout, int act, float* out, void* stream) {
+                               int H, int W, int k, const float* weight, int channels_last_cols,
+                               const float* bias, int cout, int act, float* out, void* stream) {
   L2Q_REQUIRE(in && weight && out, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0 && cout > 0, L2Q_EINVAL,
               "non-positive size");
@@ -629,12 +635,20 @@ int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long 
   ConvGeom g;
   g.sn = sn; g.sc = sc; g.sh = sh; g.sw = sw; g.C = C; g.H = H; g.W = W; g.k = k;
   g.Ho = H + k - 1; g.Wo = W + k - 1; g.Kc = C * k * k;
+  g.clast = channels_last_cols ? 1 : 0;
   g.M = (long)nb * g.Ho * g.Wo;
   L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16, L2Q_ESHAPE, "too many output pixels");
   Epilogue<float> epi{bias, nullptr, nullptr, 1.0f, act};
-  const dim3 grid((unsigned)cdiv(cout, 128), (unsigned)cdiv(g.M, 128)), block(kBlock);
+  const int bn = cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
+  const dim3 grid((unsigned)cdiv(cout, bn), (unsigned)cdiv(g.M, 128)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
-#define L2Q_CG(KS) hipLaunchKernelGGL(conv_gemm_kernel<KS>, grid, block, 0, st, in, g, weight, cout, epi, out)
+#define L2Q_CGB(KS, BNV) hipLaunchKernelGGL((conv_gemm_kernel<KS, BNV>), grid, block, 0, st, in, g, weight, cout, epi, out)
+#define L2Q_CG(KS)                                                     \
+  do {                                                                 \
+    if (bn == 32) L2Q_CGB(KS, 32);                                     \
+    else if (bn == 64) L2Q_CGB(KS, 64);                                \
+    else L2Q_CGB(KS, 128);                                             \
+  } while (0)
   switch (k) {
     case 1: L2Q_CG(1); break;
     case 2: L2Q_CG(2); break;
@@ -644,6 +658,7 @@ int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long 
     default: L2Q_CG(0); break;
   }
 #undef L2Q_CG
+#undef L2Q_CGB
   return check_launch("l2q_conv_gemm_periodic_f32");
 }
 

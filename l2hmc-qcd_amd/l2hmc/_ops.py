@@ -396,10 +396,12 @@ def conv2d_periodic(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, pool: int
 
 
 def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch.Tensor,
-                         pool: int = 1, act: Optional[str] = None) -> torch.Tensor:
+                         pool: int = 1, act: Optional[str] = None,
+                         w_clast: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PeriodicPadding(k-1) -> Conv2d(k) -> [MaxPool2d(pool)] -> [act] as implicit GEMM on
     the f32 MFMA kernel.  x: [nb, C, H, W] if layout == 'nchw' else [nb, H, W, C];
-    returns NHWC [nb, Ho, Wo, cout]."""
+    returns NHWC [nb, Ho, Wo, cout].  w_clast: the weight as [cout, k, k, C] (used for NHWC
+    inputs: contiguous gathers); made on the fly when not supplied."""
     x = x.contiguous()
     if layout == 'nchw':
         nb, C, H, W = x.shape
@@ -413,9 +415,13 @@ def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch
     pool = max(int(pool), 1)
     y = torch.empty((nb * Ho * Wo, cout), dtype=torch.float32, device=x.device)
     # im2col inside the GEMM's A-tile loader: no col matrix in HBM
-    N.call('l2q_conv_gemm_periodic_f32', x, sn, sc, sh, sw, nb, C, H, W, k,
-           w.reshape(cout, Kc).contiguous(), b.contiguous(), cout,
-           N.ACT[None if pool > 1 else act], y)
+    clast = layout != 'nchw'
+    if clast:
+        wk = (w.permute(0, 2, 3, 1) if w_clast is None else w_clast).reshape(cout, Kc).contiguous()
+    else:
+        wk = w.reshape(cout, Kc).contiguous()
+    N.call('l2q_conv_gemm_periodic_f32', x, sn, sc, sh, sw, nb, C, H, W, k, wk, int(clast),
+           b.contiguous(), cout, N.ACT[None if pool > 1 else act], y)
     if pool == 1:
         return y.reshape(nb, Ho, Wo, cout)
     out = torch.empty((nb, Ho // pool, Wo // pool, cout), dtype=torch.float32, device=x.device)

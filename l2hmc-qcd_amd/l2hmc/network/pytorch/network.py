@@ -181,6 +181,7 @@ class ConvStack(nn.Module):
         cin = (d + 2) if in_channels is None else in_channels
         self.in_channels = cin
         self.plan = []                       # (layer index of conv, k, pool, act)
+        self._wcache: dict = {}
         h, w = nt, nx
         filters = list(conv_config.filters or [])
         sizes = list(conv_config.sizes or [])
@@ -209,6 +210,17 @@ class ConvStack(nn.Module):
         self.linear_index = len(self.layers) - 1
         self.layers.append(self.activation_fn)
 
+    def _clast_weight(self, ci: int) -> Tensor:
+        """conv weight as [cout, k, k, cin] (K columns of the implicit GEMM in the order in which
+        an NHWC activation is contiguous), cached per weight version."""
+        conv = self.layers[ci]
+        ver = (conv.weight._version, ops.PARAM_GENERATION[0])
+        hit = self._wcache.get(ci)
+        if hit is None or hit[0] != ver:
+            hit = (ver, conv.weight.detach().permute(0, 2, 3, 1).contiguous())
+            self._wcache[ci] = hit
+        return hit[1]
+
     def forward(self, x: Tensor) -> Tensor:
         x = x.to(DEVICE)
         x = x.reshape(x.shape[0], self.in_channels, self.nt, self.nx).contiguous()
@@ -219,7 +231,7 @@ class ConvStack(nn.Module):
         for ci, k, pool, act in self.plan:
             conv = self.layers[ci]
             x = ops.conv2d_periodic_gemm(x, layout, conv.weight.detach(), conv.bias.detach(),
-                                         pool, act)
+                                         pool, act, w_clast=self._clast_weight(ci))
             layout = 'nhwc'
         if layout == 'nhwc':                       # reference flattens NCHW
             nb, H, W, C = x.shape

@@ -197,8 +197,9 @@ def l2q_im2col_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, col):
     col.copy_(_im2col(_as_nchw(x, sn, sc, sh, sw, nb, C, H, W), k))
 
 
-def l2q_conv_gemm_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, w, b, cout, act, out):
+def l2q_conv_gemm_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, w, clast, b, cout, act, out):
     col = _im2col(_as_nchw(x, sn, sc, sh, sw, nb, C, H, W), k)
+    w = w.reshape(cout, k, k, C).permute(0, 3, 1, 2) if clast else w.reshape(cout, C, k, k)
     out.copy_(_act(col @ w.reshape(cout, -1).T + b, act).reshape(out.shape))
 
 
