@@ -49,6 +49,10 @@ extern "C" {
 #define L2Q_ACT_ELU 4
 #define L2Q_ACT_SWISH 5
 
+/* 16-bit operand types of l2q_gemm_h */
+#define L2Q_HALF_F16 0
+#define L2Q_HALF_BF16 1
+
 const char* l2q_last_error(void);
 int l2q_version(void);
 /* performance knobs (results never depend on them): "plaq_occ" / "force_occ" in {2,3,4} pick
@@ -194,6 +198,34 @@ int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const flo
                  const float* W2, long K2, const float* bias, const float* bias2,
                  const float* coeff, float scale, int act, float* C, void* ws,
                  size_t ws_bytes, void* stream);
+/* Half-precision network layers ("fp16 nets / fp32 action", BASELINE cfg-3): what the reference
+ * gets from torch.autocast around Dynamics.forward (trainers/pytorch/trainer.py:211-219,
+ * 1278-1280: nn.Linear in fp16 / bf16, lattice arithmetic in fp32).  W / W2 are 16-bit
+ * (half_type: L2Q_HALF_F16 | L2Q_HALF_BF16), A / A2 16-bit or fp32 (a_is_f32: rounded to 16 bit
+ * as the tile is staged, no cast pass), C 16-bit or fp32 (c_is_f32); bias / bias2 / coeff fp32.
+ * fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16}.  Rounding points as autocast has them:
+ *   y = r16(acc + bias);  y = r16(act(y));  C = coeff ? scale * exp(coeff[n]) * y : r16(scale * y)
+ * (coeff needs c_is_f32: torch promotes fp32 x fp16 tensors to fp32).  ws: split-K scratch of
+ * l2q_gemm_h_ws_bytes. */
+int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M, int N, long K,
+               const void* A2, const void* W2, long K2, const float* bias, const float* bias2,
+               const float* coeff, float scale, int act, void* C, int c_is_f32, void* ws,
+               size_t ws_bytes, void* stream);
+size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2);
+/* The three heads of a half-precision U(1) LeapfrogLayer and the sub-update that consumes them
+ * in one kernel (network.py:547-551 + dynamics.py:1266-1297 / 1386-1477); s, t, q never reach
+ * memory.  Z [M][K] 16-bit (last hidden activation), W* [N][K] 16-bit, b* fp32 [N],
+ * cs / cq = nw * exp(coeff) fp32 [N] (rounding points as l2q_gemm_h):
+ *   x_update == 0: a = v (in place), b = force:  l2q_v_update's arithmetic
+ *   x_update != 0: a = x (in place), b = v, mask [N] / complement:  l2q_u1_x_update's
+ * logdet [M] fp32 (accumulate != 0: added to).  ws: l2q_u1_heads_update_h_ws_bytes. */
+int l2q_u1_heads_update_h(int half_type, const void* Z, int M, int K, long N, const void* Ws,
+                          const float* bs, const float* cs, const void* Wt, const float* bt,
+                          float scale_t, const void* Wq, const float* bq, const float* cq,
+                          int x_update, float* a, const float* b, const float* mask,
+                          int complement, float eps, int forward, int use_ncp, float* logdet,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream);
+size_t l2q_u1_heads_update_h_ws_bytes(int M, long N);
 
 /* ---------------------------------------------------------------- U(1) lattice kernels */
 /* x[nb][2][T][X] angles, elem_bytes 4 or 8.

@@ -1,0 +1,628 @@
+// gemm_f16.hip -- the dense layers of the leapfrog networks in half precision: BASELINE cfg-3
+// "fp16 nets / fp32 action" (reference: torch.autocast around Dynamics.forward,
+// trainers/pytorch/trainer.py:211-219 -- nn.Linear runs in fp16 / bf16, everything else in fp32).
+//
+//   C[M][N] = epi( A[M][K] . W[N][K]^T  (+ A2[M][K2] . W2[N][K2]^T) + bias (+ bias2) )
+//
+// W, W2 are 16-bit (converted once per weight version on the host side), A / A2 are either the
+// 16-bit output of the previous layer or fp32 lattice data (cos/sin of the links, momenta) which
+// the tile loader rounds on its way into LDS -- there is no separate cast pass over HBM.
+// Products accumulate in fp32 on v_mfma_f32_16x16x32_{f16,bf16} (gfx950's double-K form).
+// Rounding points follow autocast: the Linear output (accumulator + bias) is rounded to 16 bit,
+// the activation is evaluated on that value and rounded again; exp(coeff) and the net-weight
+// scale are applied in fp32 (torch promotes fp32 tensor x fp16 tensor to fp32).  The input
+// layer's two products share one accumulator here (autocast rounds xlayer(x) and vlayer(v)
+// separately before adding: one rounding fewer, <= 2^-11 relative).
+#include "l2q_common.hpp"
+#include "u1_math.hpp"
+
+namespace l2q {
+
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HBK = 64;            // K-slab: two MFMA K-steps of 32
+constexpr int HLD = HBK + 8;       // row stride 144 B: conflict-free ds_read_b128 fragments
+
+template <typename HT> struct MfmaH;
+template <> struct MfmaH<_Float16> {
+  using vec_t = f16x8;
+  static __device__ __forceinline__ v4f32 run(vec_t a, vec_t b, v4f32 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MfmaH<__bf16> {
+  using vec_t = bf16x8;
+  static __device__ __forceinline__ v4f32 run(vec_t a, vec_t b, v4f32 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename HT> __device__ __forceinline__ float rnd(float x) { return (float)(HT)x; }
+
+__device__ __forceinline__ float act_h(float z, int act) {
+  switch (act) {
+    case L2Q_ACT_TANH: return tanhf(z);
+    case L2Q_ACT_RELU: return z > 0.f ? z : 0.f;
+    case L2Q_ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
+    case L2Q_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case L2Q_ACT_SWISH: return z / (1.f + expf(-z));
+    default: return z;
+  }
+}
+
+struct EpiH {
+  const float* bias;
+  const float* bias2;
+  const float* coeff;
+  float scale;
+  int act;
+};
+
+// y = scale * exp(coeff[n]) * r16(act(r16(acc + bias)))   (see the header of this file)
+template <typename HT>
+__device__ __forceinline__ float epilogue_h(float acc, float cb, float cs, bool has_coeff, int act) {
+  float y = rnd<HT>(acc + cb);
+  if (act != L2Q_ACT_NONE) y = rnd<HT>(act_h(y, act));
+  y *= cs;
+  return has_coeff ? y : rnd<HT>(y);
+}
+
+// ROWS x HBK tile of the virtual K-concatenated matrix [P | P2] -> registers -> LDS (as HT).
+// S: element type in HBM (HT or float).  vec: every 16-byte vector is aligned and inside one
+// segment (K, K2 multiples of the vector length); otherwise element-wise loads.
+template <typename HT, typename S, int ROWS = 128>
+struct TileH {
+  static constexpr int VEC = 16 / sizeof(S);          // 8 halves or 4 floats
+  static constexpr int VPR = HBK / VEC;               // vectors per row: 8 or 16
+  static constexpr int RPP = kBlock / VPR;            // rows per pass: 32 or 16
+  static constexpr int NP = ROWS / RPP;               // passes: 4 or 8 for 128 rows
+  typedef HT hv __attribute__((ext_vector_type(VEC)));
+  hv reg[NP];                                         // packed: VEC/2 VGPRs per vector
+
+  __device__ __forceinline__ void fetch(const S* __restrict__ p, const S* __restrict__ p2,
+                                        long row0, long nrows, long k0, long K, long K2,
+                                        long kend, bool vec) {
+    const int tid = threadIdx.x;
+    const int kv = (tid % VPR) * VEC, r = tid / VPR;
+    const long kk = k0 + kv;
+    if (vec) {
+      const S* base = p;
+      long ld = K, kc = kk;
+      if (kk >= K) { base = p2; ld = K2; kc = kk - K; }
+      const bool kin = kk < kend;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const long row = row0 + r + (long)i * RPP;
+        if (kin && row < nrows) {
+          typedef S sv __attribute__((ext_vector_type(VEC)));
+          const sv v = *reinterpret_cast<const sv*>(base + row * ld + kc);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) reg[i][j] = (HT)v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) reg[i][j] = (HT)0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const long row = row0 + r + (long)i * RPP;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const long k = kk + j;
+          float v = 0.f;
+          if (row < nrows && k < kend) {
+            if (k < K) v = (float)p[row * K + k];
+            else if (k - K < K2) v = (float)p2[row * K2 + (k - K)];
+          }
+          reg[i][j] = (HT)v;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(HT (*lds)[HLD]) const {
+    const int tid = threadIdx.x;
+    const int kv = (tid % VPR) * VEC, r = tid / VPR;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<hv*>(&lds[r + i * RPP][kv]) = reg[i];
+  }
+};
+
+// grid x = N tiles, y = M tiles, z = K splits.  FUSED: splits == 1, epilogue applied here;
+// otherwise raw fp32 partial sums go to part[z][M][N].  AS: element type of A / A2 in HBM,
+// CT: element type of C.
+template <typename HT, typename AS, typename CT, bool FUSED>
+__global__ __launch_bounds__(kBlock, 2) void gemm_nt_h_kernel(
+    const AS* __restrict__ A, const HT* __restrict__ W, const AS* __restrict__ A2,
+    const HT* __restrict__ W2, int M, int N, long K, long K2, long kchunk, EpiH epi, int veca,
+    int vecw, CT* __restrict__ C, float* __restrict__ part) {
+  using vec_t = typename MfmaH<HT>::vec_t;
+  __shared__ __attribute__((aligned(16))) HT As[128][HLD];
+  __shared__ __attribute__((aligned(16))) HT Ws[128][HLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const long m0 = (long)blockIdx.y * 128, n0 = (long)blockIdx.x * 128;
+  const long Kt = K + K2;
+  const long kbeg = (long)blockIdx.z * kchunk;
+  long kend = kbeg + kchunk;
+  if (kend > Kt) kend = Kt;
+
+  v4f32 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4f32){0, 0, 0, 0};
+
+  TileH<HT, AS> la;
+  TileH<HT, HT> lw;
+  la.fetch(A, A2, m0, M, kbeg, K, K2, kend, veca != 0);
+  lw.fetch(W, W2, n0, N, kbeg, K, K2, kend, vecw != 0);
+  for (long k0 = kbeg; k0 < kend; k0 += HBK) {
+    __syncthreads();
+    la.store(As);
+    lw.store(Ws);
+    __syncthreads();
+    if (k0 + HBK < kend) {
+      la.fetch(A, A2, m0, M, k0 + HBK, K, K2, kend, veca != 0);
+      lw.fetch(W, W2, n0, N, k0 + HBK, K, K2, kend, vecw != 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < HBK; ks += 32) {
+      vec_t fa[4], fb[4];
+      const int kq = ks + 8 * (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const vec_t*>(&As[wm + 16 * i + (lane & 15)][kq]);
+        fb[i] = *reinterpret_cast<const vec_t*>(&Ws[wn + 16 * i + (lane & 15)][kq]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MfmaH<HT>::run(fb[j], fa[i], acc[i][j]);
+    }
+  }
+
+  // W was the MFMA "row" operand: lane holds row m = lane & 15 of tile i and the four consecutive
+  // columns n = 16 j + 4 (lane >> 4) + r of tile j -> one 8- or 16-byte store per (i, j).
+  const bool vecc = (N % 4) == 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
+    if (nb4 >= N) continue;
+    float cs[4], cb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long n = nb4 + r < N ? nb4 + r : N - 1;
+      cs[r] = 1.f; cb[r] = 0.f;
+      if (FUSED) {
+        cs[r] = epi.coeff ? epi.scale * expf(epi.coeff[n]) : epi.scale;
+        if (epi.bias) cb[r] += epi.bias[n];
+        if (epi.bias2) cb[r] += epi.bias2[n];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = m0 + wm + 16 * i + (lane & 15);
+      if (m >= M) continue;
+      if (FUSED) {
+        typedef CT cv __attribute__((ext_vector_type(4)));
+        cv o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[r] = (CT)epilogue_h<HT>(acc[i][j][r], cb[r], cs[r], epi.coeff != nullptr, epi.act);
+        CT* dst = C + m * N + nb4;
+        if (vecc) *reinterpret_cast<cv*>(dst) = o;
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = o[r];
+        }
+      } else {
+        float* dst = part + (long)blockIdx.z * M * N + m * N + nb4;
+        if (vecc) *reinterpret_cast<v4f32*>(dst) = acc[i][j];
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+template <typename HT, typename CT>
+__global__ __launch_bounds__(kBlock) void splitk_reduce_h_kernel(const float* __restrict__ part,
+                                                                 int splits, long MN, int N,
+                                                                 EpiH epi, CT* __restrict__ C) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(long)z * MN + i];     // fixed order
+  const int n = (int)(i % N);
+  const float cs = epi.coeff ? epi.scale * expf(epi.coeff[n]) : epi.scale;
+  float cb = 0.f;
+  if (epi.bias) cb += epi.bias[n];
+  if (epi.bias2) cb += epi.bias2[n];
+  C[i] = (CT)epilogue_h<HT>(s, cb, cs, epi.coeff != nullptr, epi.act);
+}
+
+static int pick_splits_h(int M, int N, long Kt) {
+  const long tiles = cdiv(M, 128) * cdiv(N, 128);
+  if (tiles >= 256 || Kt <= 8 * HBK) return 1;
+  long s = cdiv(512, tiles);
+  const long maxs = Kt / (4 * HBK) > 0 ? Kt / (4 * HBK) : 1;
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  return (int)(s < 1 ? 1 : s);
+}
+
+static bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename HT, typename AS, typename CT>
+static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, const void* A2_,
+                         const void* W2_, long K2, EpiH epi, void* C_, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+  const AS* A = (const AS*)A_;
+  const AS* A2 = (const AS*)A2_;
+  const HT* W = (const HT*)W_;
+  const HT* W2 = (const HT*)W2_;
+  CT* C = (CT*)C_;
+  const long Kt = K + K2;
+  int splits = pick_splits_h(M, N, Kt);
+  long kchunk = cdiv(cdiv(Kt, splits), HBK) * HBK;
+  splits = (int)cdiv(Kt, kchunk);
+  constexpr long VA = 16 / sizeof(AS);
+  const int veca = K % VA == 0 && K2 % VA == 0 && al16(A) && al16(A2);
+  const int vecw = K % 8 == 0 && K2 % 8 == 0 && al16(W) && al16(W2);
+  float* part = nullptr;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) {
+      set_error("l2q_gemm_h: split-K workspace too small (%zu < %zu)", ws_bytes, need);
+      return L2Q_ESHAPE;
+    }
+    part = (float*)ws;
+  }
+  const dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)splits);
+  if (splits == 1) {
+    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, true>), grid, dim3(kBlock), 0, st, A, W, A2,
+                       W2, M, N, K, K2, kchunk, epi, veca, vecw, C, part);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false>), grid, dim3(kBlock), 0, st, A, W, A2,
+                       W2, M, N, K, K2, kchunk, epi, veca, vecw, C, part);
+    const long MN = (long)M * N;
+    hipLaunchKernelGGL((splitk_reduce_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN, kBlock)),
+                       dim3(kBlock), 0, st, (const float*)part, splits, MN, N, epi, C);
+  }
+  return check_launch("l2q_gemm_h");
+}
+
+template <typename HT>
+static int gemm_h_dispatch(const void* A, int a_f32, const void* W, int M, int N, long K,
+                           const void* A2, const void* W2, long K2, EpiH epi, void* C, int c_f32,
+                           void* ws, size_t ws_bytes, hipStream_t st) {
+  if (a_f32) {
+    return c_f32 ? gemm_h_launch<HT, float, float>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st)
+                 : gemm_h_launch<HT, float, HT>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st);
+  }
+  return c_f32 ? gemm_h_launch<HT, HT, float>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st)
+               : gemm_h_launch<HT, HT, HT>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The three output heads of a U(1) LeapfrogLayer AND the sub-update that consumes them, in one
+// kernel: s, t, q ([chains][xdim] fp32 each -- 3 x 268 MB at cfg-3) never reach HBM.
+//   s = cs[n] r16(tanh(r16(Z.Ws[n] + bs[n]))),  t = r16(ct r16(Z.Wt[n] + bt[n])),  q like s
+//   XUPD = false: generalised momentum update (dynamics.py:1266-1297), a = v, b = force
+//   XUPD = true : masked link update (dynamics.py:1386-1477), a = x, b = v, keep = mask[n]
+// Tile 128 chains x 64 entries; each wavefront owns 64 x 32 = 4 x 2 MFMA tiles per head (96
+// fp32 accumulators / lane); the three W tiles share the staged Z tile.  The per-chain logdet
+// goes through per-(chain, column-group) partials and the fixed-order finalize.
+// Epilogue math of the half-precision path on the hardware transcendentals (v_exp / v_log /
+// v_sin / v_cos / v_rcp, ~1e-6 absolute): three orders of magnitude inside the 16-bit rounding
+// the heads already carry, and ~4x fewer VALU cycles than the libm forms, which matter here
+// because the epilogue (not the K = units[-1] MFMA loop) is the long part of this kernel.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_tanh_h(float x) {
+  return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f);      // saturates to +-1
+}
+
+struct HeadsHArgs {
+  const void* Z;          // [M][K]  16 bit
+  const void* W[3];       // s, t, q weights [N][K]  16 bit
+  const float* b[3];      // biases [N]
+  const float* cs;        // nw.s * exp(coeff_s[n])
+  const float* cq;
+  float st;               // nw.t
+  float eps;
+  float* a;               // v (v-update) or x (x-update), [M][N], in place
+  const float* bsrc;      // force (v-update) or v (x-update)
+  const float* mask;      // x-update: [N] keep mask (complement flips it)
+  int complement;
+  double* logdet_part;    // [M][ncols_part]
+  int M, N, K, ncols_part;
+};
+
+template <typename HT, bool XUPD, bool FWD, bool NCP, int BM>
+__global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_kernel(HeadsHArgs a, int swz,
+                                                                      int nfast, int dbg) {
+  constexpr int BN = 64, MI = BM / 32;        // MI: 16-row MFMA tiles per wavefront along m
+  using vec_t = typename MfmaH<HT>::vec_t;
+  __shared__ __attribute__((aligned(16))) HT Zs[BM][HLD];
+  __shared__ __attribute__((aligned(16))) HT Ws[3][BN][HLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 32;
+  const long mt = (a.M + BM - 1) / BM;
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const long nt = (a.N + BN - 1) / BN;
+  const long m0 = nfast ? (w / nt) * BM : (w % mt) * BM;
+  const long n0 = nfast ? (w % nt) * BN : (w / mt) * BN;
+  const HT* Z = (const HT*)a.Z;
+  const HT* W0 = (const HT*)a.W[0];
+  const HT* W1 = (const HT*)a.W[1];
+  const HT* W2 = (const HT*)a.W[2];
+  const long K = a.K;
+  const bool vec = (K % 8) == 0;
+
+  v4f32 acc[3][MI][2];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[h][i][j] = (v4f32){0, 0, 0, 0};
+
+  TileH<HT, HT, BM> lz;
+  TileH<HT, HT, BN> l0, l1, l2;
+  lz.fetch(Z, Z, m0, a.M, 0, K, 0, K, vec);
+  l0.fetch(W0, W0, n0, a.N, 0, K, 0, K, vec);
+  l1.fetch(W1, W1, n0, a.N, 0, K, 0, K, vec);
+  l2.fetch(W2, W2, n0, a.N, 0, K, 0, K, vec);
+  for (long k0 = 0; k0 < (dbg == 2 ? 0 : K); k0 += HBK) {
+    __syncthreads();
+    lz.store(Zs);
+    l0.store(Ws[0]);
+    l1.store(Ws[1]);
+    l2.store(Ws[2]);
+    __syncthreads();
+    if (k0 + HBK < K) {
+      lz.fetch(Z, Z, m0, a.M, k0 + HBK, K, 0, K, vec);
+      l0.fetch(W0, W0, n0, a.N, k0 + HBK, K, 0, K, vec);
+      l1.fetch(W1, W1, n0, a.N, k0 + HBK, K, 0, K, vec);
+      l2.fetch(W2, W2, n0, a.N, k0 + HBK, K, 0, K, vec);
+    }
+#pragma unroll
+    for (int ks = 0; ks < HBK; ks += 32) {
+      const int kq = ks + 8 * (lane >> 4);
+      vec_t fa[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        fa[i] = *reinterpret_cast<const vec_t*>(&Zs[wm + 16 * i + (lane & 15)][kq]);
+#pragma unroll
+      for (int h = 0; h < 3; ++h) {
+        vec_t fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          fb[j] = *reinterpret_cast<const vec_t*>(&Ws[h][wn + 16 * j + (lane & 15)][kq]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[h][i][j] = MfmaH<HT>::run(fb[j], fa[i], acc[h][i][j]);
+      }
+    }
+  }
+
+  if (dbg == 1) {
+    float x = 0.f;
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) x += acc[h][i][j][0] + acc[h][i][j][1] + acc[h][i][j][2] + acc[h][i][j][3];
+    if (x == 12345.f) a.a[0] = x;
+    return;
+  }
+  // ---- epilogue: heads -> update, in registers.  The MFMAs ran with W as the "row" operand:
+  // lane holds chain m = lane & 15 of tile i and the four consecutive entries
+  // n = 16 j + 4 (lane >> 4) + r of tile j: 16-byte accesses to v / x / force / mask / biases.
+  const float eps = a.eps;
+  const bool vec4 = (a.N & 3) == 0;
+  float* __restrict__ pa = a.a;
+  const float* __restrict__ pb = a.bsrc;
+  float ld[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) ld[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
+    if (nb4 >= a.N) continue;
+    float bs[4], bt[4], bq[4], cs[4], cq[4], keep[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long n = nb4 + r < a.N ? nb4 + r : a.N - 1;
+      bs[r] = a.b[0][n]; bt[r] = a.b[1][n]; bq[r] = a.b[2][n];
+      cs[r] = a.cs[n]; cq[r] = a.cq[n];
+      keep[r] = 0.f;
+      if (XUPD) {
+        keep[r] = a.mask[n];
+        if (a.complement) keep[r] = 1.f - keep[r];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const long m = m0 + wm + 16 * i + (lane & 15);
+      if (m >= a.M) continue;
+      const long o = m * (long)a.N + nb4;
+      float av[4], bv[4], out[4];
+      if (vec4) {
+        const float4 t0 = *reinterpret_cast<const float4*>(pa + o);
+        const float4 t1 = *reinterpret_cast<const float4*>(pb + o);
+        av[0] = t0.x; av[1] = t0.y; av[2] = t0.z; av[3] = t0.w;
+        bv[0] = t1.x; bv[1] = t1.y; bv[2] = t1.z; bv[3] = t1.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool in = nb4 + r < a.N;
+          av[r] = in ? pa[o + r] : 0.f;
+          bv[r] = in ? pb[o + r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = cs[r] * rnd<HT>(fast_tanh_h(rnd<HT>(acc[0][i][j][r] + bs[r])));
+        const float t = rnd<HT>(a.st * rnd<HT>(acc[1][i][j][r] + bt[r]));
+        const float q = cq[r] * rnd<HT>(fast_tanh_h(rnd<HT>(acc[2][i][j][r] + bq[r])));
+        const bool in = nb4 + r < a.N;
+        const float a0 = av[r], b0 = bv[r];
+        if (!XUPD) {
+          const float lj = FWD ? (eps * s * 0.5f) : (-eps * s * 0.5f);
+          if (in) ld[i] += lj;
+          const float es = fast_exp(lj), eq = fast_exp(eps * q);
+          const float f = b0 * eq + t;
+          out[r] = FWD ? (es * a0 - 0.5f * eps * f) : (es * (a0 + 0.5f * eps * f));
+        } else {
+          const float xj = a0, mb = 1.f - keep[r];
+          const float sj = FWD ? eps * s : -eps * s;
+          const float es = fast_exp(sj), eq = fast_exp(eps * q);
+          const float tr = b0 * eq + t;
+          float xp, l;
+          if (NCP) {
+            const float hx = xj * 0.5f;                    // |hx| <= pi/2 (x is wrapped)
+            const float ch = __cosf(hx), sh = es * __sinf(hx);
+            const float x1 = 2.f * atan2f(sh, ch);         // = 2 atan(tan(hx) es), no division
+            xp = FWD ? (x1 + eps * tr) : (x1 - es * eps * tr);
+            l = sj - __logf(ch * ch + sh * sh);            // log(es / (ch^2 + sh^2))
+          } else {
+            xp = FWD ? (xj * es + eps * tr) : (es * (xj - eps * tr));
+            l = sj;
+          }
+          if (in) ld[i] += mb * l;
+          out[r] = wrap_angle<float>(keep[r] * xj + mb * xp);
+        }
+      }
+      if (vec4) {
+        *reinterpret_cast<float4*>(pa + o) = make_float4(out[0], out[1], out[2], out[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb4 + r < a.N) pa[o + r] = out[r];
+      }
+    }
+  }
+  // chain partial of logdet over this wave's 32 entries: the four lane groups hold 4 n each
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    double x = (double)ld[i];
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    const long m = m0 + wm + 16 * i + (lane & 15);
+    if (lane < 16 && m < a.M) {
+      const long col = (n0 / BN) * 2 + (wave & 1);
+      a.logdet_part[m * a.ncols_part + col] = x;
+    }
+  }
+}
+
+__global__ void cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int n,
+                                    int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = accumulate ? out[i] + (float)in[i] : (float)in[i];
+}
+
+template <typename HT>
+static int heads_h_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, float* logdet,
+                          int accumulate, void* ws, hipStream_t st) {
+  const int bm = tuning().heads_h_bm;
+  const long ntile = cdiv(a.N, 64), mtile = cdiv(a.M, bm);
+  const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
+  const int swz = tuning().xcd_swizzle;
+  const int nfast = tuning().heads_h_order;
+  const int dbg = tuning().heads_h_dbg;
+  double* part = (double*)ws;
+  double* tmp = part + (size_t)a.M * a.ncols_part;
+  a.logdet_part = part;
+  (void)hipMemsetAsync(part, 0, (size_t)a.M * a.ncols_part * sizeof(double), st);
+#define L2Q_HH(X, F, C)                                                                          \
+  do {                                                                                           \
+    if (bm == 128)                                                                               \
+      hipLaunchKernelGGL((u1_heads_update_h_kernel<HT, X, F, C, 128>), grid, block, 0, st, a,    \
+                         swz, nfast, dbg);                                                       \
+    else                                                                                         \
+      hipLaunchKernelGGL((u1_heads_update_h_kernel<HT, X, F, C, 64>), grid, block, 0, st, a,     \
+                         swz, nfast, dbg);                                                       \
+  } while (0)
+  if (!xupd) { if (forward) L2Q_HH(false, true, false); else L2Q_HH(false, false, false); }
+  else if (use_ncp) { if (forward) L2Q_HH(true, true, true); else L2Q_HH(true, false, true); }
+  else { if (forward) L2Q_HH(true, true, false); else L2Q_HH(true, false, false); }
+#undef L2Q_HH
+  launch_finalize(part, tmp, a.M, a.ncols_part, 1, 1.0, 0.0, st);
+  hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)cdiv(a.M, 64)), dim3(64), 0, st, tmp, logdet,
+                     a.M, accumulate);
+  return check_launch("l2q_u1_heads_update_h");
+}
+
+}  // namespace l2q
+
+using namespace l2q;
+
+extern "C" {
+
+size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2) {
+  if (M <= 0 || N <= 0 || K + K2 <= 0) return 0;
+  const int splits = pick_splits_h(M, N, K + K2);
+  return splits == 1 ? 0 : (size_t)(splits + 1) * M * N * sizeof(float);
+}
+
+int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M, int N, long K,
+               const void* A2, const void* W2, long K2, const float* bias, const float* bias2,
+               const float* coeff, float scale, int act, void* C, int c_is_f32, void* ws,
+               size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(A && W && C, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(M > 0 && N > 0 && K > 0 && K2 >= 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(K2 == 0 || (A2 && W2), L2Q_EINVAL, "second operand pair missing");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
+  L2Q_REQUIRE(coeff == nullptr || c_is_f32, L2Q_EINVAL, "exp(coeff) scaling needs an fp32 output");
+  const EpiH epi{bias, bias2, coeff, scale, act};
+  const hipStream_t st = (hipStream_t)stream;
+  if (half_type == L2Q_HALF_F16)
+    return gemm_h_dispatch<_Float16>(A, a_is_f32, W, M, N, K, A2, W2, K2, epi, C, c_is_f32, ws,
+                                     ws_bytes, st);
+  return gemm_h_dispatch<__bf16>(A, a_is_f32, W, M, N, K, A2, W2, K2, epi, C, c_is_f32, ws,
+                                 ws_bytes, st);
+}
+
+size_t l2q_u1_heads_update_h_ws_bytes(int M, long N) {
+  if (M <= 0 || N <= 0) return 0;
+  return ((size_t)M * (size_t)(cdiv(N, 64) * 2) + (size_t)M) * sizeof(double);
+}
+
+int l2q_u1_heads_update_h(int half_type, const void* Z, int M, int K, long N, const void* Ws,
+                          const float* bs, const float* cs, const void* Wt, const float* bt,
+                          float scale_t, const void* Wq, const float* bq, const float* cq,
+                          int x_update, float* a, const float* b, const float* mask,
+                          int complement, float eps, int forward, int use_ncp, float* logdet,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(Z && Ws && bs && cs && Wt && bt && Wq && bq && cq && a && b && logdet && ws,
+              L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(!x_update || mask, L2Q_EINVAL, "x-update needs the mask");
+  L2Q_REQUIRE(M > 0 && K > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
+  L2Q_REQUIRE(K % 8 != 0 || (al16(Z) && al16(Ws) && al16(Wt) && al16(Wq)), L2Q_ESHAPE,
+              "operands must be 16-byte aligned");
+  L2Q_REQUIRE(ws_bytes >= l2q_u1_heads_update_h_ws_bytes(M, N), L2Q_ESHAPE, "workspace too small");
+  HeadsHArgs h;
+  h.Z = Z; h.W[0] = Ws; h.W[1] = Wt; h.W[2] = Wq; h.b[0] = bs; h.b[1] = bt; h.b[2] = bq;
+  h.cs = cs; h.cq = cq; h.st = scale_t; h.eps = eps; h.a = a; h.bsrc = b; h.mask = mask;
+  h.complement = complement; h.logdet_part = nullptr;
+  h.M = M; h.N = (int)N; h.K = K; h.ncols_part = (int)(cdiv(N, 64) * 2);
+  const hipStream_t st = (hipStream_t)stream;
+  if (half_type == L2Q_HALF_F16)
+    return heads_h_launch<_Float16>(h, x_update, forward, use_ncp, logdet, accumulate, ws, st);
+  return heads_h_launch<__bf16>(h, x_update, forward, use_ncp, logdet, accumulate, ws, st);
+}
+
+}  // extern "C"

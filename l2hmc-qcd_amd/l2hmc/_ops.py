@@ -286,6 +286,67 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+HALF_TYPES = {torch.float16: 0, torch.bfloat16: 1}
+
+
+def gemm_h(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+           a2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
+           bias2: Optional[torch.Tensor] = None, coeff: Optional[torch.Tensor] = None,
+           scale: float = 1.0, act: Optional[str] = None,
+           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Half-precision layer (include/l2q.h: l2q_gemm_h).  w / w2: float16 or bfloat16 [n, k];
+    a / a2: that type or float32 (rounded while staged); bias / bias2 / coeff float32;
+    out_dtype: w.dtype (default) or float32 (required with coeff)."""
+    m, k = a.shape
+    n = w.shape[0]
+    k2 = 0 if a2 is None else a2.shape[1]
+    hd = w.dtype
+    if hd not in HALF_TYPES:
+        raise N.L2QError(f'gemm_h: weight dtype {hd} is not a 16-bit float')
+    if w.shape[1] != k or (a2 is not None and (w2 is None or w2.shape != (n, k2))):
+        raise N.L2QError(f'gemm_h: shape mismatch a{tuple(a.shape)} w{tuple(w.shape)}')
+    if a.dtype not in (hd, torch.float32) or (a2 is not None and a2.dtype != a.dtype) or \
+            (w2 is not None and w2.dtype != hd):
+        raise N.L2QError(f'gemm_h: operand dtypes {a.dtype} / {hd}')
+    for other in (bias, bias2, coeff):
+        if other is not None and other.dtype != torch.float32:
+            raise N.L2QError('gemm_h: bias / coeff must be float32')
+    out_dtype = (torch.float32 if coeff is not None else hd) if out_dtype is None else out_dtype
+    if out_dtype not in (hd, torch.float32):
+        raise N.L2QError(f'gemm_h: output dtype {out_dtype}')
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    ws = N.workspace(int(N.load().l2q_gemm_h_ws_bytes(m, n, k, k2)), a.device)
+    N.call('l2q_gemm_h', HALF_TYPES[hd], a, int(a.dtype == torch.float32), w, m, n, k, a2, w2, k2,
+           bias, bias2, coeff, float(scale), N.ACT[act], out, int(out_dtype == torch.float32),
+           ws, ws.numel())
+    return out
+
+
+def u1_heads_update_h_(z: torch.Tensor, heads: dict, scale_t: float, a: torch.Tensor,
+                       b: torch.Tensor, eps: float, forward: bool, *,
+                       mask: Optional[torch.Tensor] = None, complement: bool = False,
+                       use_ncp: bool = True, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Half-precision heads + sub-update in one kernel (include/l2q.h: l2q_u1_heads_update_h).
+    heads: {'s': (W16, b, cs), 't': (W16, b, None), 'q': (W16, b, cq)} with cs / cq the fp32
+    per-entry scales nw * exp(coeff).  mask given: x-update (a = x, b = v), else v-update
+    (a = v, b = force); a is updated in place.  Returns logdet [nb] fp32 (acc: added into it)."""
+    m, k = z.shape
+    ws_, bs, cs = heads['s']
+    wt, bt, _ = heads['t']
+    wq, bq, cq = heads['q']
+    n = ws_.shape[0]
+    if z.dtype not in HALF_TYPES or ws_.dtype != z.dtype:
+        raise N.L2QError(f'u1_heads_update_h: dtypes {z.dtype} / {ws_.dtype}')
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.numel() != m * n:
+        raise N.L2QError('u1_heads_update_h: the lattice operands are fp32 [nb, n]')
+    logdet = acc if acc is not None else torch.empty(m, dtype=torch.float32, device=z.device)
+    ws = N.workspace(int(N.load().l2q_u1_heads_update_h_ws_bytes(m, n)), z.device)
+    N.call('l2q_u1_heads_update_h', HALF_TYPES[z.dtype], z, m, k, n, ws_, bs, cs, wt, bt,
+           float(scale_t), wq, bq, cq, int(mask is not None), a, b, mask, int(complement),
+           float(eps), int(forward), int(use_ncp), logdet, int(acc is not None), ws, ws.numel())
+    return logdet
+
+
 def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
                         force: torch.Tensor, eps: float, forward: bool) -> torch.Tensor:
     """Fused (s, t, q) heads + generalised momentum update, v in place; returns logdet [nb].

@@ -167,12 +167,35 @@ class Dynamics(nn.Module):
         self.reuse_v_inputs = True  # force / vec8 / hidden activation once per distinct x
         self.pair_v_updates = True  # adjacent v-updates on the same x in one heads kernel
         self.fuse_u1_steps = True   # U1 (small lattices, dense nets): one kernel per sub-update
+        self.net_precision = None   # torch.float16 / torch.bfloat16: see set_net_precision
+        self.fuse_half_heads = True
         self._inject: Optional[dict] = None
         self._eps_cache: dict = {}
         self._masks_native: Optional[list] = None
         self._perm: dict = {}
 
     # ------------------------------------------------------------------ construction
+    def set_net_precision(self, precision) -> None:
+        """'fp16' / 'bf16' (or the torch dtype): every LeapfrogLayer's Linear layers run in
+        half precision with fp32 accumulation, the lattice arithmetic (action, force, cos / sin,
+        updates, logdet, accept step) stays fp32 -- BASELINE cfg-3 "fp16 nets / fp32 action",
+        the reference's torch.autocast region (trainers/pytorch/trainer.py:211-219, 1276-1280).
+        None / 'float32' restores full precision."""
+        table = {None: None, 'float32': None, 'fp32': None, 'fp16': torch.float16,
+                 'bf16': torch.bfloat16, torch.float16: torch.float16,
+                 torch.bfloat16: torch.bfloat16, torch.float32: None}
+        if precision not in table:
+            raise ValueError(f'set_net_precision: {precision!r}')
+        half = table[precision]
+        if half is not None and self.group != 'U1':
+            raise ValueError('half-precision networks: U(1) only (SU(3) is complex128 by '
+                             'definition, group/su3/pytorch/group.py:41)')
+        from l2hmc.network.pytorch.network import LeapfrogLayer
+        for m in self.networks.modules():
+            if isinstance(m, LeapfrogLayer):
+                m.set_precision(half)
+        self.net_precision = half
+
     def get_models(self) -> dict:
         if self.config.use_separate_networks:
             xnet, vnet = {}, {}
@@ -483,10 +506,16 @@ class Dynamics(nn.Module):
         """Weights in the layout of the fused U(1) sub-update kernels, or None when the fused
         path does not apply (SU3, fp64, conv stack, wide layers, large lattice)."""
         if not (self.fuse_u1_steps and self.group == 'U1' and self._networks_built
-                and self._dtype == torch.float32 and self.xdim <= ops.u1_fused_max_n()):
+                and self._dtype == torch.float32 and self.xdim <= ops.u1_fused_max_n()
+                and getattr(net, 'half_dtype', None) is None):
             return None
         net._check_mode()
         return net.kernel_weights().get('fused_u1')
+
+    def _half_fused(self, net) -> bool:
+        """half-precision layers: heads + update in one kernel (s, t, q stay in registers)."""
+        return (self.group == 'U1' and self._networks_built and self.fuse_half_heads
+                and getattr(net, 'half_dtype', None) is not None)
 
     def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
                     cache: Optional[dict] = None, acc: Optional[Tensor] = None) -> Tensor:
@@ -498,6 +527,15 @@ class Dynamics(nn.Module):
         fw = self._fused_u1(vnet)
         if fw is not None:            # force + vnet + update in one launch
             return ops.u1_vstep_(xn, vn, _beta(beta), eps, forward, self.latvolume, fw, acc)
+        if self._half_fused(vnet):
+            fn = self._force_n(xn, beta)
+            x = xn
+            if isinstance(vnet.input_layer.conv_stack, ConvStack):
+                x = vnet.input_layer.conv_stack(xn)
+            w = vnet.kernel_weights()
+            z = vnet.hidden_flat_h(x.reshape(nb, -1), fn.reshape(nb, -1), w)
+            return ops.u1_heads_update_h_(z, w['h']['heads_scaled'], vnet.nw.t, vn.reshape(nb, -1),
+                                          fn.reshape(nb, -1), eps, forward)
         fn, z, w = self._v_inputs_n(vnet, xn, beta, cache)
         if z is not None:
             # heads + momentum update in one kernel: s, t, q never reach HBM
@@ -531,6 +569,17 @@ class Dynamics(nn.Module):
         if fw is not None:            # masked cos/sin + xnet + update in one launch
             return ops.u1_xstep_(xn.reshape(nb, -1), vn, mask, complement, eps, forward,
                                  self.config.use_ncp, fw, acc)
+        xnet = self._get_xnet(step, first)
+        if self._half_fused(xnet):
+            xm = ops.u1_masked_cos_sin(xn, mask, complement, self.latvolume)
+            if isinstance(xnet.input_layer.conv_stack, ConvStack):
+                xm = xnet.input_layer.conv_stack(xm)
+            w = xnet.kernel_weights()
+            z = xnet.hidden_flat_h(xm.reshape(nb, -1), vn.reshape(nb, -1), w)
+            return ops.u1_heads_update_h_(z, w['h']['heads_scaled'], xnet.nw.t,
+                                          xn.reshape(nb, -1), vn.reshape(nb, -1), eps, forward,
+                                          mask=mask, complement=complement,
+                                          use_ncp=self.config.use_ncp)
         s, t, q = self._xnet_n(step, first, xn, vn, mask, complement)
         return ops.u1_x_update_(xn.reshape(nb, -1), vn, s, t, q, mask, complement, eps,
                                 forward, self.config.use_ncp)

@@ -367,7 +367,18 @@ class LeapfrogLayer(nn.Module):
     def _versions(self):
         vs = [p._version for p in self.parameters()]
         vs += [b._version for b in self.buffers()]
-        return tuple(vs) + (self.nw.s, self.nw.t, self.nw.q, ops.PARAM_GENERATION[0])
+        return tuple(vs) + (self.nw.s, self.nw.t, self.nw.q, ops.PARAM_GENERATION[0],
+                            getattr(self, 'half_dtype', None))
+
+    def set_precision(self, half: Optional[torch.dtype]) -> None:
+        """half = torch.float16 | torch.bfloat16: the Linear layers run on the 16-bit MFMA path
+        with autocast's rounding points (what the reference gets from torch.autocast around
+        Dynamics.forward, trainers/pytorch/trainer.py:211-219); None: full precision."""
+        if half not in (None, torch.float16, torch.bfloat16):
+            raise ValueError(f'LeapfrogLayer.set_precision: {half}')
+        if half is not None and self.transl.weight.dtype != torch.float32:
+            raise ValueError('half-precision layers need fp32 master weights (the U(1) configs)')
+        self.half_dtype = half
 
     def kernel_weights(self, in_perm: Optional[Tensor] = None,
                        out_perm: Optional[Tensor] = None) -> dict:
@@ -436,6 +447,17 @@ class LeapfrogLayer(nn.Module):
                     'heads': {'s': (hs['s'][0], hs['s'][1], hs['s'][2]),
                               't': (hs['t'][0], hs['t'][1], ones),
                               'q': (hs['q'][0], hs['q'][1], hs['q'][2])}}
+            if getattr(self, 'half_dtype', None) is not None:
+                hd = self.half_dtype
+                r16 = lambda t: t.to(hd).float().contiguous()     # autocast casts the bias too
+                out['h'] = {
+                    'wx': out['wx'].to(hd), 'wv': out['wv'].to(hd),
+                    'bx': r16(out['bx']), 'bv': r16(out['bv']),
+                    'hidden': [(hw.to(hd), r16(hb)) for hw, hb in out['hidden']],
+                    'heads': {k: (w_.to(hd), r16(b_), c_) for k, (w_, b_, c_) in heads.items()},
+                    # per-entry fp32 multipliers of the fused heads + update kernel
+                    'heads_scaled': {k: (heads[k][0].to(hd), r16(heads[k][1]),
+                                         out['heads_scaled'][k][2]) for k in ('s', 't', 'q')}}
         self._head_cache[key] = out
         return out
 
@@ -451,6 +473,19 @@ class LeapfrogLayer(nn.Module):
         already applied to x)."""
         self._check_mode()
         w = self.kernel_weights() if w is None else w
+        if getattr(self, 'half_dtype', None) is not None:
+            h = w['h']
+            z = ops.gemm_h(x, h['wx'], h['bx'], a2=v, w2=h['wv'], bias2=h['bv'], act=self.act)
+            for hw, hb in h['hidden']:
+                z = ops.gemm_h(z, hw, hb, act=self.act)
+            ws, bs, cs = h['heads']['s']
+            wt, bt, _ = h['heads']['t']
+            wq, bq, cq = h['heads']['q']
+            f32 = torch.float32
+            s = ops.gemm_h(z, ws, bs, coeff=cs, scale=self.nw.s, act='tanh', out_dtype=f32)
+            t = ops.gemm_h(z, wt, bt, scale=self.nw.t, out_dtype=f32)
+            q = ops.gemm_h(z, wq, bq, coeff=cq, scale=self.nw.q, act='tanh', out_dtype=f32)
+            return s, t, q
         z = ops.gemm(x, w['wx'], w['bx'], a2=v, w2=w['wv'], bias2=w['bv'], act=self.act)
         for hw, hb in w['hidden']:
             z = ops.gemm(z, hw, hb, act=self.act)
@@ -462,9 +497,20 @@ class LeapfrogLayer(nn.Module):
         q = ops.gemm(z, wq, bq, coeff=cq, scale=self.nw.q, act='tanh')
         return s, t, q
 
+    def hidden_flat_h(self, x: Tensor, v: Tensor, w: Optional[dict] = None) -> Tensor:
+        """z = last hidden activation in 16 bit (half-precision mode)."""
+        self._check_mode()
+        h = (self.kernel_weights() if w is None else w)['h']
+        z = ops.gemm_h(x, h['wx'], h['bx'], a2=v, w2=h['wv'], bias2=h['bv'], act=self.act)
+        for hw, hb in h['hidden']:
+            z = ops.gemm_h(z, hw, hb, act=self.act)
+        return z
+
     def hidden_flat(self, x: Tensor, v: Tensor, w: dict) -> Tensor:
         """z = last hidden activation [nb, units[-1]] (input layer + hidden layers)."""
         self._check_mode()
+        if getattr(self, 'half_dtype', None) is not None:
+            raise NotImplementedError('hidden_flat feeds the fp64 fused heads kernel (SU(3))')
         z = ops.gemm(x, w['wx'], w['bx'], a2=v, w2=w['wv'], bias2=w['bv'], act=self.act)
         for hw, hb in w['hidden']:
             z = ops.gemm(z, hw, hb, act=self.act)

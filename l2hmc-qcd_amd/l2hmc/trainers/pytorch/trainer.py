@@ -39,6 +39,14 @@ class Trainer:
         self.g = self.lattice.g
         self.loss_fn = LatticeLoss(lattice=self.lattice, loss_config=cfg.loss)
         self.dynamics = self.build_dynamics(build_networks)
+        if cfg.precision in ('fp16', 'bf16') and build_networks:
+            # the reference wraps Dynamics.forward in torch.autocast(dtype=precision)
+            # (trainer.py:211-219): Linear layers in 16 bit, lattice arithmetic in fp32.  Here
+            # that applies to the sampling steps (eval_step / eval); train_step differentiates
+            # the fp32 master weights, so no GradScaler is needed.
+            if cfg.dynamics.group.upper() != 'U1':
+                raise ValueError(f'precision={cfg.precision}: SU(3) is complex128 by definition')
+            self.dynamics.set_net_precision(cfg.precision)
         evals = 2 * cfg.dynamics.nleapfrog if cfg.dynamics.merge_directions \
             else cfg.dynamics.nleapfrog
         self.timers = {k: StepTimer(evals_per_step=evals) for k in ('train', 'eval', 'hmc')}

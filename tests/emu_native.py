@@ -136,6 +136,24 @@ l2q_gemm_f32 = _gemm
 l2q_gemm_f64 = _gemm
 
 
+def l2q_gemm_h(ht, A, a32, W, M, N, K, A2, W2, K2, bias, bias2, coeff, scale, act, C, c32, ws, wsn):
+    """autocast rounding points of include/l2q.h: l2q_gemm_h, products accumulated in fp32."""
+    hd = torch.float16 if ht == 0 else torch.bfloat16
+    r16 = lambda t: t.to(hd).float()
+    z = r16(A.reshape(M, K).float()) @ W.reshape(N, K).float().T
+    if A2 is not None:
+        z = z + r16(A2.reshape(M, K2).float()) @ W2.reshape(N, K2).float().T
+    if bias is not None:
+        z = z + bias
+    if bias2 is not None:
+        z = z + bias2
+    y = r16(z)
+    if act:
+        y = r16(_act(y, act))
+    y = scale * torch.exp(coeff) * y if coeff is not None else r16(scale * y)
+    C.copy_(y.reshape(C.shape).to(C.dtype))
+
+
 def l2q_u1_plaq_reduce(x, nb, T, X, esz, out):
     th = _theta(x.reshape(nb, 2, T, X))
     out[:, 0] = torch.cos(th).sum((1, 2))
@@ -597,6 +615,26 @@ def l2q_diff_bwd_f64(x, y, a, nb, n, gx):
     if x.is_complex():                       # n counts doubles
         x, y, gx = torch.view_as_real(x), torch.view_as_real(y), torch.view_as_real(gx)
     gx.add_((2.0 * a.reshape(nb, 1) * (x.reshape(nb, n) - y.reshape(nb, n))).reshape(gx.shape))
+
+
+def l2q_u1_heads_update_h(ht, Z, M, K, N, Ws, bs, cs, Wt, bt, scale_t, Wq, bq, cq, xupd, a, b, mask,
+                          complement, eps, forward, ncp, logdet, accumulate, ws, wsn):
+    sv, tv, qv = (torch.empty(M, N) for _ in range(3))
+    one = torch.zeros(N)
+    l2q_gemm_h(ht, Z, 0, Ws, M, N, K, None, None, 0, bs, None, one, 1.0, 1, sv, 1, None, 0)
+    l2q_gemm_h(ht, Z, 0, Wt, M, N, K, None, None, 0, bt, None, None, scale_t, 0, tv, 1, None, 0)
+    l2q_gemm_h(ht, Z, 0, Wq, M, N, K, None, None, 0, bq, None, one, 1.0, 1, qv, 1, None, 0)
+    sv, qv = cs * sv, cq * qv
+    if xupd:
+        an, ld = _x_update(a.reshape(M, N), b.reshape(M, N), sv, tv, qv, mask, complement, eps,
+                           bool(forward), bool(ncp))
+    else:
+        an, ld = _v_update(a.reshape(M, N), b.reshape(M, N), sv, tv, qv, eps, bool(forward))
+    a.copy_(an.reshape(a.shape))
+    if accumulate:
+        logdet.add_(ld.to(logdet.dtype))
+    else:
+        logdet.copy_(ld)
 
 
 _TABLE = {k: v for k, v in globals().items() if k.startswith('l2q_')}

@@ -451,3 +451,99 @@ def test_apply_transition_both_and_hmc_helpers(group, golden):
         xy = dyn._stack_as_xy(x)
         assert torch.allclose(xy[..., 0].cpu(), x.cos(), atol=1e-6)
         assert torch.allclose(xy[..., 1].cpu(), x.sin(), atol=1e-6)
+
+
+@pytest.mark.parametrize('hd', ['fp16', 'bf16'])
+@pytest.mark.parametrize('lat,nb,units,act,bn', [((8, 8), 128, [32, 32], 'leaky_relu', True),
+                                                 ((16, 16), 37, [64], 'tanh', False),
+                                                 ((64, 64), 24, [128, 96], 'relu', False)])
+def test_u1_half_precision_networks(hd, lat, nb, units, act, bn):
+    """BASELINE cfg-3 "fp16 nets / fp32 action": Dynamics.set_net_precision.  (i) the network
+    outputs of the 16-bit path equal the emulator's autocast restatement; (ii) one leapfrog step
+    stays within half-precision distance of the fp32 step; (iii) the merged trajectory runs,
+    is deterministic, and its accept probabilities track the fp32 ones."""
+    import emu_native
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+    from l2hmc import native
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=list(lat), nleapfrog=2, eps=0.1,
+                             eps_hmc=0.1, verbose=False)
+    nc = cfgs.NetworkConfig(units=units, activation_fn=act, dropout_prob=0.0, use_batch_norm=bn)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                          vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+    latt = LatticeU1(nb, list(lat))
+    dyn = Dynamics(latt.action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig())).eval()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n_, p in dyn.named_parameters():
+            if n_.endswith('coeff'):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g).to(p.device))
+    x0 = latt.random().to(dyn.device)
+    v0 = torch.randn(nb, dc.xdim, generator=g).to(dyn.device)
+    ulp = 2.0 ** -10 if hd == 'fp16' else 2.0 ** -7
+    # (i) network outputs vs the emulator (CPU restatement of the rounding points)
+    dyn.set_net_precision(hd)
+    assert dyn._fused_u1(dyn._get_vnet(0)) is None
+    vnet = dyn._get_vnet(0)
+    f0 = dyn.grad_potential(x0, torch.tensor(2.5))
+    got = vnet.forward_flat(x0.reshape(nb, -1).contiguous(), f0.reshape(nb, -1).contiguous())
+    w = vnet.kernel_weights()
+    cpu_w = {'h': {'wx': w['h']['wx'].cpu(), 'wv': w['h']['wv'].cpu(), 'bx': w['h']['bx'].cpu(),
+                   'bv': w['h']['bv'].cpu(),
+                   'hidden': [(a.cpu(), b.cpu()) for a, b in w['h']['hidden']],
+                   'heads': {k: tuple(None if t is None else t.cpu() for t in v)
+                             for k, v in w['h']['heads'].items()}}}
+    real_call = native.call
+    native.call = emu_native.call
+    try:
+        want = vnet.forward_flat(x0.reshape(nb, -1).cpu().contiguous(),
+                                 f0.reshape(nb, -1).cpu().contiguous(), cpu_w)
+    finally:
+        native.call = real_call
+    for a, b in zip(got, want):
+        d = (a.cpu() - b).abs()
+        assert float(d.max()) < 8 * ulp * max(1.0, float(b.abs().max())), float(d.max())
+    # (ii) one leapfrog step, both directions, vs fp32
+    for forward in (True, False):
+        res = {}
+        for prec in (None, hd):
+            dyn.set_net_precision(prec)
+            dyn.fuse_u1_steps = False
+            xn, vn = dyn._pack(x0), v0.clone()
+            ld = dyn._lf_n(1, xn, vn, 2.5, forward)
+            res[prec] = (xn.clone(), vn.clone(), ld.clone())
+        dx = torch.remainder(res[hd][0] - res[None][0] + np.pi, 2 * np.pi) - np.pi
+        assert float(dx.abs().max()) < 40 * ulp, float(dx.abs().max())
+        scale = max(1.0, float(res[None][1].abs().max()))
+        assert float((res[hd][1] - res[None][1]).abs().max()) < 40 * ulp * scale
+        assert float((res[hd][2] - res[None][2]).abs().max()) < 2 * ulp * dc.xdim ** 0.5 * 8
+        # heads + update in one kernel == 16-bit head GEMMs followed by the fp32 update kernels
+        dyn.set_net_precision(hd)
+        dyn.fuse_half_heads = False
+        xn, vn = dyn._pack(x0), v0.clone()
+        ld = dyn._lf_n(1, xn, vn, 2.5, forward)
+        dyn.fuse_half_heads = True
+        dx = torch.remainder(res[hd][0] - xn + np.pi, 2 * np.pi) - np.pi
+        # (the fused epilogue uses the hardware exp / log / sin / cos: ~1e-6 per operation)
+        assert float(dx.abs().max()) < 1e-3, float(dx.abs().max())
+        assert float((res[hd][1] - vn).abs().max()) < 1e-3 * scale
+        assert float((res[hd][2] - ld).abs().max()) < 1e-3 * max(1.0, float(ld.abs().max()))
+    # (iii) whole merged trajectory
+    dyn.fuse_u1_steps = True
+    beta = torch.tensor(2.5)
+    out = {}
+    for prec in (None, hd, hd):
+        dyn.set_net_precision(prec)
+        nrm = torch.randn(nb, dc.xdim, generator=torch.Generator().manual_seed(3))
+        dyn._inject = {'normals': nrm.numpy(), 'u': np.full(nb, 0.5, dtype=np.float32)}
+        xo, m = dyn((x0, beta))
+        out.setdefault(prec, []).append((xo.clone(), m['acc'].clone()))
+    assert torch.equal(out[hd][0][0], out[hd][1][0]) and torch.equal(out[hd][0][1], out[hd][1][1])
+    da = (out[hd][0][1] - out[None][0][1]).abs()
+    assert float(da.max()) < 400 * ulp, float(da.max())
+    assert bool(torch.isfinite(out[hd][0][0]).all())

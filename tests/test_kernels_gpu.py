@@ -334,3 +334,98 @@ def test_conv_gemm_periodic_equals_im2col_gemm(layout, dims):
     # materialised path (the one the training tape uses)
     got2, _ = ops.conv2d_periodic_gemm_train(xin, layout, w.cuda(), b.cuda(), 1, 'leaky_relu')
     assert float((got2 - got).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('a32', [True, False])
+@pytest.mark.parametrize('shape', [(3, 5, 40, 0), (128, 96, 704, 40), (257, 130, 4104, 0),
+                                   (2, 300, 16, 16), (130, 1000, 6, 0), (300, 64, 8192, 4096),
+                                   (64, 33, 37, 11)])
+def test_gemm_h(hd, a32, shape):
+    """l2q_gemm_h (16-bit MFMA layers of "fp16 nets / fp32 action") against the emulator's
+    restatement of autocast's rounding points, and against the exact fp64 product of the
+    rounded operands (one 16-bit ulp of the output + fp32 accumulation noise)."""
+    import emu_native
+    from l2hmc import _ops as ops
+    m, n, k, k2 = shape
+    g = torch.Generator().manual_seed(17)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd)
+    b = torch.randn(n, generator=g).to(hd).float()
+    co = 0.3 * torch.randn(n, generator=g)
+    a2 = w2 = b2 = None
+    if k2:
+        a2 = torch.randn(m, k2, generator=g)
+        w2 = (torch.randn(n, k2, generator=g) / k2 ** 0.5).to(hd)
+        b2 = torch.randn(n, generator=g).to(hd).float()
+    if not a32:
+        a = a.to(hd)
+        a2 = None if a2 is None else a2.to(hd)
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    cu = lambda t: None if t is None else t.cuda()
+    for act, coeff, odt in ((None, None, hd), ('tanh', co, torch.float32), ('leaky_relu', None, hd),
+                            ('relu', None, torch.float32), ('elu', None, hd), ('swish', None, hd),
+                            (None, co, torch.float32)):
+        got = ops.gemm_h(cu(a), cu(w), cu(b), a2=cu(a2), w2=cu(w2), bias2=cu(b2), coeff=cu(coeff),
+                         scale=0.7, act=act, out_dtype=odt)
+        assert got.dtype == odt and got.shape == (m, n)
+        want = torch.empty(m, n, dtype=odt)
+        emu_native.l2q_gemm_h(ops.HALF_TYPES[hd], a, int(a32), w, m, n, k, a2, w2, k2, b, b2, coeff,
+                              0.7, N_ACT[act], want, int(odt == torch.float32), None, 0)
+        d = (got.cpu().float() - want.float()).abs()
+        tol = 2.5 * ulp * want.float().abs().clamp(min=1.0)
+        # an accumulation-order difference may flip a 16-bit rounding (twice: pre- and post-act)
+        assert bool((d <= tol).all()), (act, shape, float((d / tol).max()))
+        assert float((d > 0).float().mean()) < 0.2, (act, shape)
+
+
+N_ACT = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'leaky_relu': 3, 'elu': 4, 'swish': 5}
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('dims', [(5, 16, 40), (130, 64, 200), (256, 256, 512), (37, 24, 130),
+                                  (3, 7, 9)])
+def test_u1_heads_update_h(hd, dims):
+    """l2q_u1_heads_update_h (three 16-bit heads + v- or x-update in one kernel) against the
+    emulator: heads by the l2q_gemm_h restatement, then the reference update formulas."""
+    import emu_native
+    from l2hmc import _ops as ops
+    m, k, n = dims
+    g = torch.Generator().manual_seed(23)
+    z = torch.randn(m, k, generator=g).to(hd)
+    heads = {}
+    for nm in 'stq':
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd)
+        b = (0.1 * torch.randn(n, generator=g)).to(hd).float()
+        c = None if nm == 't' else (0.7 * torch.exp(0.3 * torch.randn(n, generator=g)))
+        heads[nm] = (w, b, c)
+    ones = torch.ones(n)
+    mask = (torch.rand(n, generator=g) < 0.5).float()
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    cu = lambda t: None if t is None else t.cuda()
+    hc = {nm: tuple(cu(t) for t in v) for nm, v in heads.items()}
+    for xupd in (False, True):
+        for forward in (True, False):
+            for ncp in ((True, False) if xupd else (True,)):
+                a = torch.randn(m, n, generator=g) if not xupd else \
+                    (2 * np.pi * torch.rand(m, n, generator=g) - np.pi)
+                b = torch.randn(m, n, generator=g)
+                want_a, want_ld = a.clone(), torch.zeros(m)
+                emu_native.l2q_u1_heads_update_h(
+                    ops.HALF_TYPES[hd], z, m, k, n, heads['s'][0], heads['s'][1], heads['s'][2],
+                    heads['t'][0], heads['t'][1], 0.9, heads['q'][0], heads['q'][1], heads['q'][2],
+                    int(xupd), want_a, b, mask, 1, 0.17, int(forward), int(ncp), want_ld, 0, None, 0)
+                got_a = a.cuda()
+                acc = torch.full((m,), 0.5, device='cuda')
+                ld = ops.u1_heads_update_h_(cu(z), hc, 0.9, got_a, cu(b), 0.17, forward,
+                                            mask=cu(mask) if xupd else None, complement=True,
+                                            use_ncp=ncp, acc=acc)
+                assert ld is acc
+                d = got_a.cpu() - want_a
+                if xupd:
+                    d = torch.remainder(d + np.pi, 2 * np.pi) - np.pi
+                scale = max(1.0, float(want_a.abs().max()))
+                assert float(d.abs().max()) < 4 * ulp * scale, (xupd, forward, ncp, float(d.abs().max()))
+                assert float((d.abs() > 1e-5 * scale).float().mean()) < 0.2
+                dl = (ld.cpu() - 0.5 - want_ld).abs().max()
+                assert float(dl) < 4 * ulp * n ** 0.5 + 1e-4 * max(1.0, float(want_ld.abs().max()))

@@ -163,3 +163,43 @@ def test_checkpoint_roundtrip_and_torch_adam_layout(monkeypatch, tmp_path):
     opt.step()
     tr2.arena.load_state_dict(opt.state_dict(), list(tr2.dynamics.parameters()))
     assert tr2.arena.step_count == 4
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('prec', ['fp16', 'bf16'])
+def test_half_precision_eval_host_logic(prec, monkeypatch):
+    """precision=fp16|bf16 (BASELINE cfg-3 "fp16 nets / fp32 action"): the Trainer switches
+    every LeapfrogLayer to the 16-bit layers for sampling, the fused fp32 sub-update kernels
+    are bypassed, results stay within half-precision distance of the fp32 trajectory, and
+    train_step keeps differentiating the fp32 master weights."""
+    import l2hmc.configs as cfgs
+    from l2hmc.trainers.pytorch.trainer import Trainer
+    emu_native.install(monkeypatch)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ov = ['dynamics.group=U1', 'dynamics.latvolume=[4,4]', 'dynamics.nchains=8',
+          'dynamics.nleapfrog=2', 'dynamics.verbose=false', 'network.units=[8,8]',
+          'network.dropout_prob=0.0', 'network.use_batch_norm=false', 'conv=none']
+    tr = Trainer(cfgs.get_config(ov + [f'precision={prec}']))
+    hd = torch.float16 if prec == 'fp16' else torch.bfloat16
+    assert tr.dynamics.net_precision == hd
+    assert all(m.half_dtype == hd for m in tr.dynamics.networks.modules() if hasattr(m, 'set_precision'))
+    assert tr.dynamics._fused_u1(tr.dynamics._get_vnet(0)) is None
+    x = tr.lattice.random()
+    nrm = torch.randn(8, 32)
+    res = {}
+    for p in (prec, None):
+        tr.dynamics.set_net_precision(p)
+        tr.dynamics._inject = {'normals': nrm.numpy(), 'u': np.full(8, 0.5, dtype=np.float32)}
+        xo, m = tr.eval_step((x, 2.0))
+        res[p] = (xo, m['acc'])
+    ulp = 2.0 ** -10 if prec == 'fp16' else 2.0 ** -7
+    assert 0 < float((res[prec][1] - res[None][1]).abs().max()) < 200 * ulp
+    tr.dynamics.set_net_precision(prec)
+    tr.dynamics._inject = None
+    _, m = tr.train_step((x, 2.0))
+    assert np.isfinite(float(m['loss']))
+    with pytest.raises(ValueError):
+        Trainer(cfgs.get_config(['dynamics.group=SU3', 'dynamics.latvolume=[2,2,2,2]',
+                                 'dynamics.nchains=2', 'dynamics.nleapfrog=1',
+                                 'network.units=[4]', f'precision={prec}']))

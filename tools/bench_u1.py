@@ -19,11 +19,16 @@ ap.add_argument('--conv', action='store_true')
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--ch', type=int, default=0, help='chains per workgroup of the fused U(1) kernels (0: auto)')
 ap.add_argument('--unfused', action='store_true', help='multi-kernel sub-updates instead of the fused U(1) kernels')
+ap.add_argument('--precision', default=None, help="'fp16' | 'bf16': half-precision Linear layers (cfg-3)")
+ap.add_argument('--units', type=int, nargs='+', default=[16, 16, 16, 16])
+ap.add_argument('--no-hmc', action='store_true')
+ap.add_argument('--no-graph', action='store_true')
+ap.add_argument('--tune', nargs=2, action='append', default=[], metavar=('KEY', 'VALUE'))
 a = ap.parse_args()
 torch.manual_seed(9992); np.random.seed(9992)
 dc = cfgs.DynamicsConfig(nchains=a.nb, group='U1', latvolume=a.L, nleapfrog=a.nlf, eps=0.1,
                          eps_hmc=0.1, verbose=False)
-nc = cfgs.NetworkConfig(units=[16, 16, 16, 16], activation_fn='leaky_relu', dropout_prob=0.2,
+nc = cfgs.NetworkConfig(units=a.units, activation_fn='leaky_relu', dropout_prob=0.2,
                         use_batch_norm=True)
 cc = cfgs.ConvolutionConfig(filters=[8, 16, 32, 64, 128], sizes=[5, 3, 3, 3, 2],
                             pool=[2, 2, 2, 2, 2]) if a.conv else cfgs.ConvolutionConfig()
@@ -32,12 +37,16 @@ spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc
 lat = LatticeU1(a.nb, a.L)
 dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cc)).eval()
 dyn.fuse_u1_steps = not a.unfused
+dyn.set_net_precision(a.precision)
 from l2hmc import native  # noqa: E402
 native.set_tuning('u1_fused_ch', a.ch)
+for k_, v_ in a.tune:
+    assert native.set_tuning(k_, int(v_)) >= 0, k_
 x = lat.random()
 beta = torch.tensor(a.beta)
-for name, fn, nlf in (('Dynamics.forward (L2HMC)', lambda x: dyn((x, beta)), 2 * a.nlf),
-                      ('apply_transition_hmc', lambda x: dyn.apply_transition_hmc((x, beta), eps=0.1, nleapfrog=2 * a.nlf), 2 * a.nlf)):
+runs = [('Dynamics.forward (L2HMC)', lambda x: dyn((x, beta)), 2 * a.nlf),
+        ('apply_transition_hmc', lambda x: dyn.apply_transition_hmc((x, beta), eps=0.1, nleapfrog=2 * a.nlf), 2 * a.nlf)]
+for name, fn, nlf in runs[:1] if a.no_hmc else runs:
     for _ in range(2):
         xo, m = fn(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -45,10 +54,11 @@ for name, fn, nlf in (('Dynamics.forward (L2HMC)', lambda x: dyn((x, beta)), 2 *
         xo, m = fn(x)
         x = dyn.g.compat_proj(xo.reshape(x.shape))
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-    print(f'U(1) {a.L} nb={a.nb} nlf={a.nlf} conv={a.conv} {name}: {dt*1e3:.2f} ms/step '
+    print(f'U(1) {a.L} nb={a.nb} nlf={a.nlf} conv={a.conv} prec={a.precision} units={a.units} {name}: {dt*1e3:.2f} ms/step '
           f'{a.nb * nlf / dt:.3e} chain*LF/s  acc={float(m["acc"].mean()):.3f}')
-for name, kw in (('graphed forward (L2HMC)', dict(mode='fb')),
-                 ('graphed hmc', dict(mode='hmc', eps=0.1, nleapfrog=2 * a.nlf))):
+graphed = [('graphed forward (L2HMC)', dict(mode='fb')),
+           ('graphed hmc', dict(mode='hmc', eps=0.1, nleapfrog=2 * a.nlf))]
+for name, kw in [] if a.no_graph else graphed[:1] if a.no_hmc else graphed:
     gt = dyn.make_graphed(x, a.beta, **kw)
     for _ in range(2):
         xo, m = gt(x)
@@ -57,5 +67,5 @@ for name, kw in (('graphed forward (L2HMC)', dict(mode='fb')),
         xo, m = gt(x)
         x = dyn.g.compat_proj(xo.reshape(x.shape))
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-    print(f'U(1) {a.L} nb={a.nb} nlf={a.nlf} conv={a.conv} {name}: {dt*1e3:.2f} ms/step '
+    print(f'U(1) {a.L} nb={a.nb} nlf={a.nlf} conv={a.conv} prec={a.precision} units={a.units} {name}: {dt*1e3:.2f} ms/step '
           f'{a.nb * 2 * a.nlf / dt:.3e} chain*LF/s  acc={float(m["acc"].mean()):.3f}')
