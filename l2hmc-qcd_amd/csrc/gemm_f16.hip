@@ -72,11 +72,11 @@ __device__ __forceinline__ float epilogue_h(float acc, float cb, float cs, bool 
 // ROWS x HBK tile of the virtual K-concatenated matrix [P | P2] -> registers -> LDS (as HT).
 // S: element type in HBM (HT or float).  vec: every 16-byte vector is aligned and inside one
 // segment (K, K2 multiples of the vector length); otherwise element-wise loads.
-template <typename HT, typename S, int ROWS = 128>
+template <typename HT, typename S, int ROWS = 128, int NT = kBlock>
 struct TileH {
   static constexpr int VEC = 16 / sizeof(S);          // 8 halves or 4 floats
   static constexpr int VPR = HBK / VEC;               // vectors per row: 8 or 16
-  static constexpr int RPP = kBlock / VPR;            // rows per pass: 32 or 16
+  static constexpr int RPP = NT / VPR;                // rows per pass: 32 or 16 (256 threads)
   static constexpr int NP = ROWS / RPP;               // passes: 4 or 8 for 128 rows
   typedef HT hv __attribute__((ext_vector_type(VEC)));
   hv reg[NP];                                         // packed: VEC/2 VGPRs per vector
@@ -134,19 +134,38 @@ struct TileH {
 // grid x = N tiles, y = M tiles, z = K splits.  FUSED: splits == 1, epilogue applied here;
 // otherwise raw fp32 partial sums go to part[z][M][N].  AS: element type of A / A2 in HBM,
 // CT: element type of C.
-template <typename HT, typename AS, typename CT, bool FUSED>
-__global__ __launch_bounds__(kBlock, 2) void gemm_nt_h_kernel(
+// NT = 256: 2 x 2 wavefronts, tile 128 x 128.  NT = 512: 2 x 4 wavefronts, tile 128 x 256 -- for
+// the wide-K input layer, where N = units[0] is a few hundred: every A element (fp32 lattice
+// data, the bulk of the traffic) is then read by one workgroup only.
+template <typename HT, typename AS, typename CT, bool FUSED, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
     const AS* __restrict__ A, const HT* __restrict__ W, const AS* __restrict__ A2,
-    const HT* __restrict__ W2, int M, int N, long K, long K2, long kchunk, EpiH epi, int veca,
-    int vecw, CT* __restrict__ C, float* __restrict__ part) {
+    const HT* __restrict__ W2, int M, int N, long K, long K2, long kchunk, int splits, EpiH epi,
+    int veca, int vecw, CT* __restrict__ C, float* __restrict__ part) {
   using vec_t = typename MfmaH<HT>::vec_t;
+  constexpr int BN = NT / 2, WN = NT / 128;            // tile width, wavefronts along N
   __shared__ __attribute__((aligned(16))) HT As[128][HLD];
-  __shared__ __attribute__((aligned(16))) HT Ws[128][HLD];
+  __shared__ __attribute__((aligned(16))) HT Ws[BN][HLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const long m0 = (long)blockIdx.y * 128, n0 = (long)blockIdx.x * 128;
+  const int wm = (wave / WN) * 64, wn = (wave % WN) * 64;
+  // 1-D grid.  Hardware block b runs on XCD b % 8; the N-tiles of one (M-tile, K-split) read the
+  // same A tile, so they are made neighbours in ONE XCD's queue (the second read hits that
+  // XCD's L2) instead of neighbours in launch order (which lands them on different XCDs).
+  const long ntn = (N + BN - 1) / BN, ntm = (M + 127) / 128;
+  const long nmz = ntm * splits;
+  long mz, nt;
+  if (nmz % kXcds == 0) {
+    const long xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
+    mz = (seq / ntn) * kXcds + xcd;
+    nt = seq % ntn;
+  } else {
+    mz = blockIdx.x / ntn;
+    nt = blockIdx.x % ntn;
+  }
+  const long zsplit = mz / ntm;
+  const long m0 = (mz % ntm) * 128, n0 = nt * BN;
   const long Kt = K + K2;
-  const long kbeg = (long)blockIdx.z * kchunk;
+  const long kbeg = zsplit * kchunk;
   long kend = kbeg + kchunk;
   if (kend > Kt) kend = Kt;
 
@@ -156,8 +175,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_h_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4f32){0, 0, 0, 0};
 
-  TileH<HT, AS> la;
-  TileH<HT, HT> lw;
+  TileH<HT, AS, 128, NT> la;
+  TileH<HT, HT, BN, NT> lw;
   la.fetch(A, A2, m0, M, kbeg, K, K2, kend, veca != 0);
   lw.fetch(W, W2, n0, N, kbeg, K, K2, kend, vecw != 0);
   for (long k0 = kbeg; k0 < kend; k0 += HBK) {
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_h_kernel(
           for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = o[r];
         }
       } else {
-        float* dst = part + (long)blockIdx.z * M * N + m * N + nb4;
+        float* dst = part + zsplit * M * N + m * N + nb4;
         if (vecc) *reinterpret_cast<v4f32*>(dst) = acc[i][j];
         else {
 #pragma unroll
@@ -257,6 +276,18 @@ static int pick_splits_h(int M, int N, long Kt) {
   return (int)(s < 1 ? 1 : s);
 }
 
+// wide: the 128 x 256 tile (512 threads, one workgroup per CU), always through split-K partials.
+static int pick_config_h(int M, int N, long Kt, bool* wide) {
+  *wide = N > 128 && Kt >= 32 * HBK && cdiv(M, 128) * cdiv(N, 128) < 256;
+  if (!*wide) return pick_splits_h(M, N, Kt);
+  const long tiles = cdiv(M, 128) * cdiv(N, 256);
+  long s = cdiv(256, tiles);
+  const long maxs = Kt / (8 * HBK);
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  return (int)(s < 1 ? 1 : s);
+}
+
 static bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename HT, typename AS, typename CT>
@@ -269,14 +300,15 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
   const HT* W2 = (const HT*)W2_;
   CT* C = (CT*)C_;
   const long Kt = K + K2;
-  int splits = pick_splits_h(M, N, Kt);
+  bool wide = false;
+  int splits = pick_config_h(M, N, Kt, &wide);
   long kchunk = cdiv(cdiv(Kt, splits), HBK) * HBK;
   splits = (int)cdiv(Kt, kchunk);
   constexpr long VA = 16 / sizeof(AS);
   const int veca = K % VA == 0 && K2 % VA == 0 && al16(A) && al16(A2);
   const int vecw = K % 8 == 0 && K2 % 8 == 0 && al16(W) && al16(W2);
   float* part = nullptr;
-  if (splits > 1) {
+  if (splits > 1 || wide) {
     const size_t need = (size_t)splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) {
       set_error("l2q_gemm_h: split-K workspace too small (%zu < %zu)", ws_bytes, need);
@@ -284,13 +316,20 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
     }
     part = (float*)ws;
   }
-  const dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)splits);
-  if (splits == 1) {
-    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, true>), grid, dim3(kBlock), 0, st, A, W, A2,
-                       W2, M, N, K, K2, kchunk, epi, veca, vecw, C, part);
+  if (wide) {
+    const dim3 grid((unsigned)(cdiv(N, 256) * cdiv(M, 128) * splits));
+    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false, 512>), grid, dim3(512), 0, st, A, W, A2,
+                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part);
+  } else if (splits == 1) {
+    const dim3 grid((unsigned)(cdiv(N, 128) * cdiv(M, 128)));
+    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, true, 256>), grid, dim3(kBlock), 0, st, A, W,
+                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part);
   } else {
-    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false>), grid, dim3(kBlock), 0, st, A, W, A2,
-                       W2, M, N, K, K2, kchunk, epi, veca, vecw, C, part);
+    const dim3 grid((unsigned)(cdiv(N, 128) * cdiv(M, 128) * splits));
+    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false, 256>), grid, dim3(kBlock), 0, st, A, W,
+                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part);
+  }
+  if (splits > 1 || wide) {
     const long MN = (long)M * N;
     hipLaunchKernelGGL((splitk_reduce_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN, kBlock)),
                        dim3(kBlock), 0, st, (const float*)part, splits, MN, N, epi, C);
@@ -572,8 +611,9 @@ extern "C" {
 
 size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2) {
   if (M <= 0 || N <= 0 || K + K2 <= 0) return 0;
-  const int splits = pick_splits_h(M, N, K + K2);
-  return splits == 1 ? 0 : (size_t)(splits + 1) * M * N * sizeof(float);
+  bool wide = false;
+  const int splits = pick_config_h(M, N, K + K2, &wide);
+  return (splits == 1 && !wide) ? 0 : (size_t)(splits + 1) * M * N * sizeof(float);
 }
 
 int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M, int N, long K,
