@@ -414,6 +414,20 @@ int l2q_su3_force_bwd(const void* xn, const void* gf, double beta, void* gx, int
  * as l2q_su3_plaq_planes.  gx += dL/dx. */
 int l2q_su3_plaq_bwd(const void* xn, const double* w, void* gx, int nb, int T, int X, int Y, int Z,
                      void* stream);
+/* ---- improved gauge actions (c1 != 0: Iwasaki / DBW2 rectangles), lattice/su3/pytorch/lattice.py
+ * :83-112 (coeffs, _rectangles), :180-196 (rectangle traces of _wilson_loops), :252-269 (action):
+ *   S = -(1/3) [ beta (1 - 8 c1) sum_P Re tr P + beta c1 sum_R Re tr R ],  12 planar 2x1 loops R
+ * per site.  out[c] = sum_R Re tr R.  ws >= nb * ceil(V / 256) doubles. */
+int l2q_su3_rect_reduce(const void* xn, int nb, int T, int X, int Y, int Z, double* out, void* ws,
+                        size_t ws_bytes, void* stream);
+/* fn += coef * TAH(U (sum of the 18 rectangle staples of the link)): with coef = beta c1 / 3 the
+ * rectangle part of grad_action = projectTAH(dS/dx x^H) (lattice.py:299-308) for c1 != 0. */
+int l2q_su3_rect_force_add(const void* xn, double coef, void* fn, int nb, int T, int X, int Y, int Z,
+                           void* stream);
+/* gx += w[c] * d(sum_R Re tr R)/dx  (cotangent of the rectangle term of the action in the
+ * Metropolis test of a training step). */
+int l2q_su3_rect_bwd(const void* xn, const double* w, void* gx, int nb, int T, int X, int Y, int Z,
+                     void* stream);
 /* l2q_v_update_bwd for complex128 momenta (SU3): v, force, gv, dv, dF complex [nb][n];
  * s, t, q, ds, dt, dq real [nb][n].  All outputs overwritten. */
 int l2q_v_update_bwd_c128(const void* v, const void* force, const double* s, const double* t,

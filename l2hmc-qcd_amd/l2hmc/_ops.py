@@ -748,6 +748,32 @@ def su3_plaq_bwd_(gx: torch.Tensor, xn: torch.Tensor, w: torch.Tensor,
     return gx
 
 
+def su3_rect_sums_n(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    """[nb]: sum over sites and the 12 planar 2x1 loops of Re tr R (c1 != 0 actions)."""
+    nb = xn.shape[0]
+    T, X, Y, Z = (int(i) for i in lat)
+    out = torch.empty(nb, dtype=torch.float64, device=xn.device)
+    ws = _ws(nb, T * X * Y * Z * 36, xn.device)
+    N.call('l2q_su3_rect_reduce', xn, nb, T, X, Y, Z, out, ws, ws.numel())
+    return out
+
+
+def su3_rect_force_add_n(xn: torch.Tensor, coef: float, fn: torch.Tensor,
+                         lat: Sequence[int]) -> torch.Tensor:
+    """fn += coef * TAH(U * rectangle staples) in place."""
+    T, X, Y, Z = (int(i) for i in lat)
+    N.call('l2q_su3_rect_force_add', xn, float(coef), fn, xn.shape[0], T, X, Y, Z)
+    return fn
+
+
+def su3_rect_bwd_(gx: torch.Tensor, xn: torch.Tensor, w: torch.Tensor,
+                  lat: Sequence[int]) -> torch.Tensor:
+    """gx += w[c] * d(sum_R Re tr R)/dx;  w [nb] float64."""
+    T, X, Y, Z = (int(i) for i in lat)
+    N.call('l2q_su3_rect_bwd', xn, w.to(torch.float64).contiguous(), gx, xn.shape[0], T, X, Y, Z)
+    return gx
+
+
 def v_update_bwd_c128(v, force, s, t, q, eps: float, forward: bool, gv, gl):
     """complex momenta: -> (dv, dF, ds, dt, dq, deps[nb])"""
     nb = v.shape[0]

@@ -167,6 +167,12 @@ class Dynamics(nn.Module):
         self.reuse_v_inputs = True  # force / vec8 / hidden activation once per distinct x
         self.pair_v_updates = True  # adjacent v-updates on the same x in one heads kernel
         self.fuse_u1_steps = True   # U1 (small lattices, dense nets): one kernel per sub-update
+        # Improved gauge action (c1 != 0): the reference evaluates H with potential_fn (the
+        # Trainer's LatticeSU3(c1), trainers/pytorch/trainer.py:499-504) but takes the leapfrog
+        # force from its own c1 = 0 lattice (dynamics.py:134-135, 1493-1499).  Reproduced: the
+        # rectangle term enters the potential energy only, the force stays (beta/3) TAH(U A_plaq).
+        owner = getattr(potential_fn, '__self__', None)
+        self.potential_c1 = float(getattr(owner, 'c1', 0.0) or 0.0) if self.group == 'SU3' else 0.0
         self.net_precision = None   # torch.float16 / torch.bfloat16: see set_net_precision
         self.fuse_half_heads = True
         self._inject: Optional[dict] = None
@@ -392,7 +398,11 @@ class Dynamics(nn.Module):
 
     def _potential_n(self, xn: Tensor, beta) -> Tensor:
         if self.group == 'SU3':
-            return (-_beta(beta) / 3.0) * ops.su3_plaq_sums_n(xn, self.latvolume)[:, 0]
+            b, c1 = _beta(beta), self.potential_c1
+            pe = (-b * (1.0 - 8.0 * c1) / 3.0) * ops.su3_plaq_sums_n(xn, self.latvolume)[:, 0]
+            if c1 != 0.0:
+                pe = pe + (-b * c1 / 3.0) * ops.su3_rect_sums_n(xn, self.latvolume)
+            return pe
         s = ops.u1_plaq_sums(xn, self.latvolume)
         return _beta(beta) * (self.volume - s[:, 0])
 

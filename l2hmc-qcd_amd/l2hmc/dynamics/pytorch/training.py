@@ -327,15 +327,25 @@ def _loss_and_seeds_su3(dyn, loss_fn, xn_init, x_prop, v_prop, tape, sumlogdet, 
     ke_p = ops.su3_kinetic_n(v_prop).clone().requires_grad_(True)
     d2 = ops.diff_norm2(x_prop, xn_init).clone().requires_grad_(True)
     sld = sumlogdet.detach().clone().requires_grad_(True)
+    c1 = dyn.potential_c1
+    leaves = [pl_p, ke_p, d2, sld]
+    if c1 != 0.0:                       # rectangle term of the improved action (potential only)
+        rs_p = ops.su3_rect_sums_n(x_prop, lat).clone().requires_grad_(True)
+        leaves.append(rs_p)
     with torch.enable_grad():
-        h_prop = ke_p + (-beta / 3.0) * pl_p[:, :, 0].sum(1)
+        h_prop = ke_p + (-beta * (1.0 - 8.0 * c1) / 3.0) * pl_p[:, :, 0].sum(1)
+        if c1 != 0.0:
+            h_prop = h_prop + (-beta * c1 / 3.0) * rs_p
         dh = tape.h_init.detach() - h_prop + sld
         acc = torch.exp(torch.minimum(dh, torch.zeros_like(dh)))
         loss = loss_fn.loss_from_sums_su3(pl_i, pl_p, d2, acc, nelem=x_prop[0].numel())
-        g_pl, g_ke, g_d2, g_sld = torch.autograd.grad(loss, [pl_p, ke_p, d2, sld], allow_unused=True)
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    g_pl, g_ke, g_d2, g_sld = grads[:4]
     gx = torch.zeros_like(x_prop)
     if g_pl is not None:
         ops.su3_plaq_bwd_(gx, x_prop, g_pl, lat)
+    if c1 != 0.0 and grads[4] is not None:
+        ops.su3_rect_bwd_(gx, x_prop, grads[4], lat)
     if g_d2 is not None:
         ops.diff_bwd_(gx, x_prop, xn_init, g_d2)
     gv = torch.zeros_like(v_prop)

@@ -3,8 +3,8 @@
 The reference builds ~18 lattice-sized temporaries per action call (roll / bmm / stack) and
 gets the force by autograd; here ``action``, ``plaqs`` and the charges come from ONE pass of
 ``l2q_su3_plaq_reduce`` (576 B per chain-site) and the force from ``l2q_su3_force``
-(explicit staples + TAH, 1152 B per chain-site).  Only the c1 == 0 (Wilson) action is built;
-the DBW2 rectangle term (lattice.py:96-112, 180-196) is SURVEY.md 8(f) item 4.
+(explicit staples + TAH, 1152 B per chain-site).  c1 != 0 (Iwasaki / DBW2, lattice.py:83-112,
+180-196) adds ``l2q_su3_rect_reduce`` / ``l2q_su3_rect_force_add`` for the 2x1 rectangles.
 """
 from __future__ import annotations
 
@@ -53,8 +53,6 @@ class LatticeSU3(Lattice):
 
     def __init__(self, nchains: int, shape: list[int], c1: float = 0.0) -> None:
         assert len(shape) == 4
-        if c1 != 0.0:
-            raise NotImplementedError('DBW2 rectangle action (c1 != 0) is not built yet')
         self.g = g.SU3()
         self.nt, self.nx, self.ny, self.nz = shape
         self.c1 = c1
@@ -71,11 +69,26 @@ class LatticeSU3(Lattice):
     def plaq_sums_n(self, xn: Tensor) -> Tensor:
         return ops.su3_plaq_sums_n(xn, self._lattice_shape)
 
+    def rect_sums_n(self, xn: Tensor) -> Tensor:
+        """[nb]: sum Re tr R over the 12 planar 2x1 loops per site (c1 != 0 actions)."""
+        return ops.su3_rect_sums_n(xn, self._lattice_shape)
+
     def action_n(self, xn: Tensor, beta) -> Tensor:
-        return (-_beta(beta) / 3.0) * self.plaq_sums_n(xn)[:, 0]
+        """-(1/3) [beta (1 - 8 c1) sum Re tr P + beta c1 sum Re tr R] (lattice.py:252-269)"""
+        b = _beta(beta)
+        if self.c1 == 0.0:
+            return (-b / 3.0) * self.plaq_sums_n(xn)[:, 0]
+        return (-b * (1.0 - 8.0 * self.c1) / 3.0) * self.plaq_sums_n(xn)[:, 0] \
+            + (-b * self.c1 / 3.0) * self.rect_sums_n(xn)
 
     def grad_action_n(self, xn: Tensor, beta) -> Tensor:
-        return ops.su3_force_n(xn, _beta(beta), self._lattice_shape)
+        """(1/3) TAH(U (c_plaq A_plaq + c_rect A_rect)): staples of the plaquettes and, for
+        c1 != 0, of the 18 rectangles through each link."""
+        b = _beta(beta)
+        if self.c1 == 0.0:
+            return ops.su3_force_n(xn, b, self._lattice_shape)
+        f = ops.su3_force_n(xn, b * (1.0 - 8.0 * self.c1), self._lattice_shape)
+        return ops.su3_rect_force_add_n(xn, b * self.c1 / 3.0, f, self._lattice_shape)
 
     # ------------------------------------------------------------ reference API
     def coeffs(self, beta: Tensor) -> dict[str, Tensor]:
@@ -85,7 +98,10 @@ class LatticeSU3(Lattice):
         return PlaqSums(self.plaq_sums_n(self.pack(x)))
 
     def _wilson_loops(self, x: Tensor, needs_rect: bool = False):
-        return self.wilson_loops(x), None
+        """(plaquette sums, rectangle sum or None): the per-chain reductions of the reference's
+        ([6, ...], [12, ...]) trace fields (lattice.py:157-199)."""
+        xn = self.pack(x)
+        return PlaqSums(self.plaq_sums_n(xn)), (self.rect_sums_n(xn) if needs_rect else None)
 
     def _plaquettes(self, x: Tensor) -> Tensor:
         return self._plaqs(self.wilson_loops(x))
@@ -122,18 +138,42 @@ class LatticeSU3(Lattice):
         return self.g.trace(self._plaquette(x, u, v))
 
     def _plaquette_field(self, x: Tensor, needs_rect: bool = False):
-        if needs_rect:
-            raise NotImplementedError('DBW2 rectangles (c1 != 0) are not built')
+        """matrix fields of the 6 plaquettes (and the 12 rectangles), lattice.py:132-155"""
         plaqs = [self._plaquette(x, u, v) for u in range(1, self.dim) for v in range(u)]
-        return torch.stack(plaqs), None
+        rects = None
+        if needs_rect:
+            rects = []
+            for u in range(1, self.dim):
+                for v in range(u):
+                    rects.extend(self._rectangles(x, u, v))
+            rects = torch.stack(rects)
+        return torch.stack(plaqs), rects
 
-    def _rectangles(self, x: Tensor, u: int, v: int):
-        raise NotImplementedError('DBW2 rectangles (c1 != 0) are not built')
+    def _rectangles(self, x: Tensor, u: int, v: int) -> tuple[Tensor, Tensor]:
+        """The two 2x1 loops of plane (u, v) as matrix fields (lattice.py:96-112): an
+        observables / debugging helper, the sampler only needs rect_sums_n."""
+        x = x.to(DEVICE).reshape(x.shape[0], *self._shape[1:])
+        xu, xv = x[:, u], x[:, v]
+        xuv = self.g.mul(xu, xv.roll(shifts=-1, dims=(u + 1)))
+        xvu = self.g.mul(xv, xu.roll(shifts=-1, dims=(v + 1)))
+        yu = xu.roll(-1, dims=v + 1)
+        yv = xv.roll(-1, dims=u + 1)
+        uu = self.g.mul(xv, xuv, adjoint_a=True)
+        ur = self.g.mul(xu, xvu, adjoint_a=True)
+        ul = self.g.mul(xuv, yu, adjoint_b=True)
+        ud = self.g.mul(xvu, yv, adjoint_b=True)
+        ul_ = ul.roll(-1, dims=u + 1)
+        ud_ = ud.roll(-1, dims=v + 1)
+        return self.g.mul(ur, ul_, adjoint_b=True), self.g.mul(uu, ud_, adjoint_b=True)
 
     def _action(self, wloops, beta: Tensor) -> Tensor:
         """The reference's unused opposite-sign variant (lattice.py:271-285): +coeff sum Re tr P / 3."""
-        ps = wloops[0] if isinstance(wloops, tuple) else wloops
-        return self.coeffs(torch.as_tensor(_beta(beta)))['plaq'] * ps.re / 3.0
+        ps, rs = wloops if isinstance(wloops, tuple) else (wloops, None)
+        c = self.coeffs(torch.as_tensor(_beta(beta)))
+        action = c['plaq'] * ps.re
+        if self.c1 != 0 and rs is not None:
+            action = action + c['rect'] * rs
+        return action / 3.0
 
     def plaq_loss(self, acc: Tensor, x1=None, x2=None, wloops1=None, wloops2=None):
         log.error('TODO')                       # a stub in the reference as well (lattice.py:351-359)
@@ -142,7 +182,7 @@ class LatticeSU3(Lattice):
         log.error('TODO')                       # (lattice.py:361-369)
 
     def action(self, x: Tensor, beta: Tensor) -> Tensor:
-        """-(beta/3) sum Re tr P (lattice.py:252-269)"""
+        """-(1/3) (c_plaq sum Re tr P + c_rect sum Re tr R) (lattice.py:252-269)"""
         return self.action_n(self.pack(x), beta)
 
     def action_with_grad(self, x: Tensor, beta: Tensor) -> tuple[Tensor, Tensor]:

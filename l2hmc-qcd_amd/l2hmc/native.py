@@ -94,6 +94,9 @@ SIGNATURES = {
     'l2q_su3_projsu_vec8_bwd': (I, [P, P, P, L, L, P]),
     'l2q_su3_force_bwd': (I, [P, P, D, P, I, I, I, I, I, P]),
     'l2q_su3_plaq_bwd': (I, [P, P, P, I, I, I, I, I, P]),
+    'l2q_su3_rect_reduce': (I, [P, I, I, I, I, I, P, P, Z, P]),
+    'l2q_su3_rect_force_add': (I, [P, D, P, I, I, I, I, I, P]),
+    'l2q_su3_rect_bwd': (I, [P, P, P, I, I, I, I, I, P]),
     'l2q_v_update_bwd_c128': (I, [P, P, P, P, P, D, I, P, P, I, L, P, P, P, P, P, P, P, Z, P]),
     'l2q_diff_bwd_f64': (I, [P, P, P, I, L, P, P]),
 }

@@ -288,3 +288,81 @@ def grad_action(x: np.ndarray, beta: float) -> np.ndarray:
     Checked against the reference's autograd result to 1.8e-15 (tests/golden).
     """
     return (beta / 3.0) * project_tah(x @ staples(x))
+
+
+# ----------------------------------------------------------------------------- c1 != 0
+def coeffs(beta: float, c1: float) -> dict:
+    """lattice/su3/pytorch/lattice.py:83-91"""
+    return {'plaq': beta * (1.0 - 8.0 * c1), 'rect': beta * c1}
+
+
+def rect_loops(x: np.ndarray) -> np.ndarray:
+    """The two rectangle traces per plane of _wilson_loops(needs_rect=True),
+    lattice/su3/pytorch/lattice.py:180-196 -> [12, nb, T, X, Y, Z] complex, in the reference's
+    order (tr_urul_, tr_uuud_ for (u, v) = (1,0), (2,0), (2,1), (3,0), (3,1), (3,2))."""
+    out = []
+    for u in range(1, 4):
+        for v in range(0, u):
+            xu, xv = x[:, u], x[:, v]
+            yuv = xu @ np.roll(xv, -1, axis=u + 1)
+            yvu = xv @ np.roll(xu, -1, axis=v + 1)
+            yu = np.roll(xu, -1, axis=v + 1)
+            yv = np.roll(xv, -1, axis=u + 1)
+            uu = adj(xv) @ yuv
+            ur = adj(xu) @ yvu
+            ul = yuv @ adj(yu)
+            ud = yvu @ adj(yv)
+            ul_ = np.roll(ul, -1, axis=u + 1)
+            ud_ = np.roll(ud, -1, axis=v + 1)
+            out.append(np.einsum('...ij,...ij->...', ur, np.conj(ul_)))
+            out.append(np.einsum('...ij,...ij->...', uu, np.conj(ud_)))
+    return np.stack(out)
+
+
+def rect_sums(x: np.ndarray) -> np.ndarray:
+    """sum Re tr R per chain (rs.real.sum of lattice.py:262)."""
+    return rect_loops(x).reshape(12, x.shape[0], -1).sum(-1).sum(0).real
+
+
+def action_c1(x: np.ndarray, beta: float, c1: float) -> np.ndarray:
+    """lattice/su3/pytorch/lattice.py:252-269 with c1 != 0."""
+    c = coeffs(beta, c1)
+    re, _ = plaq_sums(x)
+    return (c['plaq'] * re + c['rect'] * rect_sums(x)) * (-1.0 / 3.0)
+
+
+def _shift(f: np.ndarray, hops) -> np.ndarray:
+    """f(x + sum of hops); hops = [(direction, +-n), ...]"""
+    for mu, n in hops:
+        f = np.roll(f, -n, axis=mu + 1)
+    return f
+
+
+def rect_staples(x: np.ndarray) -> np.ndarray:
+    """Sum of the 18 rest-of-loop products of the 2x1 rectangles through each link, oriented so
+    that tr(U_mu(x) A) is the loop (what autograd of sum Re tr R produces, conjugate-transposed)."""
+    a = np.zeros_like(x)
+    for mu in range(4):
+        for nu in range(4):
+            if nu == mu:
+                continue
+            um, un = x[:, mu], x[:, nu]
+            M = lambda *h: _shift(um, h)      # noqa: E731
+            Nn = lambda *h: _shift(un, h)     # noqa: E731
+            m, n = mu, nu
+            s1 = M((m, 1)) @ Nn((m, 2)) @ adj(M((m, 1), (n, 1))) @ adj(M((n, 1))) @ adj(Nn())
+            s2 = Nn((m, 1)) @ adj(M((n, 1))) @ adj(M((m, -1), (n, 1))) @ adj(Nn((m, -1))) @ M((m, -1))
+            s3 = M((m, 1)) @ adj(Nn((m, 2), (n, -1))) @ adj(M((m, 1), (n, -1))) @ adj(M((n, -1))) @ Nn((n, -1))
+            s4 = adj(Nn((m, 1), (n, -1))) @ adj(M((n, -1))) @ adj(M((m, -1), (n, -1))) @ Nn((m, -1), (n, -1)) @ M((m, -1))
+            s5 = Nn((m, 1)) @ Nn((m, 1), (n, 1)) @ adj(M((n, 2))) @ adj(Nn((n, 1))) @ adj(Nn())
+            s6 = adj(Nn((m, 1), (n, -1))) @ adj(Nn((m, 1), (n, -2))) @ adj(M((n, -2))) @ Nn((n, -2)) @ Nn((n, -1))
+            a[:, mu] += s1 + s2 + s3 + s4 + s5 + s6
+    return a
+
+
+def grad_action_c1(x: np.ndarray, beta: float, c1: float) -> np.ndarray:
+    """projectTAH(dS/dx @ x^H) for the improved action (lattice.py:299-308 with c1 != 0):
+    (1/3) TAH( U (c_plaq A_plaq + c_rect A_rect) ).  Pinned to the reference's autograd result
+    in tests/golden/su3_c1.npz."""
+    c = coeffs(beta, c1)
+    return (1.0 / 3.0) * project_tah(x @ (c['plaq'] * staples(x) + c['rect'] * rect_staples(x)))

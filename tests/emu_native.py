@@ -600,6 +600,44 @@ def l2q_su3_plaq_bwd(xn, w, gx, nb, T, X, Y, Z):
     gx.add_(g.reshape(gx.shape))
 
 
+def _su3_rect_sum(x):
+    """x [nb, 4, T, X, Y, Z, 3, 3] -> [nb]: sum Re tr of the 12 planar 2x1 loops per site
+    (lattice/su3/pytorch/lattice.py:180-196, 262)"""
+    tot = 0.0
+    for u in range(4):
+        for v in range(4):
+            if u == v:
+                continue
+            a = x[:, u] @ _roll(x[:, u], u, 1) @ _roll(x[:, v], u, 2)
+            b = x[:, v] @ _roll(x[:, u], v, 1) @ _roll(_roll(x[:, u], v, 1), u, 1)
+            tot = tot + (a * b.conj()).sum((-1, -2)).real.sum((1, 2, 3, 4))
+    return tot
+
+
+def l2q_su3_rect_reduce(xn, nb, T, X, Y, Z, out, ws, wsn):
+    x = _mats(xn.reshape(nb, 4, 9, -1)).reshape(nb, 4, T, X, Y, Z, 3, 3)
+    out.copy_(_su3_rect_sum(x))
+
+
+def _rect_grad(xn, nb, T, X, Y, Z, w):
+    def f(a):
+        x = _mats(a).reshape(nb, 4, T, X, Y, Z, 3, 3)
+        return (w * _su3_rect_sum(x)).sum()
+    (g,) = _vjp(f, [xn.reshape(nb, 4, 9, -1)], [torch.ones(())])
+    return g
+
+
+def l2q_su3_rect_force_add(xn, coef, fn, nb, T, X, Y, Z):
+    # TAH(U A) = -TAH(A^H U^H) with A^H = d(sum Re tr R)/dU in torch's convention
+    g = _mats(_rect_grad(xn, nb, T, X, Y, Z, torch.ones(nb, dtype=torch.float64)))
+    u = _mats(xn.reshape(nb, 4, 9, -1))
+    fn.add_(_native(-coef * _tah(g @ _adj(u))).reshape(fn.shape))
+
+
+def l2q_su3_rect_bwd(xn, w, gx, nb, T, X, Y, Z):
+    gx.add_(_rect_grad(xn, nb, T, X, Y, Z, w.reshape(nb)).reshape(gx.shape))
+
+
 def l2q_v_update_bwd_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, dv, dF, ds, dt, dq,
                           deps, ws, wsn):
     e = torch.full((nb,), float(eps), dtype=torch.float64)

@@ -51,7 +51,7 @@ def state_dict_np(mod, prefix=''):
 
 
 def build_dynamics(group, latvolume, nb, nlf, eps, units, act, conv=None, sep=False,
-                   split=False, bn=False, dropout=0.0, nw=None, verbose=True, seed=0):
+                   split=False, bn=False, dropout=0.0, nw=None, verbose=True, seed=0, c1=0.0):
     seed_all(seed)
     dc = cfgs.DynamicsConfig(nchains=nb, group=group, latvolume=list(latvolume),
                              nleapfrog=nlf, eps=eps, eps_hmc=eps, use_ncp=True,
@@ -71,7 +71,7 @@ def build_dynamics(group, latvolume, nb, nlf, eps, units, act, conv=None, sep=Fa
         dims = {'xnet': {'x': [xdim], 'v': [xdim]}, 'vnet': {'x': [xdim], 'v': [xdim]}}
         from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3 as Lat
     spec = cfgs.InputSpec(xshape=tuple(xshape), **dims)
-    lat = Lat(nb, list(latvolume))
+    lat = Lat(nb, list(latvolume), c1=c1) if c1 else Lat(nb, list(latvolume))
     nf = NetworkFactory(input_spec=spec, network_config=nc, conv_config=cc, net_weights=nws)
     dyn = Dynamics(potential_fn=lat.action, config=dc, network_factory=nf)
     dyn.eval()

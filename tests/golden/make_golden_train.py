@@ -20,9 +20,9 @@ import torch
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 WHICH = sys.argv[1]
-if WHICH in ('f64', 'su3'):
+if WHICH in ('f64', 'su3', 'su3c1'):
     torch.set_default_dtype(torch.float64)
-sys.argv = [sys.argv[0], 'su3' if WHICH in ('f64', 'su3') else 'u1']
+sys.argv = [sys.argv[0], 'su3' if WHICH in ('f64', 'su3', 'su3c1') else 'u1']
 sys.path.insert(0, OUT)
 import make_golden as mg  # noqa: E402  (imports the reference, sets nothing else)
 import l2hmc.configs as cfgs  # noqa: E402
@@ -80,13 +80,14 @@ def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps
     print(f'  {name}: loss {float(loss):.6g} acc {npy(m["acc"])[:6]} |grad| {gn:.4g}')
 
 
-def su3_train_case(name, L, nb, nlf, units, act, beta, seed, bn, loss_cfg, eps=0.006, lr=1e-3):
+def su3_train_case(name, L, nb, nlf, units, act, beta, seed, bn, loss_cfg, eps=0.006, lr=1e-3,
+                   c1=0.0):
     """SU(3): vnet only (the xnet is never called, dynamics.py:1420-1425).  Start near
     equilibrium and pick a draw whose acceptance is not saturated so that the gradient also
     flows through acc.  The reference's train_step begins with compat_proj (projectSU)."""
     from l2hmc.group.su3.pytorch import utils as U
     dyn, lat = mg.build_dynamics('SU3', L, nb, nlf=nlf, eps=eps, units=units, act=act, bn=bn,
-                                 dropout=0.0, seed=seed)
+                                 dropout=0.0, seed=seed, c1=c1)
     mg.perturb(dyn, seed + 1)
     bt = torch.tensor(beta)
     mg.seed_all(seed + 2)
@@ -132,7 +133,7 @@ def su3_train_case(name, L, nb, nlf, units, act, beta, seed, bn, loss_cfg, eps=0
             acc_mask=npy(m['acc_mask']), sumlogdet=npy(m['sumlogdet']), loss=npy(loss), lr=lr,
             charge_weight=loss_cfg.charge_weight, plaq_weight=loss_cfg.plaq_weight,
             rmse_weight=loss_cfg.rmse_weight, use_mixed_loss=loss_cfg.use_mixed_loss,
-            units=np.array(units), activation=act, use_batch_norm=bn,
+            units=np.array(units), activation=act, use_batch_norm=bn, c1=c1,
             # the SU(3) xnet is never called: no gradient, no update -- not stored
             **{'sd.' + k: a for k, a in sd0.items() if 'xnet' not in k},
             **{'sd1.' + k: a for k, a in sd1.items() if 'xnet' not in k},
@@ -147,6 +148,13 @@ if __name__ == '__main__':
         su3_train_case('su3_train', (2, 3, 2, 4), 3, 2, [6], 'tanh', beta=6.0, seed=400, bn=False,
                        loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.05,
                                                 rmse_weight=0.1, plaq_weight=0.1))
+    elif WHICH == 'su3c1':
+        # improved action: rectangles in H (accept probability) only, Wilson force in the
+        # integrator (dynamics.py:134-135); eps small enough for a non-saturated acceptance
+        su3_train_case('su3_train_c1', (2, 3, 2, 4), 3, 2, [6], 'tanh', beta=6.0, seed=430, bn=False,
+                       loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.05,
+                                                rmse_weight=0.1, plaq_weight=0.1),
+                       eps=0.004, c1=-0.331)
     elif WHICH == 'f64':
         train_case('u1_train_f64', (4, 4), 6, 2, [8, 6], 'leaky_relu', None, beta=2.0, seed=300,
                    bn=True, loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.01))

@@ -235,7 +235,7 @@ def build_su3_train_dynamics(g):
     V = int(np.prod(L))
     spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [32 * V], 'v': [32 * V]},
                           vnet={'x': [32 * V], 'v': [32 * V]})
-    lat = LatticeSU3(nb, L)
+    lat = LatticeSU3(nb, L, c1=float(g['c1']) if 'c1' in g else 0.0)
     nf = NetworkFactory(input_spec=spec, network_config=nc, conv_config=cfgs.ConvolutionConfig())
     dyn = Dynamics(potential_fn=lat.action, config=dc, network_factory=nf)
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(g, 'sd.').items()}

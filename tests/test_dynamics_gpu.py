@@ -547,3 +547,54 @@ def test_u1_half_precision_networks(hd, lat, nb, units, act, bn):
     da = (out[hd][0][1] - out[None][0][1]).abs()
     assert float(da.max()) < 400 * ulp, float(da.max())
     assert bool(torch.isfinite(out[hd][0][0]).all())
+
+
+def test_su3_improved_action_c1(golden):
+    """c1 != 0 (lattice/su3/pytorch/lattice.py:83-112, 180-196, 252-308): rectangle sum, action,
+    force of LatticeSU3(c1) against the reference's goldens; Dynamics with the improved action as
+    potential_fn reproduces the reference's plain-HMC transition (rectangles enter H only, the
+    leapfrog force stays the Wilson force -- the reference's own split, dynamics.py:134-135)."""
+    torch.set_default_dtype(torch.float64)
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from oracle import su3 as osu3
+    g = golden('su3_c1')
+    L = [int(i) for i in g['latvolume']]
+    x = dev(g['x'])
+    nb = x.shape[0]
+    beta, c1 = torch.tensor(float(g['beta'])), float(g['c1'])
+    lat = LatticeSU3(nb, L, c1=c1)
+    xn = lat.pack(x)
+    assert err(host(lat.rect_sums_n(xn)), g['rect_sum']) < 1e-11
+    assert err(host(lat.action(x, beta)), g['action']) < 1e-11
+    assert err(host(lat.grad_action(x, beta)), g['force']) < 1e-12
+    s, f = lat.action_with_grad(x, beta)
+    assert err(host(s), g['action']) < 1e-11 and err(host(f), g['force']) < 1e-12
+    ps, rs = lat._wilson_loops(x, needs_rect=True)
+    assert err(host(ps.re), g['plaq_sum']) < 1e-11 and err(host(rs), g['rect_sum']) < 1e-11
+    assert err(host(lat._action((ps, rs), beta)), -g['action']) < 1e-11
+    urul, uuud = lat._rectangles(x, 2, 1)
+    assert err(host(urul), g['rect_21_urul']) < 1e-13 and err(host(uuud), g['rect_21_uuud']) < 1e-13
+    _, rects = lat._plaquette_field(x, needs_rect=True)
+    tr = torch.diagonal(rects, dim1=-2, dim2=-1).sum(-1)
+    assert err(host(tr), g['rects']) < 1e-13
+    # larger, ragged lattice against the oracle (kernel blocks not full, wrap in every direction)
+    L2 = [3, 5, 2, 6]
+    lat2 = LatticeSU3(3, L2, c1=-1.4088)
+    x2 = lat2.random()
+    assert err(host(lat2.action(x2, beta)), osu3.action_c1(host(x2), float(beta), -1.4088)) < 1e-10
+    assert err(host(lat2.grad_action(x2, beta)),
+               osu3.grad_action_c1(host(x2), float(beta), -1.4088)) < 1e-11
+    # Dynamics: improved action in H, Wilson force in the integrator
+    dc = cfgs.DynamicsConfig(nchains=nb, group='SU3', latvolume=L, nleapfrog=2, eps=0.02,
+                             eps_hmc=0.05, use_split_xnets=False, use_separate_networks=False,
+                             verbose=True)
+    dyn = Dynamics(lat.action, dc, None).eval()
+    assert dyn.potential_c1 == c1
+    dyn._inject = {'normals': g['hmc_normals'], 'u': g['hmc_u']}
+    xo, m = dyn.apply_transition_hmc((x, beta), eps=0.05, nleapfrog=3)
+    assert err(host(m['energy']), g['hmc_energy']) < 1e-9
+    assert err(host(m['acc']), g['hmc_acc']) < 1e-9
+    assert np.array_equal(host(m['acc_mask']), g['hmc_acc_mask'])
+    assert err(host(xo), g['hmc_x_out'].reshape(xo.shape)) < 1e-12

@@ -139,3 +139,26 @@ def test_u1(golden, name):
     # angles live on a circle: compare modulo 2 pi
     dx = np.abs(np.angle(np.exp(1j * (xo - g['x_out'].reshape(nb, -1)))))
     assert dx.max() < 2e-3, dx.max()
+
+
+def test_su3_improved_action_c1(golden):
+    """c1 != 0 (Iwasaki / DBW2 rectangles): oracle restatement against the reference's
+    rectangle traces, action and autograd force (tests/golden/make_golden_c1.py)."""
+    g = golden('su3_c1')
+    x, beta, c1 = g['x'], float(g['beta']), float(g['c1'])
+    close(su3.rect_loops(x), g['rects'], 1e-13)
+    close(su3.rect_sums(x), g['rect_sum'], 1e-11)
+    close(su3.plaq_sums(x)[0], g['plaq_sum'], 1e-11)
+    close(su3.action_c1(x, beta, c1), g['action'], 1e-11)
+    close(su3.grad_action_c1(x, beta, c1), g['force'], 1e-12)
+    # c1 -> 0 reduces to the Wilson action / force
+    close(su3.action_c1(x, beta, 0.0), su3.action(x, beta), 1e-12)
+    close(su3.grad_action_c1(x, beta, 0.0), su3.grad_action(x, beta), 1e-13)
+    # the rectangle staples are the derivative of the rectangle sum: finite differences along a
+    # random algebra direction, d/dt sum_R Re tr R (e^{tX} U) = Re tr(X U A)
+    rng = np.random.default_rng(3)
+    X = su3.project_tah(rng.normal(size=x.shape) + 1j * rng.normal(size=x.shape))
+    h = 1e-5
+    fd = (su3.rect_sums(su3.expm(h * X) @ x) - su3.rect_sums(su3.expm(-h * X) @ x)) / (2 * h)
+    an = np.einsum('...ij,...ji->...', X, x @ su3.rect_staples(x)).real.reshape(x.shape[0], -1).sum(1)
+    close(fd, an, 1e-5 * max(1.0, float(np.abs(an).max())))

@@ -90,9 +90,11 @@ def test_trainer_train_loop_host_logic(conv, monkeypatch):
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
-def test_su3_train_step_host_logic(golden, monkeypatch, f64):
-    """SU(3) tape / reverse sweep / loss seeds against the reference's autograd gradients."""
-    g = golden('su3_train')
+@pytest.mark.parametrize('name', ['su3_train', 'su3_train_c1'])
+def test_su3_train_step_host_logic(name, golden, monkeypatch, f64):
+    """SU(3) tape / reverse sweep / loss seeds against the reference's autograd gradients
+    (su3_train_c1: improved action, the rectangle term enters the accept probability)."""
+    g = golden(name)
     emu_native.install(monkeypatch)
     dyn, lat, loss_fn = helpers.build_su3_train_dynamics(g)
     out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-7, atol_rel=1e-6, adam_min_grad=1e-6)
