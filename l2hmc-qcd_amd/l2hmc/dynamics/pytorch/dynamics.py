@@ -108,6 +108,32 @@ def sigmoid(x: torch.Tensor) -> torch.Tensor:
     return 1. / (1. + torch.exp(-x))
 
 
+def to_u1(x: Tensor) -> Tensor:
+    """x wrapped into [-pi, pi) as a U(1) link angle (dynamics.py:76-78)"""
+    return ((x + PI) % TWO_PI) - PI
+
+
+def rand_unif(shape: Sequence[int], a: float, b: float, requires_grad: bool) -> Tensor:
+    """~U[a, b] (dynamics.py:85-93)"""
+    return ((a - b) * torch.rand(tuple(shape)) + b).clone().detach().requires_grad_(requires_grad)
+
+
+def random_angle(shape: Sequence[int], requires_grad: bool = True) -> Tensor:
+    """angles in (-pi, pi) (dynamics.py:96-98)"""
+    return rand_unif(shape, -PI, PI, requires_grad=requires_grad)
+
+
+class Mask:
+    """m / (1 - m) pair with ``combine(x, y) = m x + (1 - m) y`` (dynamics.py:102-110)"""
+
+    def __init__(self, m: Tensor):
+        self.m = m
+        self.mb = torch.ones_like(m) - m
+
+    def combine(self, x: Tensor, y: Tensor) -> Tensor:
+        return self.m * x + self.mb * y
+
+
 def _beta(beta) -> float:
     return float(beta.item()) if isinstance(beta, torch.Tensor) else float(beta)
 

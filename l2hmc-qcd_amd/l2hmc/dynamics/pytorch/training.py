@@ -66,6 +66,13 @@ class ParamArena:
         self.step_count = 0
         ops.PARAM_GENERATION[0] += 1
 
+    def reset_state(self) -> None:
+        """forget the Adam moments and the step counter (a fresh optimiser)"""
+        for g in self.groups.values():
+            g['m'].zero_()
+            g['v'].zero_()
+        self.step_count = 0
+
     def zero_grad(self) -> None:
         for g in self.groups.values():
             g['grad'].zero_()

@@ -24,6 +24,21 @@ class Experiment:
     def build_trainer(self, **kw) -> Trainer:
         return self.trainer
 
+    def set_net_weights(self, net_weights: cfgs.NetWeights) -> None:
+        """Scale the (s, t, q) outputs of every leapfrog network (experiment.py:227-238)."""
+        dyn = self.trainer.dynamics
+        for step in range(self.config.dynamics.nleapfrog):
+            dyn._get_xnet(step, first=True).set_net_weight(net_weights.x)
+            dyn._get_xnet(step, first=False).set_net_weight(net_weights.x)
+            dyn._get_vnet(step).set_net_weight(net_weights.v)
+
+    def visualize_model(self, x: Optional[torch.Tensor] = None):
+        """The reference renders the autograd graph of one xnet / vnet call with torchviz
+        (experiment.py:240-271); the networks here run as HIP kernels without an autograd graph,
+        so there is nothing to draw."""
+        raise NotImplementedError('visualize_model: no autograd graph on the HIP kernel path '
+                                  '(and torchviz is not a dependency)')
+
     def train(self, x: Optional[torch.Tensor] = None, nera: Optional[int] = None,
               nepoch: Optional[int] = None, beta: Optional[float] = None,
               nsteps: Optional[int] = None) -> dict:

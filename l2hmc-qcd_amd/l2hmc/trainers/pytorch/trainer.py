@@ -81,6 +81,67 @@ class Trainer:
         return Dynamics(potential_fn=self.lattice.action, config=self.config.dynamics,
                         network_factory=nf)
 
+    # -- small parts of the reference's Trainer surface (trainer.py:299-308, 473-571, 703-707,
+    #    1254-1264, 1929-1950)
+    def count_parameters(self, model: Optional[torch.nn.Module] = None) -> int:
+        model = self.dynamics if model is None else model
+        return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+    def draw_x(self) -> Tensor:
+        return self.g.random(list(self.config.dynamics.xshape)).flatten(1)
+
+    def draw_v(self) -> Tensor:
+        return self.g.random_momentum(list(self.config.dynamics.xshape))
+
+    def build_loss_fn(self) -> LatticeLoss:
+        return LatticeLoss(lattice=self.lattice, loss_config=self.config.loss)
+
+    def calc_loss(self, xinit: Tensor, xprop: Tensor, acc: Tensor) -> Tensor:
+        return self.loss_fn(xinit, xprop, acc)
+
+    def get_lr(self, step: int) -> float:
+        return self.config.learning_rate.lr_init
+
+    def reset_optimizer(self) -> None:
+        """Drop the Adam moments and the step counter (trainer.py:483-488)."""
+        if self.arena is not None:
+            self.arena.reset_state()
+
+    def should_log(self, epoch: int) -> bool:
+        return epoch % self.config.steps.log == 0 and self._rank_zero()
+
+    def should_print(self, epoch: int) -> bool:
+        return epoch % self.config.steps.print == 0 and self._rank_zero()
+
+    @staticmethod
+    def _rank_zero() -> bool:
+        from l2hmc import RANK
+        return RANK == 0
+
+    def metric_to_numpy(self, metric) -> np.ndarray:
+        if isinstance(metric, float):
+            return np.array(metric)
+        if isinstance(metric, list):
+            if isinstance(metric[0], Tensor):
+                metric = torch.stack(metric)
+            elif isinstance(metric[0], np.ndarray):
+                metric = np.stack(metric)
+            else:
+                raise ValueError(f'Unexpected value encountered: {type(metric)}')
+        if isinstance(metric, Tensor):
+            return metric.detach().cpu().numpy()
+        return np.asarray(metric)
+
+    def train_epoch(self, x: Tensor, beta, era: Optional[int] = None,
+                    nepoch: Optional[int] = None, warmup: bool = True, **kw) -> tuple[Tensor, dict]:
+        """One era at fixed beta: optional thermalisation by HMC, then `nepoch` train steps
+        (trainer.py:1478-1620 without the logging / plotting side effects)."""
+        nepoch = self.config.steps.nepoch if nepoch is None else nepoch
+        if warmup:
+            x = self.warmup(beta=float(beta), x=x)
+        out = self.train(x=x, beta=float(beta), nsteps=nepoch)
+        return out['x'], out['history']
+
     # -- steps
     def _prep(self, x: Tensor) -> Tensor:
         """every step starts with compat_proj (U1: mod 2 pi, SU3: projectSU) trainer.py:915-917"""

@@ -205,3 +205,44 @@ def test_half_precision_eval_host_logic(prec, monkeypatch):
         Trainer(cfgs.get_config(['dynamics.group=SU3', 'dynamics.latvolume=[2,2,2,2]',
                                  'dynamics.nchains=2', 'dynamics.nleapfrog=1',
                                  'network.units=[4]', f'precision={prec}']))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+def test_trainer_small_surface_host_logic(monkeypatch):
+    """count_parameters / draw_x / draw_v / calc_loss / reset_optimizer / train_epoch /
+    Experiment.set_net_weights behave like their reference namesakes."""
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch import dynamics as D
+    from l2hmc.experiment.pytorch.experiment import Experiment
+    emu_native.install(monkeypatch)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = cfgs.get_config(['dynamics.group=U1', 'dynamics.latvolume=[4,4]', 'dynamics.nchains=6',
+                           'dynamics.nleapfrog=2', 'dynamics.verbose=false', 'network.units=[8]',
+                           'network.dropout_prob=0.0', 'network.use_batch_norm=false', 'conv=none',
+                           'steps.nepoch=2'])
+    ex = Experiment(cfg)
+    tr = ex.trainer
+    assert tr.count_parameters() == sum(p.numel() for p in tr.dynamics.parameters())
+    x, v = tr.draw_x(), tr.draw_v()
+    assert x.shape == (6, 32) and float(x.abs().max()) <= np.pi + 1e-6 and v.numel() == 6 * 32
+    assert tr.get_lr(0) == tr.config.learning_rate.lr_init
+    assert isinstance(tr.metric_to_numpy([torch.ones(2), torch.zeros(2)]), np.ndarray)
+    xo, hist = tr.train_epoch(tr.lattice.random(), 2.0, nepoch=2, warmup=False)
+    assert len(hist['loss']) == 2 and tr.arena.step_count == 2
+    tr.reset_optimizer()
+    assert tr.arena.step_count == 0
+    assert all(float(g['m'].abs().max()) == 0.0 for g in tr.arena.groups.values())
+    ex.set_net_weights(cfgs.NetWeights(x=cfgs.NetWeight(0., 0., 0.), v=cfgs.NetWeight(0., 0., 0.)))
+    vnet = tr.dynamics._get_vnet(0)
+    assert (vnet.nw.s, vnet.nw.t, vnet.nw.q) == (0., 0., 0.)
+    tr.dynamics._inject = None
+    _, m = tr.eval_step((xo, 2.0))            # all heads scaled to zero: generic HMC
+    assert float(m['sumlogdet'].abs().max()) < 1e-4
+    with pytest.raises(NotImplementedError):
+        ex.visualize_model()
+    a = D.to_u1(torch.tensor([4.0, -4.0]))
+    assert float(a.abs().max()) <= np.pi
+    assert D.random_angle((3, 2)).shape == (3, 2)
+    mk = D.Mask(torch.tensor([1., 0.]))
+    assert torch.equal(mk.combine(torch.tensor([2., 2.]), torch.tensor([5., 5.])), torch.tensor([2., 5.]))
