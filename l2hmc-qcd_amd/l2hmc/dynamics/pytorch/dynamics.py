@@ -201,6 +201,7 @@ class Dynamics(nn.Module):
         self.potential_c1 = float(getattr(owner, 'c1', 0.0) or 0.0) if self.group == 'SU3' else 0.0
         self.net_precision = None   # torch.float16 / torch.bfloat16: see set_net_precision
         self.fuse_half_heads = True
+        self.merge_hmc_kicks = True  # plain HMC, non-verbose: adjacent half-kicks share one force pass
         self._inject: Optional[dict] = None
         self._eps_cache: dict = {}
         self._masks_native: Optional[list] = None
@@ -858,7 +859,22 @@ class Dynamics(nn.Module):
             eps = 1. / nlf
         nleapfrog = nlf if nleapfrog is None else nleapfrog
         h = h_init
-        for _ in range(nleapfrog):
+        if self.merge_hmc_kicks and not self.config.verbose and nleapfrog > 1:
+            # The closing half-kick of step k and the opening one of step k+1 use the same x:
+            # v - (eps/2) F - (eps/2) F == v - eps F up to one rounding of v, so one force pass
+            # serves both.  nleapfrog + 1 force evaluations instead of 2 nleapfrog.  Only
+            # without per-step metrics (they need v at the step boundary).
+            self._kick_n(x_, v_, beta, -0.5 * eps)
+            for i in range(nleapfrog):
+                if self.group == 'SU3':
+                    ops.su3_expm_mul_n(x_, v_, eps, out=x_)
+                else:
+                    ops.axpy_(x_.reshape(nb, -1), v_, eps)
+                self._kick_n(x_, v_, beta, -eps if i + 1 < nleapfrog else -0.5 * eps)
+            nleapfrog_done = True
+        else:
+            nleapfrog_done = False
+        for _ in range(0 if nleapfrog_done else nleapfrog):
             self._leapfrog_hmc_n(x_, v_, beta, eps)
             if self.config.verbose:
                 h = self._hamiltonian_n(x_, v_, beta)

@@ -598,3 +598,41 @@ def test_su3_improved_action_c1(golden):
     assert err(host(m['acc']), g['hmc_acc']) < 1e-9
     assert np.array_equal(host(m['acc_mask']), g['hmc_acc_mask'])
     assert err(host(xo), g['hmc_x_out'].reshape(xo.shape)) < 1e-12
+
+
+@pytest.mark.parametrize('group', ['SU3', 'U1'])
+def test_hmc_merged_half_kicks_equal_unmerged(group):
+    """Plain HMC without per-step metrics evaluates the force nleapfrog + 1 times (adjacent
+    half-kicks merged) instead of 2 nleapfrog: same trajectory up to one rounding of v per step."""
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    if group == 'SU3':
+        torch.set_default_dtype(torch.float64)
+        L, nb, beta, eps, tol = [4, 2, 2, 4], 3, 6.0, 0.03, 1e-12
+        lat = LatticeSU3(nb, L)
+    else:
+        torch.set_default_dtype(torch.float32)
+        L, nb, beta, eps, tol = [8, 6], 5, 3.0, 0.1, 2e-5
+        lat = LatticeU1(nb, L)
+    dc = cfgs.DynamicsConfig(nchains=nb, group=group, latvolume=L, nleapfrog=3, eps=eps,
+                             eps_hmc=eps, verbose=False, use_split_xnets=False,
+                             use_separate_networks=False)
+    dyn = Dynamics(lat.action, dc, None).eval()
+    torch.manual_seed(2)
+    x = lat.random().to(dyn.device)
+    dyn._inject = None
+    xn = dyn._pack(x)
+    vn = dyn._momentum_n(nb)
+    res = {}
+    for merged in (True, False):
+        dyn.merge_hmc_kicks = merged
+        x_, v_, hist = dyn._kernel_hmc_n(xn, vn, beta, eps=eps, nleapfrog=5)
+        res[merged] = (x_.clone(), v_.clone(), hist['acc'].clone())
+    for a, b in zip(res[True], res[False]):
+        d = a - b
+        if group == 'U1' and a.shape == res[True][0].shape:
+            d = torch.remainder(d + np.pi, 2 * np.pi) - np.pi
+        assert float(d.abs().max()) < tol * max(1.0, float(b.abs().max()))
+    torch.set_default_dtype(torch.float32)
