@@ -226,6 +226,18 @@ int l2q_u1_heads_update_h(int half_type, const void* Z, int M, int K, long N, co
                           int complement, float eps, int forward, int use_ncp, float* logdet,
                           int accumulate, void* ws, size_t ws_bytes, void* stream);
 size_t l2q_u1_heads_update_h_ws_bytes(int M, long N);
+/* Half-precision ConvStack layers (autocast runs nn.Conv2d in 16 bit too, network.py:283-326):
+ * l2q_conv_gemm_periodic_f32's implicit GEMM on the 16-bit MFMA.  in: fp32 (in_is_f32, the first
+ * layer's [cos, sin] lattice data, rounded while staged) or 16-bit; weight [cout][C k k] 16-bit in
+ * (ci, i, j) or, channels_last_cols != 0, (i, j, ci) order; bias fp32; out NHWC 16-bit
+ * = r16(act(r16(conv + bias))).  l2q_maxpool_act_nhwc_h: MaxPool2d(pool) then activation on NHWC
+ * 16-bit data. */
+int l2q_conv_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long sn, long sc, long sh,
+                             long sw, int nb, int C, int H, int W, int k, const void* weight,
+                             int channels_last_cols, const float* bias, int cout, int act,
+                             void* out, void* stream);
+int l2q_maxpool_act_nhwc_h(int half_type, const void* in, int nb, int H, int W, int C, int pool,
+                           int act, void* out, void* stream);
 
 /* ---------------------------------------------------------------- U(1) lattice kernels */
 /* x[nb][2][T][X] angles, elem_bytes 4 or 8.

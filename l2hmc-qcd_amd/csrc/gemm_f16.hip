@@ -565,6 +565,206 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Periodic conv layer of the U(1) ConvStack in half precision (autocast runs nn.Conv2d in 16
+// bit as well): implicit GEMM as gemm.hip's conv_gemm_kernel -- row m of the virtual A operand
+// is output pixel (b, ho, wo), never materialised -- on the 16-bit MFMA.  For the NHWC 16-bit
+// activations of layers 2.. the K order is (i, j, ci) and C % 8 == 0, so a thread gathers eight
+// consecutive input channels with ONE 16-byte load (VEC8); the first layer reads the fp32 NCHW
+// lattice data ([cos, sin] of the links) element-wise and rounds it while staging.
+// Output: NHWC 16-bit, r16(acc + bias) then r16(act(.)) -- autocast's rounding points.
+struct ConvGeomH {
+  long sn, sc, sh, sw;
+  int C, H, W, k, Ho, Wo, Kc;
+  int clast;            // K order: 0 (ci, i, j) -- nn.Conv2d's flatten order, 1 (i, j, ci)
+  long M;
+};
+
+template <typename HT, typename IT, int KS, int BN, bool VEC8>
+__global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __restrict__ in,
+                                                                ConvGeomH g,
+                                                                const HT* __restrict__ Wt, int N,
+                                                                const float* __restrict__ bias,
+                                                                int act, HT* __restrict__ C) {
+  constexpr int BM = 128;
+  constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  using vec_t = typename MfmaH<HT>::vec_t;
+  __shared__ __attribute__((aligned(16))) HT As[BM][HLD];
+  __shared__ __attribute__((aligned(16))) HT Ws[BN][HLD];
+  __shared__ long rbase[BM];
+  __shared__ int rr0[BM], rc0[BM];
+  const int k = KS > 0 ? KS : g.k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
+  const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+  for (int r = tid; r < BM; r += kBlock) {
+    const long m = m0 + r;
+    long base = -1;
+    int r0 = 0, c0 = 0;
+    if (m < g.M) {
+      const int wo = (int)(m % g.Wo);
+      const long t = m / g.Wo;
+      const int ho = (int)(t % g.Ho);
+      base = (t / g.Ho) * g.sn;
+      r0 = (ho - (k - 1)) % g.H; if (r0 < 0) r0 += g.H;
+      c0 = (wo - (k - 1)) % g.W; if (c0 < 0) c0 += g.W;
+    }
+    rbase[r] = base; rr0[r] = r0; rc0[r] = c0;
+  }
+  __syncthreads();
+
+  v4f32 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (v4f32){0, 0, 0, 0};
+
+  // A gather: VEC8: 8 threads x 8 channels per row, 32 rows per pass; else 64 threads x 1 column
+  constexpr int AV = VEC8 ? 8 : 1;
+  constexpr int ARPP = kBlock / (HBK / AV), ANP = BM / ARPP;      // 32 rows x 4 or 4 rows x 32
+  typedef HT av_t __attribute__((ext_vector_type(AV)));
+  av_t areg[ANP];
+  const int akv = (tid % (HBK / AV)) * AV, arq = tid / (HBK / AV);
+#define L2Q_CONVH_FETCH_A(K0)                                                           \
+  do {                                                                                  \
+    const long kk_ = (K0) + akv;                                                        \
+    const bool kin_ = kk_ < g.Kc;                                                       \
+    int j_, i_, ci_;                                                                    \
+    if (g.clast) { ci_ = (int)(kk_ % g.C); const int ij_ = (int)(kk_ / g.C); j_ = ij_ % k; i_ = ij_ / k; } \
+    else { j_ = (int)(kk_ % k); const int ij_ = (int)(kk_ / k); i_ = ij_ % k; ci_ = ij_ / k; }   \
+    const long coff_ = (long)ci_ * g.sc;                                                \
+    _Pragma("unroll") for (int p = 0; p < ANP; ++p) {                                   \
+      const int row_ = arq + p * ARPP;                                                  \
+      const long base_ = rbase[row_];                                                   \
+      av_t v_;                                                                          \
+      _Pragma("unroll") for (int e = 0; e < AV; ++e) v_[e] = (HT)0.f;                   \
+      if (kin_ && base_ >= 0) {                                                         \
+        int r_ = rr0[row_] + i_; if (r_ >= g.H) r_ -= g.H; if (r_ >= g.H) r_ %= g.H;    \
+        int c_ = rc0[row_] + j_; if (c_ >= g.W) c_ -= g.W; if (c_ >= g.W) c_ %= g.W;    \
+        const IT* src_ = in + base_ + coff_ + r_ * g.sh + c_ * g.sw;                    \
+        if (VEC8) v_ = *reinterpret_cast<const av_t*>(src_);                            \
+        else v_[0] = (HT)(float)src_[0];                                                \
+      }                                                                                 \
+      areg[p] = v_;                                                                     \
+    }                                                                                   \
+  } while (0)
+  TileH<HT, HT, BN> lw;
+  const bool vecw = (g.Kc % 8) == 0;
+  L2Q_CONVH_FETCH_A(0);
+  lw.fetch(Wt, Wt, n0, N, 0, g.Kc, 0, g.Kc, vecw);
+  for (long k0 = 0; k0 < g.Kc; k0 += HBK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < ANP; ++p) *reinterpret_cast<av_t*>(&As[arq + p * ARPP][akv]) = areg[p];
+    lw.store(Ws);
+    __syncthreads();
+    if (k0 + HBK < g.Kc) {
+      L2Q_CONVH_FETCH_A(k0 + HBK);
+      lw.fetch(Wt, Wt, n0, N, k0 + HBK, g.Kc, 0, g.Kc, vecw);
+    }
+#pragma unroll
+    for (int ks = 0; ks < HBK; ks += 32) {
+      const int kq = ks + 8 * (lane >> 4);
+      vec_t fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        fa[i] = *reinterpret_cast<const vec_t*>(&As[wm + 16 * i + (lane & 15)][kq]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        fb[j] = *reinterpret_cast<const vec_t*>(&Ws[wn + 16 * j + (lane & 15)][kq]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = MfmaH<HT>::run(fb[j], fa[i], acc[i][j]);
+    }
+  }
+#undef L2Q_CONVH_FETCH_A
+  // W was the MFMA row operand: lane owns pixel m = lane & 15 of tile i, channels 4 (lane >> 4) + r
+  const bool vecc = (N % 4) == 0;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
+    if (nb4 >= N) continue;
+    float cb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cb[r] = bias ? bias[nb4 + r < N ? nb4 + r : N - 1] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const long m = m0 + wm + 16 * i + (lane & 15);
+      if (m >= g.M) continue;
+      typedef HT cv __attribute__((ext_vector_type(4)));
+      cv o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (HT)epilogue_h<HT>(acc[i][j][r], cb[r], 1.f, false, act);
+      HT* dst = C + m * N + nb4;
+      if (vecc) *reinterpret_cast<cv*>(dst) = o;
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = o[r];
+      }
+    }
+  }
+}
+
+// out[b, ho, wo, c] = r16(act(max over the pool x pool window of in[b, ., ., c])), NHWC 16-bit
+template <typename HT>
+__global__ __launch_bounds__(kBlock) void maxpool_act_nhwc_h_kernel(const HT* __restrict__ in, int H,
+                                                                    int W, int C, int pool, int act,
+                                                                    int Ho, int Wo, long total,
+                                                                    HT* __restrict__ out) {
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  long t = idx / C;
+  const int wo = (int)(t % Wo); t /= Wo;
+  const int ho = (int)(t % Ho);
+  const long b = t / Ho;
+  float m = -INFINITY;
+  for (int i = 0; i < pool; ++i)
+    for (int j = 0; j < pool; ++j)
+      m = fmaxf(m, (float)in[((b * H + ho * pool + i) * W + wo * pool + j) * C + c]);
+  out[idx] = (HT)act_h(m, act);
+}
+
+template <typename HT, typename IT>
+static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const float* bias, int cout,
+                         int act, void* out_, hipStream_t st) {
+  const IT* in = (const IT*)in_;
+  const HT* weight = (const HT*)w_;
+  HT* out = (HT*)out_;
+  const int bn = cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
+  const dim3 grid((unsigned)cdiv(cout, bn), (unsigned)cdiv(g.M, 128)), block(kBlock);
+  // 16-byte channel gathers: 16-bit NHWC input, (i, j, ci) order, C % 8 == 0, aligned
+  const bool vec8 = sizeof(IT) == 2 && g.clast && g.sc == 1 && g.C % 8 == 0 && g.sw % 8 == 0 &&
+                    g.sh % 8 == 0 && g.sn % 8 == 0 && al16(in);
+#define L2Q_CHB(KS, BNV)                                                                         \
+  do {                                                                                           \
+    if (vec8)                                                                                    \
+      hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, sizeof(IT) == 2>), grid, block, 0, \
+                         st, in, g, weight, cout, bias, act, out);                               \
+    else                                                                                         \
+      hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, false>), grid, block, 0, st, in,   \
+                         g, weight, cout, bias, act, out);                                       \
+  } while (0)
+#define L2Q_CH(KS)                                                     \
+  do {                                                                 \
+    if (bn == 32) L2Q_CHB(KS, 32);                                     \
+    else if (bn == 64) L2Q_CHB(KS, 64);                                \
+    else L2Q_CHB(KS, 128);                                             \
+  } while (0)
+  switch (g.k) {
+    case 2: L2Q_CH(2); break;
+    case 3: L2Q_CH(3); break;
+    case 5: L2Q_CH(5); break;
+    default: L2Q_CH(0); break;
+  }
+#undef L2Q_CH
+#undef L2Q_CHB
+  return check_launch("l2q_conv_gemm_periodic_h");
+}
+
 __global__ void cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int n,
                                     int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,6 +863,49 @@ int l2q_u1_heads_update_h(int half_type, const void* Z, int M, int K, long N, co
   if (half_type == L2Q_HALF_F16)
     return heads_h_launch<_Float16>(h, x_update, forward, use_ncp, logdet, accumulate, ws, st);
   return heads_h_launch<__bf16>(h, x_update, forward, use_ncp, logdet, accumulate, ws, st);
+}
+
+int l2q_conv_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long sn, long sc, long sh,
+                             long sw, int nb, int C, int H, int W, int k, const void* weight,
+                             int channels_last_cols, const float* bias, int cout, int act,
+                             void* out, void* stream) {
+  L2Q_REQUIRE(in && weight && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0 && cout > 0, L2Q_EINVAL,
+              "non-positive size");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
+  ConvGeomH g;
+  g.sn = sn; g.sc = sc; g.sh = sh; g.sw = sw; g.C = C; g.H = H; g.W = W; g.k = k;
+  g.Ho = H + k - 1; g.Wo = W + k - 1; g.Kc = C * k * k;
+  g.clast = channels_last_cols ? 1 : 0;
+  g.M = (long)nb * g.Ho * g.Wo;
+  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16, L2Q_ESHAPE, "too many output pixels");
+  const hipStream_t st = (hipStream_t)stream;
+  if (half_type == L2Q_HALF_F16) {
+    return in_is_f32 ? conv_h_launch<_Float16, float>(in, g, weight, bias, cout, act, out, st)
+                     : conv_h_launch<_Float16, _Float16>(in, g, weight, bias, cout, act, out, st);
+  }
+  return in_is_f32 ? conv_h_launch<__bf16, float>(in, g, weight, bias, cout, act, out, st)
+                   : conv_h_launch<__bf16, __bf16>(in, g, weight, bias, cout, act, out, st);
+}
+
+int l2q_maxpool_act_nhwc_h(int half_type, const void* in, int nb, int H, int W, int C, int pool,
+                           int act, void* out, void* stream) {
+  L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && H > 0 && W > 0 && C > 0 && pool > 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
+  const int Ho = H / pool, Wo = W / pool;
+  L2Q_REQUIRE(Ho > 0 && Wo > 0, L2Q_ESHAPE, "pooling window larger than the image");
+  const long total = (long)nb * Ho * Wo * C;
+  const dim3 grid((unsigned)cdiv(total, kBlock)), block(kBlock);
+  const hipStream_t st = (hipStream_t)stream;
+  if (half_type == L2Q_HALF_F16)
+    hipLaunchKernelGGL(maxpool_act_nhwc_h_kernel<_Float16>, grid, block, 0, st, (const _Float16*)in,
+                       H, W, C, pool, act, Ho, Wo, total, (_Float16*)out);
+  else
+    hipLaunchKernelGGL(maxpool_act_nhwc_h_kernel<__bf16>, grid, block, 0, st, (const __bf16*)in, H, W,
+                       C, pool, act, Ho, Wo, total, (__bf16*)out);
+  return check_launch("l2q_maxpool_act_nhwc_h");
 }
 
 }  // extern "C"

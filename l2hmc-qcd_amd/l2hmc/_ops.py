@@ -490,6 +490,37 @@ def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch
     return out
 
 
+def conv2d_periodic_gemm_h(x: torch.Tensor, layout: str, w16: torch.Tensor, b: torch.Tensor,
+                           pool: int = 1, act: Optional[str] = None) -> torch.Tensor:
+    """Half-precision PeriodicPadding(k-1) -> Conv2d(k) -> [MaxPool2d] -> [act] (include/l2q.h:
+    l2q_conv_gemm_periodic_h).  x: fp32 or 16-bit, [nb, C, H, W] ('nchw') or [nb, H, W, C]
+    ('nhwc'); w16: 16-bit weight, [cout, C, k, k] for 'nchw' input, [cout, k, k, C] for 'nhwc'
+    input; b fp32.  Returns NHWC 16-bit."""
+    x = x.contiguous()
+    hd = w16.dtype
+    if layout == 'nchw':
+        nb, C, H, W = x.shape
+        sn, sc, sh, sw = C * H * W, H * W, W, 1
+        cout, cin, k, _ = w16.shape
+    else:
+        nb, H, W, C = x.shape
+        sn, sc, sh, sw = H * W * C, 1, W * C, C
+        cout, k, _, cin = w16.shape
+    if cin != C or hd not in HALF_TYPES or x.dtype not in (hd, torch.float32):
+        raise N.L2QError(f'conv2d_periodic_gemm_h: x {tuple(x.shape)} {x.dtype}, w {tuple(w16.shape)} {hd}')
+    Ho, Wo = H + k - 1, W + k - 1
+    pool = max(int(pool), 1)
+    y = torch.empty((nb * Ho * Wo, cout), dtype=hd, device=x.device)
+    N.call('l2q_conv_gemm_periodic_h', HALF_TYPES[hd], x, int(x.dtype == torch.float32), sn, sc, sh,
+           sw, nb, C, H, W, k, w16.reshape(cout, -1).contiguous(), int(layout != 'nchw'),
+           b.contiguous(), cout, N.ACT[None if pool > 1 else act], y)
+    if pool == 1:
+        return y.reshape(nb, Ho, Wo, cout)
+    out = torch.empty((nb, Ho // pool, Wo // pool, cout), dtype=hd, device=x.device)
+    N.call('l2q_maxpool_act_nhwc_h', HALF_TYPES[hd], y, nb, Ho, Wo, cout, pool, N.ACT[act], out)
+    return out
+
+
 def _fused_net_args(fw: dict):
     """Network part of the fused-kernel argument list, marshalled once per weight version (the
     tensors stay referenced by `fw`; device pointers are passed as plain ints)."""

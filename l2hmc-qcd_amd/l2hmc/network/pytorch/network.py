@@ -221,11 +221,53 @@ class ConvStack(nn.Module):
             self._wcache[ci] = hit
         return hit[1]
 
+    def _half_weights(self, hd: torch.dtype) -> dict:
+        """16-bit copies for the half-precision path, cached per weight version: conv weights in
+        the K order of their input layout, biases rounded like autocast does, and the Linear
+        weight with its input columns permuted from the reference's NCHW flatten order to NHWC
+        (so the activations need no transposition)."""
+        lin = self.layers[self.linear_index]
+        ver = tuple(self.layers[ci].weight._version for ci, *_ in self.plan) + \
+            (lin.weight._version, lin.bias._version, ops.PARAM_GENERATION[0], hd)
+        hit = self._wcache.get('half')
+        if hit is not None and hit['ver'] == ver:
+            return hit
+        r16 = lambda t: t.detach().to(hd).float().contiguous()
+        convs = []
+        for n, (ci, k, pool, act) in enumerate(self.plan):
+            w = self.layers[ci].weight.detach()
+            w16 = w.to(hd).contiguous() if n == 0 else w.permute(0, 2, 3, 1).to(hd).contiguous()
+            convs.append((w16, r16(self.layers[ci].bias)))
+        h, w_ = self.nt, self.nx
+        c = self.in_channels
+        for ci, k, pool, act in self.plan:
+            h, w_, c = (h + k - 1) // pool, (w_ + k - 1) // pool, self.layers[ci].out_channels
+        wl = lin.weight.detach()
+        if self.plan:                               # [out, C, H, W] -> [out, H, W, C]
+            wl = wl.reshape(wl.shape[0], c, h, w_).permute(0, 2, 3, 1).reshape(wl.shape[0], -1)
+        hit = {'ver': ver, 'convs': convs, 'lin': (wl.to(hd).contiguous(), r16(lin.bias))}
+        self._wcache['half'] = hit
+        return hit
+
+    def _forward_half(self, x: Tensor, hd: torch.dtype) -> Tensor:
+        """autocast's view of this stack: Conv2d / Linear in 16 bit, fp32 accumulation.  Returns
+        the fp32 container of the 16-bit result (it is the fp32-typed `x` input of the
+        LeapfrogLayer's first GEMM, which rounds on load: exact)."""
+        hw = self._half_weights(hd)
+        layout = 'nchw'
+        for (ci, k, pool, act), (w16, b) in zip(self.plan, hw['convs']):
+            x = ops.conv2d_periodic_gemm_h(x, layout, w16, b, pool, act)
+            layout = 'nhwc'
+        wl, bl = hw['lin']
+        return ops.gemm_h(x.reshape(x.shape[0], -1), wl, bl, act=self.act, out_dtype=torch.float32)
+
     def forward(self, x: Tensor) -> Tensor:
         x = x.to(DEVICE)
         x = x.reshape(x.shape[0], self.in_channels, self.nt, self.nx).contiguous()
         if x.dtype != torch.float32:
             raise NotImplementedError('the conv kernels are fp32 (the U(1) configs)')
+        if getattr(self, 'half_dtype', None) is not None:
+            return self._forward_half(x, self.half_dtype)
         # implicit GEMM: periodic im2col -> f32 MFMA GEMM (NHWC activations) -> pool + act
         layout = 'nchw'
         for ci, k, pool, act in self.plan:
@@ -379,6 +421,8 @@ class LeapfrogLayer(nn.Module):
         if half is not None and self.transl.weight.dtype != torch.float32:
             raise ValueError('half-precision layers need fp32 master weights (the U(1) configs)')
         self.half_dtype = half
+        if isinstance(self.input_layer.conv_stack, ConvStack):
+            self.input_layer.conv_stack.half_dtype = half
 
     def kernel_weights(self, in_perm: Optional[Tensor] = None,
                        out_perm: Optional[Tensor] = None) -> dict:

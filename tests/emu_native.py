@@ -655,6 +655,25 @@ def l2q_diff_bwd_f64(x, y, a, nb, n, gx):
     gx.add_((2.0 * a.reshape(nb, 1) * (x.reshape(nb, n) - y.reshape(nb, n))).reshape(gx.shape))
 
 
+def l2q_conv_gemm_periodic_h(ht, x, x32, sn, sc, sh, sw, nb, C, H, W, k, w, clast, b, cout, act, out):
+    hd = torch.float16 if ht == 0 else torch.bfloat16
+    r16 = lambda t: t.to(hd).float()
+    col = _im2col(r16(_as_nchw(x.float(), sn, sc, sh, sw, nb, C, H, W)), k)
+    w = w.float()
+    w = w.reshape(cout, k, k, C).permute(0, 3, 1, 2) if clast else w.reshape(cout, C, k, k)
+    y = r16(col @ w.reshape(cout, -1).T + b)
+    if act:
+        y = r16(_act(y, act))
+    out.copy_(y.reshape(out.shape).to(out.dtype))
+
+
+def l2q_maxpool_act_nhwc_h(ht, y, nb, H, W, C, pool, act, out):
+    hd = torch.float16 if ht == 0 else torch.bfloat16
+    y4 = y.float().reshape(nb, H, W, C).permute(0, 3, 1, 2)
+    o = _act(torch.nn.functional.max_pool2d(y4, pool), act).permute(0, 2, 3, 1)
+    out.copy_(o.to(hd).reshape(out.shape))
+
+
 def l2q_u1_heads_update_h(ht, Z, M, K, N, Ws, bs, cs, Wt, bt, scale_t, Wq, bq, cq, xupd, a, b, mask,
                           complement, eps, forward, ncp, logdet, accumulate, ws, wsn):
     sv, tv, qv = (torch.empty(M, N) for _ in range(3))

@@ -636,3 +636,50 @@ def test_hmc_merged_half_kicks_equal_unmerged(group):
             d = torch.remainder(d + np.pi, 2 * np.pi) - np.pi
         assert float(d.abs().max()) < tol * max(1.0, float(b.abs().max()))
     torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('hd', ['fp16', 'bf16'])
+def test_u1_half_precision_conv_stack(hd):
+    """precision = fp16 | bf16 with the default-style conv stack in front of the xnet / vnet:
+    the 16-bit conv path equals the fp32 conv path to half precision, a whole trajectory runs
+    and is deterministic."""
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    lat, nb = (16, 16), 24
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=list(lat), nleapfrog=2, eps=0.1,
+                             eps_hmc=0.1, verbose=False)
+    nc = cfgs.NetworkConfig(units=[16, 16], activation_fn='leaky_relu', dropout_prob=0.0,
+                            use_batch_norm=True)
+    cc = cfgs.ConvolutionConfig(filters=[8, 16, 32, 64, 128], sizes=[5, 3, 3, 3, 2],
+                                pool=[2, 2, 2, 2, 2])
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                          vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+    latt = LatticeU1(nb, list(lat))
+    dyn = Dynamics(latt.action, dc, NetworkFactory(spec, nc, cc)).eval()
+    x0 = latt.random().to(dyn.device)
+    ulp = 2.0 ** -10 if hd == 'fp16' else 2.0 ** -7
+    cs = dyn._get_vnet(0).input_layer.conv_stack
+    want = cs(x0)
+    dyn.set_net_precision(hd)
+    assert cs.half_dtype is not None
+    got = cs(x0)
+    assert got.dtype == torch.float32 and got.shape == want.shape
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) < 60 * ulp * scale, float((got - want).abs().max())
+    out = []
+    for _ in range(2):
+        nrm = torch.randn(nb, dc.xdim, generator=torch.Generator().manual_seed(3))
+        dyn._inject = {'normals': nrm.numpy(), 'u': np.full(nb, 0.5, dtype=np.float32)}
+        xo, m = dyn((x0, torch.tensor(2.5)))
+        out.append((xo.clone(), m['acc'].clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert bool(torch.isfinite(out[0][0]).all())
+    dyn.set_net_precision(None)
+    dyn._inject = {'normals': nrm.numpy(), 'u': np.full(nb, 0.5, dtype=np.float32)}
+    xo32, m32 = dyn((x0, torch.tensor(2.5)))
+    assert float((m32['acc'] - out[0][1]).abs().max()) < 600 * ulp

@@ -429,3 +429,49 @@ def test_u1_heads_update_h(hd, dims):
                 assert float((d.abs() > 1e-5 * scale).float().mean()) < 0.2
                 dl = (ld.cpu() - 0.5 - want_ld).abs().max()
                 assert float(dl) < 4 * ulp * n ** 0.5 + 1e-4 * max(1.0, float(want_ld.abs().max()))
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+@pytest.mark.parametrize('dims', [(3, 4, 4, 6, 5, 8), (2, 8, 6, 6, 3, 16), (5, 16, 7, 5, 3, 32),
+                                  (2, 64, 4, 4, 2, 128), (130, 4, 8, 8, 3, 3), (1, 3, 2, 3, 3, 5),
+                                  (3, 32, 9, 9, 3, 64)])
+def test_conv_gemm_periodic_h(hd, layout, dims):
+    """l2q_conv_gemm_periodic_h (+ l2q_maxpool_act_nhwc_h) against the emulator's restatement
+    (16-bit rounded operands, fp32 accumulation, autocast rounding points) -- fp32 NCHW input
+    (first layer) and 16-bit NHWC input with the 16-byte channel gathers (C % 8 == 0) or the
+    element-wise fallback."""
+    import emu_native
+    from l2hmc import _ops as ops
+    nb, C, H, W, k, cout = dims
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(nb, C, H, W, generator=g)
+    w = torch.randn(cout, C, k, k, generator=g) / (C * k * k) ** 0.5
+    b = torch.randn(cout, generator=g).to(hd).float()
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    if layout == 'nchw':
+        xin, w16 = x, w.to(hd)
+        strides = (C * H * W, H * W, W, 1)
+    else:
+        xin, w16 = x.permute(0, 2, 3, 1).contiguous().to(hd), w.permute(0, 2, 3, 1).contiguous().to(hd)
+        strides = (H * W * C, 1, W * C, C)
+    Ho, Wo = H + k - 1, W + k - 1
+    for pool, act in ((1, None), (1, 'leaky_relu'), (2, 'relu'), (2, 'tanh')):
+        if Ho // pool == 0 or Wo // pool == 0:
+            continue
+        got = ops.conv2d_periodic_gemm_h(xin.cuda(), layout, w16.cuda(), b.cuda(), pool, act)
+        y = torch.empty(nb * Ho * Wo, cout, dtype=hd)
+        emu_native.l2q_conv_gemm_periodic_h(ops.HALF_TYPES[hd], xin, int(layout == 'nchw'), *strides,
+                                            nb, C, H, W, k, w16.reshape(cout, -1),
+                                            int(layout != 'nchw'), b, cout,
+                                            N_ACT[None if pool > 1 else act], y)
+        want = y.reshape(nb, Ho, Wo, cout)
+        if pool > 1:
+            want = torch.empty(nb, Ho // pool, Wo // pool, cout, dtype=hd)
+            emu_native.l2q_maxpool_act_nhwc_h(ops.HALF_TYPES[hd], y, nb, Ho, Wo, cout, pool,
+                                              N_ACT[act], want)
+        assert got.shape == want.shape and got.dtype == hd
+        d = (got.cpu().float() - want.float()).abs()
+        tol = 2.5 * ulp * want.float().abs().clamp(min=1.0)
+        assert bool((d <= tol).all()), (pool, act, float((d / tol).max()))
+        assert float((d > 0).float().mean()) < 0.2
