@@ -238,6 +238,10 @@ int l2q_conv_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long 
                              void* out, void* stream);
 int l2q_maxpool_act_nhwc_h(int half_type, const void* in, int nb, int H, int W, int C, int pool,
                            int act, void* out, void* stream);
+/* out[b][h][w][c] = c < C ? r16(in[b][c][h][w]) : 0 for c < cpad: the fp32 NCHW lattice input of
+ * the first conv layer as 16-bit NHWC with the channels padded to a 16-byte group. */
+int l2q_nchw_to_nhwc_pad_h(int half_type, const float* in, int nb, int C, int H, int W, int cpad,
+                           void* out, void* stream);
 
 /* ---------------------------------------------------------------- U(1) lattice kernels */
 /* x[nb][2][T][X] angles, elem_bytes 4 or 8.

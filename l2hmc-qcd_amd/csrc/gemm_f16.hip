@@ -586,7 +586,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
                                                                 ConvGeomH g,
                                                                 const HT* __restrict__ Wt, int N,
                                                                 const float* __restrict__ bias,
-                                                                int act, HT* __restrict__ C) {
+                                                                int act, HT* __restrict__ C,
+                                                                int dbg) {
   constexpr int BM = 128;
   constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   __shared__ __attribute__((aligned(16))) HT Ws[BN][HLD];
   __shared__ long rbase[BM];
   __shared__ int rr0[BM], rc0[BM];
+  __shared__ __attribute__((aligned(16))) HT Cs[BM * BN];      // output tile, row stride N <= BN
   const int k = KS > 0 ? KS : g.k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
       const long base_ = rbase[row_];                                                   \
       av_t v_;                                                                          \
       _Pragma("unroll") for (int e = 0; e < AV; ++e) v_[e] = (HT)0.f;                   \
-      if (kin_ && base_ >= 0) {                                                         \
+      if (kin_ && base_ >= 0 && dbg != 2) {                                             \
         int r_ = rr0[row_] + i_; if (r_ >= g.H) r_ -= g.H; if (r_ >= g.H) r_ %= g.H;    \
         int c_ = rc0[row_] + j_; if (c_ >= g.W) c_ -= g.W; if (c_ >= g.W) c_ %= g.W;    \
         const IT* src_ = in + base_ + coff_ + r_ * g.sh + c_ * g.sw;                    \
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   const bool vecw = (g.Kc % 8) == 0;
   L2Q_CONVH_FETCH_A(0);
   lw.fetch(Wt, Wt, n0, N, 0, g.Kc, 0, g.Kc, vecw);
-  for (long k0 = 0; k0 < g.Kc; k0 += HBK) {
+  for (long k0 = 0; k0 < (dbg >= 3 ? 0 : g.Kc); k0 += HBK) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < ANP; ++p) *reinterpret_cast<av_t*>(&As[arq + p * ARPP][akv]) = areg[p];
@@ -682,7 +684,22 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   }
 #undef L2Q_CONVH_FETCH_A
   // W was the MFMA row operand: lane owns pixel m = lane & 15 of tile i, channels 4 (lane >> 4) + r
+  if (dbg == 1 || dbg == 4) {
+    float x = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) x += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (x == 12345.f) C[0] = (HT)x;
+    return;
+  }
+  // One N-tile (cout <= BN, every layer of the default stack): the workgroup's output
+  // C[m0 .. m0+127][0 .. N) is ONE contiguous range of memory.  The lanes' 4-channel pieces
+  // (8 bytes, 32-byte runs per wavefront store: ~1.2 TB/s measured) are therefore assembled in
+  // LDS and written as a flat 16-byte-per-lane stream.
+  const bool staged = BN == 128 && gridDim.x == 1 && (N % 8) == 0;   // narrower tiles: no gain measured
   const bool vecc = (N % 4) == 0;
+  if (staged) __syncthreads();                       // all fragment reads of As / Ws are done
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
@@ -692,12 +709,17 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
     for (int r = 0; r < 4; ++r) cb[r] = bias ? bias[nb4 + r < N ? nb4 + r : N - 1] : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const long m = m0 + wm + 16 * i + (lane & 15);
+      const int ml = wm + 16 * i + (lane & 15);
+      const long m = m0 + ml;
       if (m >= g.M) continue;
       typedef HT cv __attribute__((ext_vector_type(4)));
       cv o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (HT)epilogue_h<HT>(acc[i][j][r], cb[r], 1.f, false, act);
+      if (staged) {
+        *reinterpret_cast<cv*>(&Cs[(long)ml * N + nb4]) = o;
+        continue;
+      }
       HT* dst = C + m * N + nb4;
       if (vecc) *reinterpret_cast<cv*>(dst) = o;
       else {
@@ -706,26 +728,60 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
       }
     }
   }
+  if (staged) {
+    __syncthreads();
+    const long rows = g.M - m0 < BM ? g.M - m0 : BM;
+    const long total = rows * N;                      // halves, multiple of 8
+    typedef HT v8 __attribute__((ext_vector_type(8)));
+    HT* dst = C + m0 * N;
+    for (long idx = (long)tid * 8; idx < total; idx += (long)kBlock * 8)
+      *reinterpret_cast<v8*>(dst + idx) = *reinterpret_cast<const v8*>(&Cs[idx]);
+  }
 }
 
-// out[b, ho, wo, c] = r16(act(max over the pool x pool window of in[b, ., ., c])), NHWC 16-bit
-template <typename HT>
+// out[b, ho, wo, c] = r16(act(max over the pool x pool window of in[b, ., ., c])), NHWC 16-bit.
+// VEC channels per thread (8 = one 16-byte access when C % 8 == 0, else 1).
+template <typename HT, int VEC>
 __global__ __launch_bounds__(kBlock) void maxpool_act_nhwc_h_kernel(const HT* __restrict__ in, int H,
                                                                     int W, int C, int pool, int act,
                                                                     int Ho, int Wo, long total,
                                                                     HT* __restrict__ out) {
-  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  typedef HT hv __attribute__((ext_vector_type(VEC)));
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;     // over [b, ho, wo, C / VEC]
   if (idx >= total) return;
-  const int c = (int)(idx % C);
-  long t = idx / C;
+  const int cv = C / VEC;
+  const int c = (int)(idx % cv) * VEC;
+  long t = idx / cv;
   const int wo = (int)(t % Wo); t /= Wo;
   const int ho = (int)(t % Ho);
   const long b = t / Ho;
-  float m = -INFINITY;
+  float m[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) m[e] = -INFINITY;
   for (int i = 0; i < pool; ++i)
-    for (int j = 0; j < pool; ++j)
-      m = fmaxf(m, (float)in[((b * H + ho * pool + i) * W + wo * pool + j) * C + c]);
-  out[idx] = (HT)act_h(m, act);
+    for (int j = 0; j < pool; ++j) {
+      const hv v = *reinterpret_cast<const hv*>(in + ((b * H + ho * pool + i) * W + wo * pool + j) * C + c);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+    }
+  hv o;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) o[e] = (HT)act_h(m[e], act);
+  *reinterpret_cast<hv*>(out + ((b * Ho + ho) * Wo + wo) * (long)C + c) = o;
+}
+
+// fp32 NCHW -> 16-bit NHWC with the channel count padded to CP (zeros): gives the first conv
+// layer (2 or 4 input channels) the 16-byte channel gathers of the later layers.
+template <typename HT>
+__global__ __launch_bounds__(kBlock) void nchw_to_nhwc_pad_h_kernel(const float* __restrict__ in,
+                                                                    int C, long HW, int CP,
+                                                                    long total, HT* __restrict__ out) {
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;      // over [b, hw]
+  if (idx >= total) return;
+  const long b = idx / HW, p = idx % HW;
+  const float* src = in + b * C * HW + p;
+  HT* dst = out + idx * CP;
+  for (int c = 0; c < CP; ++c) dst[c] = c < C ? (HT)src[c * HW] : (HT)0.f;
 }
 
 template <typename HT, typename IT>
@@ -735,6 +791,7 @@ static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const flo
   const HT* weight = (const HT*)w_;
   HT* out = (HT*)out_;
   const int bn = cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
+  const int dbg = tuning().heads_h_dbg;        // profiling only (shared knob)
   const dim3 grid((unsigned)cdiv(cout, bn), (unsigned)cdiv(g.M, 128)), block(kBlock);
   // 16-byte channel gathers: 16-bit NHWC input, (i, j, ci) order, C % 8 == 0, aligned
   const bool vec8 = sizeof(IT) == 2 && g.clast && g.sc == 1 && g.C % 8 == 0 && g.sw % 8 == 0 &&
@@ -743,10 +800,10 @@ static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const flo
   do {                                                                                           \
     if (vec8)                                                                                    \
       hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, sizeof(IT) == 2>), grid, block, 0, \
-                         st, in, g, weight, cout, bias, act, out);                               \
+                         st, in, g, weight, cout, bias, act, out, dbg);                          \
     else                                                                                         \
       hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, false>), grid, block, 0, st, in,   \
-                         g, weight, cout, bias, act, out);                                       \
+                         g, weight, cout, bias, act, out, dbg);                                  \
   } while (0)
 #define L2Q_CH(KS)                                                     \
   do {                                                                 \
@@ -889,6 +946,23 @@ int l2q_conv_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long 
                    : conv_h_launch<__bf16, __bf16>(in, g, weight, bias, cout, act, out, st);
 }
 
+int l2q_nchw_to_nhwc_pad_h(int half_type, const float* in, int nb, int C, int H, int W, int cpad,
+                           void* out, void* stream) {
+  L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && cpad >= C, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
+  const long HW = (long)H * W, total = (long)nb * HW;
+  const dim3 grid((unsigned)cdiv(total, kBlock)), block(kBlock);
+  const hipStream_t st = (hipStream_t)stream;
+  if (half_type == L2Q_HALF_F16)
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_h_kernel<_Float16>, grid, block, 0, st, in, C, HW, cpad, total,
+                       (_Float16*)out);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_h_kernel<__bf16>, grid, block, 0, st, in, C, HW, cpad, total,
+                       (__bf16*)out);
+  return check_launch("l2q_nchw_to_nhwc_pad_h");
+}
+
 int l2q_maxpool_act_nhwc_h(int half_type, const void* in, int nb, int H, int W, int C, int pool,
                            int act, void* out, void* stream) {
   L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
@@ -896,15 +970,16 @@ int l2q_maxpool_act_nhwc_h(int half_type, const void* in, int nb, int H, int W, 
   L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
   const int Ho = H / pool, Wo = W / pool;
   L2Q_REQUIRE(Ho > 0 && Wo > 0, L2Q_ESHAPE, "pooling window larger than the image");
-  const long total = (long)nb * Ho * Wo * C;
+  const int vec = (C % 8 == 0 && al16(in) && al16(out)) ? 8 : 1;
+  const long total = (long)nb * Ho * Wo * (C / vec);
   const dim3 grid((unsigned)cdiv(total, kBlock)), block(kBlock);
   const hipStream_t st = (hipStream_t)stream;
-  if (half_type == L2Q_HALF_F16)
-    hipLaunchKernelGGL(maxpool_act_nhwc_h_kernel<_Float16>, grid, block, 0, st, (const _Float16*)in,
-                       H, W, C, pool, act, Ho, Wo, total, (_Float16*)out);
-  else
-    hipLaunchKernelGGL(maxpool_act_nhwc_h_kernel<__bf16>, grid, block, 0, st, (const __bf16*)in, H, W,
-                       C, pool, act, Ho, Wo, total, (__bf16*)out);
+#define L2Q_MP(HT, V)                                                                              \
+  hipLaunchKernelGGL((maxpool_act_nhwc_h_kernel<HT, V>), grid, block, 0, st, (const HT*)in, H, W, C, \
+                     pool, act, Ho, Wo, total, (HT*)out)
+  if (half_type == L2Q_HALF_F16) { if (vec == 8) L2Q_MP(_Float16, 8); else L2Q_MP(_Float16, 1); }
+  else { if (vec == 8) L2Q_MP(__bf16, 8); else L2Q_MP(__bf16, 1); }
+#undef L2Q_MP
   return check_launch("l2q_maxpool_act_nhwc_h");
 }
 

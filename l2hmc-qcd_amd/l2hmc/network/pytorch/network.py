@@ -236,7 +236,12 @@ class ConvStack(nn.Module):
         convs = []
         for n, (ci, k, pool, act) in enumerate(self.plan):
             w = self.layers[ci].weight.detach()
-            w16 = w.to(hd).contiguous() if n == 0 else w.permute(0, 2, 3, 1).to(hd).contiguous()
+            w16 = w.permute(0, 2, 3, 1).to(hd).contiguous()              # [cout, k, k, cin]
+            if n == 0 and w16.shape[-1] % 8:
+                # the first layer sees the 2 / 4 lattice channels padded to 8 (zeros): one
+                # 16-byte gather per tap instead of cin scalar ones
+                pad = 8 - w16.shape[-1] % 8
+                w16 = torch.nn.functional.pad(w16, (0, pad)).contiguous()
             convs.append((w16, r16(self.layers[ci].bias)))
         h, w_ = self.nt, self.nx
         c = self.in_channels
@@ -254,10 +259,10 @@ class ConvStack(nn.Module):
         the fp32 container of the 16-bit result (it is the fp32-typed `x` input of the
         LeapfrogLayer's first GEMM, which rounds on load: exact)."""
         hw = self._half_weights(hd)
-        layout = 'nchw'
+        if self.plan:
+            x = ops.nchw_to_nhwc_pad_h(x, hd, hw['convs'][0][0].shape[-1])
         for (ci, k, pool, act), (w16, b) in zip(self.plan, hw['convs']):
-            x = ops.conv2d_periodic_gemm_h(x, layout, w16, b, pool, act)
-            layout = 'nhwc'
+            x = ops.conv2d_periodic_gemm_h(x, 'nhwc', w16, b, pool, act)
         wl, bl = hw['lin']
         return ops.gemm_h(x.reshape(x.shape[0], -1), wl, bl, act=self.act, out_dtype=torch.float32)
 
