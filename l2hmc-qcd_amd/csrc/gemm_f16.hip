@@ -26,16 +26,25 @@ constexpr int HBK = 64;            // K-slab: two MFMA K-steps of 32
 constexpr int HLD = HBK + 8;       // row stride 144 B: conflict-free ds_read_b128 fragments
 
 template <typename HT> struct MfmaH;
+typedef float v16f32 __attribute__((ext_vector_type(16)));
 template <> struct MfmaH<_Float16> {
   using vec_t = f16x8;
   static __device__ __forceinline__ v4f32 run(vec_t a, vec_t b, v4f32 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  // 32x32x16: A lane l holds row l & 31, k = 8 (l >> 5) .. +7; D col = l & 31,
+  // row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).  Half the LDS fragment reads per flop of 16x16x32.
+  static __device__ __forceinline__ v16f32 run32(vec_t a, vec_t b, v16f32 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
 template <> struct MfmaH<__bf16> {
   using vec_t = bf16x8;
   static __device__ __forceinline__ v4f32 run(vec_t a, vec_t b, v4f32 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ v16f32 run32(vec_t a, vec_t b, v16f32 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
 
@@ -141,7 +150,7 @@ template <typename HT, typename AS, typename CT, bool FUSED, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
     const AS* __restrict__ A, const HT* __restrict__ W, const AS* __restrict__ A2,
     const HT* __restrict__ W2, int M, int N, long K, long K2, long kchunk, int splits, EpiH epi,
-    int veca, int vecw, CT* __restrict__ C, float* __restrict__ part) {
+    int veca, int vecw, CT* __restrict__ C, float* __restrict__ part, int patch) {
   using vec_t = typename MfmaH<HT>::vec_t;
   constexpr int BN = NT / 2, WN = NT / 128;            // tile width, wavefronts along N
   __shared__ __attribute__((aligned(16))) HT As[128][HLD];
@@ -154,7 +163,16 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
   const long ntn = (N + BN - 1) / BN, ntm = (M + 127) / 128;
   const long nmz = ntm * splits;
   long mz, nt;
-  if (nmz % kXcds == 0) {
+  if (splits == 1 && patch && ntm % 8 == 0 && ntn % 8 == 0 && ((ntm / 8) * (ntn / 8)) % kXcds == 0) {
+    // Big layers stream both operands from HBM / L2, so the ~64 workgroups an XCD runs at a time
+    // should share as many operand tiles as possible: they are made an 8 x 8 patch of tiles
+    // (8 A tiles + 8 W tiles for 64 workgroups instead of 1 + 64).
+    const long xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
+    const long p = (seq / 64) * kXcds + xcd, local = seq % 64;
+    const long pn = ntn / 8;
+    mz = (p / pn) * 8 + local / 8;
+    nt = (p % pn) * 8 + local % 8;
+  } else if (nmz % kXcds == 0) {
     const long xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
     mz = (seq / ntn) * kXcds + xcd;
     nt = seq % ntn;
@@ -169,11 +187,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
   long kend = kbeg + kchunk;
   if (kend > Kt) kend = Kt;
 
-  v4f32 acc[4][4];
+  // wavefront tile 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 fp32 accumulators / lane)
+  v16f32 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4f32){0, 0, 0, 0};
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   TileH<HT, AS, 128, NT> la;
   TileH<HT, HT, BN, NT> lw;
@@ -189,65 +210,69 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
       lw.fetch(W, W2, n0, N, k0 + HBK, K, K2, kend, vecw != 0);
     }
 #pragma unroll
-    for (int ks = 0; ks < HBK; ks += 32) {
-      vec_t fa[4], fb[4];
-      const int kq = ks + 8 * (lane >> 4);
+    for (int ks = 0; ks < HBK; ks += 16) {
+      vec_t fa[2], fb[2];
+      const int kq = ks + 8 * (lane >> 5);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const vec_t*>(&As[wm + 16 * i + (lane & 15)][kq]);
-        fb[i] = *reinterpret_cast<const vec_t*>(&Ws[wn + 16 * i + (lane & 15)][kq]);
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const vec_t*>(&As[wm + 32 * i + (lane & 31)][kq]);
+        fb[i] = *reinterpret_cast<const vec_t*>(&Ws[wn + 32 * i + (lane & 31)][kq]);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = MfmaH<HT>::run(fb[j], fa[i], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = MfmaH<HT>::run32(fb[j], fa[i], acc[i][j]);
     }
   }
 
-  // W was the MFMA "row" operand: lane holds row m = lane & 15 of tile i and the four consecutive
-  // columns n = 16 j + 4 (lane >> 4) + r of tile j -> one 8- or 16-byte store per (i, j).
+  // W was the MFMA "row" operand: lane holds row m = lane & 31 of tile i and, per register quad q,
+  // the four consecutive columns n = 32 j + 8 q + 4 (lane >> 5) + (r & 3): 8- / 16-byte stores.
   const bool vecc = (N % 4) == 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
-    if (nb4 >= N) continue;
-    float cs[4], cb[4];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long n = nb4 + r < N ? nb4 + r : N - 1;
-      cs[r] = 1.f; cb[r] = 0.f;
-      if (FUSED) {
-        cs[r] = epi.coeff ? epi.scale * expf(epi.coeff[n]) : epi.scale;
-        if (epi.bias) cb[r] += epi.bias[n];
-        if (epi.bias2) cb[r] += epi.bias2[n];
-      }
-    }
+    for (int q = 0; q < 4; ++q) {
+      const long nb4 = n0 + wn + 32 * j + 8 * q + 4 * (lane >> 5);
+      if (nb4 >= N) continue;
+      float cs[4], cb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long m = m0 + wm + 16 * i + (lane & 15);
-      if (m >= M) continue;
-      if (FUSED) {
-        typedef CT cv __attribute__((ext_vector_type(4)));
-        cv o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o[r] = (CT)epilogue_h<HT>(acc[i][j][r], cb[r], cs[r], epi.coeff != nullptr, epi.act);
-        CT* dst = C + m * N + nb4;
-        if (vecc) *reinterpret_cast<cv*>(dst) = o;
-        else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = o[r];
-        }
-      } else {
-        float* dst = part + zsplit * M * N + m * N + nb4;
-        if (vecc) *reinterpret_cast<v4f32*>(dst) = acc[i][j];
-        else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) {
+        const long n = nb4 + r < N ? nb4 + r : N - 1;
+        cs[r] = 1.f; cb[r] = 0.f;
+        if (FUSED) {
+          cs[r] = epi.coeff ? epi.scale * expf(epi.coeff[n]) : epi.scale;
+          if (epi.bias) cb[r] += epi.bias[n];
+          if (epi.bias2) cb[r] += epi.bias2[n];
         }
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long m = m0 + wm + 32 * i + (lane & 31);
+        if (m >= M) continue;
+        if (FUSED) {
+          typedef CT cv __attribute__((ext_vector_type(4)));
+          cv o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            o[r] = (CT)epilogue_h<HT>(acc[i][j][4 * q + r], cb[r], cs[r], epi.coeff != nullptr, epi.act);
+          CT* dst = C + m * N + nb4;
+          if (vecc) *reinterpret_cast<cv*>(dst) = o;
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = o[r];
+          }
+        } else {
+          float* dst = part + zsplit * M * N + m * N + nb4;
+          if (vecc) {
+            *reinterpret_cast<v4f32*>(dst) = (v4f32){acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                                     acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = acc[i][j][4 * q + r];
+          }
+        }
+      }
     }
-  }
 }
 
 template <typename HT, typename CT>
@@ -279,6 +304,10 @@ static int pick_splits_h(int M, int N, long Kt) {
 // wide: the 128 x 256 tile (512 threads, one workgroup per CU), always through split-K partials.
 static int pick_config_h(int M, int N, long Kt, bool* wide) {
   *wide = N > 128 && Kt >= 32 * HBK && cdiv(M, 128) * cdiv(N, 128) < 256;
+  if (!*wide && tuning().gemm_h_wide_fused && N >= 1024 && M >= 1024 && Kt >= 16 * HBK) {
+    *wide = true;                  // large square-ish layer: 128 x 256 tiles, epilogue in-kernel
+    return 1;
+  }
   if (!*wide) return pick_splits_h(M, N, Kt);
   const long tiles = cdiv(M, 128) * cdiv(N, 256);
   long s = cdiv(256, tiles);
@@ -307,8 +336,10 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
   constexpr long VA = 16 / sizeof(AS);
   const int veca = K % VA == 0 && K2 % VA == 0 && al16(A) && al16(A2);
   const int vecw = K % 8 == 0 && K2 % 8 == 0 && al16(W) && al16(W2);
+  const int patch = tuning().gemm_h_patch;
+  const bool wide_fused = wide && splits == 1 && (long)M * N >= 1024L * 1024L;
   float* part = nullptr;
-  if (splits > 1 || wide) {
+  if (splits > 1 || (wide && !wide_fused)) {
     const size_t need = (size_t)splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) {
       set_error("l2q_gemm_h: split-K workspace too small (%zu < %zu)", ws_bytes, need);
@@ -316,20 +347,24 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
     }
     part = (float*)ws;
   }
-  if (wide) {
+  if (wide_fused) {
+    const dim3 grid((unsigned)(cdiv(N, 256) * cdiv(M, 128)));
+    hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, true, 512>), grid, dim3(512), 0, st, A, W, A2,
+                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
+  } else if (wide) {
     const dim3 grid((unsigned)(cdiv(N, 256) * cdiv(M, 128) * splits));
     hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false, 512>), grid, dim3(512), 0, st, A, W, A2,
-                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part);
+                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
   } else if (splits == 1) {
     const dim3 grid((unsigned)(cdiv(N, 128) * cdiv(M, 128)));
     hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, true, 256>), grid, dim3(kBlock), 0, st, A, W,
-                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part);
+                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
   } else {
     const dim3 grid((unsigned)(cdiv(N, 128) * cdiv(M, 128) * splits));
     hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false, 256>), grid, dim3(kBlock), 0, st, A, W,
-                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part);
+                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
   }
-  if (splits > 1 || wide) {
+  if (splits > 1 || (wide && !wide_fused)) {
     const long MN = (long)M * N;
     hipLaunchKernelGGL((splitk_reduce_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN, kBlock)),
                        dim3(kBlock), 0, st, (const float*)part, splits, MN, N, epi, C);
@@ -870,6 +905,7 @@ size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2) {
   if (M <= 0 || N <= 0 || K + K2 <= 0) return 0;
   bool wide = false;
   const int splits = pick_config_h(M, N, K + K2, &wide);
+  if (wide && splits == 1 && (long)M * N >= 1024L * 1024L) return 0;      // fused wide tile
   return (splits == 1 && !wide) ? 0 : (size_t)(splits + 1) * M * N * sizeof(float);
 }
 

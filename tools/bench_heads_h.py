@@ -42,3 +42,11 @@ t = timeit(lambda: ops.gemm_h(z, heads['s'][0], heads['s'][1], coeff=heads['s'][
 print(f'one head gemm_h (fp32 out): {t:.1f} us  {gf / 3 / t * 1e-3:.1f} TFLOP/s')
 t = timeit(lambda: ops.gemm_h(z, heads['s'][0], heads['s'][1], act='tanh'))
 print(f'one head gemm_h (16-bit out): {t:.1f} us  {gf / 3 / t * 1e-3:.1f} TFLOP/s')
+
+if a.m >= 4096:
+    K2 = 51200
+    zz = torch.randn(a.m, K2, device='cuda').to(hd)
+    ww = (torch.randn(a.n, K2, device='cuda') / K2 ** 0.5).to(hd)
+    bb = torch.zeros(a.n, device='cuda')
+    t = timeit(lambda: ops.gemm_h(zz, ww, bb, act='leaky_relu', out_dtype=torch.float32), n=3)
+    print(f'conv-stack Linear {a.m}x{a.n}x{K2} gemm_h: {t:.1f} us  {2 * a.m * a.n * K2 / t * 1e-6:.1f} TFLOP/s')
