@@ -299,6 +299,10 @@ int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int p
 int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
                                int H, int W, int k, const float* weight, int channels_last_cols,
                                const float* bias, int cout, int act, float* out, void* stream);
+/* out[b][h][w][c] = c < C ? in[b][c][h][w] : 0 for c < cpad (fp32 NCHW -> NHWC, channels padded
+ * to a 16-byte group): lets the first conv layer use the vector gathers of the later ones. */
+int l2q_nchw_to_nhwc_pad_f32(const float* in, int nb, int C, int H, int W, int cpad, float* out,
+                             void* stream);
 
 /* ---------------------------------------------------------------- fused U(1) sub-updates (fp32)
  * One launch per L2HMC sub-update on small 2D lattices (n = 2 T X <= l2q_u1_fused_max_n()):

@@ -209,6 +209,19 @@ __global__ __launch_bounds__(kBlock) void im2col_periodic_kernel(
 }
 
 // NHWC max-pool (floor mode, stride = window) followed by the activation
+__global__ __launch_bounds__(kBlock) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, int C,
+                                                                  long HW, int CP, long total,
+                                                                  float* __restrict__ out) {
+  // out[b][hw][c] = c < C ? in[b][c][hw] : 0: the first conv layer's 2 / 4 lattice channels as
+  // NHWC padded to a 16-byte group, so that it uses the vector gathers of the later layers
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= total) return;
+  const long b = idx / HW, p = idx % HW;
+  const float* src = in + b * C * HW + p;
+  float* dst = out + idx * CP;
+  for (int c = 0; c < CP; ++c) dst[c] = c < C ? src[c * HW] : 0.f;
+}
+
 __global__ __launch_bounds__(kBlock) void maxpool_act_nhwc_kernel(const float* __restrict__ in,
                                                                   int H, int W, int C, int pool,
                                                                   int act, int Ho, int Wo,
@@ -318,6 +331,16 @@ int l2q_conv2d_periodic_f32(const float* in, const float* w, const float* bias, 
                      (hipStream_t)stream, in, w, bias, out, cin, H, W, cout, k, pool, act, Ho, Wo,
                      total);
   return check_launch("l2q_conv2d_periodic_f32");
+}
+
+int l2q_nchw_to_nhwc_pad_f32(const float* in, int nb, int C, int H, int W, int cpad, float* out,
+                             void* stream) {
+  L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && cpad >= C, L2Q_EINVAL, "bad size");
+  const long HW = (long)H * W, total = (long)nb * HW;
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3((unsigned)cdiv(total, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, in, C, HW, cpad, total, out);
+  return check_launch("l2q_nchw_to_nhwc_pad_f32");
 }
 
 int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,

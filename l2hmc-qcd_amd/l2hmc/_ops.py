@@ -490,6 +490,14 @@ def conv2d_periodic_gemm(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch
     return out
 
 
+def nchw_to_nhwc_pad(x: torch.Tensor, cpad: int) -> torch.Tensor:
+    """fp32 [nb, C, H, W] -> fp32 [nb, H, W, cpad], channels zero-padded."""
+    nb, C, H, W = x.shape
+    out = torch.empty((nb, H, W, cpad), dtype=torch.float32, device=x.device)
+    N.call('l2q_nchw_to_nhwc_pad_f32', x.contiguous(), nb, C, H, W, cpad, out)
+    return out
+
+
 def nchw_to_nhwc_pad_h(x: torch.Tensor, hd: torch.dtype, cpad: int = 8) -> torch.Tensor:
     """fp32 [nb, C, H, W] -> 16-bit [nb, H, W, cpad], channels zero-padded."""
     nb, C, H, W = x.shape

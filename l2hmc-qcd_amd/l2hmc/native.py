@@ -72,6 +72,7 @@ SIGNATURES = {
     'l2q_im2col_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, P]),
     'l2q_maxpool_act_nhwc_f32': (I, [P, I, I, I, I, I, I, P, P]),
     'l2q_conv_gemm_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, I, P, I, I, P, P]),
+    'l2q_nchw_to_nhwc_pad_f32': (I, [P, I, I, I, I, I, P, P]),
     'l2q_u1_fused_max_n': (I, []),
     'l2q_u1_vstep_f32': (I, [P, P, D, D, I, I, I, I, P, P, P, P, P, I, P, P, P, P, P, D, P, P, P, I, I, P, P]),
     'l2q_u1_xstep_f32': (I, [P, P, P, I, D, I, I, I, I, P, P, P, P, P, I, P, P, P, P, P, D, P, P, P, I, I, P, P]),

@@ -217,7 +217,11 @@ class ConvStack(nn.Module):
         ver = (conv.weight._version, ops.PARAM_GENERATION[0])
         hit = self._wcache.get(ci)
         if hit is None or hit[0] != ver:
-            hit = (ver, conv.weight.detach().permute(0, 2, 3, 1).contiguous())
+            w = conv.weight.detach().permute(0, 2, 3, 1)
+            if ci == self.plan[0][0] and w.shape[-1] % 4:     # first layer: lattice channels
+                # padded to a 16-byte group (its input is padded alike in forward)
+                w = torch.nn.functional.pad(w, (0, 4 - w.shape[-1] % 4))
+            hit = (ver, w.contiguous())
             self._wcache[ci] = hit
         return hit[1]
 
@@ -275,10 +279,14 @@ class ConvStack(nn.Module):
             return self._forward_half(x, self.half_dtype)
         # implicit GEMM: periodic im2col -> f32 MFMA GEMM (NHWC activations) -> pool + act
         layout = 'nchw'
+        if self.plan:                 # NHWC from the start (channels padded to 4): vector gathers
+            x = ops.nchw_to_nhwc_pad(x, self._clast_weight(self.plan[0][0]).shape[-1])
+            layout = 'nhwc'
         for ci, k, pool, act in self.plan:
             conv = self.layers[ci]
-            x = ops.conv2d_periodic_gemm(x, layout, conv.weight.detach(), conv.bias.detach(),
-                                         pool, act, w_clast=self._clast_weight(ci))
+            wc = self._clast_weight(ci)
+            x = ops.conv2d_periodic_gemm(x, layout, wc.permute(0, 3, 1, 2), conv.bias.detach(),
+                                         pool, act, w_clast=wc)
             layout = 'nhwc'
         if layout == 'nhwc':                       # reference flattens NCHW
             nb, H, W, C = x.shape

@@ -667,6 +667,11 @@ def l2q_conv_gemm_periodic_h(ht, x, x32, sn, sc, sh, sw, nb, C, H, W, k, w, clas
     out.copy_(y.reshape(out.shape).to(out.dtype))
 
 
+def l2q_nchw_to_nhwc_pad_f32(x, nb, C, H, W, cpad, out):
+    out.zero_()
+    out.reshape(nb, H, W, cpad)[..., :C] = x.reshape(nb, C, H, W).permute(0, 2, 3, 1)
+
+
 def l2q_nchw_to_nhwc_pad_h(ht, x, nb, C, H, W, cpad, out):
     out.zero_()
     out.reshape(nb, H, W, cpad)[..., :C] = x.reshape(nb, C, H, W).permute(0, 2, 3, 1).to(out.dtype)
