@@ -222,22 +222,33 @@ __global__ __launch_bounds__(kBlock) void nchw_to_nhwc_pad_kernel(const float* _
   for (int c = 0; c < CP; ++c) dst[c] = c < C ? src[c * HW] : 0.f;
 }
 
+// VEC channels per thread: 4 = one 16-byte access (C % 4 == 0), else 1
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void maxpool_act_nhwc_kernel(const float* __restrict__ in,
                                                                   int H, int W, int C, int pool,
                                                                   int act, int Ho, int Wo,
                                                                   long total,
                                                                   float* __restrict__ out) {
-  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+  typedef float fv __attribute__((ext_vector_type(VEC)));
+  const long idx = (long)blockIdx.x * kBlock + threadIdx.x;      // over [b, ho, wo, C / VEC]
   if (idx >= total) return;
-  const int c = (int)(idx % C);
-  const int wo = (int)((idx / C) % Wo);
-  const int ho = (int)((idx / ((long)C * Wo)) % Ho);
-  const long b = idx / ((long)C * Wo * Ho);
-  float best = -3.402823466e38f;
+  const int cv = C / VEC;
+  const int c = (int)(idx % cv) * VEC;
+  const int wo = (int)((idx / cv) % Wo);
+  const int ho = (int)((idx / ((long)cv * Wo)) % Ho);
+  const long b = idx / ((long)cv * Wo * Ho);
+  fv best;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) best[e] = -3.402823466e38f;
   for (int ph = 0; ph < pool; ++ph)
-    for (int pw = 0; pw < pool; ++pw)
-      best = fmaxf(best, in[((b * H + ho * pool + ph) * W + wo * pool + pw) * C + c]);
-  out[idx] = act_f32(best, act);
+    for (int pw = 0; pw < pool; ++pw) {
+      const fv v = *reinterpret_cast<const fv*>(in + ((b * H + ho * pool + ph) * W + wo * pool + pw) * C + c);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) best[e] = fmaxf(best[e], v[e]);
+    }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) best[e] = act_f32(best[e], act);
+  *reinterpret_cast<fv*>(out + ((b * Ho + ho) * Wo + wo) * (long)C + c) = best;
 }
 
 }  // namespace l2q
@@ -373,9 +384,13 @@ int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int p
   L2Q_REQUIRE(nb > 0 && H > 0 && W > 0 && C > 0 && pool > 0, L2Q_EINVAL, "non-positive size");
   const int Ho = H / pool, Wo = W / pool;
   L2Q_REQUIRE(Ho > 0 && Wo > 0, L2Q_ESHAPE, "pooling window larger than the image");
-  const long total = (long)nb * Ho * Wo * C;
-  hipLaunchKernelGGL(maxpool_act_nhwc_kernel, dim3((unsigned)cdiv(total, kBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, in, H, W, C, pool, act, Ho, Wo, total, out);
+  const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const long total = (long)nb * Ho * Wo * (vec ? C / 4 : C);
+  const dim3 grid((unsigned)cdiv(total, kBlock)), block(kBlock);
+  if (vec) hipLaunchKernelGGL(maxpool_act_nhwc_kernel<4>, grid, block, 0, (hipStream_t)stream, in, H,
+                              W, C, pool, act, Ho, Wo, total, out);
+  else hipLaunchKernelGGL(maxpool_act_nhwc_kernel<1>, grid, block, 0, (hipStream_t)stream, in, H, W,
+                          C, pool, act, Ho, Wo, total, out);
   return check_launch("l2q_maxpool_act_nhwc_f32");
 }
 
