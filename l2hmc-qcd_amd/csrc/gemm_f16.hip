@@ -421,7 +421,7 @@ struct HeadsHArgs {
 
 template <typename HT, bool XUPD, bool FWD, bool NCP, int BM>
 __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_kernel(HeadsHArgs a, int swz,
-                                                                      int nfast, int dbg) {
+                                                                      int nfast) {
   constexpr int BN = 64, MI = BM / 32;        // MI: 16-row MFMA tiles per wavefront along m
   using vec_t = typename MfmaH<HT>::vec_t;
   __shared__ __attribute__((aligned(16))) HT Zs[BM][HLD];
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   l0.fetch(W0, W0, n0, a.N, 0, K, 0, K, vec);
   l1.fetch(W1, W1, n0, a.N, 0, K, 0, K, vec);
   l2.fetch(W2, W2, n0, a.N, 0, K, 0, K, vec);
-  for (long k0 = 0; k0 < (dbg == 2 ? 0 : K); k0 += HBK) {
+  for (long k0 = 0; k0 < K; k0 += HBK) {
     __syncthreads();
     lz.store(Zs);
     l0.store(Ws[0]);
@@ -488,17 +488,6 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
     }
   }
 
-  if (dbg == 1) {
-    float x = 0.f;
-#pragma unroll
-    for (int h = 0; h < 3; ++h)
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) x += acc[h][i][j][0] + acc[h][i][j][1] + acc[h][i][j][2] + acc[h][i][j][3];
-    if (x == 12345.f) a.a[0] = x;
-    return;
-  }
   // ---- epilogue: heads -> update, in registers.  The MFMAs ran with W as the "row" operand:
   // lane holds chain m = lane & 15 of tile i and the four consecutive entries
   // n = 16 j + 4 (lane >> 4) + r of tile j: 16-byte accesses to v / x / force / mask / biases.
@@ -621,8 +610,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
                                                                 ConvGeomH g,
                                                                 const HT* __restrict__ Wt, int N,
                                                                 const float* __restrict__ bias,
-                                                                int act, HT* __restrict__ C,
-                                                                int dbg) {
+                                                                int act, HT* __restrict__ C) {
   constexpr int BM = 128;
   constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -677,7 +665,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
       const long base_ = rbase[row_];                                                   \
       av_t v_;                                                                          \
       _Pragma("unroll") for (int e = 0; e < AV; ++e) v_[e] = (HT)0.f;                   \
-      if (kin_ && base_ >= 0 && dbg != 2) {                                             \
+      if (kin_ && base_ >= 0) {                                                         \
         int r_ = rr0[row_] + i_; if (r_ >= g.H) r_ -= g.H; if (r_ >= g.H) r_ %= g.H;    \
         int c_ = rc0[row_] + j_; if (c_ >= g.W) c_ -= g.W; if (c_ >= g.W) c_ %= g.W;    \
         const IT* src_ = in + base_ + coff_ + r_ * g.sh + c_ * g.sw;                    \
@@ -691,7 +679,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   const bool vecw = (g.Kc % 8) == 0;
   L2Q_CONVH_FETCH_A(0);
   lw.fetch(Wt, Wt, n0, N, 0, g.Kc, 0, g.Kc, vecw);
-  for (long k0 = 0; k0 < (dbg >= 3 ? 0 : g.Kc); k0 += HBK) {
+  for (long k0 = 0; k0 < g.Kc; k0 += HBK) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < ANP; ++p) *reinterpret_cast<av_t*>(&As[arq + p * ARPP][akv]) = areg[p];
@@ -719,15 +707,6 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   }
 #undef L2Q_CONVH_FETCH_A
   // W was the MFMA row operand: lane owns pixel m = lane & 15 of tile i, channels 4 (lane >> 4) + r
-  if (dbg == 1 || dbg == 4) {
-    float x = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) x += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (x == 12345.f) C[0] = (HT)x;
-    return;
-  }
   // One N-tile (cout <= BN, every layer of the default stack): the workgroup's output
   // C[m0 .. m0+127][0 .. N) is ONE contiguous range of memory.  The lanes' 4-channel pieces
   // (8 bytes, 32-byte runs per wavefront store: ~1.2 TB/s measured) are therefore assembled in
@@ -826,7 +805,6 @@ static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const flo
   const HT* weight = (const HT*)w_;
   HT* out = (HT*)out_;
   const int bn = cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
-  const int dbg = tuning().heads_h_dbg;        // profiling only (shared knob)
   const dim3 grid((unsigned)cdiv(cout, bn), (unsigned)cdiv(g.M, 128)), block(kBlock);
   // 16-byte channel gathers: 16-bit NHWC input, (i, j, ci) order, C % 8 == 0, aligned
   const bool vec8 = sizeof(IT) == 2 && g.clast && g.sc == 1 && g.C % 8 == 0 && g.sw % 8 == 0 &&
@@ -835,10 +813,10 @@ static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const flo
   do {                                                                                           \
     if (vec8)                                                                                    \
       hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, sizeof(IT) == 2>), grid, block, 0, \
-                         st, in, g, weight, cout, bias, act, out, dbg);                          \
+                         st, in, g, weight, cout, bias, act, out);                               \
     else                                                                                         \
       hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, false>), grid, block, 0, st, in,   \
-                         g, weight, cout, bias, act, out, dbg);                                  \
+                         g, weight, cout, bias, act, out);                                       \
   } while (0)
 #define L2Q_CH(KS)                                                     \
   do {                                                                 \
@@ -871,7 +849,6 @@ static int heads_h_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, floa
   const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
   const int swz = tuning().xcd_swizzle;
   const int nfast = tuning().heads_h_order;
-  const int dbg = tuning().heads_h_dbg;
   double* part = (double*)ws;
   double* tmp = part + (size_t)a.M * a.ncols_part;
   a.logdet_part = part;
@@ -880,10 +857,10 @@ static int heads_h_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, floa
   do {                                                                                           \
     if (bm == 128)                                                                               \
       hipLaunchKernelGGL((u1_heads_update_h_kernel<HT, X, F, C, 128>), grid, block, 0, st, a,    \
-                         swz, nfast, dbg);                                                       \
+                         swz, nfast);                                                       \
     else                                                                                         \
       hipLaunchKernelGGL((u1_heads_update_h_kernel<HT, X, F, C, 64>), grid, block, 0, st, a,     \
-                         swz, nfast, dbg);                                                       \
+                         swz, nfast);                                                       \
   } while (0)
   if (!xupd) { if (forward) L2Q_HH(false, true, false); else L2Q_HH(false, false, false); }
   else if (use_ncp) { if (forward) L2Q_HH(true, true, true); else L2Q_HH(true, false, true); }

@@ -18,7 +18,6 @@ struct Tuning {
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
   int force_tile = 2;     // 2: slice-resident kernel, 1: LDS-tiled (64 sites x 4 mu), 0: flat
   int u1_fused_ch = 0;    // chains per workgroup of the fused U(1) kernels (0: auto; 1, 2, 4, 8)
-  int heads_h_dbg = 0;    // profiling only: 1 skip the epilogue, 2 skip the MFMA loop
   int gemm_h_wide_fused = 0;  // large half GEMMs: 128 x 256 tile with 512 threads (measured slower)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
   int heads_h_bm = 128;   // chains per workgroup of the half-precision heads+update kernel (64 | 128)
