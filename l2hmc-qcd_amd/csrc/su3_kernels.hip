@@ -1076,7 +1076,7 @@ int l2q_su3_force_kick(const void* xn, double beta, double coef, void* vn, int n
 int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* mask_n,
                      int complement, void* out, int nb, long V, void* stream) {
   L2Q_REQUIRE(xn && vn && out, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_expm_mul_kernel<false>, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
                      0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
@@ -1087,7 +1087,7 @@ int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* ma
 int l2q_su3_expm_mul2(const void* xn, const void* vn, double eps, const float* mask_n,
                       int complement_first, void* out, int nb, long V, void* stream) {
   L2Q_REQUIRE(xn && vn && out && mask_n, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_expm_mul_kernel<true>, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
                      0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
@@ -1097,7 +1097,7 @@ int l2q_su3_expm_mul2(const void* xn, const void* vn, double eps, const float* m
 
 int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* stream) {
   L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_project_kernel<0>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
                      (hipStream_t)stream, (const double2*)in, (double2*)out, (double*)nullptr, (int)V,
@@ -1107,7 +1107,7 @@ int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* st
 
 int l2q_su3_projsu_vec8(const void* in, double* vec, long nfields, long V, void* stream) {
   L2Q_REQUIRE(in && vec, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_project_kernel<1>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
                      (hipStream_t)stream, (const double2*)in, (double2*)nullptr, vec, (int)V, nblk);
@@ -1116,7 +1116,7 @@ int l2q_su3_projsu_vec8(const void* in, double* vec, long nfields, long V, void*
 
 int l2q_su3_project_tah(const void* in, void* out, long nfields, long V, void* stream) {
   L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_project_kernel<2>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
                      (hipStream_t)stream, (const double2*)in, (double2*)out, (double*)nullptr, (int)V,
@@ -1126,7 +1126,7 @@ int l2q_su3_project_tah(const void* in, void* out, long nfields, long V, void* s
 
 int l2q_su3_project_u(const void* in, void* out, long nfields, long V, void* stream) {
   L2Q_REQUIRE(in && out, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_project_kernel<3>, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
                      (hipStream_t)stream, (const double2*)in, (double2*)out, (double*)nullptr, (int)V,
@@ -1137,7 +1137,7 @@ int l2q_su3_project_u(const void* in, void* out, long nfields, long V, void* str
 int l2q_su3_mul(const void* a, const void* b, int adjoint_a, int adjoint_b, void* out,
                 long nfields, long V, void* stream) {
   L2Q_REQUIRE(a && b && out, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_mul_kernel, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
                      (hipStream_t)stream, (const double2*)a, (const double2*)b, adjoint_a, adjoint_b,
@@ -1148,7 +1148,7 @@ int l2q_su3_mul(const void* a, const void* b, int adjoint_a, int adjoint_b, void
 int l2q_su3_kinetic_reduce(const void* vn, int nb, long V, double* out, void* ws, size_t ws_bytes,
                            void* stream) {
   L2Q_REQUIRE(vn && out && ws, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long n = 36 * V;
   const long nblk = cdiv(n, 4L * kBlock);
   L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * sizeof(double), L2Q_ESHAPE, "workspace too small");
@@ -1162,7 +1162,7 @@ int l2q_su3_kinetic_reduce(const void* vn, int nb, long V, double* out, void* ws
 
 int l2q_su3_assemble_tah(const double* normals, void* vn, long nfields, long V, void* stream) {
   L2Q_REQUIRE(normals && vn, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_assemble_tah_kernel, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
                      (hipStream_t)stream, normals, (double2*)vn, V, nblk, nfields * V);
@@ -1172,7 +1172,7 @@ int l2q_su3_assemble_tah(const double* normals, void* vn, long nfields, long V, 
 int l2q_su3_check_su(const void* xn, int nb, long V, double* out, void* ws, size_t ws_bytes,
                      void* stream) {
   L2Q_REQUIRE(xn && out && ws, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(4 * V, kBlock);
   L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * 2 * sizeof(double), L2Q_ESHAPE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;

@@ -252,7 +252,7 @@ int l2q_su3_expm_mul_bwd(const void* xn, const void* vn, double eps, const float
                          int complement, const void* gxnew, void* gx, void* gv, double* deps,
                          int nb, long V, void* ws, size_t ws_bytes, void* stream) {
   L2Q_REQUIRE(xn && vn && gxnew && gx && gv && deps && ws, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nb > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   L2Q_REQUIRE(ws_bytes >= (size_t)nb * 4 * nblk * sizeof(double), L2Q_EINVAL, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -266,7 +266,7 @@ int l2q_su3_expm_mul_bwd(const void* xn, const void* vn, double eps, const float
 int l2q_su3_projsu_vec8_bwd(const void* in, const double* gvec, void* gm, long nfields, long V,
                             void* stream) {
   L2Q_REQUIRE(in && gvec && gm, L2Q_EINVAL, "null pointer");
-  L2Q_REQUIRE(nfields > 0 && V > 0 && V < 50000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(nfields > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL(su3_projsu_vec8_bwd_kernel, dim3((unsigned)(nfields * nblk)), dim3(kBlock), 0,
                      (hipStream_t)stream, (const double2*)in, gvec, (double2*)gm, (int)V, nblk);

@@ -43,9 +43,14 @@ class ParamArena:
     moments.  MI355X-first replacement of per-tensor optimiser loops and bucketed DDP:
     one `l2q_adam` launch, one RCCL all-reduce."""
 
-    def __init__(self, module: nn.Module):
+    def __init__(self, module: nn.Module, skip=None):
+        """skip: parameters that can never receive a gradient (the SU(3) xnet is built but never
+        called, dynamics.py:1420-1425): they stay outside the arena, keep ``grad = None`` like
+        under the reference's autograd, and cost no gradient / moment memory (2/3 of all
+        parameters at SU(3) 8^4, units [256])."""
         self.groups: dict = {}
-        params = [p for p in module.parameters() if p.requires_grad]
+        skip_ids = {id(p) for p in (skip or ())}
+        params = [p for p in module.parameters() if p.requires_grad and id(p) not in skip_ids]
         by_dtype: dict = {}
         for p in params:
             by_dtype.setdefault(p.dtype, []).append(p)
@@ -136,6 +141,8 @@ class ParamArena:
             g['v'].zero_()
         for i, st in sd['state'].items():
             p = params_in_order[int(i)]
+            if id(p) not in where:
+                continue                      # a parameter this build never trains
             g, off, n = where[id(p)]
             g['m'][off:off + n].copy_(st['exp_avg'].reshape(-1).to(g['m']))
             g['v'][off:off + n].copy_(st['exp_avg_sq'].reshape(-1).to(g['v']))
@@ -443,6 +450,55 @@ def _accumulate_eps_grads(dyn, eps_acc: dict) -> None:
         _, slope = _eps_and_slope(p)
         tot = torch.stack(lst).sum()
         p.grad.add_((slope * tot).to(p.dtype).reshape(p.shape))
+
+
+def _cat_metrics(parts: list, sizes: list) -> dict:
+    """Merge the metrics of chain micro-batches: tensors are concatenated along their chain
+    axis (the one whose extent is the micro-batch size), everything else is taken from the
+    first part."""
+    out = {}
+    for k, v0 in parts[0].items():
+        if isinstance(v0, Tensor) and v0.ndim >= 1:
+            ax = [d for d in range(v0.ndim) if v0.shape[d] == sizes[0]]
+            if ax and all(isinstance(p[k], Tensor) for p in parts):
+                a = ax[0] if v0.ndim == 1 or v0.shape[0] == sizes[0] else ax[-1]
+                out[k] = torch.cat([p[k] for p in parts], dim=a)
+                continue
+        out[k] = v0
+    return out
+
+
+def train_forward_backward_chunked(dyn, loss_fn, x: Tensor, beta, micro_batch: int,
+                                   loss_weight: float = 1.0):
+    """train_forward_backward over micro-batches of chains.  The loss is a mean over chains and
+    the chains are independent, so the gradient is the size-weighted sum of the micro-batch
+    gradients; the trajectory tape then holds `micro_batch` chains at a time (what makes the
+    16^4 shard of BASELINE cfg-5 trainable within 288 GB).  Exact for networks without
+    BatchNorm (whose batch statistics would become per-micro-batch)."""
+    nb = x.shape[0]
+    outs, mets, sizes, loss = [], [], [], 0.0
+    inj = dyn._inject
+    try:
+        for lo in range(0, nb, micro_batch):
+            hi = min(nb, lo + micro_batch)
+            if inj is not None:
+                sl = {}
+                if inj.get('normals') is not None:
+                    nrm = inj['normals']
+                    sl['normals'] = nrm[:, lo:hi] if dyn.group == 'SU3' else nrm[lo:hi]
+                if inj.get('u') is not None:
+                    sl['u'] = inj['u'][lo:hi]
+                dyn._inject = sl
+            xo, m, l = train_forward_backward(dyn, loss_fn, x[lo:hi], beta,
+                                              loss_weight=loss_weight * (hi - lo) / nb)
+            m.pop('mc_states', None)
+            outs.append(xo)
+            mets.append(m)
+            sizes.append(hi - lo)
+            loss = loss + l * ((hi - lo) / nb)
+    finally:
+        dyn._inject = inj
+    return torch.cat(outs, 0), _cat_metrics(mets, sizes), loss
 
 
 def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1.0):

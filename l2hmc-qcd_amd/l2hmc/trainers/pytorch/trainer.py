@@ -52,6 +52,9 @@ class Trainer:
         self.timers = {k: StepTimer(evals_per_step=evals) for k in ('train', 'eval', 'hmc')}
         self._estep = self._hstep = self._gstep = 0
         self.arena = None                 # flat parameter / gradient arena (built on first train_step)
+        # chains per training micro-batch (None: all at once).  Not a reference option: bounds the
+        # trajectory tape so that large lattices train within HBM (exact without BatchNorm).
+        self.micro_batch: Optional[int] = None
 
     # -- construction (trainer.py:490-562, trainers/trainer.py:292-309)
     def build_lattice(self):
@@ -181,19 +184,25 @@ class Trainer:
         clip_grad_norm -> fused Adam.  U(1) and SU(3)."""
         from l2hmc.dynamics.pytorch import training as T
         if self.arena is None:
-            self.arena = T.ParamArena(self.dynamics)
+            self.arena = self._new_arena()
         self.dynamics.train()
         xinit, beta = inputs
         beta = torch.as_tensor(beta, dtype=torch.get_default_dtype())
         xinit = self._prep(xinit)
         self.arena.zero_grad()
-        xout, metrics, loss = T.train_forward_backward(self.dynamics, self.loss_fn, xinit, beta)
+        mb = self.micro_batch
+
+        def fwd_bwd(xin, w=1.0):
+            if mb is not None and 0 < mb < xin.shape[0]:
+                return T.train_forward_backward_chunked(self.dynamics, self.loss_fn, xin, beta, mb,
+                                                        loss_weight=w)
+            return T.train_forward_backward(self.dynamics, self.loss_fn, xin, beta, loss_weight=w)
+        xout, metrics, loss = fwd_bwd(xinit)
         loss_tot = loss
         if (aw := self.config.loss.aux_weight) > 0:
             # the reference's `aux_loss += aw * aux_loss` (trainer.py:1343-1353)
             yinit = self.g.random(list(xinit.shape)).to(self.device)
-            _, _m, aux = T.train_forward_backward(self.dynamics, self.loss_fn, yinit, beta,
-                                                  loss_weight=1.0 + aw)
+            _, _m, aux = fwd_bwd(yinit, 1.0 + aw)
             loss_tot = loss + (1.0 + aw) * aux
         scale = self.arena.all_reduce()
         clip = float(self.config.learning_rate.clip_norm)
@@ -209,6 +218,13 @@ class Trainer:
         self._gstep += 1
         return xout.detach(), metrics
 
+    def _new_arena(self):
+        from l2hmc.dynamics.pytorch import training as T
+        skip = None
+        if self.config.dynamics.group.upper() == 'SU3' and self.dynamics._networks_built:
+            skip = list(self.dynamics.xnet.parameters())      # built, never called: no gradients
+        return T.ParamArena(self.dynamics, skip=skip)
+
     # -- checkpoints (trainer.py:573-680): same keys / file names as the reference
     def save_ckpt(self, era: int, epoch: int, outdir, metrics: Optional[dict] = None):
         """`ckpt-{era}-{epoch}-{step}.tar` with era / epoch / gstep / xeps / veps /
@@ -222,7 +238,7 @@ class Trainer:
         outdir = Path(outdir)
         outdir.mkdir(parents=True, exist_ok=True)
         if self.arena is None:
-            self.arena = T.ParamArena(self.dynamics)
+            self.arena = self._new_arena()
         params = list(self.dynamics.parameters())
         ckpt = {'era': era, 'epoch': epoch, 'gstep': self._gstep,
                 'xeps': [e.detach().cpu().numpy() for e in self.dynamics.xeps],
@@ -245,7 +261,7 @@ class Trainer:
         from l2hmc import _ops as ops
         ckpt = torch.load(path, map_location='cpu', weights_only=False)
         if self.arena is None:
-            self.arena = T.ParamArena(self.dynamics)
+            self.arena = self._new_arena()
         sd = ckpt['model_state_dict']
         with torch.no_grad():                       # copy INTO the arena views (keep the aliasing)
             own = self.dynamics.state_dict()

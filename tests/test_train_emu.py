@@ -246,3 +246,44 @@ def test_trainer_small_surface_host_logic(monkeypatch):
     assert D.random_angle((3, 2)).shape == (3, 2)
     mk = D.Mask(torch.tensor([1., 0.]))
     assert torch.equal(mk.combine(torch.tensor([2., 2.]), torch.tensor([5., 5.])), torch.tensor([2., 5.]))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+def test_su3_micro_batched_training_host_logic(golden, monkeypatch, f64):
+    """Trainer.micro_batch: the gradient of a train step taken in chain micro-batches equals the
+    full-batch gradient (independent chains, mean loss); the never-called SU(3) xnet stays
+    outside the gradient / moment arena."""
+    import l2hmc.configs as cfgs
+    from l2hmc.trainers.pytorch.trainer import Trainer
+    emu_native.install(monkeypatch)
+    ov = ['dynamics.group=SU3', 'dynamics.latvolume=[2,2,2,2]', 'dynamics.nchains=4',
+          'dynamics.nleapfrog=1', 'dynamics.eps=0.02', 'dynamics.verbose=false',
+          'dynamics.use_split_xnets=false', 'dynamics.use_separate_networks=false',
+          'network.units=[4]', 'network.dropout_prob=0.0', 'network.use_batch_norm=false',
+          'network.activation_fn=tanh', 'loss.aux_weight=0.0', 'learning_rate.clip_norm=0.0',
+          'conv=none']
+    grads = {}
+    for mb in (None, 2, 3):
+        torch.manual_seed(1)
+        np.random.seed(1)
+        tr = Trainer(cfgs.get_config(ov))
+        tr.micro_batch = mb
+        x = tr.lattice.random()
+        V = 16
+        nrm = torch.randn(8, 4, 4, 2, 2, 2, 2, generator=torch.Generator().manual_seed(7))
+        tr.dynamics._inject = {'normals': nrm.numpy(), 'u': np.full(4, 0.5)}
+        xo, m = tr.train_step((x, 6.0))
+        assert xo.shape[0] == 4 and m['acc'].shape == (4,)
+        grads[mb] = {k: p.grad.detach().clone() for k, p in tr.dynamics.named_parameters()
+                     if p.grad is not None}
+        # arena: vnet + eps only
+        n_arena = tr.arena.numel()
+        n_x = sum(p.numel() for p in tr.dynamics.xnet.parameters())
+        assert n_arena + n_x == tr.count_parameters()
+        assert all(p.grad is None for p in tr.dynamics.xnet.parameters())
+        sd = tr.arena.state_dict(list(tr.dynamics.parameters()), lr=1e-3)
+        assert len(sd['state']) == len(grads[mb])
+    for mb in (2, 3):
+        for k, g in grads[None].items():
+            d = float((grads[mb][k] - g).abs().max())
+            assert d <= 1e-9 * max(1.0, float(g.abs().max())), (mb, k, d)
