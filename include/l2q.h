@@ -198,6 +198,15 @@ int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const flo
                  const float* W2, long K2, const float* bias, const float* bias2,
                  const float* coeff, float scale, int act, float* C, void* ws,
                  size_t ws_bytes, void* stream);
+/* Backward GEMMs of the dense layers without transposed copies (the reverse sweep of the training
+ * step):  C[M][N] (+)= sum_k Aop[m][k] Wop[n][k]  with  Aop[m][k] = a_trans ?
+ * A[k][m] (A stored [K][M]) : A[m][k] (A stored [M][K]), Wop likewise ([K][N] resp. [N][K]).
+ *   dW += dY^T X : A = dY [nb][out] (a_trans), W = X [nb][in] (w_trans), accumulate
+ *   dX  = dY W   : A = dY [nb][out],           W = W [out][in] (w_trans)
+ * elem_bytes 4 | 8.  Transposed operands need their row length (M resp. N) to be a multiple of
+ * 16 bytes.  ws: l2q_gemm_ws_bytes(M, N, K, 0). */
+int l2q_gemm_ex(const void* A, int a_trans, const void* W, int w_trans, int M, int N, long K,
+                int elem_bytes, int accumulate, void* C, void* ws, size_t ws_bytes, void* stream);
 /* Half-precision network layers ("fp16 nets / fp32 action", BASELINE cfg-3): what the reference
  * gets from torch.autocast around Dynamics.forward (trainers/pytorch/trainer.py:211-219,
  * 1278-1280: nn.Linear in fp16 / bf16, lattice arithmetic in fp32).  W / W2 are 16-bit

@@ -13,6 +13,7 @@
 // and consumed in registers by the generalised momentum update (fused_heads_vupdate):
 // s, t, q are never written to HBM.
 #include "l2q_common.hpp"
+#include <type_traits>
 
 namespace l2q {
 
@@ -75,6 +76,7 @@ struct Epilogue {
   const T* coeff;
   T scale;
   int act;
+  int accumulate;        // C += result (gradient accumulation) instead of C = result
   __device__ __forceinline__ T colscale(int n) const {
     return coeff ? scale * exp(coeff[n]) : scale;
   }
@@ -159,10 +161,54 @@ struct TileLoader {
   }
 };
 
+// Same tile from a TRANSPOSED source: element (row r, column k) lives at p[k * ld + r] (the
+// operand is stored [K][rows], rows contiguous) -- the backward GEMMs dW = dY^T X and
+// dX = dY W read their operands this way, so no transposed copy is ever written to HBM.
+// 16-byte loads run along the rows (needs ld % VEC == 0 and an aligned base), the LDS image is
+// the same [ROWS][BK] as TileLoader's.
+template <typename T, int ROWS>
+struct TileLoaderT {
+  using vec_t = typename Mfma<T>::vec_t;
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int RV = ROWS / VEC;                // row vectors per k
+  static constexpr int KPP = kBlock / RV;              // k per pass
+  static constexpr int NP = BK / KPP;
+  T reg[NP * VEC];
+
+  __device__ __forceinline__ void fetch(const T* __restrict__ p, long row0, long nrows, long k0,
+                                        long ld, long kend) {
+    const int rv = threadIdx.x % RV, kk = threadIdx.x / RV;
+    const long row = row0 + (long)rv * VEC;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const long k = k0 + kk + i * KPP;
+      if (k < kend && row + VEC <= nrows) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(p + k * ld + row);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) reg[i * VEC + j] = e[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          reg[i * VEC + j] = (k < kend && row + j < nrows) ? p[k * ld + row + j] : (T)0;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(T (*lds)[LDP]) const {
+    const int rv = threadIdx.x % RV, kk = threadIdx.x / RV;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) lds[rv * VEC + j][kk + i * KPP] = reg[i * VEC + j];
+  }
+};
+
 // ---------------------------------------------------------------------------------------
 // Generic layer: grid x = N tiles, y = M tiles, z = K splits.  FUSED: splits == 1 and the
 // epilogue is applied here; otherwise raw partial sums go to part[z][M][N].
-template <typename T, bool FUSED, bool VECLOAD>
+// TA / TW: the A / W operand is stored transposed ([K][M] resp. [K][N]; needs K2 == 0).
+template <typename T, bool FUSED, bool VECLOAD, bool TA = false, bool TW = false>
 __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
     const T* __restrict__ A, const T* __restrict__ W, const T* __restrict__ A2,
     const T* __restrict__ W2, int M, int N, long K, long K2, long kchunk, Epilogue<T> epi,
@@ -185,18 +231,23 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
 
-  TileLoader<T, BM, VECLOAD> la;
-  TileLoader<T, BN, VECLOAD> lw;
-  la.fetch(A, A2, m0, M, kbeg, K, K2, kend);
-  lw.fetch(W, W2, n0, N, kbeg, K, K2, kend);
+  typename std::conditional<TA, TileLoaderT<T, BM>, TileLoader<T, BM, VECLOAD>>::type la;
+  typename std::conditional<TW, TileLoaderT<T, BN>, TileLoader<T, BN, VECLOAD>>::type lw;
+#define L2Q_FETCH_AW(K0)                                                   \
+  do {                                                                     \
+    if constexpr (TA) la.fetch(A, m0, M, (K0), (long)M, kend);            \
+    else la.fetch(A, A2, m0, M, (K0), K, K2, kend);                        \
+    if constexpr (TW) lw.fetch(W, n0, N, (K0), (long)N, kend);            \
+    else lw.fetch(W, W2, n0, N, (K0), K, K2, kend);                        \
+  } while (0)
+  L2Q_FETCH_AW(kbeg);
   for (long k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();                                 // previous slab fully consumed
     la.store(As);
     lw.store(Ws);
     __syncthreads();
     if (k0 + BK < kend) {                            // overlap the next slab's latency
-      la.fetch(A, A2, m0, M, k0 + BK, K, K2, kend);
-      lw.fetch(W, W2, n0, N, k0 + BK, K, K2, kend);
+      L2Q_FETCH_AW(k0 + BK);
     }
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
@@ -227,7 +278,12 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
         const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
         if (m < M) {
           const T v = acc[i][j][r];
-          dst[m * N + n] = FUSED ? cs * apply_act<T>(v + cb, epi.act) : v;
+          if (FUSED) {
+            const T y = cs * apply_act<T>(v + cb, epi.act);
+            dst[m * N + n] = epi.accumulate ? dst[m * N + n] + y : y;
+          } else {
+            dst[m * N + n] = v;
+          }
         }
       }
   }
@@ -378,7 +434,8 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const T* __restri
   T s = (T)0;
   for (int z = 0; z < splits; ++z) s += part[(long)z * MN + i];     // fixed order
   const int n = (int)(i % N);
-  C[i] = epi.colscale(n) * apply_act<T>(s + epi.colbias(n), epi.act);
+  const T y = epi.colscale(n) * apply_act<T>(s + epi.colbias(n), epi.act);
+  C[i] = epi.accumulate ? C[i] + y : y;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -566,17 +623,29 @@ static bool vec_ok(const T* A, const T* W, const T* A2, const T* W2, long K, lon
   return K % V == 0 && K2 % V == 0 && al(A) && al(W) && al(A2) && al(W2);
 }
 
+// ta / tw: operand stored transposed (see TileLoaderT); accumulate: C += result.
 template <typename T>
 static int gemm_launch(const T* A, const T* W, int M, int N, long K, const T* A2, const T* W2,
                        long K2, const T* bias, const T* bias2, const T* coeff, T scale, int act,
-                       T* C, void* ws, size_t ws_bytes, hipStream_t st) {
+                       T* C, void* ws, size_t ws_bytes, hipStream_t st, int ta = 0, int tw = 0,
+                       int accumulate = 0) {
   const long Kt = K + K2;
   int splits = pick_splits(M, N, Kt);
   long kchunk = cdiv(cdiv(Kt, splits), BK) * BK;
   splits = (int)cdiv(Kt, kchunk);
-  Epilogue<T> epi{bias, bias2, coeff, scale, act};
+  Epilogue<T> epi{bias, bias2, coeff, scale, act, accumulate};
   const dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)splits);
-  const bool vec = vec_ok<T>(A, W, A2, W2, K, K2);
+  constexpr long V = Mfma<T>::VEC;
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // per-operand vector-load conditions: K-contiguous operands need K % VEC, transposed ones
+  // their leading dimension (M resp. N) % VEC
+  const bool veca = ta ? (M % V == 0 && al(A)) : (K % V == 0 && K2 % V == 0 && al(A) && al(A2));
+  const bool vecw = tw ? (N % V == 0 && al(W)) : (K % V == 0 && K2 % V == 0 && al(W) && al(W2));
+  if ((ta || tw) && (K2 != 0 || !veca || !vecw)) {
+    set_error("l2q_gemm: transposed operands need K2 == 0 and 16-byte aligned rows");
+    return L2Q_ESHAPE;
+  }
+  const bool vec = veca && vecw;
   T* part = nullptr;
   if (splits > 1) {
     const size_t need = (size_t)splits * M * N * sizeof(T);
@@ -586,11 +655,20 @@ static int gemm_launch(const T* A, const T* W, int M, int N, long K, const T* A2
     }
     part = (T*)ws;
   }
-#define L2Q_GEMM(F, V)                                                                       \
-  hipLaunchKernelGGL((gemm_nt_kernel<T, F, V>), grid, dim3(kBlock), 0, st, A, W, A2, W2, M, N, \
-                     K, K2, kchunk, epi, C, part)
-  if (splits == 1) { if (vec) L2Q_GEMM(true, true); else L2Q_GEMM(true, false); }
-  else { if (vec) L2Q_GEMM(false, true); else L2Q_GEMM(false, false); }
+#define L2Q_GEMM(F, V, TA_, TW_)                                                               \
+  hipLaunchKernelGGL((gemm_nt_kernel<T, F, V, TA_, TW_>), grid, dim3(kBlock), 0, st, A, W, A2, \
+                     W2, M, N, K, K2, kchunk, epi, C, part)
+#define L2Q_GEMM_F(F)                                                        \
+  do {                                                                       \
+    if (ta && tw) L2Q_GEMM(F, true, true, true);                             \
+    else if (tw) L2Q_GEMM(F, true, false, true);                             \
+    else if (ta) L2Q_GEMM(F, true, true, false);                             \
+    else if (vec) L2Q_GEMM(F, true, false, false);                           \
+    else L2Q_GEMM(F, false, false, false);                                   \
+  } while (0)
+  if (splits == 1) L2Q_GEMM_F(true);
+  else L2Q_GEMM_F(false);
+#undef L2Q_GEMM_F
 #undef L2Q_GEMM
   if (splits > 1) {
     const long MN = (long)M * N;
@@ -636,6 +714,21 @@ int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const flo
                             ws_bytes, (hipStream_t)stream);
 }
 
+int l2q_gemm_ex(const void* A, int a_trans, const void* W, int w_trans, int M, int N, long K,
+                int elem_bytes, int accumulate, void* C, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(A && W && C, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(M > 0 && N > 0 && K > 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(elem_bytes == 4 || elem_bytes == 8, L2Q_EINVAL, "elem_bytes must be 4 or 8");
+  hipStream_t st = (hipStream_t)stream;
+  if (elem_bytes == 8)
+    return gemm_launch<double>((const double*)A, (const double*)W, M, N, K, nullptr, nullptr, 0,
+                               nullptr, nullptr, nullptr, 1.0, L2Q_ACT_NONE, (double*)C, ws, ws_bytes,
+                               st, a_trans, w_trans, accumulate);
+  return gemm_launch<float>((const float*)A, (const float*)W, M, N, K, nullptr, nullptr, 0, nullptr,
+                            nullptr, nullptr, 1.0f, L2Q_ACT_NONE, (float*)C, ws, ws_bytes, st,
+                            a_trans, w_trans, accumulate);
+}
+
 int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
                                int H, int W, int k, const float* weight, int channels_last_cols,
                                const float* bias, int cout, int act, float* out, void* stream) {
@@ -649,7 +742,7 @@ int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long 
   g.clast = channels_last_cols ? 1 : 0;
   g.M = (long)nb * g.Ho * g.Wo;
   L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16, L2Q_ESHAPE, "too many output pixels");
-  Epilogue<float> epi{bias, nullptr, nullptr, 1.0f, act};
+  Epilogue<float> epi{bias, nullptr, nullptr, 1.0f, act, 0};
   const int bn = cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
   const dim3 grid((unsigned)cdiv(cout, bn), (unsigned)cdiv(g.M, 128)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;

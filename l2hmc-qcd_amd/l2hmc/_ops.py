@@ -286,6 +286,41 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_ex(a: torch.Tensor, w: torch.Tensor, a_trans: bool = False, w_trans: bool = False,
+            out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """C (+)= Aop @ Wop^T without transposed copies (include/l2q.h: l2q_gemm_ex).  a: [m, k], or
+    [k, m] with a_trans; w: [n, k], or [k, n] with w_trans.  accumulate needs `out`."""
+    (k, m) = a.shape if a_trans else a.shape[::-1]
+    (kw, n) = w.shape if w_trans else w.shape[::-1]
+    if k != kw or a.dtype != w.dtype or a.dtype not in (torch.float32, torch.float64):
+        raise N.L2QError(f'gemm_ex: a{tuple(a.shape)} w{tuple(w.shape)} {a.dtype}/{w.dtype}')
+    if out is None:
+        if accumulate:
+            raise N.L2QError('gemm_ex: accumulate needs an output tensor')
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    elif out.numel() != m * n or out.dtype != a.dtype or not out.is_contiguous():
+        raise N.L2QError('gemm_ex: bad output tensor')
+    aligned = all(t.data_ptr() % 16 == 0 for t in (a, w) if t.device.type != 'cpu')
+    if (a_trans or w_trans) and not (
+            aligned and (gemm_ex_ok(m, a.dtype) if a_trans else gemm_ex_ok(k, a.dtype))
+            and (gemm_ex_ok(n, a.dtype) if w_trans else gemm_ex_ok(k, a.dtype))):
+        # rows that are not a multiple of 16 bytes: materialise the transposes instead
+        y = gemm(t2d(a) if a_trans else a, t2d(w) if w_trans else w)
+        if accumulate:
+            return add_(out, y)
+        out.copy_(y.reshape(out.shape))
+        return out
+    ws = N.workspace(N.gemm_ws_bytes(m, n, k, 0), a.device)
+    N.call('l2q_gemm_ex', a.contiguous(), int(a_trans), w.contiguous(), int(w_trans), m, n, k,
+           a.element_size(), int(accumulate), out, ws, ws.numel())
+    return out
+
+
+def gemm_ex_ok(rows: int, dtype: torch.dtype) -> bool:
+    """A transposed operand's row length must be a multiple of 16 bytes."""
+    return rows % (2 if dtype == torch.float64 else 4) == 0
+
+
 HALF_TYPES = {torch.float16: 0, torch.bfloat16: 1}
 
 

@@ -55,8 +55,11 @@ class ParamArena:
         for p in params:
             by_dtype.setdefault(p.dtype, []).append(p)
         for dt, ps in by_dtype.items():
-            n = sum(p.numel() for p in ps)
-            flat = torch.empty(n, dtype=dt, device=DEVICE)
+            # every parameter starts on a 16-byte boundary (vector loads / transposed-operand
+            # GEMMs read the views directly); the padding stays zero in all four buffers
+            q = 16 // torch.empty((), dtype=dt).element_size()
+            n = sum(-(-p.numel() // q) * q for p in ps)
+            flat = torch.zeros(n, dtype=dt, device=DEVICE)
             grad = torch.zeros(n, dtype=dt, device=DEVICE)
             off = 0
             with torch.no_grad():
@@ -65,7 +68,7 @@ class ParamArena:
                     flat[off:off + k].copy_(p.detach().reshape(-1).to(DEVICE))
                     p.data = flat[off:off + k].view(p.shape)
                     p.grad = grad[off:off + k].view(p.shape)
-                    off += k
+                    off += -(-k // q) * q
             self.groups[dt] = {'params': ps, 'flat': flat, 'grad': grad,
                                'm': torch.zeros_like(flat), 'v': torch.zeros_like(flat)}
         self.step_count = 0
@@ -83,7 +86,8 @@ class ParamArena:
             g['grad'].zero_()
 
     def numel(self) -> int:
-        return sum(g['flat'].numel() for g in self.groups.values())
+        """number of trained parameters (without the alignment padding of the flat buffers)"""
+        return sum(p.numel() for g in self.groups.values() for p in g['params'])
 
     def all_reduce(self) -> float:
         """Sum the flat gradients over ranks (RCCL over xGMI: one collective per dtype);

@@ -123,14 +123,15 @@ def _linear_bwd(dpre: Tensor, x: Tensor, weight: nn.Parameter, bias: Optional[nn
     """Backward of y = x W^T + b given dpre = dL/dy: W.grad += dpre^T x, b.grad += colsum(dpre),
     returns dL/dx = dpre W (MFMA GEMMs on transposed operands; accumulation into the flat
     gradient arena the parameters' .grad are views of)."""
-    if xT is None:
-        xT = ops.t2d(x)
-    ops.add_(weight.grad, ops.gemm(ops.t2d(dpre), xT))
+    # both operands are read transposed in the GEMM's tile loader and the result is added into
+    # the gradient arena by its epilogue: no transposed copies, no separate accumulation pass
+    # (rows that are not 16-byte multiples fall back to explicit transposes inside gemm_ex)
+    ops.gemm_ex(dpre, x, a_trans=True, w_trans=True, out=weight.grad, accumulate=True)
     if bias is not None:
         ops.colsum_(bias.grad, dpre)
     if not need_dx:
         return None
-    return ops.gemm(dpre, ops.t2d(weight.detach()))
+    return ops.gemm_ex(dpre, weight.detach(), w_trans=True)
 
 
 class PeriodicPadding(nn.Module):
@@ -621,7 +622,7 @@ class LeapfrogLayer(nn.Module):
         """Accumulates every parameter's .grad; returns (dL/dx_in, dL/dv_in) shaped like the
         inputs of forward_train."""
         z = ctx['z']
-        zT = ops.t2d(z)
+        zT = None            # (only the fall-back path of _linear_bwd transposes)
         dz = None
         for head, cot, out in ((self.scale, ds, ctx['s']), (self.transl, dt, None),
                                (self.transf, dq, ctx['q'])):

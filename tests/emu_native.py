@@ -136,6 +136,16 @@ l2q_gemm_f32 = _gemm
 l2q_gemm_f64 = _gemm
 
 
+def l2q_gemm_ex(A, ta, W, tw, M, N, K, esz, accumulate, C, ws, wsn):
+    a = A.reshape(K, M).T if ta else A.reshape(M, K)
+    w = W.reshape(K, N).T if tw else W.reshape(N, K)
+    y = (a @ w.T).reshape(C.shape)
+    if accumulate:
+        C.add_(y)
+    else:
+        C.copy_(y)
+
+
 def l2q_gemm_h(ht, A, a32, W, M, N, K, A2, W2, K2, bias, bias2, coeff, scale, act, C, c32, ws, wsn):
     """autocast rounding points of include/l2q.h: l2q_gemm_h, products accumulated in fp32."""
     hd = torch.float16 if ht == 0 else torch.bfloat16

@@ -475,3 +475,28 @@ def test_conv_gemm_periodic_h(hd, layout, dims):
         tol = 2.5 * ulp * want.float().abs().clamp(min=1.0)
         assert bool((d <= tol).all()), (pool, act, float((d / tol).max()))
         assert float((d > 0).float().mean()) < 0.2
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('shape', [(6, 8, 40), (256, 132, 260), (130, 1000, 36), (4, 4, 3), (260, 264, 700),
+                                   (36, 4100, 5)])
+def test_gemm_ex_transposed_operands(dtype, shape):
+    """l2q_gemm_ex: the backward GEMMs read transposed operands in the tile loader
+    (dW += dY^T X, dX = dY W) -- against torch.matmul in float64."""
+    from l2hmc import _ops as ops
+    m, n, k = shape
+    g = torch.Generator().manual_seed(31)
+    tol = 1e-12 if dtype == torch.float64 else 3e-4
+    for ta in (False, True):
+        for tw in (False, True):
+            a = torch.randn((k, m) if ta else (m, k), generator=g, dtype=torch.float64)
+            w = torch.randn((k, n) if tw else (n, k), generator=g, dtype=torch.float64) / k ** 0.5
+            want = (a.T if ta else a) @ (w if tw else w.T)
+            got = ops.gemm_ex(a.to(dtype).cuda(), w.to(dtype).cuda(), a_trans=ta, w_trans=tw)
+            assert float((got.cpu().double() - want).abs().max()) < tol * max(1.0, float(want.abs().max()))
+            c0 = torch.randn(m, n, generator=g, dtype=torch.float64)
+            out = c0.to(dtype).cuda()
+            ops.gemm_ex(a.to(dtype).cuda(), w.to(dtype).cuda(), a_trans=ta, w_trans=tw, out=out,
+                        accumulate=True)
+            assert float((out.cpu().double() - (c0 + want)).abs().max()) < \
+                tol * max(1.0, float(want.abs().max()))
