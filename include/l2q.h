@@ -294,9 +294,13 @@ int l2q_conv2d_periodic_f32(const float* in, const float* w, const float* bias, 
  *   col[(b*Ho + ho)*Wo + wo][(ci*k + i)*k + j] = in[b, ci, (ho+i-k+1) mod H, (wo+j-k+1) mod W]
  * with Ho = H+k-1, Wo = W+k-1 and generic element strides (sn, sc, sh, sw) of `in` (NCHW for
  * the first layer, the GEMM's NHWC output afterwards); then l2q_gemm_f32(col, weight[cout][cin k k])
- * gives the NHWC activation; l2q_maxpool_act_nhwc_f32 applies MaxPool2d(pool) + activation. */
+ * gives the NHWC activation; l2q_maxpool_act_nhwc_f32 applies MaxPool2d(pool) + activation.
+ * channels_last_cols != 0: column order (i*k + j)*C + ci instead (weight permuted to
+ * [cout][k][k][C]): contiguous runs over the channels of an NHWC input, for im2col and for its
+ * adjoint l2q_col2im_periodic_f32 alike. */
 int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
-                            int H, int W, int k, float* col, void* stream);
+                            int H, int W, int k, int channels_last_cols, float* col,
+                            void* stream);
 int l2q_maxpool_act_nhwc_f32(const float* in, int nb, int H, int W, int C, int pool, int act,
                              float* out, void* stream);
 /* The conv layer without the col matrix: im2col happens inside the A-tile loader of the f32
@@ -381,7 +385,8 @@ int l2q_bn_bwd(const void* dy, const void* x, const void* save_mean, const void*
 /* adjoint of l2q_im2col_periodic_f32 (gather form, no atomics): dx (strides sn, sc, sh, sw)
  * overwritten with the sum of the dcol entries that read each input pixel */
 int l2q_col2im_periodic_f32(const float* dcol, long sn, long sc, long sh, long sw, int nb, int C,
-                            int H, int W, int k, float* dx, void* stream);
+                            int H, int W, int k, int channels_last_cols, float* dx,
+                            void* stream);
 /* adjoint of l2q_maxpool_act_nhwc_f32: din[nb][H][W][C] overwritten (first maximum of each
  * window receives dout * act'(out)) */
 int l2q_maxpool_act_nhwc_bwd_f32(const float* dout, const float* out, const float* in, int nb,

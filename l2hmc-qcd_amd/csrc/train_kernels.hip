@@ -184,13 +184,24 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_kernel(
 // element enumerates its (ho, i) x (wo, j) pre-images in a fixed order.
 __global__ __launch_bounds__(kBlock) void col2im_periodic_kernel(
     const float* __restrict__ dcol, long sn, long sc, long sh, long sw, int C, int H, int W, int k,
-    int Ho, int Wo, int Kc, long total, float* __restrict__ dx) {
+    int Ho, int Wo, int Kc, long total, int clast, float* __restrict__ dx) {
   const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
   if (idx >= total) return;
-  const int c = (int)(idx % W);
-  const int r = (int)((idx / W) % H);
-  const int ci = (int)((idx / ((long)W * H)) % C);
-  const long b = idx / ((long)W * H * C);
+  // thread order follows the fastest index of dcol's columns: (b, ci, r, c) for the (ci, i, j)
+  // order, (b, r, c, ci) for (i, j, ci) -- there a wavefront reads runs of consecutive channels
+  int c, r, ci;
+  long b;
+  if (clast) {
+    ci = (int)(idx % C);
+    c = (int)((idx / C) % W);
+    r = (int)((idx / ((long)C * W)) % H);
+    b = idx / ((long)C * W * H);
+  } else {
+    c = (int)(idx % W);
+    r = (int)((idx / W) % H);
+    ci = (int)((idx / ((long)W * H)) % C);
+    b = idx / ((long)W * H * C);
+  }
   float acc = 0.0f;
   for (int i = 0; i < k; ++i) {
     int h0 = (r + (k - 1) - i) % H; if (h0 < 0) h0 += H;
@@ -198,7 +209,8 @@ __global__ __launch_bounds__(kBlock) void col2im_periodic_kernel(
       for (int j = 0; j < k; ++j) {
         int w0 = (c + (k - 1) - j) % W; if (w0 < 0) w0 += W;
         for (int wo = w0; wo < Wo; wo += W)
-          acc += dcol[((b * Ho + ho) * (long)Wo + wo) * Kc + (ci * k + i) * k + j];
+          acc += dcol[((b * Ho + ho) * (long)Wo + wo) * Kc +
+                      (clast ? (i * k + j) * C + ci : (ci * k + i) * k + j)];
       }
   }
   dx[b * sn + ci * sc + r * sh + c * sw] = acc;
@@ -539,14 +551,16 @@ int l2q_bn_bwd(const void* dy, const void* x, const void* save_mean, const void*
 }
 
 int l2q_col2im_periodic_f32(const float* dcol, long sn, long sc, long sh, long sw, int nb, int C,
-                            int H, int W, int k, float* dx, void* stream) {
+                            int H, int W, int k, int channels_last_cols, float* dx,
+                            void* stream) {
   L2Q_REQUIRE(dcol && dx, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0, L2Q_EINVAL, "non-positive size");
   const int Ho = H + k - 1, Wo = W + k - 1, Kc = C * k * k;
   const long total = (long)nb * C * H * W;
   L2Q_REQUIRE(cdiv(total, kBlock) < 0x7fffffffL, L2Q_ESHAPE, "grid too large");
   hipLaunchKernelGGL(col2im_periodic_kernel, dim3(grid1(total)), dim3(kBlock), 0,
-                     (hipStream_t)stream, dcol, sn, sc, sh, sw, C, H, W, k, Ho, Wo, Kc, total, dx);
+                     (hipStream_t)stream, dcol, sn, sc, sh, sw, C, H, W, k, Ho, Wo, Kc, total,
+                     channels_last_cols ? 1 : 0, dx);
   return check_launch("l2q_col2im_periodic_f32");
 }
 

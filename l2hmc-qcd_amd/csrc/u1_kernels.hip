@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void conv2d_periodic_kernel(
 template <int KS>
 __global__ __launch_bounds__(kBlock) void im2col_periodic_kernel(
     const float* __restrict__ in, long sn, long sc, long sh, long sw, int C, int H, int W, int kr,
-    int Ho, int Wo, int Kc, long Mrows, float* __restrict__ col) {
+    int Ho, int Wo, int Kc, long Mrows, int clast, float* __restrict__ col) {
   const int k = KS > 0 ? KS : kr;
   const long m = (long)blockIdx.x * 4 + threadIdx.y;
   if (m >= Mrows) return;
@@ -201,7 +201,9 @@ __global__ __launch_bounds__(kBlock) void im2col_periodic_kernel(
   int r0 = (ho - (k - 1)) % H; if (r0 < 0) r0 += H;
   int c0 = (wo - (k - 1)) % W; if (c0 < 0) c0 += W;
   for (int kk = threadIdx.x; kk < Kc; kk += 64) {
-    const int j = kk % k, ij = kk / k, i = ij % k, ci = ij / k;
+    int j, i, ci;                 // column order (ci, i, j), or (i, j, ci) with clast
+    if (clast) { ci = kk % C; const int ij = kk / C; j = ij % k; i = ij / k; }
+    else { j = kk % k; const int ij = kk / k; i = ij % k; ci = ij / k; }
     int r = r0 + i; if (r >= H) r -= H; if (r >= H) r %= H;
     int c = c0 + j; if (c >= W) c -= W; if (c >= W) c %= W;
     out[kk] = inb[ci * sc + r * sh + c * sw];
@@ -355,7 +357,8 @@ int l2q_nchw_to_nhwc_pad_f32(const float* in, int nb, int C, int H, int W, int c
 }
 
 int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
-                            int H, int W, int k, float* col, void* stream) {
+                            int H, int W, int k, int channels_last_cols, float* col,
+                            void* stream) {
   L2Q_REQUIRE(in && col, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0, L2Q_EINVAL, "non-positive size");
   const int Ho = H + k - 1, Wo = W + k - 1, Kc = C * k * k;
@@ -365,7 +368,7 @@ int l2q_im2col_periodic_f32(const float* in, long sn, long sc, long sh, long sw,
   hipStream_t st = (hipStream_t)stream;
 #define L2Q_I2C(KS)                                                                              \
   hipLaunchKernelGGL(im2col_periodic_kernel<KS>, grid, block, 0, st, in, sn, sc, sh, sw, C, H, W, \
-                     k, Ho, Wo, Kc, Mrows, col)
+                     k, Ho, Wo, Kc, Mrows, channels_last_cols ? 1 : 0, col)
   switch (k) {
     case 1: L2Q_I2C(1); break;
     case 2: L2Q_I2C(2); break;

@@ -70,7 +70,7 @@ SIGNATURES = {
     'l2q_axpy': (I, [P, D, P, L, I, P]),
     'l2q_u1_masked_cos_sin': (I, [P, P, I, P, I, L, I, P]),
     'l2q_conv2d_periodic_f32': (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
-    'l2q_im2col_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, P]),
+    'l2q_im2col_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, I, P, P]),
     'l2q_maxpool_act_nhwc_f32': (I, [P, I, I, I, I, I, I, P, P]),
     'l2q_conv_gemm_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, I, P, I, I, P, P]),
     'l2q_nchw_to_nhwc_pad_f32': (I, [P, I, I, I, I, I, P, P]),
@@ -85,7 +85,7 @@ SIGNATURES = {
     'l2q_scaled_tanh_bwd': (I, [P, P, P, D, I, I, I, P, P]),
     'l2q_bn_train_fwd': (I, [P, P, P, D, D, P, P, I, I, I, P, P, P, P]),
     'l2q_bn_bwd': (I, [P, P, P, P, P, I, I, I, P, P, P, P]),
-    'l2q_col2im_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, P, P]),
+    'l2q_col2im_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, I, P, P]),
     'l2q_maxpool_act_nhwc_bwd_f32': (I, [P, P, P, I, I, I, I, I, I, P, P]),
     'l2q_u1_force_bwd': (I, [P, P, D, I, I, I, I, P, P]),
     'l2q_u1_plaq_bwd': (I, [P, P, P, I, I, I, I, P, P]),

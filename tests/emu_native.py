@@ -221,8 +221,17 @@ def l2q_select_rows(a, b, mask, out, nb, row_bytes):
     out.copy_(torch.where(m, a, b))
 
 
-def l2q_im2col_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, col):
-    col.copy_(_im2col(_as_nchw(x, sn, sc, sh, sw, nb, C, H, W), k))
+def _clast_cols(col, C, k, to_clast):
+    """reorder the K columns between (ci, i, j) and (i, j, ci)"""
+    M = col.shape[0]
+    if to_clast:
+        return col.reshape(M, C, k, k).permute(0, 2, 3, 1).reshape(M, -1)
+    return col.reshape(M, k, k, C).permute(0, 3, 1, 2).reshape(M, -1)
+
+
+def l2q_im2col_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, clast, col):
+    c = _im2col(_as_nchw(x, sn, sc, sh, sw, nb, C, H, W), k)
+    col.copy_(_clast_cols(c, C, k, True) if clast else c)
 
 
 def l2q_conv_gemm_periodic_f32(x, sn, sc, sh, sw, nb, C, H, W, k, w, clast, b, cout, act, out):
@@ -335,7 +344,9 @@ def l2q_bn_bwd(dy, x, mean, invstd, gamma, M, N, esz, dx, dgamma, dbeta):
     dbeta.add_(gb)
 
 
-def l2q_col2im_periodic_f32(dcol, sn, sc, sh, sw, nb, C, H, W, k, dx):
+def l2q_col2im_periodic_f32(dcol, sn, sc, sh, sw, nb, C, H, W, k, clast, dx):
+    if clast:
+        dcol = _clast_cols(dcol.reshape(-1, C * k * k), C, k, False).contiguous()
     (g,) = _vjp(lambda a: _im2col(a, k), [torch.zeros(nb, C, H, W, dtype=dcol.dtype)], [dcol])
     if sw == 1:
         dx.copy_(g.reshape(dx.shape))
