@@ -166,6 +166,12 @@ class Dynamics(nn.Module):
             self.vnet = self.networks['vnet']
             self.register_module('xnet', self.networks['xnet'])
             self.register_module('vnet', self.networks['vnet'])
+            if self.group == 'SU3':
+                # The SU(3) xnet is built (its tensors are state_dict / checkpoint keys) but never
+                # called (dynamics.py:1420-1425): 264 M of the 446 M parameters at
+                # 8^4 / units [256], 34 GB at 16^4.  It keeps its freshly initialised values but
+                # lives in host memory, not HBM.
+                self.xnet.to('cpu')
         else:
             self._networks_built = False
             self.xnet = dummy_network
