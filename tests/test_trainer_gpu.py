@@ -136,3 +136,48 @@ def test_minor_lattice_group_helpers():
                                torch.diagonal(h @ h, dim1=-2, dim2=-1).sum(-1).real,
                                torch.linalg.det(h).real), -1)
     assert float((ev.sort(-1).values - torch.linalg.eigvalsh(h)).abs().max()) < 1e-8
+
+
+@pytest.mark.parametrize('sampler', ['hmc', 'l2hmc', 'l2hmc_fp16'])
+def test_u1_samplers_reproduce_exact_plaquette(sampler):
+    """Size-independent property: in the 2D U(1) gauge theory <cos theta_P> = I1(beta) / I0(beta)
+    (lattice/u1/pytorch/lattice.py:37-42; torus corrections ~ (I1/I0)^V).  Plain HMC and the
+    generalised L2HMC update with RANDOM (untrained) networks -- whose Jacobian enters the accept
+    step -- both have to sample that distribution; so does the 16-bit-network variant."""
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1, plaq_exact
+    from l2hmc.network.pytorch.network import NetworkFactory
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(11)
+    np.random.seed(11)
+    L, nb, beta = [8, 8], 1024, 2.0
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=4, eps=0.05,
+                             eps_hmc=0.125, verbose=False)
+    nc = cfgs.NetworkConfig(units=[16, 16], activation_fn='leaky_relu', dropout_prob=0.0,
+                            use_batch_norm=False)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                          vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+    lat = LatticeU1(nb, L)
+    dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig())).eval()
+    if sampler == 'l2hmc_fp16':
+        dyn.set_net_precision('fp16')
+    x = lat.random().to(dyn.device)
+    b = torch.tensor(beta)
+    plaqs, accs = [], []
+    nsteps, ntherm = 260, 120
+    for i in range(nsteps):
+        if sampler == 'hmc':
+            xo, m = dyn.apply_transition_hmc((x, b), eps=0.125, nleapfrog=8)
+        else:
+            xo, m = dyn((x, b))
+        x = dyn.g.compat_proj(xo.reshape(x.shape))
+        if i >= ntherm:
+            plaqs.append(lat.plaqs(x).mean())
+            accs.append(m['acc'].mean())
+    est = float(torch.stack(plaqs).mean())
+    acc = float(torch.stack(accs).mean())
+    exact = float(plaq_exact(torch.tensor(beta)))
+    print(f'{sampler}: <plaq> = {est:.5f}  exact {exact:.5f}  <acc> = {acc:.3f}')
+    assert acc > 0.2, acc                      # the chains do move
+    assert abs(est - exact) < 4e-3, (sampler, est, exact, acc)
