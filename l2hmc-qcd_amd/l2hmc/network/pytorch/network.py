@@ -522,8 +522,9 @@ class LeapfrogLayer(nn.Module):
     def _check_mode(self):
         if self.training and (self.net_config.dropout_prob > 0 or self.net_config.use_batch_norm):
             raise NotImplementedError(
-                'LeapfrogLayer: train-mode dropout / batch-norm statistics are part of the '
-                'training path (SURVEY.md 8(f) item 1), not built yet -- call .eval()')
+                'LeapfrogLayer: train-mode dropout / batch-norm statistics belong to the training '
+                'entry points (forward_train / Trainer.train_step); this is the eval-mode forward '
+                '-- call .eval()')
 
     def forward_flat(self, x: Tensor, v: Tensor, w: Optional[dict] = None
                      ) -> tuple[Tensor, Tensor, Tensor]:
