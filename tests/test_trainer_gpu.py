@@ -217,3 +217,22 @@ def test_su3_hmc_reproduces_strong_coupling_plaquette():
         assert abs(est - series) < 5e-4, (est, series)
     finally:
         torch.set_default_dtype(old)
+
+
+def test_cli_precision_and_improved_action():
+    """`python -m l2hmc` end to end with the non-default switches: 16-bit layers + the default
+    conv stack for U(1), the improved gauge action (c1 != 0) for SU(3)."""
+    from l2hmc.__main__ import main
+    torch.set_default_dtype(torch.float32)
+    out = main(['mode=test', 'dynamics.nchains=16', 'dynamics.latvolume=[8,8]', 'precision=fp16',
+                'steps.nera=1', 'steps.nepoch=2', 'steps.test=2', 'seed=3'])
+    assert {'train', 'eval', 'hmc'} <= set(out) and np.isfinite(out['train']['loss_last'])
+    old = torch.get_default_dtype()
+    try:
+        out = main(['mode=test', 'dynamics.group=SU3', 'dynamics.nchains=4',
+                    'dynamics.latvolume=[2,2,2,2]', 'dynamics.nleapfrog=2', 'network.units=[4]',
+                    'network.use_batch_norm=false', 'network.dropout_prob=0.0', 'conv=none',
+                    'c1=-0.331', 'steps.nera=1', 'steps.nepoch=2', 'steps.test=2', 'seed=3'])
+        assert {'train', 'eval', 'hmc'} <= set(out) and np.isfinite(out['train']['loss_last'])
+    finally:
+        torch.set_default_dtype(old)
