@@ -221,6 +221,16 @@ int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M,
                const float* coeff, float scale, int act, void* C, int c_is_f32, void* ws,
                size_t ws_bytes, void* stream);
 size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2);
+/* The U(1) xnet's input layer in half precision with its [cos(m x), sin(m x)] input
+ * (dynamics.py:1161-1185, network.py:430-451) formed inside the GEMM's tile loader:
+ *   C = r16(act(r16([cos(keep x) | sin(keep x)] . W^T + A2 . W2^T + bias + bias2))),
+ * x [M][xdim] fp32 link angles, keep = mask[xdim] (complement: 1 - mask), W [N][2 xdim] 16-bit,
+ * A2 [M][K2] fp32 (the momenta), W2 [N][K2] 16-bit, C [M][N] 16-bit.
+ * ws: l2q_gemm_h_ws_bytes(M, N, 2 xdim, K2). */
+int l2q_gemm_h_u1x(int half_type, const float* x, const float* mask, int complement, const void* W,
+                   int M, int N, long xdim, const float* A2, const void* W2, long K2,
+                   const float* bias, const float* bias2, int act, void* C, void* ws,
+                   size_t ws_bytes, void* stream);
 /* The three heads of a half-precision U(1) LeapfrogLayer and the sub-update that consumes them
  * in one kernel (network.py:547-551 + dynamics.py:1266-1297 / 1386-1477); s, t, q never reach
  * memory.  Z [M][K] 16-bit (last hidden activation), W* [N][K] 16-bit, b* fp32 [N],

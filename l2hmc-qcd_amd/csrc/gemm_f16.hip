@@ -90,12 +90,64 @@ struct TileH {
   typedef HT hv __attribute__((ext_vector_type(VEC)));
   hv reg[NP];                                         // packed: VEC/2 VGPRs per vector
 
+  // cs_mask != nullptr (fp32 sources only): the first operand is VIRTUAL -- column kk < K / 2
+  // is cos(keep[kk] p[row][kk]), column K / 2 + kk is sin(.), keep = mask or 1 - mask: the U(1)
+  // xnet's [cos(m x), sin(m x)] input (dynamics.py:1161-1185) formed inside the tile loader from
+  // the link angles, instead of by a kernel that writes 2 x the field to HBM for this GEMM to read
+  // back.  p then has row stride K / 2.  (v_sin / v_cos: |argument| <= pi, error ~1e-6, far inside
+  // the 16-bit rounding that follows.)
   __device__ __forceinline__ void fetch(const S* __restrict__ p, const S* __restrict__ p2,
                                         long row0, long nrows, long k0, long K, long K2,
-                                        long kend, bool vec) {
+                                        long kend, bool vec, const float* __restrict__ cs_mask = nullptr,
+                                        int cs_compl = 0) {
     const int tid = threadIdx.x;
     const int kv = (tid % VPR) * VEC, r = tid / VPR;
     const long kk = k0 + kv;
+    if (sizeof(S) == 4 && cs_mask != nullptr && kk < K) {
+      const long xd = K >> 1;
+      const bool is_sin = kk >= xd;
+      const long col = is_sin ? kk - xd : kk;
+      float keep[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float m = col + j < xd ? cs_mask[col + j] : 0.f;
+        keep[j] = cs_compl ? 1.f - m : m;
+      }
+      const bool kin = kk < kend;
+      const bool whole = vec && (xd % VEC) == 0;         // vector entirely inside one half
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const long row = row0 + r + (long)i * RPP;
+        if (whole) {
+          typedef S sv __attribute__((ext_vector_type(VEC)));
+          sv xv;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) xv[j] = (S)0;
+          if (kin && row < nrows) xv = *reinterpret_cast<const sv*>(p + row * xd + col);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float a = keep[j] * (float)xv[j];
+            reg[i][j] = (HT)((kin && row < nrows) ? (is_sin ? __sinf(a) : __cosf(a)) : 0.f);
+          }
+          continue;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = 0.f;
+          if (kin && row < nrows && col + j < xd) {
+            const float a = keep[j] * (float)p[row * xd + col + j];
+            v = is_sin ? __sinf(a) : __cosf(a);
+          } else if (kin && row < nrows && !is_sin && col + j >= xd) {
+            // a vector straddling the cos | sin boundary (xdim not a multiple of VEC)
+            const long c2 = col + j - xd;
+            const float m2 = cs_mask[c2];
+            v = __sinf((cs_compl ? 1.f - m2 : m2) * (float)p[row * xd + c2]);
+          }
+          reg[i][j] = (HT)v;
+        }
+      }
+      return;
+    }
     if (vec) {
       const S* base = p;
       long ld = K, kc = kk;
@@ -150,7 +202,8 @@ template <typename HT, typename AS, typename CT, bool FUSED, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
     const AS* __restrict__ A, const HT* __restrict__ W, const AS* __restrict__ A2,
     const HT* __restrict__ W2, int M, int N, long K, long K2, long kchunk, int splits, EpiH epi,
-    int veca, int vecw, CT* __restrict__ C, float* __restrict__ part, int patch) {
+    int veca, int vecw, CT* __restrict__ C, float* __restrict__ part, int patch,
+    const float* __restrict__ cs_mask, int cs_compl) {
   using vec_t = typename MfmaH<HT>::vec_t;
   constexpr int BN = NT / 2, WN = NT / 128;            // tile width, wavefronts along N
   __shared__ __attribute__((aligned(16))) HT As[128][HLD];
@@ -198,7 +251,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
 
   TileH<HT, AS, 128, NT> la;
   TileH<HT, HT, BN, NT> lw;
-  la.fetch(A, A2, m0, M, kbeg, K, K2, kend, veca != 0);
+  la.fetch(A, A2, m0, M, kbeg, K, K2, kend, veca != 0, cs_mask, cs_compl);
   lw.fetch(W, W2, n0, N, kbeg, K, K2, kend, vecw != 0);
   for (long k0 = kbeg; k0 < kend; k0 += HBK) {
     __syncthreads();
@@ -206,7 +259,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_nt_h_kernel(
     lw.store(Ws);
     __syncthreads();
     if (k0 + HBK < kend) {
-      la.fetch(A, A2, m0, M, k0 + HBK, K, K2, kend, veca != 0);
+      la.fetch(A, A2, m0, M, k0 + HBK, K, K2, kend, veca != 0, cs_mask, cs_compl);
       lw.fetch(W, W2, n0, N, k0 + HBK, K, K2, kend, vecw != 0);
     }
 #pragma unroll
@@ -322,7 +375,7 @@ static bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintp
 template <typename HT, typename AS, typename CT>
 static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, const void* A2_,
                          const void* W2_, long K2, EpiH epi, void* C_, void* ws, size_t ws_bytes,
-                         hipStream_t st) {
+                         hipStream_t st, const float* cs_mask = nullptr, int cs_compl = 0) {
   const AS* A = (const AS*)A_;
   const AS* A2 = (const AS*)A2_;
   const HT* W = (const HT*)W_;
@@ -350,19 +403,19 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
   if (wide_fused) {
     const dim3 grid((unsigned)(cdiv(N, 256) * cdiv(M, 128)));
     hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, true, 512>), grid, dim3(512), 0, st, A, W, A2,
-                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
+                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch, cs_mask, cs_compl);
   } else if (wide) {
     const dim3 grid((unsigned)(cdiv(N, 256) * cdiv(M, 128) * splits));
     hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false, 512>), grid, dim3(512), 0, st, A, W, A2,
-                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
+                       W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch, cs_mask, cs_compl);
   } else if (splits == 1) {
     const dim3 grid((unsigned)(cdiv(N, 128) * cdiv(M, 128)));
     hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, true, 256>), grid, dim3(kBlock), 0, st, A, W,
-                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
+                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch, cs_mask, cs_compl);
   } else {
     const dim3 grid((unsigned)(cdiv(N, 128) * cdiv(M, 128) * splits));
     hipLaunchKernelGGL((gemm_nt_h_kernel<HT, AS, CT, false, 256>), grid, dim3(kBlock), 0, st, A, W,
-                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch);
+                       A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch, cs_mask, cs_compl);
   }
   if (splits > 1 || (wide && !wide_fused)) {
     const long MN = (long)M * N;
@@ -375,10 +428,13 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
 template <typename HT>
 static int gemm_h_dispatch(const void* A, int a_f32, const void* W, int M, int N, long K,
                            const void* A2, const void* W2, long K2, EpiH epi, void* C, int c_f32,
-                           void* ws, size_t ws_bytes, hipStream_t st) {
+                           void* ws, size_t ws_bytes, hipStream_t st,
+                           const float* cs_mask = nullptr, int cs_compl = 0) {
   if (a_f32) {
-    return c_f32 ? gemm_h_launch<HT, float, float>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st)
-                 : gemm_h_launch<HT, float, HT>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st);
+    return c_f32 ? gemm_h_launch<HT, float, float>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes,
+                                                   st, cs_mask, cs_compl)
+                 : gemm_h_launch<HT, float, HT>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st,
+                                                cs_mask, cs_compl);
   }
   return c_f32 ? gemm_h_launch<HT, HT, float>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st)
                : gemm_h_launch<HT, HT, HT>(A, W, M, N, K, A2, W2, K2, epi, C, ws, ws_bytes, st);
@@ -933,6 +989,24 @@ int l2q_u1_heads_update_h(int half_type, const void* Z, int M, int K, long N, co
   if (half_type == L2Q_HALF_F16)
     return heads_h_launch<_Float16>(h, x_update, forward, use_ncp, logdet, accumulate, ws, st);
   return heads_h_launch<__bf16>(h, x_update, forward, use_ncp, logdet, accumulate, ws, st);
+}
+
+int l2q_gemm_h_u1x(int half_type, const float* x, const float* mask, int complement, const void* W,
+                   int M, int N, long xdim, const float* A2, const void* W2, long K2,
+                   const float* bias, const float* bias2, int act, void* C, void* ws,
+                   size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(x && mask && W && C, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(M > 0 && N > 0 && xdim > 0 && K2 >= 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(K2 == 0 || (A2 && W2), L2Q_EINVAL, "second operand pair missing");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
+  const EpiH epi{bias, bias2, nullptr, 1.f, act};
+  const hipStream_t st = (hipStream_t)stream;
+  if (half_type == L2Q_HALF_F16)
+    return gemm_h_dispatch<_Float16>(x, 1, W, M, N, 2 * xdim, A2, W2, K2, epi, C, 0, ws, ws_bytes, st,
+                                     mask, complement);
+  return gemm_h_dispatch<__bf16>(x, 1, W, M, N, 2 * xdim, A2, W2, K2, epi, C, 0, ws, ws_bytes, st,
+                                 mask, complement);
 }
 
 int l2q_conv_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long sn, long sc, long sh,

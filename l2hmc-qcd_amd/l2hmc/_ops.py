@@ -357,6 +357,27 @@ def gemm_h(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_h_u1x(x: torch.Tensor, mask: torch.Tensor, complement: bool, w: torch.Tensor,
+               bias: torch.Tensor, a2: torch.Tensor, w2: torch.Tensor, bias2: torch.Tensor,
+               act: Optional[str]) -> torch.Tensor:
+    """Input layer of the half-precision U(1) xnet with the masked cos / sin formed in the tile
+    loader (include/l2q.h: l2q_gemm_h_u1x).  x [nb, xdim] fp32 angles, w [n, 2 xdim] 16-bit,
+    a2 = v [nb, k2] fp32, w2 [n, k2] 16-bit -> [nb, n] 16-bit."""
+    m, xdim = x.shape
+    n = w.shape[0]
+    k2 = a2.shape[1]
+    hd = w.dtype
+    if w.shape[1] != 2 * xdim or w2.shape != (n, k2) or hd not in HALF_TYPES or \
+            x.dtype != torch.float32 or a2.dtype != torch.float32:
+        raise N.L2QError(f'gemm_h_u1x: x{tuple(x.shape)} w{tuple(w.shape)} w2{tuple(w2.shape)}')
+    out = torch.empty((m, n), dtype=hd, device=x.device)
+    ws = N.workspace(int(N.load().l2q_gemm_h_ws_bytes(m, n, 2 * xdim, k2)), x.device)
+    N.call('l2q_gemm_h_u1x', HALF_TYPES[hd], x.contiguous(), mask.reshape(-1).contiguous(),
+           int(complement), w, m, n, xdim, a2.contiguous(), w2, k2, bias, bias2, N.ACT[act], out,
+           ws, ws.numel())
+    return out
+
+
 def u1_heads_update_h_(z: torch.Tensor, heads: dict, scale_t: float, a: torch.Tensor,
                        b: torch.Tensor, eps: float, forward: bool, *,
                        mask: Optional[torch.Tensor] = None, complement: bool = False,

@@ -614,11 +614,14 @@ class Dynamics(nn.Module):
                                  self.config.use_ncp, fw, acc)
         xnet = self._get_xnet(step, first)
         if self._half_fused(xnet):
-            xm = ops.u1_masked_cos_sin(xn, mask, complement, self.latvolume)
-            if isinstance(xnet.input_layer.conv_stack, ConvStack):
-                xm = xnet.input_layer.conv_stack(xm)
             w = xnet.kernel_weights()
-            z = xnet.hidden_flat_h(xm.reshape(nb, -1), vn.reshape(nb, -1), w)
+            if isinstance(xnet.input_layer.conv_stack, ConvStack):
+                xm = ops.u1_masked_cos_sin(xn, mask, complement, self.latvolume)
+                xm = xnet.input_layer.conv_stack(xm)
+                z = xnet.hidden_flat_h(xm.reshape(nb, -1), vn.reshape(nb, -1), w)
+            else:                      # cos / sin of the masked links formed in the GEMM's loader
+                z = xnet.hidden_flat_h_u1x(xn.reshape(nb, -1), mask, complement,
+                                           vn.reshape(nb, -1), w)
             return ops.u1_heads_update_h_(z, w['h']['heads_scaled'], xnet.nw.t,
                                           xn.reshape(nb, -1), vn.reshape(nb, -1), eps, forward,
                                           mask=mask, complement=complement,

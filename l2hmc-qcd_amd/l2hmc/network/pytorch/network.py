@@ -565,6 +565,17 @@ class LeapfrogLayer(nn.Module):
             z = ops.gemm_h(z, hw, hb, act=self.act)
         return z
 
+    def hidden_flat_h_u1x(self, x: Tensor, mask: Tensor, complement: bool, v: Tensor,
+                          w: Optional[dict] = None) -> Tensor:
+        """hidden_flat_h for the U(1) xnet without a conv stack: the [cos(m x), sin(m x)] input
+        is formed from the link angles inside the first GEMM's tile loader."""
+        self._check_mode()
+        h = (self.kernel_weights() if w is None else w)['h']
+        z = ops.gemm_h_u1x(x, mask, complement, h['wx'], h['bx'], v, h['wv'], h['bv'], self.act)
+        for hw, hb in h['hidden']:
+            z = ops.gemm_h(z, hw, hb, act=self.act)
+        return z
+
     def hidden_flat(self, x: Tensor, v: Tensor, w: dict) -> Tensor:
         """z = last hidden activation [nb, units[-1]] (input layer + hidden layers)."""
         self._check_mode()

@@ -676,6 +676,13 @@ def l2q_diff_bwd_f64(x, y, a, nb, n, gx):
     gx.add_((2.0 * a.reshape(nb, 1) * (x.reshape(nb, n) - y.reshape(nb, n))).reshape(gx.shape))
 
 
+def l2q_gemm_h_u1x(ht, x, mask, complement, W, M, N, xdim, A2, W2, K2, bias, bias2, act, C, ws, wsn):
+    keep = (1.0 - mask if complement else mask).reshape(1, xdim)
+    a = keep * x.reshape(M, xdim)
+    A = torch.cat([torch.cos(a), torch.sin(a)], 1).contiguous()
+    l2q_gemm_h(ht, A, 1, W, M, N, 2 * xdim, A2, W2, K2, bias, bias2, None, 1.0, act, C, 0, ws, wsn)
+
+
 def l2q_conv_gemm_periodic_h(ht, x, x32, sn, sc, sh, sw, nb, C, H, W, k, w, clast, b, cout, act, out):
     hd = torch.float16 if ht == 0 else torch.bfloat16
     r16 = lambda t: t.to(hd).float()

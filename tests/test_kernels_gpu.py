@@ -500,3 +500,33 @@ def test_gemm_ex_transposed_operands(dtype, shape):
                         accumulate=True)
             assert float((out.cpu().double() - (c0 + want)).abs().max()) < \
                 tol * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('dims', [(5, 24, 32), (130, 40, 128), (256, 256, 512), (33, 17, 50), (300, 64, 2048)])
+def test_gemm_h_u1x(hd, dims):
+    """l2q_gemm_h_u1x: the half-precision xnet input layer with [cos(m x), sin(m x)] formed in the
+    tile loader, against the emulator (cos / sin materialised, then the l2q_gemm_h restatement)."""
+    import emu_native
+    from l2hmc import _ops as ops
+    m, n, xdim = dims
+    g = torch.Generator().manual_seed(37)
+    x = 2 * np.pi * torch.rand(m, xdim, generator=g) - np.pi
+    v = torch.randn(m, xdim, generator=g)
+    mask = (torch.rand(xdim, generator=g) < 0.5).float()
+    w = (torch.randn(n, 2 * xdim, generator=g) / (2 * xdim) ** 0.5).to(hd)
+    w2 = (torch.randn(n, xdim, generator=g) / xdim ** 0.5).to(hd)
+    b = torch.randn(n, generator=g).to(hd).float()
+    b2 = torch.randn(n, generator=g).to(hd).float()
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    for complement in (False, True):
+        for act in (None, 'leaky_relu', 'tanh'):
+            got = ops.gemm_h_u1x(x.cuda(), mask.cuda(), complement, w.cuda(), b.cuda(), v.cuda(),
+                                 w2.cuda(), b2.cuda(), act)
+            want = torch.empty(m, n, dtype=hd)
+            emu_native.l2q_gemm_h_u1x(ops.HALF_TYPES[hd], x, mask, int(complement), w, m, n, xdim, v,
+                                      w2, xdim, b, b2, N_ACT[act], want, None, 0)
+            d = (got.cpu().float() - want.float()).abs()
+            tol = 2.5 * ulp * want.float().abs().clamp(min=1.0)
+            assert bool((d <= tol).all()), (complement, act, float((d / tol).max()))
+            assert float((d > 0).float().mean()) < 0.25
