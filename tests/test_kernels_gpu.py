@@ -530,3 +530,34 @@ def test_gemm_h_u1x(hd, dims):
             tol = 2.5 * ulp * want.float().abs().clamp(min=1.0)
             assert bool((d <= tol).all()), (complement, act, float((d / tol).max()))
             assert float((d > 0).float().mean()) < 0.25
+
+
+def test_lattice_edge_shapes_vs_oracle():
+    """Degenerate and ragged lattices: extent 1 in some or all directions (a link is its own
+    neighbour), a single chain, odd extents, kernel blocks far from full -- action, plaquette,
+    Wilson and improved-action force (SU(3)) and action / force (U(1)) against the oracle."""
+    from oracle import su3 as osu3, u1 as ou1
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    torch.set_default_dtype(torch.float64)
+    b = torch.tensor(5.5)
+    for L in ([2, 2, 2, 2], [1, 2, 3, 4], [3, 1, 1, 5], [1, 1, 1, 1], [2, 7, 3, 3]):
+        for nb in (1, 3):
+            lat, lat0 = LatticeSU3(nb, L, c1=-0.331), LatticeSU3(nb, L)
+            torch.manual_seed(1)
+            x = lat.random()
+            xh = host(x)
+            assert err(host(lat.action(x, b)), osu3.action_c1(xh, 5.5, -0.331)) < 1e-11, L
+            assert err(host(lat.grad_action(x, b)), osu3.grad_action_c1(xh, 5.5, -0.331)) < 1e-12, L
+            assert err(host(lat0.grad_action(x, b)), osu3.grad_action(xh, 5.5)) < 1e-12, L
+            assert err(host(lat0.plaqs(x)), osu3.plaqs(xh)) < 1e-14, L
+    torch.set_default_dtype(torch.float32)
+    b = torch.tensor(2.5)
+    for L in ([2, 2], [2, 6], [3, 5], [1, 4], [1, 1], [7, 2]):
+        for nb in (1, 5):
+            lat = LatticeU1(nb, L)
+            torch.manual_seed(1)
+            x = lat.random()
+            xh = host(x).astype(np.float64)
+            assert err(host(lat.action(x, b)), ou1.action(xh, 2.5)) < 2e-5, L
+            assert err(host(lat.grad_action(x, b)).reshape(xh.shape), ou1.grad_action(xh, 2.5)) < 1e-5, L
