@@ -488,15 +488,23 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_tile_kernel(
 // Per site and sweep the links are read from HBM once (+ the x-halo of the tile); ~17 of the
 // 19 operands of a link come from LDS instead of L2 (the flat kernel issues 76 matrix loads
 // per site to L2 and leaves the SIMDs idle 53 % of the time waiting for them).
-constexpr int kFS = 128;
-// 0: carried t-staple + register prefetch of the slice after next (143 spilled VGPRs, 0.97 ms)
-// 1: no prefetch (59 spills, 0.64 ms)   2: no prefetch, t-staple re-read from slice t-1 through
-// L2 (18 spills, 0.56 ms) -- measured on MI355X at cfg-4; the register budget decides.
+// Register budget decides this kernel.  A workgroup is 64 sites x 4 directions = 4 wavefronts and
+// is compiled for ONE wavefront per SIMD (__launch_bounds__(256, 1)): the unified register file
+// then gives each wavefront 512 registers, and the ~70 values that do not fit the 256 VGPRs live
+// in AGPRs (v_accvgpr moves) instead of scratch memory.  Measured on MI355X at cfg-4:
+//   128-site tiles, 2 waves/SIMD (256 registers):  variant 0: 143 spilled VGPRs, 0.97 ms;
+//     variant 1: 59 spills, 0.64 ms;  variant 2: 18 spills, 0.56-0.58 ms
+//   64-site tiles, 1 wave/SIMD (256 VGPR + 72 AGPR, no scratch):  variant 0: 0.52 ms;
+//     variant 1: 0.54 ms;  variant 2: 0.56 ms   (without the scheduling fences: 0.55 ms;
+//     staple loops fully unrolled: 512 registers + 660 B scratch)
+// 0: carried t-staple + register prefetch of the slice after next   1: no prefetch
+// 2: no prefetch, t-staple re-read from slice t-1 through L2
+constexpr int kFS = 64;
 #ifndef L2Q_FS_VARIANT
-#define L2Q_FS_VARIANT 2
+#define L2Q_FS_VARIANT 0
 #endif
 // compiler-only fence: keeps hipcc from hoisting the next staple's operand loads above the
-// current staple's arithmetic (register budget is 256 at 2 waves/SIMD)
+// current staple's arithmetic
 #define L2Q_SCHED_FENCE() asm volatile("" ::: "memory")
 
 struct SPos {
@@ -547,7 +555,7 @@ __device__ __forceinline__ void fs_put(double2* slot, int rho, int lt, const M3&
 }
 
 template <bool KICK>
-__global__ __launch_bounds__(4 * kFS, 2) void su3_force_slice_kernel(
+__global__ __launch_bounds__(4 * kFS, 1) void su3_force_slice_kernel(
     const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
     double2* __restrict__ out) {
   extern __shared__ double2 fs_lds[];                   // [2][4][9][kFS]
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(4 * kFS, 2) void su3_force_slice_kernel(
   const int tc = r / nsb, sb = r % nsb;
   const int Vs = d.X * d.Y * d.Z, V = d.V, T = d.T;
   const int tile0 = sb * kFS;
-  const int lt = threadIdx.x & (kFS - 1), mu = threadIdx.x >> 7;      // mu is wave-uniform
+  const int lt = threadIdx.x & (kFS - 1), mu = threadIdx.x / kFS;      // mu is wave-uniform
   const int tlen = (T + tsplit - 1) / tsplit;
   const int t0 = tc * tlen, t1 = min(T, t0 + tlen);
   const double2* xc = xn + c * 36L * V;
