@@ -499,10 +499,10 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_tile_kernel(
 //     staple loops fully unrolled: 512 registers + 660 B scratch)
 // 0: carried t-staple + register prefetch of the slice after next   1: no prefetch
 // 2: no prefetch, t-staple re-read from slice t-1 through L2
-constexpr int kFS = 64;
-#ifndef L2Q_FS_VARIANT
-#define L2Q_FS_VARIANT 0
-#endif
+// The plain force runs the 64-site / one-wave / variant-0 build (0.52 ms vs 0.56 ms), the fused
+// v += coef F variant (two more HBM streams) the 128-site / two-wave / variant-2 build
+// (0.72 ms vs 0.77 ms): A/B measured on one MI355X.
+constexpr int kFSPlain = 64, kFSKick = 128;
 // compiler-only fence: keeps hipcc from hoisting the next staple's operand loads above the
 // current staple's arithmetic
 #define L2Q_SCHED_FENCE() asm volatile("" ::: "memory")
@@ -527,6 +527,7 @@ __device__ __forceinline__ SPos sp_move(SPos p, int dir, int sgn, const Dims& d)
 
 // link rho of spatial site q in a slice: LDS copy if q is inside the tile (wave-uniform),
 // else the global slice; one code path through a flat pointer
+template <int kFS>
 __device__ __forceinline__ void fs_get(M3& m, const double2* slot, const double2* __restrict__ gsl,
                                        int rho, int q, int tile0, int V) {
   const int li = q - tile0;
@@ -540,6 +541,7 @@ __device__ __forceinline__ void fs_get(M3& m, const double2* slot, const double2
   }
 }
 
+template <int kFS>
 __device__ __forceinline__ void fs_own(M3& m, const double2* slot, int rho, int lt) {
   const double2* l = slot + rho * 9 * kFS + lt;
 #pragma unroll
@@ -549,13 +551,14 @@ __device__ __forceinline__ void fs_own(M3& m, const double2* slot, int rho, int 
   }
 }
 
+template <int kFS>
 __device__ __forceinline__ void fs_put(double2* slot, int rho, int lt, const M3& m) {
 #pragma unroll
   for (int e = 0; e < 9; ++e) slot[(rho * 9 + e) * kFS + lt] = make_double2(m.re[e], m.im[e]);
 }
 
-template <bool KICK>
-__global__ __launch_bounds__(4 * kFS, 1) void su3_force_slice_kernel(
+template <bool KICK, int kFS, int VARIANT>
+__global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_kernel(
     const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
     double2* __restrict__ out) {
   extern __shared__ double2 fs_lds[];                   // [2][4][9][kFS]
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(4 * kFS, 1) void su3_force_slice_kernel(
       const int sl = (ta + k) % T;
       M3 tmp;
       load_link(tmp, xc + mu * 9 * V, V, sl * Vs + sp);
-      fs_put(fs_lds + k * kSlot, mu, lt, tmp);
+      fs_put<kFS>(fs_lds + k * kSlot, mu, lt, tmp);
     }
   }
   __syncthreads();
@@ -617,25 +620,24 @@ __global__ __launch_bounds__(4 * kFS, 1) void su3_force_slice_kernel(
           const SPos pp = sp_move(p, nu, +1, d), pm = sp_move(p, nu, -1, d);
           M3 a, b, t;
           // up:   U_nu(s+t) U_t(s+nu)^H U_nu(s)^H
-          fs_own(a, nxt, nu, lt);
-          fs_get(b, cur, gcur, 0, pp.q, tile0, V);
+          fs_own<kFS>(a, nxt, nu, lt);
+          fs_get<kFS>(b, cur, gcur, 0, pp.q, tile0, V);
           m3_mul_na(t, a, b);
-          fs_own(a, cur, nu, lt);
+          fs_own<kFS>(a, cur, nu, lt);
           m3_mac_na(acc, t, a);
           L2Q_SCHED_FENCE();
           // down: U_nu(s+t-nu)^H U_t(s-nu)^H U_nu(s-nu)
-          fs_get(a, nxt, gnxt, nu, pm.q, tile0, V);
-          fs_get(b, cur, gcur, 0, pm.q, tile0, V);
+          fs_get<kFS>(a, nxt, gnxt, nu, pm.q, tile0, V);
+          fs_get<kFS>(b, cur, gcur, 0, pm.q, tile0, V);
           m3_mul_aa(t, a, b);
-          fs_get(a, cur, gcur, nu, pm.q, tile0, V);
+          fs_get<kFS>(a, cur, gcur, nu, pm.q, tile0, V);
           m3_mac_nn(acc, t, a);
           L2Q_SCHED_FENCE();
         }
       } else {
-#if L2Q_FS_VARIANT != 2
-        acc = dcarry;                                  // down staple in the t direction
-#else
-        {                                              // t-direction down staple from slice t-1 (L2)
+        if constexpr (VARIANT != 2) {
+          acc = dcarry;                                // down staple in the t direction
+        } else {                                       // t-direction down staple from slice t-1 (L2)
           const double2* gprv = xc + (long)((tcur - 1 + T) % T) * Vs;
           M3 a, b, t;
           load_link(a, gprv, V, pmu.q);
@@ -645,14 +647,13 @@ __global__ __launch_bounds__(4 * kFS, 1) void su3_force_slice_kernel(
           m3_mul_nn(acc, t, a);
           L2Q_SCHED_FENCE();
         }
-#endif
         {
           M3 a, b, t;
           // up (nu = t): U_t(s+mu) U_mu(s+t)^H U_t(s)^H
-          fs_get(a, cur, gcur, 0, pmu.q, tile0, V);
-          fs_own(b, nxt, mu, lt);
+          fs_get<kFS>(a, cur, gcur, 0, pmu.q, tile0, V);
+          fs_own<kFS>(b, nxt, mu, lt);
           m3_mul_na(t, a, b);
-          fs_own(a, cur, 0, lt);
+          fs_own<kFS>(a, cur, 0, lt);
           m3_mac_na(acc, t, a);
           L2Q_SCHED_FENCE();
         }
@@ -663,23 +664,23 @@ __global__ __launch_bounds__(4 * kFS, 1) void su3_force_slice_kernel(
           const SPos pmm = sp_move(pmu, nu, -1, d);
           M3 a, b, t;
           // up:   U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H
-          fs_get(a, cur, gcur, nu, pmu.q, tile0, V);
-          fs_get(b, cur, gcur, mu, pp.q, tile0, V);
+          fs_get<kFS>(a, cur, gcur, nu, pmu.q, tile0, V);
+          fs_get<kFS>(b, cur, gcur, mu, pp.q, tile0, V);
           m3_mul_na(t, a, b);
-          fs_own(a, cur, nu, lt);
+          fs_own<kFS>(a, cur, nu, lt);
           m3_mac_na(acc, t, a);
           L2Q_SCHED_FENCE();
           // down: U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu)
-          fs_get(a, cur, gcur, nu, pmm.q, tile0, V);
-          fs_get(b, cur, gcur, mu, pm.q, tile0, V);
+          fs_get<kFS>(a, cur, gcur, nu, pmm.q, tile0, V);
+          fs_get<kFS>(b, cur, gcur, mu, pm.q, tile0, V);
           m3_mul_aa(t, a, b);
-          fs_get(a, cur, gcur, nu, pm.q, tile0, V);
+          fs_get<kFS>(a, cur, gcur, nu, pm.q, tile0, V);
           m3_mac_nn(acc, t, a);
           L2Q_SCHED_FENCE();
         }
       }
       M3 u, ua, f;
-      fs_own(u, cur, mu, lt);
+      fs_own<kFS>(u, cur, mu, lt);
       m3_mul_nn(ua, u, acc);
       m3_tah(f, ua);
       const int s = tcur * Vs + sp;
@@ -696,32 +697,25 @@ __global__ __launch_bounds__(4 * kFS, 1) void su3_force_slice_kernel(
     }
     // prefetch this thread's link of the slice after next (hidden behind the carry staple,
     // the barrier and the partner wavefront's work)
-#if L2Q_FS_VARIANT == 0
     M3 pre;
-    if (more) load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
-#endif
-#if L2Q_FS_VARIANT != 2
-    if (mu != 0 && more) {
+    if constexpr (VARIANT == 0) {
+      if (more) load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
+    }
+    if (VARIANT != 2 && mu != 0 && more) {
       // next iteration's t-direction down staple of link (tnext, sp, mu), all from slice tcur:
       //   U_t(tcur, sp+mu)^H U_mu(tcur, sp)^H U_t(tcur, sp)
       M3 a, b, t;
-      fs_get(a, cur, gcur, 0, pmu.q, tile0, V);
-      fs_own(b, cur, mu, lt);
+      fs_get<kFS>(a, cur, gcur, 0, pmu.q, tile0, V);
+      fs_own<kFS>(b, cur, mu, lt);
       m3_mul_aa(t, a, b);
-      fs_own(a, cur, 0, lt);
+      fs_own<kFS>(a, cur, 0, lt);
       m3_mul_nn(dcarry, t, a);
     }
-#endif
     __syncthreads();                                    // slice tcur fully consumed
-#if L2Q_FS_VARIANT == 0
-    if (more) fs_put(fs_lds + slot_cur * kSlot, mu, lt, pre);
-#else
     if (more) {
-      M3 pre;
-      load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
-      fs_put(fs_lds + slot_cur * kSlot, mu, lt, pre);
+      if constexpr (VARIANT != 0) load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
+      fs_put<kFS>(fs_lds + slot_cur * kSlot, mu, lt, pre);
     }
-#endif
     slot_cur ^= 1;
     __syncthreads();
   }
@@ -921,6 +915,8 @@ template <bool KICK>
 static void launch_force(const double2* xn, Dims d, int nb, long nblk, double coef, double2* out,
                          hipStream_t st) {
   const int Vs_ = d.X * d.Y * d.Z;
+  constexpr int kFS = KICK ? kFSKick : kFSPlain;
+  constexpr int kVar = KICK ? 2 : 0;
   if (tuning().force_tile == 2 && Vs_ % kFS == 0) {
     const int nsb = Vs_ / kFS;
     int tsplit = (int)cdiv(512, (long)nb * nsb);       // >= ~2 resident rounds of 256 CUs
@@ -931,14 +927,13 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
     const size_t lds = 2ul * 4 * 9 * kFS * sizeof(double2);
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<false>,
+      (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<KICK, kFS, kVar>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL((su3_force_slice_kernel<KICK>), dim3((unsigned)((long)nb * nsb * tsplit)),
-                       dim3(4 * kFS), lds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, out);
+    hipLaunchKernelGGL((su3_force_slice_kernel<KICK, kFS, kVar>),
+                       dim3((unsigned)((long)nb * nsb * tsplit)), dim3(4 * kFS), lds, st, xn, d, nsb,
+                       tsplit, tuning().xcd_swizzle, coef, out);
     return;
   }
   if (tuning().force_tile) {
