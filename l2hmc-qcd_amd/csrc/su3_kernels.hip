@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_tile_kernel(
 // The plain force runs the 64-site / one-wave / variant-0 build (0.52 ms vs 0.56 ms), the fused
 // v += coef F variant (two more HBM streams) the 128-site / two-wave / variant-2 build
 // (0.72 ms vs 0.77 ms): A/B measured on one MI355X.
-constexpr int kFSPlain = 64, kFSKick = 128;
+constexpr int kFSPlain = 128, kFSKick = 128, kLptPlain = 2;
 // compiler-only fence: keeps hipcc from hoisting the next staple's operand loads above the
 // current staple's arithmetic
 #define L2Q_SCHED_FENCE() asm volatile("" ::: "memory")
@@ -557,8 +557,11 @@ __device__ __forceinline__ void fs_put(double2* slot, int rho, int lt, const M3&
   for (int e = 0; e < 9; ++e) slot[(rho * 9 + e) * kFS + lt] = make_double2(m.re[e], m.im[e]);
 }
 
-template <bool KICK, int kFS, int VARIANT>
-__global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_kernel(
+// LPT: links (directions) per thread.  2: a workgroup of 2 kFS threads covers mu = g and g + 2
+// one after the other -- the 128-site tile (half the x-halo of the 64-site one) at one wavefront
+// per SIMD.
+template <bool KICK, int kFS, int VARIANT, int LPT>
+__global__ __launch_bounds__(4 * kFS / LPT, (kFS == 64 || LPT == 2) ? 1 : 2) void su3_force_slice_kernel(
     const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
     double2* __restrict__ out) {
   extern __shared__ double2 fs_lds[];                   // [2][4][9][kFS]
@@ -570,11 +573,11 @@ __global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_ke
   const int tc = r / nsb, sb = r % nsb;
   const int Vs = d.X * d.Y * d.Z, V = d.V, T = d.T;
   const int tile0 = sb * kFS;
-  const int lt = threadIdx.x & (kFS - 1), mu = threadIdx.x / kFS;      // mu is wave-uniform
+  const int lt = threadIdx.x & (kFS - 1), g = threadIdx.x / kFS;       // g (hence mu) is wave-uniform
+  constexpr int MUSTEP = 4 / LPT;
   const int tlen = (T + tsplit - 1) / tsplit;
   const int t0 = tc * tlen, t1 = min(T, t0 + tlen);
   const double2* xc = xn + c * 36L * V;
-  double2* oc = out + (c * 4 + mu) * 9L * V;
   SPos p;
   p.q = tile0 + lt;
   {
@@ -588,17 +591,18 @@ __global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_ke
   {
     const int ta = (t0 - 1 + T) % T;
 #pragma unroll 1
-    for (int k = 0; k < 2; ++k) {
-      const int sl = (ta + k) % T;
+    for (int k = 0; k < 2 * LPT; ++k) {
+      const int sl = (ta + (k & 1)) % T, mu = g + MUSTEP * (k >> 1);
       M3 tmp;
       load_link(tmp, xc + mu * 9 * V, V, sl * Vs + sp);
-      fs_put<kFS>(fs_lds + k * kSlot, mu, lt, tmp);
+      fs_put<kFS>(fs_lds + (k & 1) * kSlot, mu, lt, tmp);
     }
   }
   __syncthreads();
   int slot_cur = 0;
-  M3 dcarry;
-  m3_zero(dcarry);
+  M3 dcarry_[LPT], pre_[LPT];
+#pragma unroll
+  for (int h = 0; h < LPT; ++h) m3_zero(dcarry_[h]);
   const int niter = (t1 - t0) + 1;
 #pragma unroll 1
   for (int it = 0; it < niter; ++it) {
@@ -609,6 +613,10 @@ __global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_ke
     const double2* gcur = xc + (long)tcur * Vs;
     const double2* gnxt = xc + (long)tnext * Vs;
     const bool more = it + 1 < niter;
+#pragma unroll
+    for (int h = 0; h < LPT; ++h) {
+    const int mu = g + MUSTEP * h;
+    double2* oc = out + (c * 4 + mu) * 9L * V;
     SPos pmu = p;
     if (mu != 0) pmu = sp_move(p, mu, +1, d);
     if (it > 0) {
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_ke
         }
       } else {
         if constexpr (VARIANT != 2) {
-          acc = dcarry;                                // down staple in the t direction
+          acc = dcarry_[h];                                // down staple in the t direction
         } else {                                       // t-direction down staple from slice t-1 (L2)
           const double2* gprv = xc + (long)((tcur - 1 + T) % T) * Vs;
           M3 a, b, t;
@@ -697,9 +705,8 @@ __global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_ke
     }
     // prefetch this thread's link of the slice after next (hidden behind the carry staple,
     // the barrier and the partner wavefront's work)
-    M3 pre;
     if constexpr (VARIANT == 0) {
-      if (more) load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
+      if (more) load_link(pre_[h], xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
     }
     if (VARIANT != 2 && mu != 0 && more) {
       // next iteration's t-direction down staple of link (tnext, sp, mu), all from slice tcur:
@@ -709,12 +716,17 @@ __global__ __launch_bounds__(4 * kFS, kFS == 64 ? 1 : 2) void su3_force_slice_ke
       fs_own<kFS>(b, cur, mu, lt);
       m3_mul_aa(t, a, b);
       fs_own<kFS>(a, cur, 0, lt);
-      m3_mul_nn(dcarry, t, a);
+      m3_mul_nn(dcarry_[h], t, a);
+    }
     }
     __syncthreads();                                    // slice tcur fully consumed
     if (more) {
-      if constexpr (VARIANT != 0) load_link(pre, xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
-      fs_put<kFS>(fs_lds + slot_cur * kSlot, mu, lt, pre);
+#pragma unroll
+      for (int h = 0; h < LPT; ++h) {
+        const int mu = g + MUSTEP * h;
+        if constexpr (VARIANT != 0) load_link(pre_[h], xc + mu * 9 * V, V, ((tnext + 1) % T) * Vs + sp);
+        fs_put<kFS>(fs_lds + slot_cur * kSlot, mu, lt, pre_[h]);
+      }
     }
     slot_cur ^= 1;
     __syncthreads();
@@ -917,6 +929,7 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
   const int Vs_ = d.X * d.Y * d.Z;
   constexpr int kFS = KICK ? kFSKick : kFSPlain;
   constexpr int kVar = KICK ? 2 : 0;
+  constexpr int kLpt = KICK ? 1 : kLptPlain;
   if (tuning().force_tile == 2 && Vs_ % kFS == 0) {
     const int nsb = Vs_ / kFS;
     int tsplit = (int)cdiv(512, (long)nb * nsb);       // >= ~2 resident rounds of 256 CUs
@@ -927,12 +940,12 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
     const size_t lds = 2ul * 4 * 9 * kFS * sizeof(double2);
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<KICK, kFS, kVar>,
+      (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<KICK, kFS, kVar, kLpt>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL((su3_force_slice_kernel<KICK, kFS, kVar>),
-                       dim3((unsigned)((long)nb * nsb * tsplit)), dim3(4 * kFS), lds, st, xn, d, nsb,
+    hipLaunchKernelGGL((su3_force_slice_kernel<KICK, kFS, kVar, kLpt>),
+                       dim3((unsigned)((long)nb * nsb * tsplit)), dim3(4 * kFS / kLpt), lds, st, xn, d, nsb,
                        tsplit, tuning().xcd_swizzle, coef, out);
     return;
   }
