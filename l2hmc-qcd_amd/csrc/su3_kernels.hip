@@ -499,9 +499,10 @@ __global__ __launch_bounds__(kBlock, OCC) void su3_force_tile_kernel(
 //     staple loops fully unrolled: 512 registers + 660 B scratch)
 // 0: carried t-staple + register prefetch of the slice after next   1: no prefetch
 // 2: no prefetch, t-staple re-read from slice t-1 through L2
-// The plain force runs the 64-site / one-wave / variant-0 build (0.52 ms vs 0.56 ms), the fused
-// v += coef F variant (two more HBM streams) the 128-site / two-wave / variant-2 build
-// (0.72 ms vs 0.77 ms): A/B measured on one MI355X.
+// The plain force runs 128-site tiles with two links per thread at one wavefront per SIMD,
+// variant 0 (same-box A/B: 0.51 ms; 64-site one-wave build 0.55 ms; 128-site two-wave variant 2
+// 0.59 ms); the fused v += coef F variant (two more HBM streams) keeps the 128-site / two-wave /
+// variant-2 build (0.73 ms vs 0.75-0.77 ms for the one-wave builds).
 constexpr int kFSPlain = 128, kFSKick = 128, kLptPlain = 2;
 // compiler-only fence: keeps hipcc from hoisting the next staple's operand loads above the
 // current staple's arithmetic
