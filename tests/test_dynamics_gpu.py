@@ -683,3 +683,64 @@ def test_u1_half_precision_conv_stack(hd):
     dyn._inject = {'normals': nrm.numpy(), 'u': np.full(nb, 0.5, dtype=np.float32)}
     xo32, m32 = dyn((x0, torch.tensor(2.5)))
     assert float((m32['acc'] - out[0][1]).abs().max()) < 600 * ulp
+
+
+@pytest.mark.parametrize('sep,split', [(False, False), (True, False), (False, True), (True, True)])
+def test_u1_network_sharing_modes_vs_oracle(sep, split):
+    """use_separate_networks / use_split_xnets (dynamics.py:226-237, network.py:669-801): which
+    LeapfrogLayer a sub-update calls -- one shared pair, one per leapfrog step, first / second
+    xnets -- against the oracle driven by the same state_dict, on a merged trajectory."""
+    import l2hmc.configs as cfgs
+    from oracle import network as onet
+    from oracle.dynamics import DynamicsOracle
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(21)
+    np.random.seed(21)
+    L, nb, nlf, beta = [6, 4], 5, 3, 2.0
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=nlf, eps=0.07,
+                             eps_hmc=0.1, verbose=False, use_split_xnets=split,
+                             use_separate_networks=sep)
+    nc = cfgs.NetworkConfig(units=[8, 6], activation_fn='tanh', dropout_prob=0.0,
+                            use_batch_norm=False)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                          vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+    lat = LatticeU1(nb, L)
+    dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig())).eval()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n_, p in dyn.named_parameters():
+            if n_.endswith('coeff'):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g).to(p.device))
+    sd = {k: v.detach().cpu().numpy() for k, v in dyn.state_dict().items()
+          if not k.startswith('networks.')}
+    kw = dict(nunits=2, activation='tanh', conv=None, use_batch_norm=False)
+
+    def vnet(step, x, f):
+        pre = f'vnet.{step}.' if sep else 'vnet.'
+        return onet.leapfrog_layer(x, f, helpers.sub(sd, pre), **kw)
+
+    def xnet(step, first, x, v):
+        pre = 'xnet.'
+        if sep:
+            pre += f'{step}.'
+            if split:
+                pre += 'first.' if first else 'second.'
+        return onet.leapfrog_layer(x, v, helpers.sub(sd, pre), **kw)
+    orc = DynamicsOracle('U1', tuple(L), nlf, [sd[f'xeps.{i}'] for i in range(nlf)],
+                         [sd[f'veps.{i}'] for i in range(nlf)],
+                         np.stack([host(m)[0] for m in dyn.masks]), vnet=vnet, xnet=xnet,
+                         dtype=np.float32)
+    x = lat.random()
+    nrm = torch.randn(nb, 2, *L, generator=g).numpy()
+    u = np.full(nb, 0.5, dtype=np.float32)
+    want_x, want_m = orc.apply_transition_fb(host(x), beta, nrm, u)
+    for fused in (True, False):
+        dyn.fuse_u1_steps = fused
+        dyn._inject = {'normals': nrm, 'u': u}
+        xo, m = dyn((x, torch.tensor(beta)))
+        assert err(host(m['acc']), want_m['acc']) < 2e-3, (sep, split, fused)
+        d = np.abs(np.angle(np.exp(1j * (host(xo) - want_x.reshape(nb, -1)))))
+        assert d.max() < 2e-4, (sep, split, fused, d.max())
