@@ -744,3 +744,68 @@ def test_u1_network_sharing_modes_vs_oracle(sep, split):
         assert err(host(m['acc']), want_m['acc']) < 2e-3, (sep, split, fused)
         d = np.abs(np.angle(np.exp(1j * (host(xo) - want_x.reshape(nb, -1)))))
         assert d.max() < 2e-4, (sep, split, fused, d.max())
+
+
+def test_u1_net_weights_vs_oracle():
+    """NetWeights (configs.py NetWeight s / t / q multipliers of the xnet and vnet outputs, set by
+    NetworkFactory and Experiment.set_net_weights) against the oracle's `nw` scaling, on a merged
+    trajectory; (0, 0, 0) weights reduce L2HMC to a reversible leapfrog with zero log-Jacobian."""
+    import l2hmc.configs as cfgs
+    from oracle import network as onet
+    from oracle.dynamics import DynamicsOracle
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(23)
+    np.random.seed(23)
+    L, nb, nlf, beta = [4, 6], 4, 2, 2.5
+    nwx, nwv = (0.5, 2.0, 0.0), (1.5, 0.0, 0.7)
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=nlf, eps=0.08,
+                             eps_hmc=0.1, verbose=False)
+    nc = cfgs.NetworkConfig(units=[8], activation_fn='leaky_relu', dropout_prob=0.0,
+                            use_batch_norm=False)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                          vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+    lat = LatticeU1(nb, L)
+    nws = cfgs.NetWeights(x=cfgs.NetWeight(*nwx), v=cfgs.NetWeight(*nwv))
+    dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig(),
+                                                  net_weights=nws)).eval()
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for n_, p in dyn.named_parameters():
+            if n_.endswith('coeff'):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g).to(p.device))
+    sd = {k: v.detach().cpu().numpy() for k, v in dyn.state_dict().items()
+          if not k.startswith('networks.')}
+    kw = dict(nunits=1, activation='leaky_relu', conv=None, use_batch_norm=False)
+
+    def vnet(step, x, f):
+        return onet.leapfrog_layer(x, f, helpers.sub(sd, f'vnet.{step}.'), nw=nwv, **kw)
+
+    def xnet(step, first, x, v):
+        which = 'first' if first else 'second'
+        return onet.leapfrog_layer(x, v, helpers.sub(sd, f'xnet.{step}.{which}.'), nw=nwx, **kw)
+    orc = DynamicsOracle('U1', tuple(L), nlf, [sd[f'xeps.{i}'] for i in range(nlf)],
+                         [sd[f'veps.{i}'] for i in range(nlf)],
+                         np.stack([host(m)[0] for m in dyn.masks]), vnet=vnet, xnet=xnet,
+                         dtype=np.float32)
+    x = lat.random()
+    nrm = torch.randn(nb, 2, *L, generator=g).numpy()
+    u = np.full(nb, 0.5, dtype=np.float32)
+    want_x, want_m = orc.apply_transition_fb(host(x), beta, nrm, u)
+    for fused in (True, False):
+        dyn.fuse_u1_steps = fused
+        dyn._inject = {'normals': nrm, 'u': u}
+        xo, m = dyn((x, torch.tensor(beta)))
+        assert err(host(m['acc']), want_m['acc']) < 2e-3, fused
+        d = np.abs(np.angle(np.exp(1j * (host(xo) - want_x.reshape(nb, -1)))))
+        assert d.max() < 2e-4, (fused, d.max())
+    # all multipliers zero: generic leapfrog, sum of log-Jacobians vanishes
+    from l2hmc.network.pytorch.network import LeapfrogLayer
+    for mod in dyn.networks.modules():
+        if isinstance(mod, LeapfrogLayer):
+            mod.set_net_weight(cfgs.NetWeight(0., 0., 0.))
+    dyn._inject = {'normals': nrm, 'u': u}
+    xo, m = dyn((x, torch.tensor(beta)))
+    assert float(m['sumlogdet'].abs().max()) < 1e-4
