@@ -685,11 +685,13 @@ def test_u1_half_precision_conv_stack(hd):
     assert float((m32['acc'] - out[0][1]).abs().max()) < 600 * ulp
 
 
+@pytest.mark.parametrize('ncp', [True, False])
 @pytest.mark.parametrize('sep,split', [(False, False), (True, False), (False, True), (True, True)])
-def test_u1_network_sharing_modes_vs_oracle(sep, split):
+def test_u1_network_sharing_modes_vs_oracle(sep, split, ncp):
     """use_separate_networks / use_split_xnets (dynamics.py:226-237, network.py:669-801): which
     LeapfrogLayer a sub-update calls -- one shared pair, one per leapfrog step, first / second
-    xnets -- against the oracle driven by the same state_dict, on a merged trajectory."""
+    xnets -- and the x-update form (use_ncp, dynamics.py:1386-1477) against the oracle driven by
+    the same state_dict, on a merged trajectory."""
     import l2hmc.configs as cfgs
     from oracle import network as onet
     from oracle.dynamics import DynamicsOracle
@@ -702,7 +704,7 @@ def test_u1_network_sharing_modes_vs_oracle(sep, split):
     L, nb, nlf, beta = [6, 4], 5, 3, 2.0
     dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=nlf, eps=0.07,
                              eps_hmc=0.1, verbose=False, use_split_xnets=split,
-                             use_separate_networks=sep)
+                             use_separate_networks=sep, use_ncp=ncp)
     nc = cfgs.NetworkConfig(units=[8, 6], activation_fn='tanh', dropout_prob=0.0,
                             use_batch_norm=False)
     spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
@@ -732,7 +734,7 @@ def test_u1_network_sharing_modes_vs_oracle(sep, split):
     orc = DynamicsOracle('U1', tuple(L), nlf, [sd[f'xeps.{i}'] for i in range(nlf)],
                          [sd[f'veps.{i}'] for i in range(nlf)],
                          np.stack([host(m)[0] for m in dyn.masks]), vnet=vnet, xnet=xnet,
-                         dtype=np.float32)
+                         use_ncp=ncp, dtype=np.float32)
     x = lat.random()
     nrm = torch.randn(nb, 2, *L, generator=g).numpy()
     u = np.full(nb, 0.5, dtype=np.float32)
