@@ -811,3 +811,57 @@ def test_u1_net_weights_vs_oracle():
     dyn._inject = {'normals': nrm, 'u': u}
     xo, m = dyn((x, torch.tensor(beta)))
     assert float(m['sumlogdet'].abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('sep', [False, True])
+def test_su3_separate_networks_vs_oracle(sep):
+    """SU(3) with one vnet per leapfrog step (use_separate_networks) or a shared one, freshly
+    initialised weights, against the oracle on a merged trajectory -- the fused heads / paired
+    v-update / cached-input paths must pick the right network for each step."""
+    import l2hmc.configs as cfgs
+    from oracle import network as onet
+    from oracle.dynamics import DynamicsOracle
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.network.pytorch.network import NetworkFactory
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(31)
+    np.random.seed(31)
+    L, nb, nlf, beta = [2, 4, 2, 2], 3, 3, 5.8
+    V = int(np.prod(L))
+    dc = cfgs.DynamicsConfig(nchains=nb, group='SU3', latvolume=L, nleapfrog=nlf, eps=0.02,
+                             eps_hmc=0.02, verbose=False, use_split_xnets=False,
+                             use_separate_networks=sep)
+    nc = cfgs.NetworkConfig(units=[6, 4], activation_fn='tanh', dropout_prob=0.0,
+                            use_batch_norm=False)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [32 * V], 'v': [32 * V]},
+                          vnet={'x': [32 * V], 'v': [32 * V]})
+    lat = LatticeSU3(nb, L)
+    dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig())).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n_, p in dyn.vnet.named_parameters():
+            if n_.endswith('coeff'):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g, dtype=torch.float64).to(p.device))
+    sd = {k: v.detach().cpu().numpy() for k, v in dyn.vnet.state_dict().items()}
+
+    def vnet(step, xv, fv):
+        return onet.leapfrog_layer(xv, fv, helpers.sub(sd, f'{step}.') if sep else sd, nunits=2,
+                                   activation='tanh')
+    xeps = [float(e.detach()) for e in dyn.xeps]
+    veps = [float(e.detach()) for e in dyn.veps]
+    orc = DynamicsOracle('SU3', tuple(L), nlf, xeps, veps,
+                         np.stack([host(m)[0] for m in dyn.masks]), vnet=vnet)
+    x = lat.random()
+    nrm = torch.randn(8, nb, 4, *L, generator=g, dtype=torch.float64).numpy()
+    u = np.full(nb, 0.5)
+    want_x, want_m = orc.apply_transition_fb(host(x), beta, nrm, u)
+    dyn._inject = {'normals': nrm, 'u': u}
+    xo, m = dyn((x, torch.tensor(beta)))
+    assert err(host(m['acc']), want_m['acc']) < 1e-6
+    assert err(host(xo), want_x.reshape(nb, -1)) < 1e-8
+    # same trajectory without the structural savings (input cache, paired v-updates, fused heads)
+    dyn.reuse_v_inputs = dyn.pair_v_updates = False
+    dyn._inject = {'normals': nrm, 'u': u}
+    xo2, m2 = dyn((x, torch.tensor(beta)))
+    assert err(host(xo2), host(xo)) < 1e-10 and err(host(m2['acc']), host(m['acc'])) < 1e-9
