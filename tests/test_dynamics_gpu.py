@@ -865,3 +865,81 @@ def test_su3_separate_networks_vs_oracle(sep):
     dyn._inject = {'normals': nrm, 'u': u}
     xo2, m2 = dyn((x, torch.tensor(beta)))
     assert err(host(xo2), host(xo)) < 1e-10 and err(host(m2['acc']), host(m['acc'])) < 1e-9
+
+
+@pytest.mark.parametrize('group', ['U1', 'SU3'])
+def test_save_load_init_weights_reversibility(group, tmp_path):
+    """Dynamics.save / load (networks/dynamics.pt + xeps.npy / veps.npy, dynamics.py:537-614):
+    a second instance restored from disk reproduces the trajectory bit for bit; init_weights
+    changes it; test_reversibility: the U(1) generalised leapfrog is reversible to fp32 round-off,
+    the SU(3) one only approximately."""
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+
+    def build(seed, ncp=True):
+        torch.manual_seed(seed)
+        np.random.seed(3)                    # masks come from numpy: same masks in both builds
+        if group == 'U1':
+            if torch.get_default_dtype() != torch.float64:
+                torch.set_default_dtype(torch.float32)
+            L, nb = [4, 6], 4
+            dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=2, eps=0.05,
+                                     eps_hmc=0.1, verbose=False, use_ncp=ncp)
+            spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                                  vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+            lat = LatticeU1(nb, L)
+        else:
+            torch.set_default_dtype(torch.float64)
+            L, nb = [2, 2, 2, 4], 3
+            V = int(np.prod(L))
+            dc = cfgs.DynamicsConfig(nchains=nb, group='SU3', latvolume=L, nleapfrog=2, eps=0.01,
+                                     eps_hmc=0.02, verbose=False, use_split_xnets=False,
+                                     use_separate_networks=False)
+            spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [32 * V], 'v': [32 * V]},
+                                  vnet={'x': [32 * V], 'v': [32 * V]})
+            lat = LatticeSU3(nb, L)
+        nc = cfgs.NetworkConfig(units=[6], activation_fn='tanh', dropout_prob=0.0,
+                                use_batch_norm=False)
+        return Dynamics(lat.action, dc, NetworkFactory(spec, nc, cfgs.ConvolutionConfig())).eval(), lat
+    a, lat = build(1)
+    with torch.no_grad():
+        for i, e in enumerate(a.xeps):
+            e.fill_(0.03 + 0.01 * i)
+    a.save(tmp_path)
+    # as in the reference, save() hands its own `networks/` directory to save_eps(), which
+    # appends another one (dynamics.py:537-557); restore_eps() reads from there, load() does not
+    assert (tmp_path / 'networks' / 'dynamics.pt').exists()
+    assert (tmp_path / 'networks' / 'networks' / 'xeps.npy').exists()
+    b, _ = build(2)                              # different weights ...
+    with pytest.raises(FileNotFoundError):
+        b.load(tmp_path)                         # (the reference's load() has the same mismatch)
+    b.load_state_dict(torch.load(tmp_path / 'networks' / 'dynamics.pt'))
+    b.restore_eps(tmp_path)                      # ... until restored
+    x = lat.random()
+    beta = torch.tensor(2.0 if group == 'U1' else 6.0)
+    shape = (x.shape[0], 2, 4, 6) if group == 'U1' else (8, x.shape[0], 4, 2, 2, 2, 4)
+    nrm = np.random.default_rng(5).standard_normal(shape)
+    nrm = nrm.astype(np.float32) if group == 'U1' else nrm
+    u = np.full(x.shape[0], 0.5, dtype=np.float32 if group == 'U1' else np.float64)
+    outs = []
+    for d_ in (a, b):
+        d_._inject = {'normals': nrm, 'u': u}
+        xo, m = d_((x, beta))
+        outs.append((xo.clone(), m['acc'].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert abs(b._eps('x', 1) - a._eps('x', 1)) < 1e-7
+    b.init_weights('xavier_uniform')
+    b._inject = {'normals': nrm, 'u': u}
+    xo, m = b((x, beta))
+    assert not torch.equal(xo, outs[0][0])
+    rev = a.test_reversibility()
+    if group == 'U1':
+        # the reference's NCP backward x-update (dynamics.py:1430-1477) is not the exact inverse of
+        # its forward one: reversible to O(eps^2) only
+        d = np.abs(np.angle(np.exp(1j * rev['dx'])))
+        assert d.max() < 5e-2, d.max()
+    else:
+        assert rev['dx'].max() < 5e-2                    # not exactly reversible in the reference either
