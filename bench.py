@@ -11,12 +11,20 @@ nleapfrog = 4 (=> 8 executed LF steps), vnet units [256] (conf/su3test.yaml of t
 Synthetic hot-start gauge field, random-init networks.  Chains are independent: with N GPUs
 every rank runs its own 256 chains (weak scaling), no data-path collective.
 
+``--gpus N`` from a bare shell re-executes itself under ``torch.distributed.run`` with N ranks
+(one per GPU, backend nccl = RCCL over xGMI); under torchrun (RANK / WORLD_SIZE set) it checks
+that the world size equals N.  ``--mode train`` times ``Trainer.train_step`` instead (tape +
+reverse sweep + ONE all-reduce of the flat gradient + fused Adam) and reports the collective's
+time and bandwidth.
+
 Prints ONE JSON line (rank 0).  ``roofline`` is measured live with HIP events recorded on the
 launch stream around every kernel launch of the timed region.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,18 +32,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6       # MI355X fp64 matrix peak (datasheet; v_mfma_f64_16x16x4_f64)
 
-# algorithmic bytes per (chain * site) -- SURVEY.md section 8(d)
+# algorithmic bytes per (chain * site) -- SURVEY.md section 8(d): one 3x3 complex128 link is
+# 144 B, a site has 4 links; vec8 = 4 * 8 * 8 B = 256 B per site
 ALG_BYTES = {
-    'l2q_su3_plaq_reduce': 576, 'l2q_su3_force': 1152, 'l2q_su3_force_kick': 1728,
-    'l2q_su3_expm_mul': 1728, 'l2q_su3_projsu_vec8': 832, 'l2q_v_update': 2592,
-    'l2q_su3_kinetic_reduce': 576, 'l2q_su3_pack': 1152, 'l2q_su3_unpack': 1152,
-    'l2q_select_rows': 1728, 'l2q_su3_assemble_tah': 832, 'l2q_scale_f64': 1152,
+    'l2q_su3_plaq_reduce': 576,            # read x
+    'l2q_su3_force': 1152,                 # read x, write F
+    'l2q_su3_force_kick': 1728,            # read x, read + write v
+    'l2q_su3_force_vec8': 1408,            # read x, write F and vec8(F)
+    'l2q_su3_expm_mul': 1728,              # read x, v; write x
+    'l2q_su3_expm_mul2': 1728,
+    'l2q_su3_expm_mul2_vec8': 1984,        # + write vec8(x')
+    'l2q_su3_projsu_vec8': 832,            # read field, write vec8
+    'l2q_v_update': 2592,
+    'l2q_su3_kinetic_reduce': 576,
+    'l2q_su3_pack': 1152, 'l2q_su3_unpack': 1152,
+    'l2q_select_rows': 1152,               # the selected source row is read, the output written
+    'l2q_su3_assemble_tah': 832,           # 8 normals per link in, one TAH matrix out
+    'l2q_scale_f64': 1152,
 }
 
 
@@ -49,10 +65,36 @@ def parse():
     ap.add_argument('--nleapfrog', type=int, default=4)
     ap.add_argument('--units', type=int, nargs='+', default=[256])
     ap.add_argument('--beta', type=float, default=6.0)
-    ap.add_argument('--mode', choices=['l2hmc', 'hmc'], default='l2hmc')
+    ap.add_argument('--mode', choices=['l2hmc', 'hmc', 'train'], default='l2hmc')
+    ap.add_argument('--micro-batch', type=int, default=None,
+                    help='train mode: chains per tape micro-batch (needed at 16^4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-chains', type=int, default=32)
+    ap.add_argument('--no-spot-check', action='store_true')
+    ap.add_argument('--cpu-chains', type=int, default=16)
     return ap.parse_args()
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def respawn_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` from a bare shell: one rank per GPU through torch.distributed.run
+    (the reference's counterpart: process-group init + DDP wrap, utils/dist.py:126-144,
+    trainers/pytorch/trainer.py:246-257)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 
 def build(args, seed):
@@ -82,7 +124,27 @@ def build(args, seed):
     return dyn, lat
 
 
-def hot_start(lat, args, seed):
+def build_trainer(args, seed):
+    """Trainer (train_step) at the same shapes; model from the base seed on every rank."""
+    import l2hmc.configs as cfgs
+    from l2hmc.trainers.pytorch.trainer import Trainer
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    L = ','.join(str(i) for i in args.lattice)
+    units = ','.join(str(u) for u in args.units)
+    cfg = cfgs.get_config([
+        'dynamics.group=SU3', f'dynamics.latvolume=[{L}]', f'dynamics.nchains={args.nchains}',
+        f'dynamics.nleapfrog={args.nleapfrog}', 'dynamics.eps=0.01', 'dynamics.verbose=false',
+        'dynamics.use_split_xnets=false', 'dynamics.use_separate_networks=false',
+        f'network.units=[{units}]', 'network.activation_fn=tanh', 'network.dropout_prob=0.0',
+        'network.use_batch_norm=false', 'conv=none', 'loss.plaq_weight=0.1',
+        'loss.rmse_weight=0.1', 'loss.charge_weight=0.0'])
+    tr = Trainer(cfg)
+    tr.micro_batch = args.micro_batch
+    return tr
+
+
+def hot_start(args, seed):
     """x = projectSU(randn + i randn) (SU3.random, group/su3/pytorch/group.py:113-119), drawn on
     the device generator and projected by the HIP kernel."""
     from l2hmc import _ops as ops
@@ -114,7 +176,7 @@ class KernelTimer:
             e0.record()
             orig(name, *a)
             e1.record()
-            fl = 2.0 * a[2] * a[3] * (a[4] + a[7]) if name.startswith('l2q_gemm') else 0.0
+            fl = 2.0 * a[2] * a[3] * (a[4] + a[7]) if name in ('l2q_gemm_f64', 'l2q_gemm_f32') else 0.0
             timer.records.append((name, fl, e0, e1))
         native.call = timed_call
         import l2hmc._ops as ops
@@ -131,38 +193,76 @@ class KernelTimer:
 
 
 def cpu_baseline(dyn, args):
-    """The numpy oracle (a port of the reference's PyTorch-CPU path, pinned to golden vectors)
-    timed on the host cores on a bounded sample of the same workload."""
-    from oracle import network as onet, su3 as osu3
-    from oracle.dynamics import DynamicsOracle
+    """oracle/torch_cpu.py -- a torch-CPU restatement of the reference's path with the
+    reference's method (roll-based Wilson loops, autograd force, torch.matrix_exp; pinned to the
+    reference fixtures by tests/test_oracle_golden.py) -- timed on all host cores on a bounded
+    sample of the same workload."""
+    from oracle import torch_cpu as tc
     nbc = args.cpu_chains
     L = tuple(args.lattice)
-    rng = np.random.default_rng(1)
     nlf = 1
+    gen = torch.Generator().manual_seed(1)
     masks = [m.numpy().reshape(-1) for m in dyn.masks[:nlf]]
-    vnet = None
+    w = None
     if args.mode == 'l2hmc':
-        w = {k: v.detach().cpu().numpy() for k, v in dyn.vnet.state_dict().items()}
-
-        def vnet(step, xv, fv):
-            return onet.leapfrog_layer(xv, fv, w, nunits=len(args.units), activation='tanh')
-    orc = DynamicsOracle('SU3', L, nlf, [0.01] * nlf, [0.01] * nlf, masks, vnet=vnet)
-    x = osu3.project_su(rng.normal(size=(nbc, 4, *L, 3, 3)) + 1j * rng.normal(size=(nbc, 4, *L, 3, 3)))
-    nrm = rng.normal(size=(8, nbc, 4, *L))
-    u = rng.random(nbc)
+        w = {k: v.detach().cpu() for k, v in dyn.vnet.state_dict().items()}
+    sim = tc.TorchSU3Dynamics(L, nlf, [0.01] * nlf, [0.01] * nlf, masks, w, nunits=len(args.units))
+    z = torch.randn((nbc, 4, *L, 3, 3, 2), dtype=torch.float64, generator=gen)
+    x = tc.project_su(torch.view_as_complex(z))
+    nrm = torch.randn((8, nbc, 4, *L), dtype=torch.float64, generator=gen)
+    u = torch.rand(nbc, dtype=torch.float64, generator=gen)
     t0 = time.perf_counter()
     if args.mode == 'l2hmc':
-        orc.apply_transition_fb(x, args.beta, nrm, u)
+        sim.apply_transition_fb(x, args.beta, nrm, u)
         nsteps = 2 * nlf
     else:
-        orc.apply_transition_hmc(x, args.beta, nrm, u, 0.01, 2)
+        sim.apply_transition_hmc(x, args.beta, nrm, u, 0.01, 2)
         nsteps = 2
     dt = time.perf_counter() - t0
-    return {'value': nbc * nsteps / dt, 'unit': 'chain*leapfrog-steps/s', 'cores': 1,
-            'kind': 'port',
+    return {'value': round(nbc * nsteps / dt, 2), 'unit': 'chain*leapfrog-steps/s',
+            'cores': torch.get_num_threads(), 'host_cpus': os.cpu_count(), 'kind': 'port',
             'sample': f'{nbc} chains x {nsteps} LF steps of the same {args.mode} trajectory '
                       f'(SU(3) {"x".join(map(str, L))}, units {args.units}) in {dt:.1f} s; '
-                      'single-threaded numpy'}
+                      f'oracle/torch_cpu.py on {torch.get_num_threads()} torch threads'}
+
+
+def spot_check(dyn, lat, x, args):
+    """Untimed sanity of what was timed (rank 0): observables of the output configuration and one
+    force evaluation of two of its chains through the HIP kernels vs the numpy oracle; acceptance
+    of plain HMC after a short thermalisation (the random-init L2HMC networks reject everything
+    from a hot start, so `accept_prob_mean` alone says nothing about the integrator)."""
+    from oracle import su3 as osu3
+    from l2hmc import _ops as ops
+    L = tuple(args.lattice)
+    x4 = x.reshape(args.nchains, 4, *L, 3, 3)
+    pick = [0, args.nchains - 1] if args.nchains > 1 else [0]
+    xh = x4[pick].cpu().numpy()
+    met = lat.calc_metrics(x4)
+    pl = met['plaqs'][pick].cpu().numpy()
+    qi = met['intQ'][pick].cpu().numpy()
+    f = ops.su3_unpack(ops.su3_force_n(ops.su3_pack(x4[pick]), args.beta, L), L).cpu().numpy()
+    av, mx = osu3.check_su(xh)
+    out = {'chains': pick,
+           'plaq_abs_err': float(np.abs(pl - osu3.plaqs(xh)).max()),
+           'intQ_abs_err': float(np.abs(qi - osu3.int_charges(xh)).max()),
+           'force_abs_err': float(np.abs(f - osu3.grad_action(xh, args.beta)).max()),
+           'checkSU_max': float(mx.max()), 'plaq': [round(float(p), 6) for p in pl]}
+    ok = (out['plaq_abs_err'] < 1e-10 and out['intQ_abs_err'] < 1e-9
+          and out['force_abs_err'] < 1e-11 and out['checkSU_max'] < 1e-10)
+    # plain HMC, eps = 0.05 x 8 steps, 24 trajectories from the hot start at this beta
+    old = dyn.config.verbose
+    dyn.config.verbose = False
+    xs, accs, plq = x, [], []
+    beta = torch.tensor(args.beta)
+    for i in range(24):
+        xs, m = dyn.apply_transition_hmc((xs, beta), eps=0.05, nleapfrog=8)
+        accs.append(float(m['acc'].mean()))
+    dyn.config.verbose = old
+    plq = float(lat.calc_metrics(xs.reshape(x4.shape))['plaqs'].mean())
+    out.update({'hmc_acc_last8': round(float(np.mean(accs[-8:])), 4),
+                'hmc_plaq_after_24_traj': round(plq, 5), 'ok': bool(ok)})
+    assert ok, f'spot check against the oracle failed: {out}'
+    return out
 
 
 def secondary(dyn, x, beta, args, nlf_exec):
@@ -192,40 +292,111 @@ def secondary(dyn, x, beta, args, nlf_exec):
     return res
 
 
+def load_traffic(args):
+    """profiles/pmc_traffic.json: HBM/fabric bytes per launch from separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes (tools/pmc_collect.sh).  An entry is used only if it was
+    measured on THIS lattice / chain count and on the kernel template the library dispatches now
+    (l2q_kernel_name); otherwise traffic is null with the reason."""
+    from l2hmc import native
+    f = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    pmc = json.load(open(f)) if os.path.exists(f) else {}
+    L = [int(i) for i in args.lattice]
+
+    def traffic(name):
+        t = pmc.get(name)
+        if t is None:
+            return None, 'no PMC pass recorded for this entry point'
+        if t.get('lattice') != L or t.get('nchains') != args.nchains:
+            return None, (f"PMC pass was taken at lattice {t.get('lattice')} x {t.get('nchains')} "
+                          f"chains, this run is {L} x {args.nchains}")
+        now = native.kernel_name(name, L)
+        if now and now not in t.get('kernel', ''):
+            return None, f"PMC pass was taken on `{t.get('kernel')}`, the library now dispatches `{now}`"
+        return t['total_bytes'], t.get('source')
+    return traffic
+
+
+def allreduce_probe(tr, dist, world, reps=5):
+    """Time of the ONE collective of a training step: all-reduce of the flat gradient arena
+    (trainers/pytorch/trainer.py:246-257, 1296-1304 = DDP's bucketed all-reduce in the reference)."""
+    nbytes = sum(g['grad'].numel() * g['grad'].element_size() for g in tr.arena.groups.values())
+    out = {'bytes': nbytes, 'ranks': world}
+    if dist is None:
+        out['note'] = 'single rank: no collective'
+        return out
+    for _ in range(2):
+        tr.arena.all_reduce()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tr.arena.all_reduce()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    out.update({'ms': round(dt * 1e3, 3), 'algbw_GBps': round(nbytes / dt / 1e9, 2),
+                'busbw_GBps': round(nbytes / dt / 1e9 * 2 * (world - 1) / world, 2)})
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with '
+                 f'--nproc-per-node {args.gpus} (or from a bare shell, which self-spawns)')
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU path)'
     # L2Q_BENCH_SHARE_GPU=1 + L2Q_BENCH_BACKEND=gloo: functional test of the N>1 path on a
     # 1-GPU box (all ranks on device 0); the real runs use one GPU per rank and RCCL.
     share = os.environ.get('L2Q_BENCH_SHARE_GPU') == '1'
+    if not share and torch.cuda.device_count() < world:
+        sys.exit(f'bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible')
     torch.cuda.set_device(0 if share else local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(os.environ.get('L2Q_BENCH_BACKEND', 'nccl'), rank=rank,
-                                world_size=world)                      # nccl = RCCL over xGMI
-    dyn, lat = build(args, seed=9992)
-    x = hot_start(lat, args, seed=9992 * (rank + 1))
+        backend = os.environ.get('L2Q_BENCH_BACKEND', 'nccl')             # nccl = RCCL over xGMI
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+    seed = 9992
+    train = args.mode == 'train'
+    if train:
+        tr = build_trainer(args, seed)
+        dyn, lat = tr.dynamics, tr.lattice
+    else:
+        dyn, lat = build(args, seed)
+    x = hot_start(args, seed=seed * (rank + 1))
+    if train:
+        # per-rank stream for momenta / accept uniforms (chains differ, the model does not)
+        torch.manual_seed(seed * (rank + 1))
+        torch.cuda.manual_seed(seed * (rank + 1))
     beta = torch.tensor(args.beta)
     nlf_exec = 2 * args.nleapfrog
 
     def step(xin):
+        if train:
+            return tr.train_step((xin, args.beta))
         if args.mode == 'l2hmc':
-            xo, m = dyn((xin, beta))
-        else:
-            xo, m = dyn.apply_transition_hmc((xin, beta), eps=0.01, nleapfrog=nlf_exec)
-        return xo, m
+            return dyn((xin, beta))
+        return dyn.apply_transition_hmc((xin, beta), eps=0.01, nleapfrog=nlf_exec)
 
     # set-up, not a measured or counted step: the first two trajectories of a process grow
     # PyTorch's caching-allocator pool (hipMalloc is synchronous: 28 + 5 calls, 2.6 s + 1.4 s at
     # the 16^4 shard, DESIGN.md section 6) and build the native-order weight copies.  Doing that
     # here keeps the W warm-up steps of the contract what they are meant to be even for W = 0 / 1.
-    for _ in range(2):
+    # (train mode: the first step also builds the parameter arena; weights stay in sync because
+    # every rank applies the same all-reduced gradient.)
+    for _ in range(1 if train else 2):
         step(x)
     torch.cuda.synchronize()
     timer = KernelTimer()
@@ -252,6 +423,7 @@ def main():
         dt = float(t.item())
     acc = m['acc']
     assert torch.isfinite(acc).all() and torch.isfinite(x).all(), 'non-finite trajectory'
+    ar = allreduce_probe(tr, dist, world) if train else None
 
     if rank == 0:
         V = int(np.prod(args.lattice))
@@ -262,55 +434,62 @@ def main():
         for name, (cnt, tt, fl) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
             ent = {'launches': cnt, 'avg_ms': round(tt / cnt * 1e3, 4),
                    'share': round(tt / total_k, 4)}
-            if name in ALG_BYTES:
+            if name in ALG_BYTES and not (train and args.micro_batch):
                 ent['GB/s'] = round(sites * ALG_BYTES[name] / (tt / cnt) / 1e9, 1)
             kernels[name] = ent
-        traffic_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
-
-        def traffic(name):
-            t = pmc.get(name)
-            return (None, None) if t is None else (t['total_bytes'], t.get('source'))
+        if len(kernels) > 24:                      # train mode: ~60 entry points; keep the top
+            kernels = dict(list(kernels.items())[:24])
+        traffic = load_traffic(args)
 
         def hbm_roof(name):
             cnt, tt, _ = ks[name]
             ach = sites * ALG_BYTES[name] / (tt / cnt) / 1e9
-            tr, src = traffic(name)
-            return {'kernel': name, 'bound': 'hbm', 'achieved': round(ach, 1),
+            tr_, src = traffic(name)
+            return {'kernel': name, 'symbol': native_name(name), 'bound': 'hbm',
+                    'achieved': round(ach, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': tr, 'traffic_source': src, 'avg_ms': round(tt / cnt * 1e3, 4),
+                    'traffic': tr_, 'traffic_source': src, 'avg_ms': round(tt / cnt * 1e3, 4),
                     'launches': cnt, 'algorithmic_bytes_per_launch': sites * ALG_BYTES[name],
                     'time_s': tt}
+
+        def native_name(name):
+            from l2hmc import native
+            return native.kernel_name(name, [int(i) for i in args.lattice])
 
         def mfma_roof(names, label, flops):
             cnt = sum(ks[n][0] for n in names)
             tt = sum(ks[n][1] for n in names)
             ach = flops / tt / 1e12
-            tr, src = traffic(names[0])
+            tr_, src = traffic(names[0])
             return {'kernel': label, 'bound': 'mfma', 'achieved': round(ach, 2),
                     'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                    'frac': round(ach / FP64_MFMA_PEAK_TF, 4), 'traffic': tr,
+                    'frac': round(ach / FP64_MFMA_PEAK_TF, 4), 'traffic': tr_,
                     'traffic_source': src, 'avg_ms': round(tt / cnt * 1e3, 4), 'launches': cnt,
                     'time_s': tt}
 
         rooflines = []
-        force_name = 'l2q_su3_force' if 'l2q_su3_force' in ks else 'l2q_su3_force_kick'
-        rooflines.append(hbm_roof(force_name))
-        rooflines.append(hbm_roof('l2q_su3_plaq_reduce'))
-        heads = [n for n in ('l2q_vnet_heads_vupdate_pair_f64', 'l2q_vnet_heads_vupdate_f64')
-                 if n in ks]
-        if heads:
-            per = 3 * 2.0 * args.nchains * args.units[-1] * 36 * V       # s, t, q heads
-            rooflines.append(mfma_roof(heads, 'l2q_vnet_heads_vupdate[_pair]_f64 (3 heads + '
-                                       'v-update)', per * sum(ks[n][0] for n in heads)))
-        if 'l2q_gemm_f64' in ks:
-            rooflines.append(mfma_roof(['l2q_gemm_f64'], 'l2q_gemm_f64 (input + hidden layers)',
-                                       ks['l2q_gemm_f64'][2]))
+        if not (train and args.micro_batch):
+            for fname in ('l2q_su3_force', 'l2q_su3_force_vec8', 'l2q_su3_force_kick'):
+                if fname in ks:
+                    rooflines.append(hbm_roof(fname))
+            if 'l2q_su3_plaq_reduce' in ks:
+                rooflines.append(hbm_roof('l2q_su3_plaq_reduce'))
+            heads = [n for n in ('l2q_vnet_heads_vupdate_pair_f64', 'l2q_vnet_heads_vupdate_f64')
+                     if n in ks]
+            if heads:
+                per = 3 * 2.0 * args.nchains * args.units[-1] * 36 * V       # s, t, q heads
+                rooflines.append(mfma_roof(heads, 'l2q_vnet_heads_vupdate[_pair]_f64 (3 heads + '
+                                           'v-update)', per * sum(ks[n][0] for n in heads)))
+            if 'l2q_gemm_f64' in ks:
+                rooflines.append(mfma_roof(['l2q_gemm_f64'], 'l2q_gemm_f64 (input + hidden layers)',
+                                           ks['l2q_gemm_f64'][2]))
         # `roofline` = the dominant kernel (largest share of the timed region) among those
-        roofline = dict(max(rooflines, key=lambda r: r['time_s']))
-        for r in rooflines + [roofline]:
+        roofline = dict(max(rooflines, key=lambda r: r['time_s'])) if rooflines else None
+        for r in rooflines + ([roofline] if roofline else []):
             r.pop('time_s', None)
         nchain_lf = world * args.nchains * nlf_exec * args.steps
+        what = {'l2hmc': 'Dynamics.forward merged L2HMC', 'hmc': 'apply_transition_hmc',
+                'train': 'Trainer.train_step (tape + reverse sweep + all-reduce + Adam)'}[args.mode]
         out = {
             'metric': 'chain*leapfrog-steps/sec, 4D SU(3) 8^4 fp64 '
                       '(+ plaquette/force-kernel HBM GB/s in "rooflines")',
@@ -321,20 +500,27 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'4D SU(3) {"x".join(map(str, args.lattice))}, beta={args.beta}, '
-                                   f'{args.nchains} chains/GPU, complex128/fp64, '
-                                   f'{"Dynamics.forward merged L2HMC" if args.mode == "l2hmc" else "apply_transition_hmc"}, '
+                                   f'{args.nchains} chains/GPU, complex128/fp64, {what}, '
                                    f'nleapfrog={args.nleapfrog} ({nlf_exec} LF steps/trajectory), '
                                    f'vnet units {args.units}, verbose=False',
                        'global_chains': world * args.nchains, 'parallelism': f'chains sharded x{world}'},
+            'rccl_ranks': world if (dist is not None and backend == 'nccl') else (0 if dist is None else f'{world} ({backend})'),
             'roofline': roofline,
             'rooflines': rooflines,
             'kernel_time_fraction_of_wall': round(total_k / dt, 4),
             'kernels': kernels,
             'accept_prob_mean': round(float(acc.mean()), 4),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['secondary'] = secondary(dyn, x, beta, args, nlf_exec)
-            out['cpu_baseline'] = cpu_baseline(dyn, args)
+        if train:
+            out['train'] = {'params_trained': tr.arena.numel(), 'grad_allreduce': ar,
+                            'micro_batch': args.micro_batch, 'loss': m.get('loss'),
+                            'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+        if world == 1 and not train:
+            if not args.no_spot_check:
+                out['spot_check'] = spot_check(dyn, lat, x, args)
+            if not args.no_cpu_baseline:
+                out['secondary'] = secondary(dyn, x, beta, args, nlf_exec)
+                out['cpu_baseline'] = cpu_baseline(dyn, args)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

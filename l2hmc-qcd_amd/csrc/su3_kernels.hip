@@ -976,6 +976,28 @@ static bool dims_ok(int nb, int T, int X, int Y, int Z) {
 
 extern "C" {
 
+int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, size_t buf_bytes) {
+  L2Q_REQUIRE(entry && buf && buf_bytes > 0, L2Q_EINVAL, "null pointer");
+  const int Vs = X * Y * Z;
+  const Tuning& t = tuning();
+  buf[0] = 0;
+  if (!strcmp(entry, "l2q_su3_plaq_reduce")) {
+    if (t.plaq_sweep == 2 && Vs % kSlice == 0)
+      snprintf(buf, buf_bytes, "su3_plaq_slice_kernel<%s>", (kSlice % (Y * Z)) == 0 ? "true" : "false");
+    else if (t.plaq_sweep == 1) snprintf(buf, buf_bytes, "su3_plaq_sweep_kernel<%d>", t.plaq_occ);
+    else snprintf(buf, buf_bytes, "su3_plaq_kernel<%d>", t.plaq_occ);
+  } else if (!strcmp(entry, "l2q_su3_force") || !strcmp(entry, "l2q_su3_force_kick")) {
+    const bool kick = !strcmp(entry, "l2q_su3_force_kick");
+    const int fs = kick ? kFSKick : kFSPlain;
+    if (t.force_tile == 2 && Vs % fs == 0)
+      snprintf(buf, buf_bytes, "su3_force_slice_kernel<%s, %d, %d, %d>", kick ? "true" : "false", fs,
+               kick ? 2 : 0, kick ? 1 : kLptPlain);
+    else if (t.force_tile) snprintf(buf, buf_bytes, "su3_force_tile_kernel<%s, %d>", kick ? "true" : "false", t.force_occ);
+    else snprintf(buf, buf_bytes, "su3_force_kernel<%s, %d>", kick ? "true" : "false", t.force_occ);
+  }
+  return L2Q_OK;
+}
+
 size_t l2q_reduce_ws_bytes(int nb, long n_per_chain) {
   if (nb <= 0 || n_per_chain <= 0) return 0;
   // two partial arrays of up to 2 doubles per 256-item block

@@ -24,6 +24,7 @@ SIGNATURES = {
     'l2q_last_error': (C.c_char_p, []),
     'l2q_version': (I, []),
     'l2q_set_tuning': (I, [C.c_char_p, I]),
+    'l2q_kernel_name': (I, [C.c_char_p, I, I, I, I, C.c_char_p, Z]),
     'l2q_reduce_ws_bytes': (Z, [I, L]),
     'l2q_transpose': (I, [P, P, L, I, I, I, P]),
     'l2q_su3_pack': (I, [P, P, I, L, P]),
@@ -159,6 +160,14 @@ def call(name: str, *args):
 
 def set_tuning(key: str, value: int) -> int:
     return load().l2q_set_tuning(key.encode(), int(value))
+
+
+def kernel_name(entry: str, lat) -> str:
+    """Device-kernel template `entry` dispatches for this lattice under the current tuning."""
+    buf = C.create_string_buffer(256)
+    T, X, Y, Zz = (int(i) for i in lat)
+    rc = load().l2q_kernel_name(entry.encode(), T, X, Y, Zz, buf, 256)
+    return buf.value.decode() if rc == 0 else ''
 
 
 class Workspace:

@@ -162,3 +162,51 @@ def test_su3_improved_action_c1(golden):
     fd = (su3.rect_sums(su3.expm(h * X) @ x) - su3.rect_sums(su3.expm(-h * X) @ x)) / (2 * h)
     an = np.einsum('...ij,...ji->...', X, x @ su3.rect_staples(x)).real.reshape(x.shape[0], -1).sum(1)
     close(fd, an, 1e-5 * max(1.0, float(np.abs(an).max())))
+
+
+# ---------------------------------------------------------------- torch-CPU oracle (all cores)
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_torch_cpu_oracle_su3_ops(golden):
+    """oracle/torch_cpu.py (bench.py's cpu_baseline) against the reference fixtures."""
+    import torch
+    from oracle import torch_cpu as tc
+    g = golden('su3_ops')
+    x, v, beta = _t(g['x']), _t(g['v']), float(g['beta'])
+    close(tc.action(x, beta).numpy(), g['action'], 1e-10)
+    close(tc.grad_action(x, beta).numpy(), g['force'], 1e-13)
+    close(tc.rand_tah3(_t(g['normals'])).numpy(), g['v'], 0.0)
+    close(tc.kinetic(v).numpy(), g['kinetic'], 1e-10)
+    close(tc.project_su(_t(g['general'])).numpy(), g['projsu_general'], 1e-12)
+    close(tc.tah(_t(g['general'])).numpy(), g['tah_general'], 1e-15)
+    close(tc.su3_to_vec(tc.project_su(x)).numpy(), g['vec_x'], 1e-12)
+    close(tc.su3_to_vec(_t(g['general'])).numpy(), g['vec_general'], 1e-15)
+    close((torch.linalg.matrix_exp(float(g['eps_expm']) * v) @ x).numpy(), g['expm_v_x'], 1e-14)
+
+
+def test_torch_cpu_oracle_trajectories(golden):
+    from oracle import torch_cpu as tc
+    g = golden('su3_hmc')
+    L = [int(i) for i in g['latvolume']]
+    d = tc.TorchSU3Dynamics(L, 2, [0.02] * 2, [0.02] * 2, [np.zeros(36 * int(np.prod(L)))] * 2)
+    xo, m = d.apply_transition_hmc(_t(g['x']), float(g['beta']), _t(g['normals']), g['u'],
+                                   float(g['eps']), int(g['nleapfrog']))
+    close(m['x_prop'].numpy(), g['x_prop'], 1e-12)
+    close(m['acc'].numpy(), g['acc'], 1e-8)
+    assert np.array_equal(m['acc_mask'].numpy(), g['acc_mask'])
+    close(xo.numpy().reshape(g['x_out'].shape), g['x_out'], 1e-12)
+    g = golden('su3_l2hmc')
+    L = [int(i) for i in g['latvolume']]
+    w = {k[5:]: _t(v) for k, v in g.items() if k.startswith('vnet.')}
+    d = tc.TorchSU3Dynamics(L, int(g['nleapfrog']), g['xeps'], g['veps'], g['masks'], w, nunits=1)
+    xo, m = d.apply_transition_fb(_t(g['x']), float(g['beta']), _t(g['normals']), g['u'])
+    close(m['v_init'].numpy(), g['v_init'], 0.0)
+    close(m['x_prop'].numpy(), g['x_prop'], 1e-7)
+    close(m['v_prop'].numpy(), g['v_prop'], 1e-6)
+    close(m['acc'].numpy(), g['acc'], 1e-5)
+    assert np.array_equal(m['acc_mask'].numpy(), g['acc_mask'])
+    close(m['sumlogdet'].numpy(), g['sumlogdet'], 1e-6)
+    close(xo.numpy().reshape(g['x_out'].shape), g['x_out'], 1e-7)

@@ -1,0 +1,318 @@
+"""GPU parity at the BASELINE shapes themselves (VERDICT r01 "next" item 1).
+
+The reference goldens are 3x4x5x3 lattices (spatial volume 60 => only the fall-back kernels run).
+These tests run the kernels that cfg-4 / cfg-5 actually launch -- slice-resident plaquette /
+force, split-K input GEMM with K = 262 144 (8^4) / 4 194 304 (16^4), fused heads with
+N = 147 456 / 2 359 296 -- against the numpy oracle on the same seeded inputs:
+
+* cfg-4: ``Dynamics`` at 8^4, vnet units [256], one merged nleapfrog = 4 trajectory with injected
+  draws (x_prop, energies, acc, bit-exact accept mask with one accept and one reject).
+* cfg-5: 16^4 with a full 256-chain allocation (9.66 GB per field: byte offsets past 2^32,
+  chain * 36 * V element offsets up to 6e8).  The 256 chains are copies of 2 distinct chains
+  (chain c = base[c % 2]), every chain of every kernel output is compared on the device with
+  the oracle's result for its base chain -- so an index that wraps anywhere in the allocation
+  shows up.  Kernels, a plain-HMC transition and one merged L2HMC trajectory (nleapfrog = 1,
+  units [256]: 23 GB of fp64 weights).
+"""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(autouse=True)
+def _f64_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _build(L, nb, nlf, units, eps, head_scale, seed):
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.network.pytorch.network import NetworkFactory
+    V = int(np.prod(L))
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dc = cfgs.DynamicsConfig(nchains=nb, group='SU3', latvolume=list(L), nleapfrog=nlf, eps=eps,
+                             eps_hmc=eps, verbose=True, use_split_xnets=False,
+                             use_separate_networks=False, merge_directions=True)
+    nc = cfgs.NetworkConfig(units=list(units), activation_fn='tanh', dropout_prob=0.0,
+                            use_batch_norm=False)
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [32 * V], 'v': [32 * V]},
+                          vnet={'x': [32 * V], 'v': [32 * V]})
+    lat = LatticeSU3(nb, list(L))
+    nf = NetworkFactory(spec, nc, cfgs.ConvolutionConfig(),
+                        cfgs.NetWeights(x=cfgs.NetWeight(0., 1., 1.), v=cfgs.NetWeight(1., 1., 1.)))
+    dyn = Dynamics(lat.action, dc, nf)
+    # random-init heads are O(1) per entry: dH ~ -50 over a trajectory and every chain rejects
+    # with acc = 1e-20.  Scaling the three head layers (weights are inputs of the test, the
+    # same numbers go to the oracle) puts acc strictly inside (0, 1).
+    with torch.no_grad():
+        for lin in (dyn.vnet.scale.layer, dyn.vnet.transl, dyn.vnet.transf.layer):
+            lin.weight.mul_(head_scale)
+            lin.bias.mul_(head_scale)
+    dyn.eval()
+    return dyn, lat
+
+
+def _oracle(dyn, L, nlf, units):
+    from oracle import network as onet
+    from oracle.dynamics import DynamicsOracle
+    w = {k: host(v) for k, v in dyn.vnet.state_dict().items()}
+
+    def vnet(step, xv, fv):
+        return onet.leapfrog_layer(xv, fv, w, nunits=len(units), activation='tanh')
+    xe = [float(p) for p in dyn.xeps]
+    ve = [float(p) for p in dyn.veps]
+    masks = [host(m).reshape(-1) for m in dyn.masks]
+    return DynamicsOracle('SU3', tuple(L), nlf, xe, ve, masks, vnet=vnet)
+
+
+def _hot(rng, nb, L):
+    from oracle import su3 as osu3
+    z = rng.normal(size=(nb, 4, *L, 3, 3)) + 1j * rng.normal(size=(nb, 4, *L, 3, 3))
+    return osu3.project_su(z)
+
+
+def _warm(rng, nb, L, delta=0.1):
+    """near-cold start exp(delta * TAH): plaquette ~0.95.  From a hot start the leapfrog energy
+    error has one sign (H decreases, acc = 1 for every chain); here dH < 0 with acc inside (0, 1),
+    so accept AND reject outcomes can be pinned."""
+    from oracle import su3 as osu3
+    return osu3.expm(delta * osu3.rand_tah3(rng.normal(size=(8, nb, 4, *L))))
+
+
+def _mixed_uniforms(acc):
+    """accept uniforms giving alternating accept / reject with a margin of half the gap"""
+    assert np.all(acc > 1e-3) and np.all(acc < 1 - 1e-3), f'acc not inside (0,1): {acc}'
+    u = np.where(np.arange(acc.size) % 2 == 0, 0.5 * (1.0 + acc), 0.5 * acc)
+    return u
+
+
+def test_cfg4_trajectory_8x4_units256():
+    """8^4, units [256], nleapfrog 4 merged: the shapes bench.py times."""
+    L, nb, nlf, units = (8, 8, 8, 8), 2, 4, [256]
+    dyn, lat = _build(L, nb, nlf, units, eps=0.01, head_scale=0.03, seed=11)
+    orc = _oracle(dyn, L, nlf, units)
+    rng = np.random.default_rng(4)
+    x = _hot(rng, nb, L)
+    nrm = rng.normal(size=(8, nb, 4, *L))
+    beta = 6.0
+    xo_ref, mo = orc.apply_transition_fb(x, beta, nrm, np.zeros(nb), history=True)
+    u = _mixed_uniforms(mo['acc'])
+    xo_ref, mo = orc.apply_transition_fb(x, beta, nrm, u, history=True)
+    assert mo['acc_mask'].tolist() == [0.0, 1.0]
+    from l2hmc import _ops as ops
+    for verbose in (True, False):
+        dyn.config.verbose = verbose
+        dyn._inject = {'normals': nrm, 'u': u}
+        xo, m = dyn((dev(x), torch.tensor(beta)))
+        mc = m['mc_states']
+        assert np.abs(host(mc.init.v) - mo['v_init']).max() < 1e-14
+        # same conditioning as the 3x4x5x3 golden (projectSU(force) feeds the vnet)
+        assert np.abs(host(mc.proposed.x) - mo['x_prop']).max() < 1e-7
+        assert np.abs(host(mc.proposed.v) - mo['v_prop']).max() < 1e-6
+        assert np.abs(host(m['acc']) - mo['acc']).max() < 1e-5
+        assert np.array_equal(host(m['acc_mask']), mo['acc_mask'])       # bit-exact
+        assert np.abs(host(m['sumlogdet']) - mo['acc_mask'] * mo['sumlogdet']).max() < 1e-6
+        assert np.abs(host(xo) - xo_ref.reshape(nb, -1)).max() < 1e-7
+        if verbose:
+            assert m['energy'].shape == (2 * nlf + 1, nb)
+            assert np.abs(host(m['energy']) - mo['energy']).max() < 1e-5  # |H| ~ 2.6e2
+            assert np.abs(host(m['logdet']) - mo['logdet']).max() < 1e-6
+    # observables of the output configuration through the slice-resident plaquette kernel
+    from oracle import su3 as osu3
+    met = lat.calc_metrics(xo.reshape(x.shape))
+    xo4 = xo_ref.reshape(x.shape)
+    assert np.abs(host(met['plaqs']) - osu3.plaqs(xo4)).max() < 1e-10
+    assert np.abs(host(met['intQ']) - osu3.int_charges(xo4)).max() < 1e-9
+    assert np.abs(host(met['sinQ']) - osu3.sin_charges(xo4)).max() < 1e-9
+    # all variants of the force / plaquette kernels agree at this shape
+    xn = ops.su3_pack(dev(x))
+    f_ref = osu3.grad_action(x, beta)
+    from l2hmc import native
+    try:
+        for ft in (2, 1, 0):
+            native.set_tuning('force_tile', ft)
+            f = ops.su3_unpack(ops.su3_force_n(xn, beta, L), L)
+            assert np.abs(host(f) - f_ref).max() < 1e-12, ft
+        for ps in (2, 1, 0):
+            native.set_tuning('plaq_sweep', ps)
+            s = host(ops.su3_plaq_sums_n(xn, L))
+            re, im = osu3.plaq_sums(x)
+            assert np.abs(s - np.stack([re, im], 1)).max() < 1e-8, ps
+    finally:
+        native.set_tuning('force_tile', 2)
+        native.set_tuning('plaq_sweep', 2)
+
+
+# --------------------------------------------------------------------------- cfg-5 shapes
+L16 = (16, 16, 16, 16)
+NB16 = 256
+
+
+def _tile(a2, nb=NB16):
+    """[2, ...] device tensor -> [nb, ...] with chain c = a2[c % 2]"""
+    return a2.repeat(nb // 2, *([1] * (a2.dim() - 1))).contiguous()
+
+
+def _maxdiff_tiled(out, ref2):
+    """max |out[c] - ref2[c % 2]| over all chains, computed on the device in slabs"""
+    nb = out.shape[0]
+    ref2 = ref2.to(out.device)
+    worst = 0.0
+    for c0 in range(0, nb, 32):
+        blk = out[c0:c0 + 32]
+        d = (blk.reshape(blk.shape[0] // 2, 2, -1) - ref2.reshape(1, 2, -1)).abs().max()
+        worst = max(worst, float(d))
+    return worst
+
+
+def test_cfg5_kernels_16x4_256chains():
+    """Every SU(3) kernel of the trajectory on a 256-chain 16^4 allocation (9.66 GB per field)."""
+    from l2hmc import _ops as ops
+    from oracle import su3 as osu3
+    L, V = L16, 16 ** 4
+    rng = np.random.default_rng(16)
+    x2 = _hot(rng, 2, L)
+    v2 = osu3.rand_tah3(rng.normal(size=(8, 2, 4, *L)))
+    beta, eps = 6.2, 0.05
+    xn2 = ops.su3_pack(dev(x2))
+    vn2 = ops.su3_pack(dev(v2))
+    xn = _tile(xn2)
+    vn = _tile(vn2)
+    assert xn.numel() * 16 > 2 ** 32 and xn.shape == (NB16, 4, 9, V)
+
+    def as_native(a):           # oracle result (reference layout, 2 chains) -> native, device
+        return ops.su3_pack(dev(a))
+
+    # plaquette sums / per-plane sums / kinetic energy / checkSU
+    re, im = osu3.plaq_sums(x2)
+    s = ops.su3_plaq_sums_n(xn, L)
+    assert _maxdiff_tiled(s, dev(np.stack([re, im], 1))) < 1e-7          # sums ~ 1e4
+    ke = ops.su3_kinetic_n(vn)
+    assert _maxdiff_tiled(ke, dev(osu3.kinetic_energy(v2))) < 1e-6       # ~ 1e6
+    assert float(ops.su3_check_su_n(xn).abs().max()) < 1e-13
+    # force (slice-resident kernel) and the fused kick
+    f_ref = as_native(osu3.grad_action(x2, beta))
+    f = ops.su3_force_n(xn, beta, L)
+    assert _maxdiff_tiled(f, f_ref) < 1e-12
+    vk = vn.clone()
+    ops.su3_force_kick_n(xn, beta, -0.5 * eps, vk, L)
+    assert _maxdiff_tiled(vk, vn2 - 0.5 * eps * f_ref) < 1e-12
+    del vk
+    # su3_to_vec(projectSU(.)) of links and of the force
+    xv = ops.su3_projsu_vec8_n(xn)
+    xv_ref = dev(osu3.group_to_vec(x2))                                   # [2,4,T,X,Y,Z,8]
+    xv_ref_n = xv_ref.reshape(2, 4, V, 8).permute(0, 1, 3, 2).contiguous()
+    assert _maxdiff_tiled(xv.reshape(NB16, -1), xv_ref_n.reshape(2, -1)) < 1e-12
+    del xv
+    # masked expm update, both halves in one kernel
+    m = (rng.random(36 * V) < 0.5).astype(np.float32)
+    mn = ops.pack_entries(dev(m).reshape(1, -1), V).reshape(-1).contiguous()
+    m4 = m.reshape(1, 4, *L, 3, 3)
+    e = osu3.expm(eps * v2)
+    y = m4 * x2 + e @ ((1 - m4) * x2)
+    y = (1 - m4) * y + e @ (m4 * y)
+    out = ops.su3_expm_mul2_n(xn, vn, eps, mn, False)
+    assert _maxdiff_tiled(out, as_native(y)) < 1e-13
+    del out, f
+    # momenta from normals (randTAH3 order), tiled normals
+    nrm2 = rng.normal(size=(8, 2, 4, V))
+    nrm = dev(nrm2).repeat(1, NB16 // 2, 1, 1).contiguous()
+    va = ops.su3_assemble_tah_n(nrm)
+    assert _maxdiff_tiled(va, as_native(osu3.rand_tah3(nrm2.reshape(8, 2, 4, *L)))) < 1e-15
+
+
+def test_cfg5_hmc_transition_16x4_256chains():
+    """apply_transition_hmc on 256 chains of 16^4: kick / expm / plaquette / kinetic / accept /
+    select at cfg-5 addresses; cold-start and unitarity properties."""
+    from oracle import su3 as osu3
+    from oracle.dynamics import DynamicsOracle
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
+    from l2hmc.group.su3.pytorch import utils as U
+    L, nb = L16, NB16
+    dc = cfgs.DynamicsConfig(nchains=nb, group='SU3', latvolume=list(L), nleapfrog=1, eps=0.02,
+                             eps_hmc=0.02, verbose=False, use_split_xnets=False,
+                             use_separate_networks=False, merge_directions=True)
+    lat = LatticeSU3(nb, list(L))
+    dyn = Dynamics(lat.action, dc, None)
+    rng = np.random.default_rng(160)
+    x2 = _warm(rng, 2, L)
+    nrm2 = rng.normal(size=(8, 2, 4, *L))
+    beta, eps, nlf = 6.2, 0.01, 1
+    orc = DynamicsOracle('SU3', L, 1, [eps], [eps], [np.zeros(36 * 16 ** 4, np.float32)])
+    _, mo = orc.apply_transition_hmc(x2, beta, nrm2, np.zeros(2), eps, nlf)
+    u2 = _mixed_uniforms(mo['acc'])
+    xo_ref, mo = orc.apply_transition_hmc(x2, beta, nrm2, u2, eps, nlf)
+    x = _tile(dev(x2))
+    nrm = dev(nrm2).repeat(1, nb // 2, *([1] * 5)).contiguous()
+    u = dev(u2).repeat(nb // 2)
+    dyn.merge_hmc_kicks = False
+    dyn._inject = {'normals': nrm, 'u': u}
+    xo, m = dyn.apply_transition_hmc((x, torch.tensor(beta)), eps=eps, nleapfrog=nlf)
+    del x, nrm
+    assert _maxdiff_tiled(m['acc'], dev(mo['acc'])) < 1e-6               # |H| ~ 1e6
+    assert torch.equal(m['acc_mask'].cpu(), torch.from_numpy(mo['acc_mask']).repeat(nb // 2))
+    assert _maxdiff_tiled(xo, dev(xo_ref.reshape(2, -1))) < 1e-12
+    xp = m['mc_states'].proposed.x
+    assert _maxdiff_tiled(xp, dev(mo['x_prop'])) < 1e-12
+    av, mx = U.checkSU(xp)
+    assert float(mx.max()) < 1e-13
+    del xp, xo, m
+    gc.collect()
+    torch.cuda.empty_cache()
+    # cold start: every plaquette = 1, force = 0, at every chain offset
+    eye = torch.eye(3, dtype=torch.complex128, device='cuda')
+    xc = eye.expand(nb, 4, *L, 3, 3).contiguous()
+    met = lat.calc_metrics(xc)
+    assert float((met['plaqs'] - 1.0).abs().max()) < 1e-14
+    assert float(met['intQ'].abs().max()) < 1e-12
+    f = lat.grad_action(xc, torch.tensor(beta))
+    assert float(f.abs().max()) < 1e-14
+
+
+def test_cfg5_l2hmc_trajectory_16x4_256chains():
+    """One merged L2HMC trajectory (nleapfrog = 1) of the cfg-5 per-GPU shard: 16^4, 256 chains,
+    units [256] (K = 4 194 304 split-K input GEMM, N = 2 359 296 heads)."""
+    L, nb, nlf, units = L16, NB16, 1, [256]
+    free, total = torch.cuda.mem_get_info()
+    if total < 200 * 2 ** 30:
+        pytest.skip('needs the 288 GB of an MI355X')
+    dyn, lat = _build(L, nb, nlf, units, eps=0.005, head_scale=0.01, seed=12)
+    orc = _oracle(dyn, L, nlf, units)
+    rng = np.random.default_rng(5)
+    x2 = _warm(rng, 2, L)
+    nrm2 = rng.normal(size=(8, 2, 4, *L))
+    beta = 6.2
+    _, mo = orc.apply_transition_fb(x2, beta, nrm2, np.zeros(2))
+    u2 = _mixed_uniforms(mo['acc'])
+    xo_ref, mo = orc.apply_transition_fb(x2, beta, nrm2, u2)
+    x = _tile(dev(x2))
+    nrm = dev(nrm2).repeat(1, nb // 2, *([1] * 5)).contiguous()
+    dyn.config.verbose = False
+    dyn._inject = {'normals': nrm, 'u': dev(u2).repeat(nb // 2)}
+    xo, m = dyn((x, torch.tensor(beta)))
+    del x, nrm
+    assert _maxdiff_tiled(m['acc'], dev(mo['acc'])) < 1e-4               # |H| ~ 1e6, 16x the sites
+    assert torch.equal(m['acc_mask'].cpu(), torch.from_numpy(mo['acc_mask']).repeat(nb // 2))
+    assert _maxdiff_tiled(xo, dev(xo_ref.reshape(2, -1))) < 1e-7
+    assert _maxdiff_tiled(m['sumlogdet'], dev(mo['acc_mask'] * mo['sumlogdet'])) < 1e-6

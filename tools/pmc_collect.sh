@@ -1,0 +1,22 @@
+#!/usr/bin/env bash
+# HBM/fabric traffic of the SU(3) kernels at the bench.py shapes (cfg-4: 8^4 x 256 chains), as
+# MI355X_MICROARCH.md prescribes: one rocprofv3 --pmc pass per counter (FETCH_SIZE and
+# WRITE_SIZE do not fit one pass), no trace domains beside --kernel-trace.  Run ON the GPU box:
+#   bash tools/pmc_collect.sh rNN      -> gpurun_out/pmc_rNN/{FETCH_SIZE,WRITE_SIZE,...}/
+#                                         profiles/rNN_pmc_counters.txt, profiles/pmc_traffic.json
+set -u
+tag="${1:-r02}"
+cd "$(dirname "$0")/.."
+root="$PWD"
+out="$root/gpurun_out/pmc_$tag"
+mkdir -p "$out"
+export TMPDIR=/tmp
+for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU"; do
+  d="$out/$(echo "$ctr" | tr ' ' '_')"
+  mkdir -p "$d"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d "$d" -o p --output-format csv \
+      -- python "$root/tools/kprof.py" > "$d/stdout.log" 2>&1)
+  echo "pass [$ctr]: rc=$? $(ls "$d" | tr '\n' ' ')"
+done
+python tools/pmc_summary.py "$out/*/p_counter_collection.csv" "profiles/${tag}_pmc_counters.txt" \
+    profiles/pmc_traffic.json

@@ -12,11 +12,15 @@ import sys
 ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'su3_plaq_slice_kernel': 'l2q_su3_plaq_reduce', 'su3_plaq_kernel': None, 'su3_plaq_sweep_kernel': None,
     'su3_force_slice_kernel<false': 'l2q_su3_force', 'su3_force_tile_kernel<false': None,
-    'su3_force_kernel<false': None,
+    'su3_force_kernel<false': None, 'su3_force_rows_kernel<0': 'l2q_su3_force',
+    'su3_force_rows_kernel<1': 'l2q_su3_force_kick', 'su3_force_rows_kernel<2': 'l2q_su3_force_vec8',
+    'su3_force_slice_kernel<true': 'l2q_su3_force_kick',
+    'su3_expm_mul_kernel<true, true>': 'l2q_su3_expm_mul2_vec8',
     'fused_heads_vupdate_kernel<true, true, true>': 'l2q_vnet_heads_vupdate_pair_f64',
     'fused_heads_vupdate_kernel<true, true, false>': 'l2q_vnet_heads_vupdate_f64',
     'gemm_nt_kernel<double, false, true>': 'l2q_gemm_f64',
-    'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
+    'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_expm_mul_kernel<true, false>': 'l2q_su3_expm_mul2',
+    'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
 }
 
 
@@ -49,7 +53,8 @@ def main():
             for frag, entry in ENTRY.items():
                 if entry and frag in k:
                     traffic[entry] = {'read_bytes': rd, 'write_bytes': wr, 'total_bytes': rd + wr,
-                                      'source': f'{sys.argv[2]} ({k})'}
+                                      'kernel': k.replace('l2q::', ''), 'lattice': [8, 8, 8, 8],
+                                      'nchains': 256, 'source': f'{sys.argv[2]} ({k})'}
         if 'TCC_HIT_sum' in v:
             h, m = sum(v['TCC_HIT_sum']), sum(v['TCC_MISS_sum'])
             lines.append(f'    -> L2 hit rate {h / (h + m):.3f}')
