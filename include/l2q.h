@@ -115,6 +115,12 @@ int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* ma
  * FMA contraction (1e-16).  `out` may alias xn. */
 int l2q_su3_expm_mul2(const void* xn, const void* vn, double eps, const float* mask_n,
                       int complement_first, void* out, int nb, long V, void* stream);
+/* l2q_su3_expm_mul2 that also writes vec[nb*4][8][V] = su3_to_vec(projectSU(x')) of the updated
+ * links (group.py:138-147): the vnet input of the v-update that follows the x-update in a
+ * leapfrog step (dynamics.py:1154-1156, 1204-1206), formed while x' is in registers. */
+int l2q_su3_expm_mul2_vec8(const void* xn, const void* vn, double eps, const float* mask_n,
+                           int complement_first, void* out, double* vec, int nb, long V,
+                           void* stream);
 /* projectSU on every link (group/su3/pytorch/utils.py:341-346); out may alias in. */
 int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* stream);
 /* su3_to_vec(projectSU(.)) -> vec[nfields][8][V] double (group.py:138-147); the vnet

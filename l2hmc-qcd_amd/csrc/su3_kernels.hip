@@ -738,12 +738,15 @@ __global__ __launch_bounds__(4 * kFS / LPT, (kFS == 64 || LPT == 2) ? 1 : 2) voi
 // out = keep (.) x + expm(eps v) @ ((1-keep) (.) x).  TWO: the two half-updates of one
 // leapfrog step (keep = mask then keep = 1 - mask, or the reverse order when `complement`)
 // applied back to back with ONE expm(eps v) and one pass over x -- both are local to a link.
-template <bool TWO>
+// VEC8: additionally emit su3_to_vec(projectSU(x')) (the vnet input of the next v-update,
+// group/su3/pytorch/group.py:138-147) while x' is in registers -- saves the pass that re-reads it.
+template <bool TWO, bool VEC8>
 __global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
                                                               const double2* __restrict__ vn,
                                                               double eps,
                                                               const float* __restrict__ mask,
                                                               int complement, double2* out,
+                                                              double* __restrict__ out_vec,
                                                               int V, long nblk) {
   const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;     // f = chain*4 + mu
   const int s = (int)blk * kBlock + threadIdx.x;
@@ -781,6 +784,14 @@ __global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
     m3_mul_nn(r, e, x);
   }
   store_link(out + f * 9L * V, V, s, r);
+  if constexpr (VEC8) {
+    M3 p;
+    m3_project_su(p, r);
+    double w[8];
+    m3_to_vec8(w, p);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) out_vec[(f * 8 + a) * (long)V + s] = w[a];
+  }
 }
 
 // MODE 0: projectSU -> links;  1: projectSU -> vec8;  2: projectTAH -> links;  3: projectU
@@ -1117,9 +1128,9 @@ int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* ma
   L2Q_REQUIRE(xn && vn && out, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
-  hipLaunchKernelGGL(su3_expm_mul_kernel<false>, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
+  hipLaunchKernelGGL((su3_expm_mul_kernel<false, false>), dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
                      0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
-                     complement, (double2*)out, (int)V, nblk);
+                     complement, (double2*)out, (double*)nullptr, (int)V, nblk);
   return check_launch("l2q_su3_expm_mul");
 }
 
@@ -1128,10 +1139,22 @@ int l2q_su3_expm_mul2(const void* xn, const void* vn, double eps, const float* m
   L2Q_REQUIRE(xn && vn && out && mask_n, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
   const long nblk = cdiv(V, kBlock);
-  hipLaunchKernelGGL(su3_expm_mul_kernel<true>, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
+  hipLaunchKernelGGL((su3_expm_mul_kernel<true, false>), dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
                      0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
-                     complement_first, (double2*)out, (int)V, nblk);
+                     complement_first, (double2*)out, (double*)nullptr, (int)V, nblk);
   return check_launch("l2q_su3_expm_mul2");
+}
+
+int l2q_su3_expm_mul2_vec8(const void* xn, const void* vn, double eps, const float* mask_n,
+                           int complement_first, void* out, double* vec, int nb, long V,
+                           void* stream) {
+  L2Q_REQUIRE(xn && vn && out && mask_n && vec, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  hipLaunchKernelGGL((su3_expm_mul_kernel<true, true>), dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
+                     0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
+                     complement_first, (double2*)out, vec, (int)V, nblk);
+  return check_launch("l2q_su3_expm_mul2_vec8");
 }
 
 int l2q_su3_project_su(const void* in, void* out, long nfields, long V, void* stream) {

@@ -147,6 +147,17 @@ def su3_expm_mul2_n(xn: torch.Tensor, vn: torch.Tensor, eps: float, mask_n: torc
     return out
 
 
+def su3_expm_mul2_vec8_n(xn: torch.Tensor, vn: torch.Tensor, eps: float, mask_n: torch.Tensor,
+                         complement_first: bool, out: Optional[torch.Tensor] = None):
+    """su3_expm_mul2_n + su3_projsu_vec8_n of its result in one pass: (x', vec8(x'))."""
+    nb, _, _, V = xn.shape
+    out = torch.empty_like(xn) if out is None else out
+    vec = torch.empty((nb, 4, 8, V), dtype=torch.float64, device=xn.device)
+    N.call('l2q_su3_expm_mul2_vec8', xn, vn, float(eps), mask_n, int(complement_first), out, vec,
+           nb, V)
+    return out, vec
+
+
 def su3_project_su_n(xn: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(xn)
     nf, V = xn.numel() // (9 * xn.shape[-1]), xn.shape[-1]

@@ -198,6 +198,7 @@ class Dynamics(nn.Module):
         self.fuse_x_updates = True  # SU3: both x half-updates of a LF step in one kernel
         self.reuse_v_inputs = True  # force / vec8 / hidden activation once per distinct x
         self.pair_v_updates = True  # adjacent v-updates on the same x in one heads kernel
+        self.fuse_x_vec8 = True     # SU3: the x-update also emits the next vnet input vec8(x')
         self.fuse_u1_steps = True   # U1 (small lattices, dense nets): one kernel per sub-update
         # Improved gauge action (c1 != 0): the reference evaluates H with potential_fn (the
         # Trainer's LatticeSU3(c1), trainers/pytorch/trainer.py:499-504) but takes the leapfrog
@@ -524,8 +525,11 @@ class Dynamics(nn.Module):
         hit = cache is not None and cache.get('valid', False)
         fn = cache['F'] if hit else self._force_n(xn, beta)
         if cache is not None and not hit:
+            pre = cache.get('xv_pre')          # vec8(x) emitted by the x-update that produced x
             cache.clear()
             cache.update({'valid': True, 'F': fn})
+            if pre is not None:
+                cache['xv_pre'] = pre
         if not self._can_fuse_heads(vnet):
             return fn, None, None
         p = self._perms()
@@ -536,7 +540,8 @@ class Dynamics(nn.Module):
         if cache is not None and 'xv' in cache:
             xv, fv = cache['xv'], cache['fv']
         else:
-            xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
+            pre = cache.pop('xv_pre', None) if cache is not None else None
+            xv = pre if pre is not None else ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
             fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
             if cache is not None:
                 cache['xv'], cache['fv'] = xv, fv
@@ -678,7 +683,13 @@ class Dynamics(nn.Module):
         if self.group == 'SU3' and self.fuse_x_updates:
             # both half-updates share expm(eps v): one kernel, one pass over x
             eps = self._eps('x', st)
-            ops.su3_expm_mul2_n(xn, vn, eps if forward else -eps, m, not forward, out=xn)
+            if (cache is not None and self.fuse_x_vec8 and self.reuse_v_inputs
+                    and self._can_fuse_heads(self._get_vnet(st))):
+                _, xv = ops.su3_expm_mul2_vec8_n(xn, vn, eps if forward else -eps, m, not forward,
+                                                 out=xn)
+                cache['xv_pre'] = xv.reshape(xn.shape[0], -1)
+            else:
+                ops.su3_expm_mul2_n(xn, vn, eps if forward else -eps, m, not forward, out=xn)
         else:
             for comp, first in order:
                 l = self._update_x_n(st, xn, vn, m, comp, forward, first)

@@ -36,6 +36,7 @@ SIGNATURES = {
     'l2q_su3_force_kick': (I, [P, D, D, P, I, I, I, I, I, P]),
     'l2q_su3_expm_mul': (I, [P, P, D, P, I, P, I, L, P]),
     'l2q_su3_expm_mul2': (I, [P, P, D, P, I, P, I, L, P]),
+    'l2q_su3_expm_mul2_vec8': (I, [P, P, D, P, I, P, P, I, L, P]),
     'l2q_su3_project_su': (I, [P, P, L, L, P]),
     'l2q_su3_projsu_vec8': (I, [P, P, L, L, P]),
     'l2q_su3_project_tah': (I, [P, P, L, L, P]),

@@ -541,6 +541,11 @@ def l2q_su3_expm_mul2(xn, vn, eps, mask_n, complement_first, out, nb, V):
     out.copy_(_expm_mul(x1, vn.reshape(nb, 4, 9, V), eps, 1 - k1).reshape(out.shape))
 
 
+def l2q_su3_expm_mul2_vec8(xn, vn, eps, mask_n, complement_first, out, vec, nb, V):
+    l2q_su3_expm_mul2(xn, vn, eps, mask_n, complement_first, out, nb, V)
+    l2q_su3_projsu_vec8(out, vec, nb * 4, V)
+
+
 def l2q_su3_project_su(xn, out, nf, V):
     out.copy_(_native(_proj_su(_mats(xn.reshape(nf, 9, V)))).reshape(out.shape))
 

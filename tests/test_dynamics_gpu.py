@@ -138,6 +138,11 @@ def test_su3_l2hmc_trajectory(golden):
     # (the lean path pairs adjacent v-updates in one kernel: same arithmetic, equal to rounding)
     assert err(host(xo2), host(xo)) < 1e-13 and err(host(m2['acc']), host(m['acc'])) < 1e-10
     assert err(host(m2['sumlogdet']), g['sumlogdet']) < 1e-6
+    # the x-update that also emits vec8(x') (fuse_x_vec8) changes nothing
+    dyn.fuse_x_vec8 = False
+    xo3, m3 = dyn((dev(g['x']), torch.tensor(float(g['beta']))))
+    dyn.fuse_x_vec8 = True
+    assert err(host(xo3), host(xo2)) < 1e-13 and err(host(m3['acc']), host(m2['acc'])) < 1e-10
     assert m2['acc'].dtype == torch.float64 and m2['acc_mask'].dtype == torch.float32
     dyn.pair_v_updates = False
     xo2b, m2b = dyn((dev(g['x']), torch.tensor(float(g['beta']))))
@@ -547,6 +552,71 @@ def test_u1_half_precision_networks(hd, lat, nb, units, act, bn):
     da = (out[hd][0][1] - out[None][0][1]).abs()
     assert float(da.max()) < 400 * ulp, float(da.max())
     assert bool(torch.isfinite(out[hd][0][0]).all())
+
+
+def _bf16_golden_check(g, dyn, fused: bool, has_conv: bool):
+    """Compare Dynamics.set_net_precision('bf16') with the REAL reference run under
+    torch.autocast('cpu', dtype=torch.bfloat16) (tests/golden/make_golden_bf16.py).  Tolerances in
+    bf16 ulps (2^-7 relative to the largest magnitude): the 16-bit layers round after every Linear
+    and activation like autocast does; the one structural difference is that the input layer's two
+    Linears share one fp32 accumulator here (one rounding) while autocast rounds each and their
+    sum (three roundings), so outputs agree to ~1-2 ulp with about half of the entries bit-equal."""
+    from l2hmc.dynamics.pytorch.dynamics import State
+    ulp = 2.0 ** -7
+    dyn.set_net_precision('bf16')
+    dyn.fuse_half_heads = fused
+    x = torch.from_numpy(g['x']).to(dyn.device)
+    beta = torch.tensor(float(g['beta']))
+    nb = x.shape[0]
+    v = torch.from_numpy(g['normals']).reshape(nb, -1).to(dyn.device)
+    f = dyn.grad_potential(x, beta)
+    assert err(host(f), g['force']) < 1e-5
+    exact = []
+
+    def close_ulps(got, ref, n_ulp):
+        got, ref = host(got).reshape(ref.shape), ref
+        scale = max(1.0, float(np.abs(ref).max()))
+        e = float(np.abs(got - ref).max())
+        assert e <= n_ulp * ulp * scale, (e, n_ulp * ulp * scale)
+        exact.append(float((got == ref).mean()))
+    for a, k in zip(dyn._call_vnet(0, (x, f)), ('vnet_s', 'vnet_t', 'vnet_q')):
+        close_ulps(a, g[k], 2.5 if not has_conv else 4)
+    m0, mb0 = dyn._get_mask(0)
+    xm = dyn.unflatten(m0.to(dyn.device)) * x
+    for a, k in zip(dyn._call_xnet(0, (xm, v), first=True), ('xnet_s', 'xnet_t', 'xnet_q')):
+        close_ulps(a, g[k], 2.5 if not has_conv else 4)
+    assert min(exact) > (0.3 if not has_conv else 0.15), exact      # rounding points line up
+    # sub-updates (fp32 lattice arithmetic on 16-bit network outputs): 1e-3 = eps/2 * 2 ulp
+    st, ld = dyn._update_v_fwd(0, State(x, v, beta))
+    assert err(host(st.v).reshape(nb, -1), g['v_fwd'].reshape(nb, -1)) < 2e-3
+    assert err(host(ld), g['logdet_v_fwd']) < 8e-3
+    for key, fn, mk, first in (('x_fwd', dyn._update_x_fwd, m0, True), ('x_bwd', dyn._update_x_bwd, mb0, False)):
+        st, ld = fn(0, State(x, v, beta), mk, first=first)
+        dx = np.abs(np.angle(np.exp(1j * (host(st.x) - g[key]))))
+        assert dx.max() < 2e-3, (key, dx.max())
+        assert err(host(ld), g['logdet_' + key]) < 8e-3
+    # merged trajectory: the reference's own bf16-vs-fp32 distance is the yardstick
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    xo, m = dyn((x, beta))
+    dyn._inject = None
+    yard = float(np.abs(g['acc'] - g['acc_fp32']).max())
+    assert err(host(m['acc']), g['acc']) < max(3 * yard, 5e-3)
+    assert np.array_equal(host(m['acc_mask']), g['acc_mask'])          # bit-exact accept / reject
+    margin = float(np.abs(g['acc'] - g['u']).min())
+    assert margin > 0.05, margin
+    dx = np.abs(np.angle(np.exp(1j * (host(xo) - g['x_out'].reshape(nb, -1)))))
+    assert dx.max() < 5e-3, dx.max()
+    assert err(host(m['energy']), g['energy']) < 0.1                   # |H| ~ 1e2, dH within bf16 noise
+
+
+@pytest.mark.parametrize('name', ['u1_bf16', 'u1_bf16_tanh', 'u1_bf16_conv'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_u1_bf16_reference_golden(golden, name, fused):
+    """BASELINE cfg-3 ("16-bit nets / fp32 action") pinned to the reference itself."""
+    torch.set_default_dtype(torch.float32)
+    g = golden(name)
+    dyn, lat = build_u1_dynamics(g)
+    _bf16_golden_check(g, dyn, fused, has_conv=bool(g['conv_filters'].size))
 
 
 def test_su3_improved_action_c1(golden):

@@ -152,6 +152,37 @@ def test_expm_mul_masked(ops, golden):
     assert err(host(ops.su3_unpack(got, L)), g['x_bwd']) < 1e-13
 
 
+def test_expm_mul2_vec8(ops, golden):
+    """l2q_su3_expm_mul2_vec8 == l2q_su3_expm_mul2 followed by l2q_su3_projsu_vec8, and both
+    against the reference's two half-updates / su3_to_vec(projectSU(.)) via the oracle."""
+    from oracle import su3 as osu3
+    g = golden('su3_l2hmc')
+    L = tuple(int(i) for i in g['latvolume'])
+    V = int(np.prod(L))
+    xn = ops.su3_pack(dev(g['x']))
+    vn = ops.su3_pack(dev(g['v_fwd']))
+    eps = 0.037
+    m = ops.pack_entries(dev(g['masks'][0:1]), V).reshape(-1)
+    for comp in (False, True):
+        x2 = ops.su3_expm_mul2_n(xn, vn, eps, m, comp)
+        v8 = ops.su3_projsu_vec8_n(x2)
+        xf, vf = ops.su3_expm_mul2_vec8_n(xn, vn, eps, m, comp)
+        assert err(host(xf), host(x2)) < 1e-15
+        assert err(host(vf), host(v8)) < 1e-13
+        m4 = g['masks'][0].reshape(1, 4, *L, 3, 3)
+        keep = (1 - m4) if comp else m4
+        e = osu3.expm(eps * g['v_fwd'])
+        y = keep * g['x'] + e @ ((1 - keep) * g['x'])
+        y = (1 - keep) * y + e @ (keep * y)
+        assert err(host(ops.su3_unpack(xf, L)), y) < 1e-13
+        ref = np.moveaxis(osu3.group_to_vec(y).reshape(y.shape[0], 4, V, 8), -1, -2)
+        assert err(host(vf), ref) < 1e-11
+    # in place (out aliases xn), as the trajectory calls it
+    xc = xn.clone()
+    xo, vo = ops.su3_expm_mul2_vec8_n(xc, vn, eps, m, True, out=xc)
+    assert xo.data_ptr() == xc.data_ptr() and err(host(xo), host(xf)) == 0.0 and err(host(vo), host(vf)) == 0.0
+
+
 def test_v_update_su3(ops, golden):
     g = golden('su3_l2hmc')
     L = tuple(int(i) for i in g['latvolume'])

@@ -287,3 +287,31 @@ def test_su3_micro_batched_training_host_logic(golden, monkeypatch, f64):
         for k, g in grads[None].items():
             d = float((grads[mb][k] - g).abs().max())
             assert d <= 1e-9 * max(1.0, float(g.abs().max())), (mb, k, d)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('name', ['u1_bf16', 'u1_bf16_tanh'])
+def test_bf16_rounding_points_vs_reference_autocast(name, golden, monkeypatch):
+    """The emulator's restatement of where the 16-bit layers round (tests/emu_native.py,
+    l2q_gemm_h) against the REAL reference run under torch.autocast('cpu', bfloat16)
+    (tests/golden/make_golden_bf16.py): pins the emulator that the GPU half-precision kernel
+    tests compare with, and the product's host logic for precision='bf16'."""
+    g = golden(name)
+    emu_native.install(monkeypatch)
+    dyn, lat = helpers.build_u1_dynamics(g)
+    dyn.set_net_precision('bf16')
+    dyn.fuse_half_heads = False           # gemm_h + fp32 update kernels (the emulated set)
+    x = torch.from_numpy(g['x'])
+    beta = torch.tensor(float(g['beta']))
+    nb = x.shape[0]
+    f = dyn.grad_potential(x, beta)
+    ulp = 2.0 ** -7
+    for a, k in zip(dyn._call_vnet(0, (x, f)), ('vnet_s', 'vnet_t', 'vnet_q')):
+        ref = g[k]
+        d = np.abs(a.numpy() - ref)
+        assert d.max() <= 2.5 * ulp * max(1.0, np.abs(ref).max()), (k, d.max())
+        assert (d == 0).mean() > 0.3, (k, (d == 0).mean())
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    xo, m = dyn((x, beta))
+    assert np.abs(m['acc'].numpy() - g['acc']).max() < max(3 * np.abs(g['acc'] - g['acc_fp32']).max(), 5e-3)
+    assert np.array_equal(m['acc_mask'].numpy(), g['acc_mask'])
