@@ -16,7 +16,9 @@ struct Tuning {
   int xcd_swizzle = 1;
   int plaq_sweep = 2;     // 2: slice-resident kernel (LDS + register prefetch), 1: L2 t-sweep, 0: flat
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
-  int force_tile = 2;     // 2: slice-resident kernel, 1: LDS-tiled (64 sites x 4 mu), 0: flat
+  int force_tile = 4;     // 4: slice-resident, staples split by plane over wavefronts (su3_force_nu.hip), 3: rows
+                          // split over wavefronts (su3_force_rows.hip), 2: slice-resident
+                          // thread-per-link, 1: LDS-tiled (64 sites x 4 mu), 0: flat
   int u1_fused_ch = 0;    // chains per workgroup of the fused U(1) kernels (0: auto; 1, 2, 4, 8)
   int gemm_h_wide_fused = 0;  // large half GEMMs: 128 x 256 tile with 512 threads (measured slower)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)

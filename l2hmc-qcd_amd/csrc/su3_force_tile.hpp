@@ -1,0 +1,85 @@
+// su3_force_tile.hpp -- addressing helpers shared by the slice-resident force kernels that split a
+// link's work over wavefronts (su3_force_rows.hip, su3_force_nu.hip): buffer loads with the
+// uniform part of the address in the scalar offset, ds_read_b128 with immediate entry offsets.
+#pragma once
+#include "l2q_common.hpp"
+#include "su3_math.hpp"
+#include "su3_links.hpp"
+
+namespace l2q {
+
+constexpr int kRS = 64;                       // sites per tile
+constexpr int kEnt = kRS * 16;                // bytes between entries of a link in LDS
+constexpr int kPlaneB = 9 * kEnt;             // bytes of one link direction of a tile
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 buf_ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  union { v4u u; double2 d; } c;
+  c.u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return c.d;
+}
+
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double2 v) {
+  union { v4u u; double2 d; } c;
+  c.d = v;
+  __builtin_amdgcn_raw_buffer_store_b128(c.u, rs, voff, soff, 0);
+}
+
+struct R3 {
+  double re[3], im[3];
+};
+
+__device__ __forceinline__ void r3_zero(R3& a) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { a.re[k] = 0.0; a.im[k] = 0.0; }
+}
+
+// one periodic hop of a spatial site index q = (x*Y + y)*Z + z in direction dir (1, 2, 3)
+__device__ __forceinline__ int hop(int q, int x, int y, int z, int dir, int sgn, const Dims& d) {
+  const int n = dir == 1 ? d.X : dir == 2 ? d.Y : d.Z;
+  const int st = dir == 1 ? d.Y * d.Z : dir == 2 ? d.Z : 1;
+  const int c = dir == 1 ? x : dir == 2 ? y : z;
+  if (sgn > 0) return (c + 1 == n) ? q - (n - 1) * st : q + st;
+  return (c == 0) ? q + (n - 1) * st : q - st;
+}
+
+extern __shared__ __attribute__((aligned(16))) char fr_lds[];
+
+__device__ __forceinline__ double2 lds_ld(int addr) {
+  return *reinterpret_cast<const double2*>(fr_lds + addr);
+}
+
+// Operand loads.  IN (compile time): the operand's site is inside the tile for every lane ->
+// ds_read_b128 from the LDS copy at byte address `lds` (entry e at + e * kEnt); otherwise a
+// buffer load from the chain: per-lane site offset `voff`, uniform (link, slice) offset `soff`.
+template <bool IN>
+__device__ __forceinline__ void ld_full(M3& m, int lds, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int V16) {
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double2 d = IN ? lds_ld(lds + e * kEnt) : buf_ld(rs, voff, soff + e * V16);
+    m.re[e] = d.x; m.im[e] = d.y;
+  }
+}
+
+// row `row` of the link (row is wave-uniform)
+template <bool IN>
+__device__ __forceinline__ void ld_row(R3& a, int lds, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int V16, int row) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double2 d = IN ? lds_ld(lds + (3 * row + k) * kEnt) : buf_ld(rs, voff, soff + (3 * row + k) * V16);
+    a.re[k] = d.x; a.im[k] = d.y;
+  }
+}
+
+// conj of column `col` of the link = row `col` of its adjoint
+template <bool IN>
+__device__ __forceinline__ void ld_colc(R3& a, int lds, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int V16, int col) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double2 d = IN ? lds_ld(lds + (3 * k + col) * kEnt) : buf_ld(rs, voff, soff + (3 * k + col) * V16);
+    a.re[k] = d.x; a.im[k] = -d.y;
+  }
+}
+
+}  // namespace l2q

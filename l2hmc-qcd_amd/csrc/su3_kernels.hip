@@ -933,6 +933,19 @@ __global__ void check_finalize_kernel(const double* __restrict__ psum,
 
 }  // namespace l2q
 
+namespace l2q {
+// su3_force_rows.hip
+bool force_rows_applicable(const Dims& d);
+int force_rows_inmask(const Dims& d);
+// su3_force_nu.hip
+bool force_nu_applicable(const Dims& d);
+int force_nu_inmask(const Dims& d);
+void launch_force_nu(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
+                     hipStream_t st);
+void launch_force_rows(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
+                       hipStream_t st);
+}  // namespace l2q
+
 using namespace l2q;
 
 template <bool KICK>
@@ -942,7 +955,15 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
   constexpr int kFS = KICK ? kFSKick : kFSPlain;
   constexpr int kVar = KICK ? 2 : 0;
   constexpr int kLpt = KICK ? 1 : kLptPlain;
-  if (tuning().force_tile == 2 && Vs_ % kFS == 0) {
+  if (tuning().force_tile == 4 && force_nu_applicable(d)) {
+    launch_force_nu(KICK, xn, d, nb, coef, out, st);
+    return;
+  }
+  if (tuning().force_tile >= 3 && force_rows_applicable(d)) {
+    launch_force_rows(KICK, xn, d, nb, coef, out, st);
+    return;
+  }
+  if (tuning().force_tile >= 2 && Vs_ % kFS == 0) {
     const int nsb = Vs_ / kFS;
     int tsplit = (int)cdiv(512, (long)nb * nsb);       // >= ~2 resident rounds of 256 CUs
     if (tsplit > d.T) tsplit = d.T;
@@ -1000,7 +1021,11 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
   } else if (!strcmp(entry, "l2q_su3_force") || !strcmp(entry, "l2q_su3_force_kick")) {
     const bool kick = !strcmp(entry, "l2q_su3_force_kick");
     const int fs = kick ? kFSKick : kFSPlain;
-    if (t.force_tile == 2 && Vs % fs == 0)
+    if (t.force_tile == 4 && Vs % 64 == 0)
+      snprintf(buf, buf_bytes, "su3_force_nu_kernel<%d, %d>", kick ? 1 : 0, force_nu_inmask(Dims{T, X, Y, Z, T * X * Y * Z}));
+    else if (t.force_tile >= 3 && Vs % 64 == 0)
+      snprintf(buf, buf_bytes, "su3_force_rows_kernel<%d, %d>", kick ? 1 : 0, force_rows_inmask(Dims{T, X, Y, Z, T * X * Y * Z}));
+    else if (t.force_tile >= 2 && Vs % fs == 0)
       snprintf(buf, buf_bytes, "su3_force_slice_kernel<%s, %d, %d, %d>", kick ? "true" : "false", fs,
                kick ? 2 : 0, kick ? 1 : kLptPlain);
     else if (t.force_tile) snprintf(buf, buf_bytes, "su3_force_tile_kernel<%s, %d>", kick ? "true" : "false", t.force_occ);
