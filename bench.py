@@ -70,7 +70,7 @@ def parse():
                     help='train mode: chains per tape micro-batch (needed at 16^4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-spot-check', action='store_true')
-    ap.add_argument('--cpu-chains', type=int, default=16)
+    ap.add_argument('--cpu-chains', type=int, default=64)
     return ap.parse_args()
 
 

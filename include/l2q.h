@@ -373,8 +373,13 @@ int l2q_u1_xstep_f32(float* x, const float* v, const float* mask, int complement
  * Conventions: "g*" / "d*" arguments are cotangents with the shape of the quantity they
  * belong to; arguments documented "+=" are accumulated into, all others are overwritten. */
 
+/* y = act(x) element-wise (ACTIVATION_FNS, network.py:40-46); y may alias x.  The training tape
+ * uses it for swish, whose derivative needs the pre-activation (the GEMM epilogues fuse the
+ * activation and keep only its output). */
+int l2q_act_fwd(const void* x, int act, long n, int elem_bytes, void* y, void* stream);
 /* dx = dy * act'(z) from the activation OUTPUT y = act(z) (tanh, relu, leaky_relu, elu, none);
- * dx may alias dy.  (network.py:447-451, 536-538) */
+ * for swish (not invertible) `y` must hold the PRE-activation z.  dx may alias dy.
+ * (network.py:447-451, 536-538) */
 int l2q_act_bwd(const void* dy, const void* y, int act, long n, int elem_bytes, void* dx,
                 void* stream);
 /* out = alpha * a * b element-wise (nn.Dropout mask, network.py:540-541); out may alias a */

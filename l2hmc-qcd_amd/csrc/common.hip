@@ -129,7 +129,10 @@ __global__ void accept_kernel(const T* h0, const T* h1, const T* sld, const T* u
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
   const T dh = h0[i] - h1[i] + sld[i];
-  const T a = exp(dh < (T)0 ? dh : (T)0);
+  // torch.minimum propagates NaN (dynamics.py:1065-1079): a diverged trajectory (inf - inf in
+  // H) must show up as acc = NaN in the metrics and be rejected ((NaN > u) is false), not be
+  // reported as a perfectly accepted proposal
+  const T a = (dh != dh) ? dh : exp(dh < (T)0 ? dh : (T)0);
   acc[i] = a;
   mask[i] = (a > u[i]) ? 1.0f : 0.0f;
 }

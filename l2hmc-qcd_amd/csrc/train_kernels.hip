@@ -24,9 +24,31 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y
     case L2Q_ACT_RELU: d = yy > (T)0 ? (T)1 : (T)0; break;
     case L2Q_ACT_LEAKY_RELU: d = yy > (T)0 ? (T)1 : (T)0.01; break;
     case L2Q_ACT_ELU: d = yy > (T)0 ? (T)1 : yy + (T)1; break;     // y = e^z - 1 -> dy/dz = y + 1
+    case L2Q_ACT_SWISH: {                                           // `y` holds the PRE-activation z
+      const T sg = (T)1 / ((T)1 + exp(-yy));
+      d = sg * ((T)1 + yy * ((T)1 - sg));
+      break;
+    }
     default: d = (T)1; break;
   }
   dx[i] = dy[i] * d;
+}
+
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, int act, long n, T* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T z = x[i];
+  T r;
+  switch (act) {
+    case L2Q_ACT_TANH: r = tanh(z); break;
+    case L2Q_ACT_RELU: r = z > (T)0 ? z : (T)0; break;
+    case L2Q_ACT_LEAKY_RELU: r = z > (T)0 ? z : (T)0.01 * z; break;
+    case L2Q_ACT_ELU: r = z > (T)0 ? z : expm1(z); break;
+    case L2Q_ACT_SWISH: r = z / ((T)1 + exp(-z)); break;
+    default: r = z; break;
+  }
+  y[i] = r;
 }
 
 template <typename T>
@@ -447,12 +469,19 @@ int l2q_act_bwd(const void* dy, const void* y, int act, long n, int elem_bytes, 
                 void* stream) {
   L2Q_REQUIRE(dy && y && dx, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(n > 0, L2Q_EINVAL, "non-positive size");
-  L2Q_REQUIRE(act != L2Q_ACT_SWISH, L2Q_EINVAL,
-              "swish needs the pre-activation; not supported by the training path");
   hipStream_t st = (hipStream_t)stream;
   L2Q_DISPATCH_T(elem_bytes, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(grid1(n)), dim3(kBlock), 0,
                                                 st, (const T*)dy, (const T*)y, act, n, (T*)dx));
   return check_launch("l2q_act_bwd");
+}
+
+int l2q_act_fwd(const void* x, int act, long n, int elem_bytes, void* y, void* stream) {
+  L2Q_REQUIRE(x && y, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(n > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  L2Q_DISPATCH_T(elem_bytes, hipLaunchKernelGGL(act_fwd_kernel<T>, dim3(grid1(n)), dim3(kBlock), 0,
+                                                st, (const T*)x, act, n, (T*)y));
+  return check_launch("l2q_act_fwd");
 }
 
 int l2q_mul(const void* a, const void* b, double alpha, long n, int elem_bytes, void* out,

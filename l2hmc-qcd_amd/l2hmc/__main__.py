@@ -6,6 +6,7 @@ the plain-HMC baseline for ``steps.test`` steps, and report the model improvemen
 instead of plots / wandb artefacts.
 
     python -m l2hmc dynamics.group=SU3 dynamics.latvolume=[4,4,4,4] steps.nera=1 steps.nepoch=5
+    python -m l2hmc --config-name su3test outdir=runs/su3test     # flat config + dataset dump
 """
 from __future__ import annotations
 
@@ -30,7 +31,19 @@ def _summary(res: dict, nb: int) -> dict:
 
 def main(argv=None) -> dict:
     overrides = list(sys.argv[1:] if argv is None else argv)
-    cfg = cfgs.get_config(overrides)
+    config_name, outdir = 'config', None
+    rest = []
+    it = iter(overrides)
+    for a in it:                                   # hydra's --config-name / -cn; outdir=<dir>
+        if a in ('--config-name', '-cn'):
+            config_name = next(it)
+        elif a.startswith('--config-name='):
+            config_name = a.partition('=')[2]
+        elif a.startswith('outdir='):
+            outdir = a.partition('=')[2]
+        else:
+            rest.append(a)
+    cfg = cfgs.get_config(rest, config_name=config_name)
     from l2hmc.experiment.pytorch.experiment import Experiment
     ex = Experiment(cfg)
     out: dict = {}
@@ -51,6 +64,11 @@ def main(argv=None) -> dict:
                 out[job] = _summary(res, nb)
         if 'dQint_mean' in out.get('eval', {}) and out.get('hmc', {}).get('dQint_mean', 0) > 0:
             out['model_improvement'] = out['eval']['dQint_mean'] / out['hmc']['dQint_mean']
+    if outdir is not None:
+        # the reference's per-job dataset dump (utils/history.py:894-909, experiment save_dataset)
+        for job, hist in ex.trainer.histories.items():
+            if hist.history:
+                out.setdefault('datasets', {})[job] = str(hist.save_dataset(outdir, job))
     print(json.dumps(out))
     return out
 

@@ -651,8 +651,16 @@ def u1_fused_max_n() -> int:
 
 
 # ---------------------------------------------------------------------------- training (VJPs)
+def act_fwd(x: torch.Tensor, act: Optional[str]) -> torch.Tensor:
+    """act(x) (new tensor)."""
+    y = torch.empty_like(x)
+    N.call('l2q_act_fwd', x.contiguous(), N.ACT[act], x.numel(), x.element_size(), y)
+    return y
+
+
 def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: Optional[str]) -> torch.Tensor:
-    """dy * act'(z) from the activation output y (in place on dy)."""
+    """dy * act'(z) from the activation output y -- for swish from the pre-activation z -- in
+    place on dy."""
     if N.ACT[act] == 0:
         return dy
     N.call('l2q_act_bwd', dy, y, N.ACT[act], dy.numel(), dy.element_size(), dy)

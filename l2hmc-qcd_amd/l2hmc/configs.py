@@ -411,11 +411,16 @@ class ExperimentConfig(BaseConfig):
                          self.framework])
 
 
-def get_config(overrides: Optional[list[str]] = None) -> dict:
+def get_config(overrides: Optional[list[str]] = None, config_name: str = 'config') -> dict:
     """Compose ``conf/config.yaml`` + group defaults + dotted overrides (hydra-compatible
-    subset: defaults list, ``group=option``, ``a.b.c=value``, ``${a.b}`` interpolation)."""
-    from l2hmc.utils.compose import compose
-    return compose(CONF_DIR, 'config', overrides or [])
+    subset: defaults list, ``group=option``, ``a.b.c=value``, ``${a.b}`` interpolation).
+    ``config_name`` other than 'config' names a FLAT primary file (conf/su3test.yaml,
+    conf/su3-min.yaml of the reference): it is layered over the composed defaults, command-line
+    overrides on top."""
+    from l2hmc.utils.compose import compose, compose_flat
+    if config_name in (None, 'config'):
+        return compose(CONF_DIR, 'config', overrides or [])
+    return compose_flat(CONF_DIR, config_name, overrides or [])
 
 
 def instantiate(cfg: dict) -> ExperimentConfig:

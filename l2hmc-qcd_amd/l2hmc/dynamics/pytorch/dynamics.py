@@ -205,6 +205,20 @@ class Dynamics(nn.Module):
         # force from its own c1 = 0 lattice (dynamics.py:134-135, 1493-1499).  Reproduced: the
         # rectangle term enters the potential energy only, the force stays (beta/3) TAH(U A_plaq).
         owner = getattr(potential_fn, '__self__', None)
+        # The trajectory evaluates H with the built-in Wilson (+ c1 rectangle) action kernels, not
+        # by calling potential_fn: that is only equivalent if potential_fn IS the action of a
+        # lattice of this group and shape.  Anything else (a lambda, a partial, a custom
+        # potential) would be silently ignored in energy / acc / the training seeds -- refuse it.
+        want = LatticeSU3 if self.group == 'SU3' else LatticeU1
+        if not (isinstance(owner, want)
+                and getattr(potential_fn, '__name__', '') in ('action', 'potential_energy')):
+            raise ValueError(
+                'Dynamics(potential_fn=...): expected the bound `action` of a '
+                f'{want.__name__} (got {potential_fn!r}); the HIP trajectory computes the Wilson / '
+                'improved gauge action itself and cannot call an arbitrary potential')
+        if [int(i) for i in owner._lattice_shape] != [int(i) for i in self.config.latvolume]:
+            raise ValueError(f'potential_fn belongs to a lattice of shape {owner._lattice_shape}, '
+                             f'config.latvolume is {list(self.config.latvolume)}')
         self.potential_c1 = float(getattr(owner, 'c1', 0.0) or 0.0) if self.group == 'SU3' else 0.0
         self.net_precision = None   # torch.float16 / torch.bfloat16: see set_net_precision
         self.fuse_half_heads = True
@@ -1225,7 +1239,20 @@ class GraphedTransition:
 
     Outputs are views of the graph's static buffers: valid until the next call (clone to keep).
     Random draws come from the device generator (graph-safe philox offsets), i.e. successive
-    replays draw fresh momenta / accept uniforms."""
+    replays draw fresh momenta / accept uniforms.
+
+    What a captured graph freezes, and how that is kept safe:
+    * device pointers of the kernel-order weight copies (`LeapfrogLayer.kernel_weights`), the
+      native masks and the reduction workspace; host floats (step sizes, beta) as kernel
+      arguments.  The graph keeps references to the weight / mask copies it recorded and pins the
+      workspace block (`native.pin_workspace`: a later, larger request allocates a new block
+      instead of freeing this one), so a replay never reads freed memory.
+    * parameters.  `__call__` compares a signature of everything the capture depended on --
+      `ops.PARAM_GENERATION` (bumped by the fused Adam step / checkpoint loads, which bypass
+      `Tensor._version`), identity and version of every parameter (incl. xeps / veps: `assign_eps`
+      makes new ones), the masks, the network precision and the fusion switches -- and
+      RE-CAPTURES when it changed, so a replay after `train_step`, `load_ckpt`, `assign_eps`,
+      `set_masks` or `set_net_precision` uses the current model."""
 
     def __init__(self, dyn: Dynamics, x: Tensor, beta: float, mode: str, eps, nleapfrog,
                  warmup: int):
@@ -1233,24 +1260,50 @@ class GraphedTransition:
         if not torch.cuda.is_available():
             raise RuntimeError('GraphedTransition needs a GPU')
         self.dyn, self.beta, self.mode = dyn, beta, mode
+        self._eps, self._nleapfrog, self._warmup = eps, nleapfrog, max(1, warmup)
         self.static_x = x.to(DEVICE).clone()
+        self.captures = 0
+        self._capture()
 
-        def run():
-            if mode == 'fb':
-                return dyn.apply_transition_fb((self.static_x, beta))
-            return dyn.apply_transition_hmc((self.static_x, beta), eps=eps, nleapfrog=nleapfrog)
+    def _signature(self) -> tuple:
+        d = self.dyn
+        params = tuple((id(p), p._version) for p in d.parameters())
+        masks = tuple(id(m) for m in d.masks)
+        flags = (d.fuse_heads, d.fuse_x_updates, d.reuse_v_inputs, d.pair_v_updates,
+                 d.fuse_u1_steps, d.fuse_half_heads, d.merge_hmc_kicks,
+                 getattr(d, 'fuse_x_vec8', None), d.net_precision, d.config.verbose, d.training)
+        return (ops.PARAM_GENERATION[0], params, masks, flags)
+
+    def _run(self):
+        if self.mode == 'fb':
+            return self.dyn.apply_transition_fb((self.static_x, self.beta))
+        return self.dyn.apply_transition_hmc((self.static_x, self.beta), eps=self._eps,
+                                             nleapfrog=self._nleapfrog)
+
+    def _capture(self) -> None:
+        from l2hmc import native
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):              # warm-up: caches, workspaces, weight copies
-            for _ in range(max(1, warmup)):
-                run()
+            for _ in range(self._warmup):
+                self._run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # everything the recorded kernels point at, kept alive for the life of this graph
+        self._pinned = [native.pin_workspace(), list(self.dyn._native_masks())]
+        from l2hmc.network.pytorch.network import LeapfrogLayer
+        for m in self.dyn.modules():
+            if isinstance(m, LeapfrogLayer):
+                self._pinned.append(dict(m._head_cache))
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out_x, self.out_metrics = run()
+            self.out_x, self.out_metrics = self._run()
+        self._sig = self._signature()
+        self.captures += 1
 
     def __call__(self, x: Tensor):
+        if self._signature() != self._sig:
+            self._capture()                        # the model changed since the capture
         self.static_x.copy_(x.reshape(self.static_x.shape))
         self.graph.replay()
         return self.out_x, self.out_metrics

@@ -8,6 +8,7 @@ import torch
 
 import l2hmc.configs as cfgs
 from l2hmc.trainers.pytorch.trainer import Trainer
+from l2hmc.utils import dist as D
 from l2hmc.utils.dist import setup_torch
 
 
@@ -16,10 +17,20 @@ class Experiment:
                  keep=None, skip=None) -> None:
         self.cfg = cfg
         self.config = cfgs.instantiate(cfg) if isinstance(cfg, dict) else cfg
+        # Data parallelism: the MODEL must be identical on every rank, the CHAINS
+        # must differ.  (1) everything is seeded with the base seed, the Trainer builds networks
+        # and numpy masks from it; (2) rank 0's parameters / buffers and masks are broadcast (DDP
+        # constructor semantics, trainers/pytorch/trainer.py:246-257 of the reference) so that a
+        # nondeterministic initialiser cannot split the replicas; (3) only then torch / cuda /
+        # numpy are reseeded per rank (`chain_seed`), so lattice.random(), momenta and accept
+        # uniforms are independent streams.  The reference seeds everything with
+        # seed * (rank + 1) (utils/dist.py:340), which also makes its numpy masks rank-dependent.
         self._rank = setup_torch(seed=self.config.seed, backend=self.config.backend,
                                  port=self.config.port)
         self.trainer = Trainer(self.config, build_networks=build_networks)
         self.lattice = self.trainer.lattice
+        D.sync_model(self.trainer.dynamics)
+        D.seed_everything(D.chain_seed(self.config.seed, self._rank))
 
     def build_trainer(self, **kw) -> Trainer:
         return self.trainer

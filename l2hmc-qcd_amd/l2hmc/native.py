@@ -80,6 +80,7 @@ SIGNATURES = {
     'l2q_u1_fused_max_n': (I, []),
     'l2q_u1_vstep_f32': (I, [P, P, D, D, I, I, I, I, P, P, P, P, P, I, P, P, P, P, P, D, P, P, P, I, I, P, P]),
     'l2q_u1_xstep_f32': (I, [P, P, P, I, D, I, I, I, I, P, P, P, P, P, I, P, P, P, P, P, D, P, P, P, I, I, P, P]),
+    'l2q_act_fwd': (I, [P, I, L, I, P, P]),
     'l2q_act_bwd': (I, [P, P, I, L, I, P, P]),
     'l2q_mul': (I, [P, P, D, L, I, P, P]),
     'l2q_axpy_rows': (I, [P, P, I, L, I, P, P]),
@@ -172,15 +173,23 @@ def kernel_name(entry: str, lat) -> str:
 
 
 class Workspace:
-    """Grow-only scratch buffer for the order-stable reductions and split-K partials."""
+    """Grow-only scratch buffer for the order-stable reductions and split-K partials.  A block
+    that a captured HIP graph points at is pinned (`pin`): growing then allocates a new block
+    and keeps the pinned one alive instead of handing its memory back to the allocator."""
 
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
+        self.pinned: list = []
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+    def pin(self) -> Optional[torch.Tensor]:
+        if self.buf is not None and not any(b is self.buf for b in self.pinned):
+            self.pinned.append(self.buf)
         return self.buf
 
 
@@ -189,6 +198,11 @@ _WS = Workspace()
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     return _WS.get(nbytes, device)
+
+
+def pin_workspace() -> Optional[torch.Tensor]:
+    """Keep the current workspace block alive for good (a captured HIP graph references it)."""
+    return _WS.pin()
 
 
 def reduce_ws_bytes(nb: int, n_per_chain: int) -> int:

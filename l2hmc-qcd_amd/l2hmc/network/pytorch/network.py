@@ -600,14 +600,27 @@ class LeapfrogLayer(nn.Module):
         else:
             xf = x.reshape(nb, -1).contiguous()
         vf = v.reshape(nb, -1).contiguous()
+        # swish is not invertible: its derivative needs the pre-activation, so for swish the
+        # layers run without the fused activation and the tape keeps z_pre next to act(z_pre)
+        swish = self.act == 'swish'
+        if swish and conv_ctx is not None:
+            raise NotImplementedError('training: swish inside the conv stack (its kernels fuse the '
+                                      'activation with the max-pool) -- use another activation_fn')
+        fused = None if swish else self.act
         z = ops.gemm(xf, il.xlayer.weight.detach(), il.xlayer.bias.detach(), a2=vf,
-                     w2=il.vlayer.weight.detach(), bias2=il.vlayer.bias.detach(), act=self.act)
+                     w2=il.vlayer.weight.detach(), bias2=il.vlayer.bias.detach(), act=fused)
+        pre = [z] if swish else None
+        if swish:
+            z = ops.act_fwd(z, 'swish')
         acts = [z]
         for h in self.hidden_layers:
-            z = ops.gemm(z, h.weight.detach(), h.bias.detach(), act=self.act)
+            z = ops.gemm(z, h.weight.detach(), h.bias.detach(), act=fused)
+            if swish:
+                pre.append(z)
+                z = ops.act_fwd(z, 'swish')
             acts.append(z)
-        ctx: dict = {'xf': xf, 'vf': vf, 'acts': acts, 'conv': conv_ctx, 'xshape': tuple(x.shape),
-                     'vshape': tuple(v.shape)}
+        ctx: dict = {'xf': xf, 'vf': vf, 'acts': acts, 'pre': pre, 'conv': conv_ctx,
+                     'xshape': tuple(x.shape), 'vshape': tuple(v.shape)}
         p = float(self.net_config.dropout_prob)
         if p > 0 and self.training:
             keep = torch.bernoulli(torch.full_like(z, 1.0 - p))
@@ -656,12 +669,13 @@ class LeapfrogLayer(nn.Module):
         if 'drop' in ctx:
             dz = ops.mul(dz, ctx['drop'], 1.0 / (1.0 - float(self.net_config.dropout_prob)))
         acts = ctx['acts']
+        dact = ctx['pre'] if ctx.get('pre') is not None else acts   # swish: from the pre-activation
         for i in range(len(self.hidden_layers) - 1, -1, -1):
             h = self.hidden_layers[i]
-            dpre = ops.act_bwd(dz, acts[i + 1], self.act)
+            dpre = ops.act_bwd(dz, dact[i + 1], self.act)
             dz = _linear_bwd(dpre, acts[i], h.weight, h.bias)
         il = self.input_layer
-        dpre = ops.act_bwd(dz, acts[0], self.act)
+        dpre = ops.act_bwd(dz, dact[0], self.act)
         dxf = _linear_bwd(dpre, ctx['xf'], il.xlayer.weight, il.xlayer.bias)
         dvf = _linear_bwd(dpre, ctx['vf'], il.vlayer.weight, il.vlayer.bias)
         if ctx['conv'] is not None:

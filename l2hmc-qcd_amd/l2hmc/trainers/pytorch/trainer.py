@@ -22,6 +22,7 @@ from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3
 from l2hmc.lattice.u1.pytorch.lattice import LatticeU1, plaq_exact
 from l2hmc.loss.pytorch.loss import LatticeLoss
 from l2hmc.network.pytorch.network import NetworkFactory
+from l2hmc.utils.history import BaseHistory
 from l2hmc.utils.step_timer import StepTimer
 
 Tensor = torch.Tensor
@@ -50,6 +51,8 @@ class Trainer:
         evals = 2 * cfg.dynamics.nleapfrog if cfg.dynamics.merge_directions \
             else cfg.dynamics.nleapfrog
         self.timers = {k: StepTimer(evals_per_step=evals) for k in ('train', 'eval', 'hmc')}
+        # per-job metric stores with the reference's dataset dump (utils/history.py:157-263, 854-909)
+        self.histories = {k: BaseHistory(steps=cfg.steps) for k in ('train', 'eval', 'hmc')}
         self._estep = self._hstep = self._gstep = 0
         self.arena = None                 # flat parameter / gradient arena (built on first train_step)
         # chains per training micro-batch (None: all at once).  Not a reference option: bounds the
@@ -183,6 +186,20 @@ class Trainer:
         dynamics/pytorch/training.py) -> data-parallel all-reduce of the flat gradient ->
         clip_grad_norm -> fused Adam.  U(1) and SU(3)."""
         from l2hmc.dynamics.pytorch import training as T
+        if not self.config.dynamics.merge_directions:
+            # the reference would train on `apply_transition` (one random direction per step with
+            # its swapped accept-probability arguments, dynamics.py:704-742, 1031-1063); the tape /
+            # reverse sweep here covers the merged forward+backward trajectory only.  Training a
+            # different transition than eval_step samples with would be silent and wrong.
+            raise NotImplementedError(
+                'train_step: dynamics.merge_directions=False is not differentiated by this build '
+                '(sampling with it works: eval_step / Dynamics.apply_transition); train with '
+                'merge_directions=True')
+        gas = int(getattr(self.config, 'gradient_accumulation_steps', 1) or 1)
+        if gas != 1:
+            raise NotImplementedError(
+                f'gradient_accumulation_steps={gas}: not implemented (Trainer.micro_batch bounds '
+                'the tape memory instead: same gradient, one optimiser step per train_step)')
         if self.arena is None:
             self.arena = self._new_arena()
         self.dynamics.train()
@@ -297,6 +314,7 @@ class Trainer:
         x = self.lattice.random() if x is None else x
         timer = self.timers['train']
         history: dict[str, list] = {}
+        patience, stuck = 10, 0                     # trainer.py:1532, 1594-1600 of the reference
         for step in range(nsteps):
             timer.start()
             x, metrics = self.train_step((x, beta))
@@ -309,7 +327,23 @@ class Trainer:
                 if isinstance(v, Tensor):
                     v = v.detach().float().cpu() if not v.is_complex() else v.detach().cpu()
                 history.setdefault(k, []).append(v)
+            avgs = self.histories['train'].update(record)
+            x, stuck = self._redraw_if_stuck(x, avgs, stuck, patience, step)
         return {'history': history, 'x': x, 'timer': timer}
+
+    def _redraw_if_stuck(self, x: Tensor, avgs: dict, stuck: int, patience: int, step: int):
+        """The reference's stuck-chain rescue (trainers/pytorch/trainer.py:1209-1215 in `eval`,
+        :1594-1600 in `train_epoch`): at logging steps, a mean acceptance below 1e-5 counts as
+        stuck; once `patience` such observations have accumulated the chains are redrawn from
+        `lattice.random()` and the counter restarts."""
+        if step % max(1, int(self.config.steps.log)) != 0:
+            return x, stuck
+        if float(np.real(avgs.get('acc', 1.0))) < 1e-5:
+            if stuck < patience:
+                return x, stuck + 1
+            x = self.lattice.random()
+            return x, 0
+        return x, stuck
 
     def warmup(self, beta: float, nsteps: int = 100, tol: float = 1e-5,
                x: Optional[Tensor] = None) -> Tensor:
@@ -327,14 +361,19 @@ class Trainer:
 
     def eval(self, beta: Optional[float] = None, x: Optional[Tensor] = None,
              job_type: str = 'eval', nsteps: Optional[int] = None, eps: Optional[float] = None,
-             nleapfrog: Optional[int] = None) -> dict:
-        """(trainer.py:1085-1252) returns {'history': {key: [per-step tensors]}, 'x': x}"""
+             nleapfrog: Optional[int] = None, dynamic_step_size: Optional[bool] = None) -> dict:
+        """(trainer.py:1085-1252) returns {'history': {key: [per-step tensors]}, 'x': x}.
+        Stuck chains are redrawn (patience 5, :1106, 1209-1215); with `dynamic_step_size` the HMC
+        step size follows the acceptance towards 0.66 in 10 % steps (:1216-1224)."""
         assert job_type in ('eval', 'hmc')
         beta = self.config.annealing_schedule.beta_final if beta is None else beta
         nsteps = self.config.steps.test if nsteps is None else nsteps
         x = self.lattice.random() if x is None else x
         timer = self.timers[job_type]
         history: dict[str, list] = {}
+        patience, stuck = 5, 0
+        if job_type == 'hmc' and dynamic_step_size and eps is None:
+            eps = self.config.dynamics.eps_hmc
         for step in range(nsteps):
             timer.start()
             if job_type == 'hmc':
@@ -346,8 +385,16 @@ class Trainer:
             dt = timer.stop()
             record = {'step': step, 'dt': dt, 'beta': beta}
             record.update({k: v for k, v in metrics.items() if k not in ('beta',)})
+            if job_type == 'hmc' and dynamic_step_size and eps is not None:
+                record['eps'] = eps
             for k, v in record.items():
                 if isinstance(v, Tensor):
                     v = v.detach().float().cpu() if not v.is_complex() else v.detach().cpu()
                 history.setdefault(k, []).append(v)
+            avgs = self.histories[job_type].update(record)
+            x, stuck = self._redraw_if_stuck(x, avgs, stuck, patience, step)
+            if job_type == 'hmc' and dynamic_step_size and eps is not None \
+                    and step % max(1, int(self.config.steps.log)) == 0:
+                acc_avg = float(metrics['acc_mask'].float().mean())
+                eps = eps - eps / 10. if acc_avg < 0.66 else eps + eps / 10.
         return {'history': history, 'x': x, 'timer': timer}

@@ -137,6 +137,33 @@ def compose(conf_dir: os.PathLike, config_name: str = 'config',
     return _resolve(cfg, cfg)
 
 
+def compose_flat(conf_dir: os.PathLike, config_name: str, overrides: list[str] | None = None) -> dict:
+    """A flat primary file (no `defaults` list; the reference ships conf/su3test.yaml and
+    conf/su3-min.yaml for `--config-name`): string values of group keys become group selections,
+    mappings are merged over the composed group, scalars over the top level; command-line
+    overrides win over the file."""
+    conf_dir = Path(conf_dir)
+    name = config_name if config_name.endswith('.yaml') else config_name + '.yaml'
+    flat = _load(conf_dir / name)
+    flat.pop('defaults', None)
+    groups = {g.name for g in conf_dir.iterdir() if g.is_dir()}
+    sel, rest = [], {}
+    for k, v in flat.items():
+        if k in groups and isinstance(v, str):
+            sel.append(f'{k}={v}')
+        else:
+            rest[k] = v
+    overrides = list(overrides or [])
+    group_ovs = [o for o in overrides if o.partition('=')[0].lstrip('+~') in groups]
+    value_ovs = [o for o in overrides if o not in group_ovs]
+    cfg = compose(conf_dir, 'config', sel + group_ovs)
+    _merge(cfg, rest)
+    for ov in value_ovs:
+        key, _, val = ov.partition('=')
+        _set_dotted(cfg, key.lstrip('+~'), yaml.safe_load(val))
+    return _resolve(cfg, cfg)
+
+
 def _instantiate_node(node: Any) -> Any:
     if isinstance(node, dict):
         kwargs = {k: _instantiate_node(v) for k, v in node.items() if k != '_target_'}

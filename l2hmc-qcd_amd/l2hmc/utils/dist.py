@@ -111,8 +111,37 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     """rank-0 parameters / buffers to every rank (DDP constructor semantics)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
+    nccl = dist.get_backend() == 'nccl'
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+        if nccl and not t.is_cuda:
+            # host-resident tensors (the never-called SU(3) xnet lives in host memory) cannot go
+            # through RCCL directly: stage them through the device in <= 1 GiB pieces
+            flat = t.data.reshape(-1)
+            step = max(1, (1 << 30) // max(1, flat.element_size()))
+            for lo in range(0, flat.numel(), step):
+                buf = flat[lo:lo + step].cuda()
+                dist.broadcast(buf, src=src)
+                flat[lo:lo + step].copy_(buf.cpu())
+        else:
+            dist.broadcast(t.data, src=src)
+
+
+def sync_model(dynamics, src: int = 0) -> None:
+    """Make `dynamics` identical on every rank: broadcast rank `src`'s parameters, buffers and
+    the numpy-drawn leapfrog masks.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    broadcast_parameters(dynamics, src=src)
+    masks = getattr(dynamics, 'masks', None)
+    if masks:
+        dev = next(dynamics.parameters()).device if any(True for _ in dynamics.parameters()) else 'cpu'
+        if dist.get_backend() == 'gloo':
+            dev = 'cpu'
+        stacked = torch.stack([m.reshape(-1).float() for m in masks]).to(dev).contiguous()
+        dist.broadcast(stacked, src=src)
+        dynamics.set_masks([stacked[i].cpu().numpy() for i in range(stacked.shape[0])])
+    from l2hmc import _ops as ops
+    ops.PARAM_GENERATION[0] += 1          # cached kernel-order weight copies are stale now
 
 
 def cleanup() -> None:

@@ -281,8 +281,16 @@ def l2q_u1_xstep_f32(x, v, mask, complement, eps, forward, ncp, nb, n, *net_and_
 
 
 # ---- training entry points (VJPs by autograd of the restatements above)
+def l2q_act_fwd(x, act, n, esz, y):
+    y.copy_(_act(x, act))
+
+
 def l2q_act_bwd(dy, y, act, n, esz, dx):
     a = ACT[act]
+    if a == 'swish':                       # y holds the pre-activation
+        sg = torch.sigmoid(y)
+        dx.copy_(dy * sg * (1 + y * (1 - sg)))
+        return
     if a == 'tanh':
         d = 1 - y * y
     elif a == 'relu':

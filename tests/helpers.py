@@ -249,3 +249,59 @@ def build_su3_train_dynamics(g):
         use_mixed_loss=bool(g['use_mixed_loss']), charge_weight=float(g['charge_weight']),
         plaq_weight=float(g['plaq_weight']), rmse_weight=float(g['rmse_weight'])))
     return dyn, lat, loss_fn
+
+
+def check_leapfrog_layer_backward(act: str, device: str, dtype, tol: float):
+    """LeapfrogLayer.forward_train / backward (dense layers, no conv / batch-norm) against
+    torch.autograd of the same arithmetic written with torch ops -- network.py:430-551 of the
+    reference is exactly this arithmetic under autograd."""
+    import torch
+    import l2hmc.configs as cfgs
+    from l2hmc.network.pytorch.network import LeapfrogLayer
+    torch.manual_seed(3)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        nb, xdim = 5, 24
+        nc = cfgs.NetworkConfig(units=[16, 12], activation_fn=act, dropout_prob=0.0,
+                                use_batch_norm=False)
+        net = LeapfrogLayer(xshape=(nb, xdim), network_config=nc,
+                            input_shapes={'x': xdim, 'v': xdim},
+                            net_weight=cfgs.NetWeight(0.7, 1.1, 0.9)).to(device).train()
+        with torch.no_grad():
+            net.scale.coeff.normal_(0, 0.3)
+            net.transf.coeff.normal_(0, 0.3)
+        x = torch.randn(nb, xdim, device=device)
+        v = torch.randn(nb, xdim, device=device)
+        gs, gt, gq = (torch.randn(nb, xdim, device=device) for _ in range(3))
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        s, t, q, ctx = net.forward_train(x, v)
+        dx, dv = net.backward(ctx, gs.clone(), gt.clone(), gq.clone())
+        got = {n: p.grad.clone() for n, p in net.named_parameters()}
+        # torch reference
+        f = {'tanh': torch.tanh, 'relu': torch.relu, 'swish': torch.nn.functional.silu,
+             'elu': torch.nn.functional.elu,
+             'leaky_relu': lambda z: torch.nn.functional.leaky_relu(z, 0.01)}[act]
+        xr, vr = x.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        il = net.input_layer
+        z = f(torch.nn.functional.linear(xr, il.xlayer.weight, il.xlayer.bias)
+              + torch.nn.functional.linear(vr, il.vlayer.weight, il.vlayer.bias))
+        for h in net.hidden_layers:
+            z = f(torch.nn.functional.linear(z, h.weight, h.bias))
+        sr = net.nw.s * torch.exp(net.scale.coeff) * torch.tanh(net.scale.layer(z))
+        tr = net.nw.t * net.transl(z)
+        qr = net.nw.q * torch.exp(net.transf.coeff) * torch.tanh(net.transf.layer(z))
+        ((sr * gs).sum() + (tr * gt).sum() + (qr * gq).sum()).backward()
+        worst = max(float((s - sr).abs().max()), float((t - tr).abs().max()),
+                    float((q - qr).abs().max()))
+        assert worst < tol, ('forward', worst)
+        assert float((dx.reshape(nb, -1) - xr.grad).abs().max()) < tol
+        assert float((dv.reshape(nb, -1) - vr.grad).abs().max()) < tol
+        for n, p in net.named_parameters():
+            e = float((got[n] - p.grad).abs().max())
+            assert e < tol * max(1.0, float(p.grad.abs().max())), (n, e)
+    finally:
+        torch.set_default_dtype(old)

@@ -118,3 +118,34 @@ def test_reference_api_surface_present():
                              'LeapfrogLayer NetworkFactory')):
         missing += [f'{mod.__name__}.{n}' for n in names.split() if not hasattr(mod, n)]
     assert not missing, missing
+
+
+def test_flat_configs_and_history(tmp_path):
+    """conf/su3test.yaml / conf/su3-min.yaml (the reference's flat `--config-name` files) compose
+    over the defaults; BaseHistory stacks per-step metrics and dumps the dataset (utils/history.py
+    :157-263, 854-909 of the reference)."""
+    import numpy as np
+    import torch
+    import l2hmc.configs as c
+    from l2hmc.utils.history import BaseHistory
+    ec = c.instantiate(c.get_config(['dynamics.nchains=3'], config_name='su3test'))
+    assert (ec.dynamics.group, ec.dynamics.nleapfrog, ec.network.units) == ('SU3', 4, [256])
+    assert ec.dynamics.nchains == 3 and ec.conv.filters == [] and ec.net_weights.x.s == 0.0
+    assert ec.loss.plaq_weight == 0.1 and ec.learning_rate.lr_init == 1e-4 and ec.steps.test == 50
+    em = c.instantiate(c.get_config([], config_name='su3-min'))
+    assert (em.dynamics.nleapfrog, em.network.units, em.dynamics.eps) == (1, [1], 0.06)
+    assert em.net_weights.x.q == 0.0 and em.loss.rmse_weight == 1.0 and not em.loss.use_mixed_loss
+    h = BaseHistory(ec.steps)
+    for i in range(6):
+        avgs = h.update({'era': 0, 'step': i, 'acc': torch.full((4,), 0.25 * (i % 4)),
+                         'energy': torch.ones(3, 4) * i, 'loss': -1.5, 'plaqs': {'mean': 0.5}})
+    assert avgs['acc'] == 0.25 and avgs['plaqs/mean'] == 0.5 and 'loss=' in h.era_summary(0)
+    ds = h.get_dataset(therm_frac=0.5)
+    get = (lambda k: ds[k]) if isinstance(ds, dict) else (lambda k: (tuple(ds[k].dims), ds[k].values))
+    assert get('acc')[0] == ('chain', 'draw') and get('acc')[1].shape == (4, 3)
+    assert get('energy')[0] == ('chain', 'leapfrog', 'draw') and get('energy')[1].shape == (4, 3, 3)
+    f = h.save_dataset(tmp_path, 'eval')
+    z = np.load(f)
+    assert z['energy'].shape == (4, 3, 6) and z['plaqs_mean'].shape == (6,)
+    rows = (tmp_path / 'eval_avgs.csv').read_text().strip().splitlines()
+    assert len(rows) == 7 and rows[0].split(',')[0] == 'acc'

@@ -136,3 +136,56 @@ def test_two_rank_train_step_equals_single_process(tmp_path):
     assert float((r0['grads'] - one['grads']).abs().max()) < 1e-12 * max(gn, 1.0)
     assert abs(0.5 * (r0['loss'] + r1['loss']) - one['loss']) < 1e-12 * max(abs(one['loss']), 1.0)
     assert float((r0['params'] - one['params']).abs().max()) < 1e-7
+
+
+# ------------------------------------------------------------------ Experiment under 2 ranks
+def _experiment_worker(rank, world, port, out):
+    """`python -m l2hmc`-style construction on every rank: the model (parameters, buffers, masks)
+    must come out identical, the chains / momenta / accept uniforms must not."""
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import numpy as np
+    import emu_native
+    from l2hmc import native
+    import l2hmc.configs as cfgs
+    from l2hmc.experiment.pytorch.experiment import Experiment
+    from l2hmc.utils import dist as D
+    native.call = emu_native.call
+    import l2hmc._ops as ops
+    ops.N.call = emu_native.call
+    cfg = cfgs.get_config(['dynamics.group=U1', 'dynamics.latvolume=[4,4]', 'dynamics.nchains=6',
+                           'dynamics.nleapfrog=2', 'conv=none', 'network.units=[8,8]',
+                           'backend=gloo', f'port={port}', 'seed=4321'])
+    # a rank-dependent perturbation BEFORE construction: whatever the local RNG state is, the
+    # replicas must end up with rank 0's model
+    torch.manual_seed(17 + rank)
+    np.random.seed(17 + rank)
+    ex = Experiment(cfg)
+    dyn = ex.trainer.dynamics
+    if rank == 1:                      # and an explicit divergence that sync_model has to repair
+        with torch.no_grad():
+            for p in dyn.parameters():
+                p.add_(0.125)
+        dyn.set_masks([1.0 - m.numpy().reshape(-1) for m in dyn.masks])
+    D.sync_model(dyn)
+    params = torch.cat([p.detach().reshape(-1).cpu().double() for p in dyn.parameters()])
+    masks = torch.stack([m.reshape(-1) for m in dyn.masks])
+    x = ex.lattice.random()
+    v = torch.randn(4)
+    xo, m = ex.trainer.eval_step((x, 2.0))
+    torch.save({'params': params, 'masks': masks, 'x': x.cpu(), 'v': v, 'np': np.random.rand(3),
+                'xo': xo.cpu(), 'acc': m['acc'].cpu()}, os.path.join(out, f'e{rank}.pt'))
+    D.cleanup()
+
+
+def test_experiment_two_ranks_same_model_different_chains(tmp_path):
+    port = _free_port()
+    mp.spawn(_experiment_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'e{i}.pt', weights_only=False) for i in range(2))
+    assert torch.equal(r0['params'], r1['params']) and r0['params'].numel() > 1000
+    assert torch.equal(r0['masks'], r1['masks'])
+    assert not torch.equal(r0['x'], r1['x'])                        # independent chains
+    assert not torch.equal(r0['v'], r1['v']) and not (r0['np'] == r1['np']).all()
+    assert not torch.equal(r0['xo'], r1['xo'])

@@ -268,6 +268,47 @@ def test_graphed_transition_u1(golden, name):
     assert np.array_equal(host(m_h['acc_mask']), g['hmc_acc_mask'])
 
 
+def test_graphed_transition_follows_model_changes(golden):
+    """a replay after the model changed must not use the weights / step sizes frozen
+    at capture time, and growing the global workspace must not invalidate the graph."""
+    torch.set_default_dtype(torch.float32)
+    from l2hmc import native, _ops as ops
+    g = golden('u1_c1')
+    dyn, lat = build_u1_dynamics(g, verbose=False)
+    x, beta = dev(g['x']), float(g['beta'])
+    dyn._inject = {'normals': dev(g['normals']), 'u': dev(g['u'])}
+    gt = dyn.make_graphed(x, beta)
+    xo0 = gt(x)[0].clone()
+    assert gt.captures == 1
+    ws0 = native._WS.buf
+    # (1) a larger workspace request: the block the graph points at must stay alive and intact
+    big = native.workspace(ws0.numel() * 4 + (1 << 20), x.device)
+    assert big is not ws0 and any(b is ws0 for b in native._WS.pinned)
+    junk = [torch.full((ws0.numel() // 4 + 64,), 7.0, device=x.device) for _ in range(4)]
+    xo1 = gt(x)[0].clone()
+    assert gt.captures == 1 and err(host(xo1), host(xo0)) == 0.0
+    del junk
+    # (2) parameters modified in place (what the fused Adam step does through the arena)
+    with torch.no_grad():
+        for p in dyn.vnet.parameters():
+            p.mul_(0.5)
+    ops.PARAM_GENERATION[0] += 1
+    xo_e = dyn((x, beta))[0].clone()
+    xo2 = gt(x)[0].clone()
+    assert gt.captures == 2
+    assert err(host(xo2), host(xo_e)) == 0.0 and err(host(xo2), host(xo0)) > 1e-4
+    # (3) new step sizes, (4) new masks
+    dyn.assign_eps(0.07)
+    xo_e = dyn((x, beta))[0].clone()
+    assert err(host(gt(x)[0]), host(xo_e)) == 0.0 and gt.captures == 3
+    dyn.set_masks([1.0 - m.numpy().reshape(-1) for m in dyn.masks])
+    xo_e = dyn((x, beta))[0].clone()
+    assert err(host(gt(x)[0]), host(xo_e)) == 0.0 and gt.captures == 4
+    # unchanged model: plain replays
+    gt(x); gt(x)
+    assert gt.captures == 4
+
+
 def test_graphed_transition_su3(golden):
     torch.set_default_dtype(torch.float64)
     g = golden('su3_l2hmc')

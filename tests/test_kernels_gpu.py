@@ -293,6 +293,14 @@ def test_accept_select(ops):
     a = dev(np.arange(4 * 6, dtype=np.float64).reshape(4, 6)); b = -a
     out = host(ops.select_rows(a, b, mask))
     assert np.array_equal(out, np.where(host(mask)[:, None] > 0, host(a), host(b)))
+    # a diverged chain (H = inf - inf = NaN): acc is NaN like torch.minimum gives, and it is rejected
+    for dt in (np.float64, np.float32):
+        h0 = dev(np.array([1.0, np.inf, np.nan, 2.0], dtype=dt)); h1 = dev(np.array([1.5, np.inf, 0.0, 1.0], dtype=dt))
+        z = dev(np.zeros(4, dtype=dt)); u = dev(np.array([0.1, 0.0, 0.0, 0.5], dtype=dt))
+        acc, mask = ops.accept(h0, h1, z, u)
+        acc = host(acc)
+        assert np.isnan(acc[1]) and np.isnan(acc[2]) and abs(acc[0] - np.exp(-0.5)) < 1e-6 and acc[3] == 1.0
+        assert host(mask).tolist() == [1.0, 0.0, 0.0, 1.0]
 
 
 @pytest.mark.parametrize('cplx', [True, False])

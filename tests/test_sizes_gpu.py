@@ -298,7 +298,9 @@ def test_cfg5_l2hmc_trajectory_16x4_256chains():
     free, total = torch.cuda.mem_get_info()
     if total < 200 * 2 ** 30:
         pytest.skip('needs the 288 GB of an MI355X')
-    dyn, lat = _build(L, nb, nlf, units, eps=0.005, head_scale=0.01, seed=12)
+    # calibrated with tools/cal_cfg5.py: from the near-cold start the element-masked x half-updates
+    # (which leave the group manifold) give dH ~ -9e6 eps^2; eps = 3e-4 => dH = -0.83, acc = 0.436
+    dyn, lat = _build(L, nb, nlf, units, eps=3e-4, head_scale=0.003, seed=12)
     orc = _oracle(dyn, L, nlf, units)
     rng = np.random.default_rng(5)
     x2 = _warm(rng, 2, L)
