@@ -70,7 +70,7 @@ def parse():
                     help='train mode: chains per tape micro-batch (needed at 16^4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-spot-check', action='store_true')
-    ap.add_argument('--cpu-chains', type=int, default=64)
+    ap.add_argument('--cpu-chains', type=int, default=32)
     return ap.parse_args()
 
 
@@ -198,6 +198,10 @@ def cpu_baseline(dyn, args):
     reference fixtures by tests/test_oracle_golden.py) -- timed on all host cores on a bounded
     sample of the same workload."""
     from oracle import torch_cpu as tc
+    # torch's intra-op pool on small 3x3 batches scales to ~16 threads and then collapses
+    # (tools/cpu_threads_probe.py on the 256-CPU GPU host: 35 / 45 / 54 / 33 / 19 / 8 chain*LF/s at
+    # 4 / 8 / 16 / 32 / 64 / 128 threads), so the baseline runs on 16 and says so in `cores`
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     nbc = args.cpu_chains
     L = tuple(args.lattice)
     nlf = 1

@@ -55,7 +55,9 @@ extern "C" {
 
 const char* l2q_last_error(void);
 int l2q_version(void);
-/* performance knobs (results never depend on them): "plaq_occ" / "force_occ" in {2,3,4} pick
+/* performance knobs (results never depend on them), kept PER DEVICE: the call applies to the
+ * calling thread's current HIP device -- the library's only state besides the last-error text
+ * is this per-device table: "plaq_occ" / "force_occ" in {2,3,4} pick
  * the register-allocation variant (min waves per SIMD) of the stencil kernels; "xcd_swizzle"
  * in {0,1}.  Returns the previous value, or L2Q_EINVAL for an unknown key/value. */
 int l2q_set_tuning(const char* key, int value);

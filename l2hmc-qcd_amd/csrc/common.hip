@@ -14,9 +14,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Performance knobs are per DEVICE (the only state the library keeps besides the last-error
+// text): one process per GPU is the deployment model, but a process that drives several devices
+// gets an independent table for each -- `tuning()` resolves to the table of the current HIP
+// device of the calling thread.  Results never depend on the knobs.
 Tuning& tuning() {
-  static Tuning t;
-  return t;
+  static Tuning t[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  return t[dev];
 }
 
 // out[c][k] = scale * sum_b partial[c][b][k] + offset   (fixed order)

@@ -948,6 +948,17 @@ void launch_force_rows(bool kick, const double2* xn, Dims d, int nb, double coef
 
 using namespace l2q;
 
+// force_tile = 4 picks per lattice (same-box A/B, tools/force_bench.py): the plane-split kernel
+// wins when its 64-site tile holds whole (y,z)-planes (8^4: 0.466 vs 0.575 ms) and for the fused
+// kick; on 16^4 (tile = 4 z-rows: y AND x leave the tile) the plain force is 7 % faster with the
+// 128-site thread-per-link kernel (2.11 vs 2.26 ms at 64 chains).
+template <bool KICK>
+static bool nu_preferred(const Dims& d) {
+  const int Vs_ = d.X * d.Y * d.Z;
+  const bool slice_ok = Vs_ % (KICK ? kFSKick : kFSPlain) == 0;
+  return KICK || !slice_ok || (force_nu_inmask(d) & 2) != 0;
+}
+
 template <bool KICK>
 static void launch_force(const double2* xn, Dims d, int nb, long nblk, double coef, double2* out,
                          hipStream_t st) {
@@ -955,11 +966,11 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
   constexpr int kFS = KICK ? kFSKick : kFSPlain;
   constexpr int kVar = KICK ? 2 : 0;
   constexpr int kLpt = KICK ? 1 : kLptPlain;
-  if (tuning().force_tile == 4 && force_nu_applicable(d)) {
+  if (tuning().force_tile == 4 && force_nu_applicable(d) && nu_preferred<KICK>(d)) {
     launch_force_nu(KICK, xn, d, nb, coef, out, st);
     return;
   }
-  if (tuning().force_tile >= 3 && force_rows_applicable(d)) {
+  if (tuning().force_tile == 3 && force_rows_applicable(d)) {
     launch_force_rows(KICK, xn, d, nb, coef, out, st);
     return;
   }
@@ -1021,9 +1032,10 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
   } else if (!strcmp(entry, "l2q_su3_force") || !strcmp(entry, "l2q_su3_force_kick")) {
     const bool kick = !strcmp(entry, "l2q_su3_force_kick");
     const int fs = kick ? kFSKick : kFSPlain;
-    if (t.force_tile == 4 && Vs % 64 == 0)
-      snprintf(buf, buf_bytes, "su3_force_nu_kernel<%d, %d>", kick ? 1 : 0, force_nu_inmask(Dims{T, X, Y, Z, T * X * Y * Z}));
-    else if (t.force_tile >= 3 && Vs % 64 == 0)
+    const Dims dd{T, X, Y, Z, T * X * Y * Z};
+    if (t.force_tile == 4 && force_nu_applicable(dd) && (kick ? nu_preferred<true>(dd) : nu_preferred<false>(dd)))
+      snprintf(buf, buf_bytes, "su3_force_nu_kernel<%d, %d>", kick ? 1 : 0, force_nu_inmask(dd));
+    else if (t.force_tile == 3 && Vs % 64 == 0)
       snprintf(buf, buf_bytes, "su3_force_rows_kernel<%d, %d>", kick ? 1 : 0, force_rows_inmask(Dims{T, X, Y, Z, T * X * Y * Z}));
     else if (t.force_tile >= 2 && Vs % fs == 0)
       snprintf(buf, buf_bytes, "su3_force_slice_kernel<%s, %d, %d, %d>", kick ? "true" : "false", fs,

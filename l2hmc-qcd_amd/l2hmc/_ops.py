@@ -682,7 +682,11 @@ def axpy_rows_(y: torch.Tensor, a: torch.Tensor, x: torch.Tensor) -> torch.Tenso
 
 
 def add_(y: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
-    """y += alpha * x (float32 / float64, any shape)."""
+    """y += alpha * x (float32 / float64 / complex128 as pairs of doubles, any shape)."""
+    if y.is_complex():
+        N.call('l2q_axpy', torch.view_as_real(x), float(alpha), torch.view_as_real(y),
+               2 * y.numel(), y.element_size() // 2)
+        return y
     N.call('l2q_axpy', x, float(alpha), y, y.numel(), y.element_size())
     return y
 

@@ -202,11 +202,32 @@ def _x_step(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, mask: Tensor, comple
     return x_new, ld
 
 
-def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, forward: bool):
-    """x, v native [nb, 4, 9, V] complex128."""
+def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, forward: bool,
+                share: Optional[dict] = None):
+    """x, v native [nb, 4, 9, V] complex128.
+
+    `share` (trajectory-local): the closing v-update of one leapfrog step and the opening one of
+    the next (also across the momentum flip) act on the SAME x, hence -- with one shared vnet,
+    the SU(3) default -- on the same force and the same (s, t, q).  The second of such a pair
+    reuses the first one's force / network evaluation (the eval path does the same,
+    Dynamics.reuse_v_inputs) and is recorded as a tape entry that points at its `primary`: the
+    reverse sweep adds its (dF, ds, dt, dq) cotangents to the primary's before ONE backward pass
+    through the network, the projections and the force.  9 instead of 16 network / force
+    evaluations forward AND backward in a merged nleapfrog = 4 trajectory; exact (the cotangents
+    are summed either way)."""
     nb, _, _, V = x.shape
     eps = dyn._eps('v', st)
     vnet = dyn._get_vnet(st)
+    hit = (share is not None and share.get('x') is x and share.get('net') is vnet
+           and not vnet.training_needs_fresh_forward())
+    if hit:
+        F, sn, tn, qn = share['F'], share['s'], share['t'], share['q']
+        v_new = v.clone()
+        ld = ops.v_update_(v_new.reshape(nb, -1), F.reshape(nb, -1), sn, tn, qn, eps, forward)
+        tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
+                             's': sn, 't': tn, 'q': qn, 'ctx': None, 'net': vnet, 'eps': eps,
+                             'primary': share['idx']})
+        return v_new, ld
     F = ops.su3_force_n(x, beta, dyn.latvolume)
     xv = ops.su3_projsu_vec8_n(x).reshape(nb, -1)
     fv = ops.su3_projsu_vec8_n(F).reshape(nb, -1)
@@ -217,6 +238,10 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
     ld = ops.v_update_(v_new.reshape(nb, -1), F.reshape(nb, -1), sn, tn, qn, eps, forward)
     tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
                          's': sn, 't': tn, 'q': qn, 'ctx': ctx, 'net': vnet, 'eps': eps})
+    if share is not None:
+        share.clear()
+        share.update({'x': x, 'net': vnet, 'F': F, 's': sn, 't': tn, 'q': qn,
+                      'idx': len(tape.entries) - 1})
     return v_new, ld
 
 
@@ -232,7 +257,7 @@ def _x_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, mask: Tensor, co
     return x_new
 
 
-def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool):
+def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool, share: Optional[dict] = None):
     """One generalised leapfrog step (dynamics.py:1187-1228), functional (new tensors)."""
     if forward:
         st, order = step, ((False, True), (True, False))         # (complement, first)
@@ -241,10 +266,10 @@ def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool):
         order = ((True, False), (False, True))
     m = dyn._native_masks()[st]
     if dyn.group == 'SU3':
-        v, ld = _v_step_su3(dyn, tape, st, x, v, beta, forward)
+        v, ld = _v_step_su3(dyn, tape, st, x, v, beta, forward, share)
         for comp, _first in order:
             x = _x_step_su3(dyn, tape, st, x, v, m, comp, forward)
-        v, l = _v_step_su3(dyn, tape, st, x, v, beta, forward)
+        v, l = _v_step_su3(dyn, tape, st, x, v, beta, forward, share)
         return x, v, ld + l
     v, ld = _v_step(dyn, tape, st, x, v, beta, forward)
     for comp, first in order:
@@ -273,8 +298,9 @@ def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
                             'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet,
                             'xeps': dyn.xeps[0], 'veps': dyn.veps[0]}, history)
     nlf = dyn.config.nleapfrog
+    share = {} if (dyn.group == 'SU3' and getattr(dyn, 'reuse_v_inputs', True)) else None
     for step in range(nlf):
-        x, v, ld = _lf_train(dyn, tape, step, x, v, beta, True)
+        x, v, ld = _lf_train(dyn, tape, step, x, v, beta, True, share)
         sumlogdet = sumlogdet + ld
         if verbose:
             sldf = sldf + ld
@@ -284,7 +310,7 @@ def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
     v = ops.scale(v, -1.0) if dyn.group == 'SU3' else -v
     tape.entries.append({'kind': 'flip'})
     for step in range(nlf):
-        x, v, ld = _lf_train(dyn, tape, step, x, v, beta, False)
+        x, v, ld = _lf_train(dyn, tape, step, x, v, beta, False, share)
         sumlogdet = sumlogdet + ld
         if verbose:
             sldb = sldb + ld
@@ -419,7 +445,9 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
     nb, _, _, V = gx.shape
     gx, gv = gx.contiguous(), gv.contiguous()
     eps_acc: dict = {}
-    for e in reversed(tape.entries):
+    pend: dict = {}            # primary tape index -> cotangents deferred by the sharing v-update
+    for idx in range(len(tape.entries) - 1, -1, -1):
+        e = tape.entries[idx]
         kind = e['kind']
         if kind == 'flip':
             gv = ops.scale(gv, -1.0)
@@ -429,6 +457,16 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
             dv, dF, dsn, dtn, dqn, deps = ops.v_update_bwd_c128(
                 v.reshape(nb, -1), F.reshape(nb, -1), e['s'], e['t'], e['q'], e['eps'],
                 e['forward'], gv.reshape(nb, -1), gl)
+            if e.get('primary') is not None:
+                # same x, force and (s, t, q) as the primary entry: hand the cotangents over
+                assert e['primary'] not in pend
+                pend[e['primary']] = (dF, dsn, dtn, dqn)
+                gv = dv.reshape(v.shape)
+                eps_acc.setdefault(('v', e['step']), []).append(deps)
+                continue
+            if idx in pend:
+                pF, ps, pt, pq = pend.pop(idx)
+                ops.add_(dF, pF); ops.add_(dsn, ps); ops.add_(dtn, pt); ops.add_(dqn, pq)
             ds, dt, dq = (ops.unpack_entries(a, V, 9) for a in (dsn, dtn, dqn))
             dxr, dfr = e['net'].backward(e['ctx'], ds, dt, dq)
             dF = dF.reshape(F.shape)
@@ -442,6 +480,7 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
                                               gx, gv)
             # the kernel differentiates w.r.t. the signed step it was called with
             eps_acc.setdefault(('x', e['step']), []).append(deps if e['forward'] else -deps)
+    assert not pend
     _accumulate_eps_grads(dyn, eps_acc)
 
 

@@ -588,6 +588,13 @@ class LeapfrogLayer(nn.Module):
 
 
     # ---- training path (train-mode semantics: dropout active, BatchNorm batch statistics)
+    def training_needs_fresh_forward(self) -> bool:
+        """True when two forward_train calls on the same input differ on purpose (fresh dropout
+        mask per call, BatchNorm running statistics updated per call): the trajectory tape must
+        then evaluate every v-update separately, like the reference's autograd graph does."""
+        return self.training and (float(self.net_config.dropout_prob) > 0
+                                  or bool(self.net_config.use_batch_norm))
+
     def forward_train(self, x: Tensor, v: Tensor) -> tuple[Tensor, Tensor, Tensor, dict]:
         """(s, t, q, ctx).  x: the network's x input ([nb, C, T, X] when there is a conv stack,
         otherwise anything flattenable to [nb, Kx]); v likewise.  reference: network.py:522-551
