@@ -32,77 +32,6 @@ constexpr int kNuThreads = kRS * 12;
 constexpr int kNuOffS0 = 0, kNuOffS1 = 3 * kPlaneB, kNuOffT = 6 * kPlaneB, kNuOffX = 7 * kPlaneB;
 constexpr int kNuLds = kNuOffX + 2 * 4 * kPlaneB;       // exchange: [2 publishers][4 mu][9][kRS]
 
-// Operand: LDS (IN, compile time) at byte address lds, else the chain buffer at (voff, soff).
-template <bool IN>
-struct Opnd {
-  int lds, voff, soff;
-};
-
-// t = A * B^H (ADJ_A = false) or A^H * B^H (ADJ_A = true); B streamed by rows
-template <bool ADJ_A, bool IN>
-__device__ __forceinline__ void mul_xh_stream(M3& t, const M3& a, const Opnd<IN>& b,
-                                              __amdgpu_buffer_rsrc_t rs, int V16) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    R3 br;
-    ld_row<IN>(br, b.lds, rs, b.voff, b.soff, V16, j);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      double sr = 0.0, si = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double ar = ADJ_A ? a.re[3 * k + i] : a.re[3 * i + k];
-        const double ai = ADJ_A ? -a.im[3 * k + i] : a.im[3 * i + k];
-        const double xr = br.re[k], xi = -br.im[k];           // conj(B_jk)
-        sr = fma(ar, xr, sr); sr = fma(-ai, xi, sr);
-        si = fma(ar, xi, si); si = fma(ai, xr, si);
-      }
-      t.re[3 * i + j] = sr; t.im[3 * i + j] = si;
-    }
-  }
-}
-
-// acc += T * C^H (ADJ_C = true) or T * C (ADJ_C = false); C streamed by rows
-template <bool ADJ_C, bool IN>
-__device__ __forceinline__ void mac_stream(M3& acc, const M3& t, const Opnd<IN>& c,
-                                           __amdgpu_buffer_rsrc_t rs, int V16) {
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    R3 cr;
-    ld_row<IN>(cr, c.lds, rs, c.voff, c.soff, V16, q);
-    if (ADJ_C) {
-      // acc_iq += sum_k t_ik conj(C_qk)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        double sr = acc.re[3 * i + q], si = acc.im[3 * i + q];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double xr = cr.re[k], xi = -cr.im[k];
-          sr = fma(t.re[3 * i + k], xr, sr); sr = fma(-t.im[3 * i + k], xi, sr);
-          si = fma(t.re[3 * i + k], xi, si); si = fma(t.im[3 * i + k], xr, si);
-        }
-        acc.re[3 * i + q] = sr; acc.im[3 * i + q] = si;
-      }
-    } else {
-      // acc_ij += t_iq C_qj
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          double sr = acc.re[3 * i + j], si = acc.im[3 * i + j];
-          sr = fma(t.re[3 * i + q], cr.re[j], sr); sr = fma(-t.im[3 * i + q], cr.im[j], sr);
-          si = fma(t.re[3 * i + q], cr.im[j], si); si = fma(t.im[3 * i + q], cr.re[j], si);
-          acc.re[3 * i + j] = sr; acc.im[3 * i + j] = si;
-        }
-    }
-  }
-}
-
-template <bool IN>
-__device__ __forceinline__ void ld_m(M3& m, const Opnd<IN>& o, __amdgpu_buffer_rsrc_t rs, int V16) {
-  ld_full<IN>(m, o.lds, rs, o.voff, o.soff, V16);
-}
-
 template <int INM>
 __device__ __forceinline__ constexpr bool nu_in(int dir) { return dir == 0 ? true : ((INM >> (dir - 1)) & 1) != 0; }
 

@@ -304,7 +304,10 @@ def test_accept_select(ops):
 
 
 @pytest.mark.parametrize('cplx', [True, False])
-@pytest.mark.parametrize('shape', [(3, 4, 3888), (70, 16, 200), (130, 256, 1000)])
+@pytest.mark.parametrize('shape', [(3, 4, 3888), (70, 16, 200), (130, 256, 1000),
+                                   # >= 512 tiles: the producer / consumer (persistent) kernel; full K,
+                                   # short K with ragged M and N, one tile more than a round
+                                   (256, 256, 8192), (200, 64, 9000), (256, 128, 8256)])
 def test_fused_heads_vupdate(ops, cplx, shape):
     """the fused (s,t,q)-heads + momentum-update kernel == three GEMMs + l2q_v_update"""
     m, k, n = shape

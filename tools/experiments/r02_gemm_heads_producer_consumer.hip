@@ -1,0 +1,1116 @@
+// gemm.hip -- dense layers of the xnet / vnet leapfrog networks on the CDNA4 matrix cores.
+//
+//   C[M][N] = epi( A[M][K] . W[N][K]^T  (+ A2[M][K2] . W2[N][K2]^T) + bias (+ bias2) )
+//
+// Both operands are K-contiguous (nn.Linear weight layout), so one LDS-tiled "NT" kernel
+// serves every layer.  fp64 uses v_mfma_f64_16x16x4_f64, fp32 v_mfma_f32_16x16x4_f32 (exact
+// IEEE fma chains, no reduced-precision path).  256-thread workgroups = 2x2 wavefronts, each
+// owning a (BM/2)x(BN/2) quadrant of 16x16 MFMA tiles; operands are staged through LDS in
+// K-slabs of 16 with 16-byte global loads and a register prefetch of the next slab.
+// The L2HMC layers are skinny (M = #chains <= a few hundred, K or N = 32V..36V ~ 1e5), so
+// the input layer splits K across workgroups with a fixed-order second-stage reduce
+// (deterministic, no atomics), and the three output heads (s, t, q) are computed together
+// and consumed in registers by the generalised momentum update (fused_heads_vupdate):
+// s, t, q are never written to HBM.
+#include "l2q_common.hpp"
+#include <type_traits>
+
+namespace l2q {
+
+#ifndef L2Q_BK
+#define L2Q_BK 16
+#endif
+#ifndef L2Q_HEADS_OCC
+#define L2Q_HEADS_OCC 2
+#endif
+constexpr int BK = L2Q_BK, LDP = BK + 2;   // +2: conflict-free ds_read_b64 / ds_read_b32 fragments
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+  using acc_t = v4f64;
+  using vec_t = double2;
+  static constexpr int VEC = 2;
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mfma<float> {
+  using acc_t = v4f32;
+  using vec_t = float4;
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// 1 / d for finite positive d: v_rcp_f64 seed (~2^-26) + two Newton steps (5 instructions instead
+// of the ~12 of the IEEE division sequence); error ~1 ulp
+__device__ __forceinline__ double rcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return r;
+}
+
+__device__ __forceinline__ double fast_tanh(double x) {
+  // tanh(x) = 1 - 2 / (exp(2x) + 1).  |x| is clamped to 20 (tanh(20) rounds to 1 in fp64) so that
+  // exp stays finite for the Newton reciprocal; NaN is passed through.
+  const double c = fmin(fmax(x, -20.0), 20.0);
+  const double t = 1.0 - 2.0 * rcp_nr(exp(2.0 * c) + 1.0);
+  return (x != x) ? x : t;
+}
+
+// exp(x) for the step-size-scaled arguments of the momentum update (|eps s / 2|, |eps q| ~ 1e-2):
+// degree-11 Taylor polynomial for |x| < 1/8 (remainder < 2e-18), libm otherwise.
+__device__ __forceinline__ double exp_small(double x) {
+  if (fabs(x) < 0.125) {
+    double r = 1.0 / 39916800.0;
+    r = fma(r, x, 1.0 / 3628800.0);
+    r = fma(r, x, 1.0 / 362880.0);
+    r = fma(r, x, 1.0 / 40320.0);
+    r = fma(r, x, 1.0 / 5040.0);
+    r = fma(r, x, 1.0 / 720.0);
+    r = fma(r, x, 1.0 / 120.0);
+    r = fma(r, x, 1.0 / 24.0);
+    r = fma(r, x, 1.0 / 6.0);
+    r = fma(r, x, 0.5);
+    r = fma(r, x, 1.0);
+    return fma(r, x, 1.0);
+  }
+  return exp(x);
+}
+__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+
+template <typename T>
+__device__ __forceinline__ T apply_act(T z, int act) {
+  switch (act) {
+    case L2Q_ACT_TANH: return fast_tanh(z);
+    case L2Q_ACT_RELU: return z > (T)0 ? z : (T)0;
+    case L2Q_ACT_LEAKY_RELU: return z > (T)0 ? z : (T)0.01 * z;
+    case L2Q_ACT_ELU: return z > (T)0 ? z : expm1(z);
+    case L2Q_ACT_SWISH: return z / ((T)1 + exp(-z));
+    default: return z;
+  }
+}
+
+// y = scale * exp(coeff[n]) * act(acc + bias[n] + bias2[n])
+template <typename T>
+struct Epilogue {
+  const T* bias;
+  const T* bias2;
+  const T* coeff;
+  T scale;
+  int act;
+  int accumulate;        // C += result (gradient accumulation) instead of C = result
+  __device__ __forceinline__ T colscale(int n) const {
+    return coeff ? scale * exp(coeff[n]) : scale;
+  }
+  __device__ __forceinline__ T colbias(int n) const {
+    T b = (T)0;
+    if (bias) b += bias[n];
+    if (bias2) b += bias2[n];
+    return b;
+  }
+};
+
+// Operand tile loader: ROWS x BK elements of the virtual K-concatenated matrix [P | P2]
+// (row stride K resp. K2), zero outside [kbeg, kend) and beyond nrows.  VECLOAD: 16-byte
+// loads (needs K, K2, kbeg multiples of VEC and 16-byte aligned bases), else scalar.
+template <typename T, int ROWS, bool VECLOAD>
+struct TileLoader {
+  using vec_t = typename Mfma<T>::vec_t;
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int VPR = BK / VEC;                 // vectors per row
+  static constexpr int RPP = kBlock / VPR;             // rows per pass
+  static constexpr int NP = (ROWS + RPP - 1) / RPP;    // passes
+  static constexpr int SRPP = kBlock / BK;             // scalar path: rows per pass
+  static constexpr int SNP = (ROWS + SRPP - 1) / SRPP;
+  T reg[VECLOAD ? NP * VEC : SNP];
+
+  __device__ __forceinline__ void fetch(const T* __restrict__ p, const T* __restrict__ p2,
+                                        long row0, long nrows, long k0, long K, long K2,
+                                        long kend) {
+    const int tid = threadIdx.x;
+    if (VECLOAD) {
+      const int kv = (tid % VPR) * VEC, r = tid / VPR;
+      const long kk = k0 + kv;
+      const T* base = p;
+      long ld = K, kc = kk;
+      if (kk >= K) { base = p2; ld = K2; kc = kk - K; }
+      const bool kin = kk < kend;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const long row = row0 + r + (long)i * RPP;
+        vec_t v;
+        if (kin && row < nrows && (r + i * RPP) < ROWS) {
+          v = *reinterpret_cast<const vec_t*>(base + row * ld + kc);
+        } else {
+          v = vec_t{};
+        }
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) reg[i * VEC + j] = e[j];
+      }
+    } else {
+      const int kq = tid % BK, r = tid / BK;
+      const long kk = k0 + kq;
+#pragma unroll
+      for (int i = 0; i < SNP; ++i) {
+        const long row = row0 + r + (long)i * SRPP;
+        T v = (T)0;
+        if (kk < kend && row < nrows && (r + i * SRPP) < ROWS) {
+          if (kk < K) v = p[row * K + kk];
+          else if (kk - K < K2) v = p2[row * K2 + (kk - K)];
+        }
+        reg[i] = v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(T (*lds)[LDP]) const {
+    const int tid = threadIdx.x;
+    if (VECLOAD) {
+      const int kv = (tid % VPR) * VEC, r = tid / VPR;
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (r + i * RPP < ROWS) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) lds[r + i * RPP][kv + j] = reg[i * VEC + j];
+        }
+    } else {
+      const int kq = tid % BK, r = tid / BK;
+#pragma unroll
+      for (int i = 0; i < SNP; ++i)
+        if (r + i * SRPP < ROWS) lds[r + i * SRPP][kq] = reg[i];
+    }
+  }
+};
+
+// Same tile from a TRANSPOSED source: element (row r, column k) lives at p[k * ld + r] (the
+// operand is stored [K][rows], rows contiguous) -- the backward GEMMs dW = dY^T X and
+// dX = dY W read their operands this way, so no transposed copy is ever written to HBM.
+// 16-byte loads run along the rows (needs ld % VEC == 0 and an aligned base), the LDS image is
+// the same [ROWS][BK] as TileLoader's.
+template <typename T, int ROWS>
+struct TileLoaderT {
+  using vec_t = typename Mfma<T>::vec_t;
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int RV = ROWS / VEC;                // row vectors per k
+  static constexpr int KPP = kBlock / RV;              // k per pass
+  static constexpr int NP = BK / KPP;
+  T reg[NP * VEC];
+
+  __device__ __forceinline__ void fetch(const T* __restrict__ p, long row0, long nrows, long k0,
+                                        long ld, long kend) {
+    const int rv = threadIdx.x % RV, kk = threadIdx.x / RV;
+    const long row = row0 + (long)rv * VEC;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const long k = k0 + kk + i * KPP;
+      if (k < kend && row + VEC <= nrows) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(p + k * ld + row);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) reg[i * VEC + j] = e[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          reg[i * VEC + j] = (k < kend && row + j < nrows) ? p[k * ld + row + j] : (T)0;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(T (*lds)[LDP]) const {
+    const int rv = threadIdx.x % RV, kk = threadIdx.x / RV;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) lds[rv * VEC + j][kk + i * KPP] = reg[i * VEC + j];
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Generic layer: grid x = N tiles, y = M tiles, z = K splits.  FUSED: splits == 1 and the
+// epilogue is applied here; otherwise raw partial sums go to part[z][M][N].
+// TA / TW: the A / W operand is stored transposed ([K][M] resp. [K][N]; needs K2 == 0).
+template <typename T, bool FUSED, bool VECLOAD, bool TA = false, bool TW = false>
+__global__ __launch_bounds__(kBlock, 2) void gemm_nt_kernel(
+    const T* __restrict__ A, const T* __restrict__ W, const T* __restrict__ A2,
+    const T* __restrict__ W2, int M, int N, long K, long K2, long kchunk, Epilogue<T> epi,
+    T* __restrict__ C, T* __restrict__ part) {
+  constexpr int BM = 128, BN = 128;
+  using acc_t = typename Mfma<T>::acc_t;
+  __shared__ T As[BM][LDP];
+  __shared__ T Ws[BN][LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+  const long Kt = K + K2;
+  const long kbeg = (long)blockIdx.z * kchunk;
+  long kend = kbeg + kchunk;
+  if (kend > Kt) kend = Kt;
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
+
+  typename std::conditional<TA, TileLoaderT<T, BM>, TileLoader<T, BM, VECLOAD>>::type la;
+  typename std::conditional<TW, TileLoaderT<T, BN>, TileLoader<T, BN, VECLOAD>>::type lw;
+#define L2Q_FETCH_AW(K0)                                                   \
+  do {                                                                     \
+    if constexpr (TA) la.fetch(A, m0, M, (K0), (long)M, kend);            \
+    else la.fetch(A, A2, m0, M, (K0), K, K2, kend);                        \
+    if constexpr (TW) lw.fetch(W, n0, N, (K0), (long)N, kend);            \
+    else lw.fetch(W, W2, n0, N, (K0), K, K2, kend);                        \
+  } while (0)
+  L2Q_FETCH_AW(kbeg);
+  for (long k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();                                 // previous slab fully consumed
+    la.store(As);
+    lw.store(Ws);
+    __syncthreads();
+    if (k0 + BK < kend) {                            // overlap the next slab's latency
+      L2Q_FETCH_AW(k0 + BK);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      T fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = As[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
+        fb[i] = Ws[wn + 16 * i + (lane & 15)][ks + (lane >> 4)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  T* dst = FUSED ? C : part + (long)blockIdx.z * M * N;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long n = n0 + wn + 16 * j + (lane & 15);
+    if (n >= N) continue;
+    T cs = (T)1, cb = (T)0;
+    if (FUSED) { cs = epi.colscale((int)n); cb = epi.colbias((int)n); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+        if (m < M) {
+          const T v = acc[i][j][r];
+          if (FUSED) {
+            const T y = cs * apply_act<T>(v + cb, epi.act);
+            dst[m * N + n] = epi.accumulate ? dst[m * N + n] + y : y;
+          } else {
+            dst[m * N + n] = v;
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Periodic conv layer as an implicit GEMM: the im2col matrix is never materialised.  Row m of
+// the virtual A operand is output pixel (b, ho, wo), column kk = (ci*k + i)*k + j reads
+// in[b, ci, (ho+i-(k-1)) mod H, (wo+j-(k-1)) mod W] through generic element strides (NCHW for
+// the first layer, the previous layer's NHWC output afterwards).  The (b, ho, wo) decomposition
+// of the tile's 128 rows is done once per workgroup (LDS), the (ci, i, j) decomposition of a
+// thread's K column once per slab and divides by the compile-time kernel size only.
+// Materialised, the five col matrices of the default U(1) conv stack are 2.1 GB per call at
+// cfg-2 (written, then read again by the GEMM).
+struct ConvGeom {
+  long sn, sc, sh, sw;
+  int C, H, W, k, Ho, Wo, Kc;
+  int clast;            // column order of the virtual A / the weight rows: 0: (ci, i, j), 1: (i, j, ci)
+  long M;
+};
+
+// BN = 32 / 64 / 128 output-channel tile: the conv layers have 8..128 channels, a fixed 128-wide
+// tile would spend most MFMAs on padding.
+// VEC4: NHWC input, (i, j, ci) K order, C % 4 == 0: a thread gathers four consecutive input
+// channels of one tap with one 16-byte load (4x fewer gather instructions than element-wise).
+template <int KS, int BN, bool VEC4>
+__global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __restrict__ in,
+                                                              ConvGeom g,
+                                                              const float* __restrict__ Wt, int N,
+                                                              Epilogue<float> epi,
+                                                              float* __restrict__ C) {
+  using T = float;
+  constexpr int BM = 128;
+  constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;       // wavefront grid over the tile
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  using acc_t = Mfma<T>::acc_t;
+  __shared__ T As[BM][LDP];
+  __shared__ T Ws[BN][LDP];
+  __shared__ long rbase[BM];
+  __shared__ int rr0[BM], rc0[BM];
+  const int k = KS > 0 ? KS : g.k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
+  const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+  for (int r = tid; r < BM; r += kBlock) {
+    const long m = m0 + r;
+    long base = -1;
+    int r0 = 0, c0 = 0;
+    if (m < g.M) {
+      const int wo = (int)(m % g.Wo);
+      const long t = m / g.Wo;
+      const int ho = (int)(t % g.Ho);
+      base = (t / g.Ho) * g.sn;
+      r0 = (ho - (k - 1)) % g.H; if (r0 < 0) r0 += g.H;
+      c0 = (wo - (k - 1)) % g.W; if (c0 < 0) c0 += g.W;
+    }
+    rbase[r] = base; rr0[r] = r0; rc0[r] = c0;
+  }
+  __syncthreads();
+
+  acc_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
+
+  constexpr int AV = VEC4 ? 4 : 1;
+  constexpr int SRPP = kBlock / (BK / AV), SNP = BM / SRPP;       // rows per pass, passes
+  const int kq = (tid % (BK / AV)) * AV, rq = tid / (BK / AV);
+  T areg[SNP][AV];
+// gather this thread's K column(s) (kk = K0 + kq ..) for its SNP rows of the tile
+#define L2Q_CONV_FETCH_A(K0)                                                            \
+  do {                                                                                  \
+    const long kk_ = (K0) + kq;                                                         \
+    const bool kin_ = kk_ < g.Kc;                                                       \
+    int j_, i_, ci_;                                                                    \
+    if (g.clast) { ci_ = (int)(kk_ % g.C); const int ij_ = (int)(kk_ / g.C); j_ = ij_ % k; i_ = ij_ / k; } \
+    else { j_ = (int)(kk_ % k); const int ij_ = (int)(kk_ / k); i_ = ij_ % k; ci_ = ij_ / k; }   \
+    const long coff_ = (long)ci_ * g.sc;                                                \
+    _Pragma("unroll") for (int p = 0; p < SNP; ++p) {                                   \
+      const int row_ = rq + p * SRPP;                                                   \
+      const long base_ = rbase[row_];                                                   \
+      _Pragma("unroll") for (int e = 0; e < AV; ++e) areg[p][e] = (T)0;                 \
+      if (kin_ && base_ >= 0) {                                                         \
+        int r_ = rr0[row_] + i_; if (r_ >= g.H) r_ -= g.H; if (r_ >= g.H) r_ %= g.H;    \
+        int c_ = rc0[row_] + j_; if (c_ >= g.W) c_ -= g.W; if (c_ >= g.W) c_ %= g.W;    \
+        const T* src_ = in + base_ + coff_ + r_ * g.sh + c_ * g.sw;                     \
+        if (VEC4) {                                                                     \
+          const float4 v_ = *reinterpret_cast<const float4*>(src_);                     \
+          areg[p][0] = v_.x; areg[p][AV > 1 ? 1 : 0] = v_.y;                            \
+          areg[p][AV > 2 ? 2 : 0] = v_.z; areg[p][AV > 3 ? 3 : 0] = v_.w;               \
+        } else {                                                                        \
+          areg[p][0] = src_[0];                                                         \
+        }                                                                               \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
+  TileLoader<T, BN, false> lw;
+  L2Q_CONV_FETCH_A(0);
+  lw.fetch(Wt, Wt, n0, N, 0, g.Kc, 0, g.Kc);      // (p2 unused: K2 = 0; a literal nullptr crashes hipcc 7.2 at -O2+)
+  for (long k0 = 0; k0 < g.Kc; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < SNP; ++p)
+#pragma unroll
+      for (int e = 0; e < AV; ++e) As[rq + p * SRPP][kq + e] = areg[p][e];
+    lw.store(Ws);
+    __syncthreads();
+    if (k0 + BK < g.Kc) {
+      L2Q_CONV_FETCH_A(k0 + BK);
+      lw.fetch(Wt, Wt, n0, N, k0 + BK, g.Kc, 0, g.Kc);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      T fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = As[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = Ws[wn + 16 * j + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const long n = n0 + wn + 16 * j + (lane & 15);
+    if (n >= N) continue;
+    const T cs = epi.colscale((int)n), cb = epi.colbias((int)n);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+        if (m < g.M) C[m * N + n] = cs * apply_act<T>(acc[i][j][r] + cb, epi.act);
+      }
+  }
+#undef L2Q_CONV_FETCH_A
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const T* __restrict__ part,
+                                                               int splits, long MN, int N,
+                                                               Epilogue<T> epi, T* __restrict__ C) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= MN) return;
+  T s = (T)0;
+  for (int z = 0; z < splits; ++z) s += part[(long)z * MN + i];     // fixed order
+  const int n = (int)(i % N);
+  const T y = epi.colscale(n) * apply_act<T>(s + epi.colbias(n), epi.act);
+  C[i] = epi.accumulate ? C[i] + y : y;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused output heads + generalised momentum update (dynamics.py:1266-1297 with
+// network.py:547-551):  for every chain m and entry n
+//     s = cs[n] tanh(z.Ws[n] + bs[n]),  t = ct (z.Wt[n] + bt[n]),  q = cq[n] tanh(z.Wq[n] + bq[n])
+//     forward : v' = exp(eps s/2) v - eps/2 (F exp(eps q) + t)
+//     backward: v' = exp(-eps s/2) (v + eps/2 (F exp(eps q) + t))
+//     logdet_part[m][.] = +- sum_n eps s / 2
+// Tile 64 (chains) x 64 (entries), each wavefront 32 x 32 = 2x2 MFMA tiles for each of the
+// three heads (48 fp64 accumulators / lane, no spills at 2 waves/SIMD).  The three W tiles share the staged Z tile.
+// CPLX: v, F are complex (SU(3)); the real heads act on both parts, t on the real part.
+constexpr int kHeadsBN = 64;
+
+struct HeadsArgs {
+  const double* Z;        // [M][K]
+  const double* W[3];     // s, t, q weights [N][K]
+  const double* b[3];     // biases [N]
+  const double* cs;       // per-column scale of s: nw.s * exp(coeff_s[n])   (may be null -> ss)
+  const double* cq;       // per-column scale of q
+  double ss, st, sq;      // scalar scales (used where the vector is null; st always)
+  double eps;
+  double eps2;            // second update of a pair (PAIR kernels)
+  int fwd2, flip;         // its direction; v -> -v between the two updates
+  double* v;              // [M][N] (x2 if complex), updated in place
+  const double* F;        // [M][N] (x2 if complex)
+  double* logdet_part;    // [M][ncols_part]
+  int M, N, K, ncols_part;
+};
+
+// PAIR: the closing v-update of one leapfrog step and the opening v-update of the next act on
+// the same x, hence the same (s, t, q): both are applied here from one evaluation of the heads
+// (optionally with the momentum flip of the merged trajectory in between).
+template <bool CPLX, bool FWD, bool PAIR>
+__global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_kernel(HeadsArgs a, int swz, int stagger) {
+  constexpr int BM = 64, BN = kHeadsBN, NJ = BN / 32;
+  using T = double;
+  using acc_t = v4f64;
+  __shared__ T Zs[BM][LDP];
+  __shared__ T Ws[3][BN][LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * (BN / 2);
+  // logical block order: m fastest, so the M/64 blocks that share a W tile are adjacent and
+  // (after the XCD swizzle) on the same XCD's L2
+  const long mt = (a.M + BM - 1) / BM;
+  // The two workgroups co-resident on a CU start together and would otherwise run their
+  // MFMA-free epilogues at the same time; delaying the second resident set once keeps one
+  // block's epilogue under the other's MFMA main loop for the rest of the launch.
+  if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const long m0 = (w % mt) * BM, n0 = (w / mt) * BN;
+
+  acc_t acc[3][2][NJ];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[h][i][j] = (acc_t){0, 0, 0, 0};
+
+  TileLoader<T, BM, true> lz;
+  TileLoader<T, BN, true> lw0, lw1, lw2;
+  const long K = a.K;
+  lz.fetch(a.Z, nullptr, m0, a.M, 0, K, 0, K);
+  lw0.fetch(a.W[0], nullptr, n0, a.N, 0, K, 0, K);
+  lw1.fetch(a.W[1], nullptr, n0, a.N, 0, K, 0, K);
+  lw2.fetch(a.W[2], nullptr, n0, a.N, 0, K, 0, K);
+  for (long k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    lz.store(Zs);
+    lw0.store(Ws[0]);
+    lw1.store(Ws[1]);
+    lw2.store(Ws[2]);
+    __syncthreads();
+    if (k0 + BK < K) {
+      lz.fetch(a.Z, nullptr, m0, a.M, k0 + BK, K, 0, K);
+      lw0.fetch(a.W[0], nullptr, n0, a.N, k0 + BK, K, 0, K);
+      lw1.fetch(a.W[1], nullptr, n0, a.N, k0 + BK, K, 0, K);
+      lw2.fetch(a.W[2], nullptr, n0, a.N, k0 + BK, K, 0, K);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      T fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = Zs[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+      for (int h = 0; h < 3; ++h) {
+        T fb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = Ws[h][wn + 16 * j + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[h][i][j] = Mfma<T>::run(fa[i], fb[j], acc[h][i][j]);
+      }
+    }
+  }
+
+  // ---- epilogue: heads -> momentum update in registers
+  const double eps = a.eps, heps = 0.5 * a.eps;
+  double ld[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ld[i][r] = 0.0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long n = n0 + wn + 16 * j + (lane & 15);
+    if (n >= a.N) continue;
+    const double bs = a.b[0][n], bt = a.b[1][n], bq = a.b[2][n];
+    const double cs = a.cs ? a.cs[n] : a.ss;
+    const double cq = a.cq ? a.cq[n] : a.sq;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+        if (m >= a.M) continue;
+        const double s = cs * fast_tanh(acc[0][i][j][r] + bs);
+        const double t = a.st * (acc[1][i][j][r] + bt);
+        const double q = cq * fast_tanh(acc[2][i][j][r] + bq);
+        const double lj = FWD ? heps * s : -heps * s;
+        ld[i][r] += lj;
+        const double es = exp_small(lj), eq = exp_small(eps * q);
+        const long o = m * (long)a.N + n;
+        double vr, vi = 0.0, fr0, fi0 = 0.0;
+        if (CPLX) {
+          const double2 vv = reinterpret_cast<const double2*>(a.v)[o];
+          const double2 ff = reinterpret_cast<const double2*>(a.F)[o];
+          vr = vv.x; vi = vv.y; fr0 = ff.x; fi0 = ff.y;
+        } else {
+          vr = a.v[o]; fr0 = a.F[o];
+        }
+        {
+          const double fr = fr0 * eq + t, fi = fi0 * eq;
+          if (FWD) { vr = es * vr - heps * fr; vi = es * vi - heps * fi; }
+          else { vr = es * (vr + heps * fr); vi = es * (vi + heps * fi); }
+        }
+        if (PAIR) {
+          if (a.flip) { vr = -vr; vi = -vi; }
+          const double h2 = 0.5 * a.eps2;
+          const double lj2 = a.fwd2 ? h2 * s : -h2 * s;
+          ld[i][r] += lj2;
+          const double es2 = exp_small(lj2), eq2 = exp_small(a.eps2 * q);
+          const double fr = fr0 * eq2 + t, fi = fi0 * eq2;
+          if (a.fwd2) { vr = es2 * vr - h2 * fr; vi = es2 * vi - h2 * fi; }
+          else { vr = es2 * (vr + h2 * fr); vi = es2 * (vi + h2 * fi); }
+        }
+        if (CPLX) reinterpret_cast<double2*>(a.v)[o] = make_double2(vr, vi);
+        else a.v[o] = vr;
+      }
+  }
+  // row partial of logdet over this wave's columns: butterfly over the 16 column lanes
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double x = ld[i][r];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+      if ((lane & 15) == 0 && m < a.M) {
+        const long col = (n0 / BN) * 2 + (wave & 1);
+        a.logdet_part[m * a.ncols_part + col] = x;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same fused heads + momentum update with the workgroup split into PRODUCER and CONSUMER
+// wavefronts (round 2).  In the kernel above a workgroup is MFMA-bound for ~3/4 of its life and
+// VALU / memory-bound for the rest (16 entries per lane: two 16-byte loads, four to six fp64
+// transcendentals, one store); two such workgroups per CU start together and drift back into
+// phase, so the matrix pipe idles while both run their epilogues (39.8 TFLOP/s where the K-loop
+// alone sustains ~60).  Here a 768-thread workgroup owns a CU for the whole launch and walks a
+// list of 64 x 64 tiles:
+//   wavefronts 0-7 (producers, two per SIMD so that one's LDS / barrier stalls are covered by the
+//     other's MFMAs): the K-loop of tile i (operands staged through LDS, a 32 x 16 wavefront tile
+//     per head = 24 fp64 accumulators per lane), then the three pre-activation tiles go to an LDS
+//     exchange buffer (3 x 64 x 66 doubles);
+//   wavefronts 8-11 (consumers): the update of tile i-1 from that buffer -- one row of 64 entries
+//     per wavefront and step, i.e. 1 KiB coalesced loads / stores of v and F, prefetched two steps
+//     ahead -- while the producers' MFMAs of tile i run.
+// s_barrier is workgroup-wide on gfx950, so the two roles run in LOCKSTEP: every K-slab has the
+// producers' two barriers, and the consumers process one row between them (16 slabs = the 16
+// rows a consumer wavefront owns).  The consumers always arrive early; the producers never wait
+// for anything but each other.
+constexpr int kXLD = 66;                        // row stride of the exchange tiles (doubles)
+constexpr int kHeadsWsLds = (64 + 3 * kHeadsBN) * LDP * 8 + 3 * 64 * kXLD * 8;
+
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt: a
+// consumer would then sit at every step until its global STORE of the previous row is
+// acknowledged (~1-2 us) and the producers, in lockstep, with it.  Nothing here communicates
+// through global memory inside a launch, so LDS ordering is all the barrier has to provide.
+__device__ __forceinline__ void ws_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool CPLX, bool FWD, bool PAIR>
+__global__ __launch_bounds__(768, 1) void fused_heads_ws_kernel(HeadsArgs a, int swz) {
+  constexpr int BM = 64, BN = kHeadsBN;
+  static_assert(BN == 64, "consumer mapping assumes 64-column tiles");
+  using T = double;
+  using acc_t = v4f64;
+  extern __shared__ __attribute__((aligned(16))) char hw_lds[];
+  T (*Zs)[LDP] = reinterpret_cast<T (*)[LDP]>(hw_lds);
+  T (*Ws0)[LDP] = reinterpret_cast<T (*)[LDP]>(hw_lds + 64 * LDP * 8);
+  T (*Ws1)[LDP] = Ws0 + BN;
+  T (*Ws2)[LDP] = Ws1 + BN;
+  T* X = reinterpret_cast<T*>(hw_lds + (64 + 3 * BN) * LDP * 8);          // [3][64][kXLD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < 8;                     // 8 producer wavefronts (two per SIMD), 4 consumers
+  const long mt = (a.M + BM - 1) / BM;
+  const long ntiles = mt * ((a.N + BN - 1) / BN);
+  const long G = gridDim.x;
+  const long rounds = (ntiles + G - 1) / G;
+  const long bl = xcd_swizzle(blockIdx.x, G, swz);      // neighbouring tiles (same W tile) share an XCD
+  const long K = a.K;
+  const int nslab = (int)((K + BK - 1) / BK);         // <= 16 (the launcher checks)
+  const double eps = a.eps, heps = 0.5 * a.eps;
+
+  if (producer) {
+    // wavefront tile 32 x 16 per head: 6 accumulator tiles; staging: one 16-byte vector of Z and of
+    // each W head per thread and K-slab (64 rows x 8 vectors = 512 producer threads)
+    const int wm = (wave >> 2) * 32, wn = (wave & 3) * 16;
+    const int lrow = tid >> 3, lkv = (tid & 7) * 2;    // staging coordinates (tid < 512)
+    static_assert(BK == 16, "staging map assumes 16-wide K slabs");
+    for (long r = 0; r < rounds; ++r) {
+      const long w = r * G + bl;
+      const bool have = w < ntiles;
+      const long m0 = (w % mt) * BM, n0 = (w / mt) * BN;
+      acc_t acc[3][2];
+#pragma unroll
+      for (int h = 0; h < 3; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[h][i] = (acc_t){0, 0, 0, 0};
+      double2 rz, rw0, rw1, rw2;
+      auto fetch = [&](long k0) {
+        const double2 zero = make_double2(0.0, 0.0);
+        const long kk = k0 + lkv;
+        const bool kin = kk < K;
+        const long zr = m0 + lrow, wr = n0 + lrow;
+        rz = (kin && zr < a.M) ? *reinterpret_cast<const double2*>(a.Z + zr * K + kk) : zero;
+        const bool win = kin && wr < a.N;
+        rw0 = win ? *reinterpret_cast<const double2*>(a.W[0] + wr * K + kk) : zero;
+        rw1 = win ? *reinterpret_cast<const double2*>(a.W[1] + wr * K + kk) : zero;
+        rw2 = win ? *reinterpret_cast<const double2*>(a.W[2] + wr * K + kk) : zero;
+      };
+      if (have) fetch(0);
+      for (int sl = 0; sl < 16; ++sl) {
+        const bool live = have && sl < nslab;
+        ws_barrier();
+        if (live) {
+          Zs[lrow][lkv] = rz.x; Zs[lrow][lkv + 1] = rz.y;
+          Ws0[lrow][lkv] = rw0.x; Ws0[lrow][lkv + 1] = rw0.y;
+          Ws1[lrow][lkv] = rw1.x; Ws1[lrow][lkv + 1] = rw1.y;
+          Ws2[lrow][lkv] = rw2.x; Ws2[lrow][lkv + 1] = rw2.y;
+        }
+        ws_barrier();
+        if (live) {
+          if (sl + 1 < nslab) fetch((long)(sl + 1) * BK);
+#pragma unroll
+          for (int ks = 0; ks < BK; ks += 4) {
+            T fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = Zs[wm + 16 * i + (lane & 15)][ks + (lane >> 4)];
+            const T fb0 = Ws0[wn + (lane & 15)][ks + (lane >> 4)];
+            const T fb1 = Ws1[wn + (lane & 15)][ks + (lane >> 4)];
+            const T fb2 = Ws2[wn + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[0][i] = Mfma<T>::run(fa[i], fb0, acc[0][i]);
+              acc[1][i] = Mfma<T>::run(fa[i], fb1, acc[1][i]);
+              acc[2][i] = Mfma<T>::run(fa[i], fb2, acc[2][i]);
+            }
+          }
+        }
+      }
+      ws_barrier();                                // consumers are done with the previous tile
+      if (have) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              X[(h * 64 + wm + 16 * i + Mfma<T>::row(lane, rr)) * kXLD + wn + (lane & 15)] = acc[h][i][rr];
+      }
+      ws_barrier();                                // this tile's pre-activations are published
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumers
+  const int cw = wave - 8;                            // rows cw * 16 + i of the tile, column = lane
+  auto process_tile = [&](long w, bool lockstep) {
+    const bool have = w >= 0 && w < ntiles;
+    const long m0 = have ? (w % mt) * BM : 0, n0 = have ? (w / mt) * BN : 0;
+    const long n = n0 + lane;
+    const bool ncol = have && n < a.N;
+    double bs = 0, bt = 0, bq = 0, cs = 0, cq = 0;
+    if (ncol) {
+      bs = a.b[0][n]; bt = a.b[1][n]; bq = a.b[2][n];
+      cs = a.cs ? a.cs[n] : a.ss;
+      cq = a.cq ? a.cq[n] : a.sq;
+    }
+    double2 vbuf[3], fbuf[3];
+    auto issue = [&](int i) {
+      const long m = m0 + cw * 16 + i;
+      const int sl = i % 3;
+      vbuf[sl] = make_double2(0.0, 0.0);
+      fbuf[sl] = make_double2(0.0, 0.0);
+      if (ncol && i < 16 && m < a.M) {
+        const long o = m * (long)a.N + n;
+        if (CPLX) {
+          vbuf[sl] = reinterpret_cast<const double2*>(a.v)[o];
+          fbuf[sl] = reinterpret_cast<const double2*>(a.F)[o];
+        } else {
+          vbuf[sl].x = a.v[o];
+          fbuf[sl].x = a.F[o];
+        }
+      }
+    };
+    issue(0);
+    issue(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (lockstep) ws_barrier();
+      issue(i + 2);
+      const long m = m0 + cw * 16 + i;
+      const bool on = ncol && m < a.M;
+      double lj_tot = 0.0;
+      if (on) {
+        const int xr = (cw * 16 + i) * kXLD + lane;
+        const double s = cs * fast_tanh(X[xr] + bs);
+        const double t = a.st * (X[64 * kXLD + xr] + bt);
+        const double q = cq * fast_tanh(X[2 * 64 * kXLD + xr] + bq);
+        const double lj = FWD ? heps * s : -heps * s;
+        lj_tot = lj;
+        const double es = exp_small(lj), eq = exp_small(eps * q);
+        double vr = vbuf[i % 3].x, vi = vbuf[i % 3].y;
+        const double fr0 = fbuf[i % 3].x, fi0 = fbuf[i % 3].y;
+        {
+          const double fr = fr0 * eq + t, fi = fi0 * eq;
+          if (FWD) { vr = es * vr - heps * fr; vi = es * vi - heps * fi; }
+          else { vr = es * (vr + heps * fr); vi = es * (vi + heps * fi); }
+        }
+        if (PAIR) {
+          if (a.flip) { vr = -vr; vi = -vi; }
+          const double h2 = 0.5 * a.eps2;
+          const double lj2 = a.fwd2 ? h2 * s : -h2 * s;
+          lj_tot += lj2;
+          const double es2 = exp_small(lj2), eq2 = exp_small(a.eps2 * q);
+          const double fr = fr0 * eq2 + t, fi = fi0 * eq2;
+          if (a.fwd2) { vr = es2 * vr - h2 * fr; vi = es2 * vi - h2 * fi; }
+          else { vr = es2 * (vr + h2 * fr); vi = es2 * (vi + h2 * fi); }
+        }
+        const long o = m * (long)a.N + n;
+        if (CPLX) reinterpret_cast<double2*>(a.v)[o] = make_double2(vr, vi);
+        else a.v[o] = vr;
+      }
+      // logdet partial of this row over the tile's 64 columns: fixed butterfly
+      double x = lj_tot;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (lane == 0 && have && m < a.M) a.logdet_part[m * a.ncols_part + n0 / BN] = x;
+      if (lockstep) ws_barrier();
+    }
+  };
+  for (long r = 0; r < rounds; ++r) {
+    process_tile(r == 0 ? -1 : (r - 1) * G + bl, true);   // tile of the previous round
+    ws_barrier();
+    ws_barrier();
+  }
+  process_tile((rounds - 1) * G + bl, false);              // drain: the last tile, no partner left
+}
+
+static int pick_splits(int M, int N, long Kt) {
+  const long tiles = cdiv(M, 128) * cdiv(N, 128);
+  if (tiles >= 256 || Kt <= 8 * BK) return 1;
+  long s = cdiv(512, tiles);
+  const long maxs = Kt / (4 * BK) > 0 ? Kt / (4 * BK) : 1;
+  if (s > maxs) s = maxs;
+  if (s > 128) s = 128;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <typename T>
+static bool vec_ok(const T* A, const T* W, const T* A2, const T* W2, long K, long K2) {
+  constexpr long V = Mfma<T>::VEC;
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return K % V == 0 && K2 % V == 0 && al(A) && al(W) && al(A2) && al(W2);
+}
+
+// ta / tw: operand stored transposed (see TileLoaderT); accumulate: C += result.
+template <typename T>
+static int gemm_launch(const T* A, const T* W, int M, int N, long K, const T* A2, const T* W2,
+                       long K2, const T* bias, const T* bias2, const T* coeff, T scale, int act,
+                       T* C, void* ws, size_t ws_bytes, hipStream_t st, int ta = 0, int tw = 0,
+                       int accumulate = 0) {
+  const long Kt = K + K2;
+  int splits = pick_splits(M, N, Kt);
+  long kchunk = cdiv(cdiv(Kt, splits), BK) * BK;
+  splits = (int)cdiv(Kt, kchunk);
+  Epilogue<T> epi{bias, bias2, coeff, scale, act, accumulate};
+  const dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)splits);
+  constexpr long V = Mfma<T>::VEC;
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // per-operand vector-load conditions: K-contiguous operands need K % VEC, transposed ones
+  // their leading dimension (M resp. N) % VEC
+  const bool veca = ta ? (M % V == 0 && al(A)) : (K % V == 0 && K2 % V == 0 && al(A) && al(A2));
+  const bool vecw = tw ? (N % V == 0 && al(W)) : (K % V == 0 && K2 % V == 0 && al(W) && al(W2));
+  if ((ta || tw) && (K2 != 0 || !veca || !vecw)) {
+    set_error("l2q_gemm: transposed operands need K2 == 0 and 16-byte aligned rows");
+    return L2Q_ESHAPE;
+  }
+  const bool vec = veca && vecw;
+  T* part = nullptr;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * M * N * sizeof(T);
+    if (!ws || ws_bytes < need) {
+      set_error("l2q_gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
+      return L2Q_ESHAPE;
+    }
+    part = (T*)ws;
+  }
+#define L2Q_GEMM(F, V, TA_, TW_)                                                               \
+  hipLaunchKernelGGL((gemm_nt_kernel<T, F, V, TA_, TW_>), grid, dim3(kBlock), 0, st, A, W, A2, \
+                     W2, M, N, K, K2, kchunk, epi, C, part)
+#define L2Q_GEMM_F(F)                                                        \
+  do {                                                                       \
+    if (ta && tw) L2Q_GEMM(F, true, true, true);                             \
+    else if (tw) L2Q_GEMM(F, true, false, true);                             \
+    else if (ta) L2Q_GEMM(F, true, true, false);                             \
+    else if (vec) L2Q_GEMM(F, true, false, false);                           \
+    else L2Q_GEMM(F, false, false, false);                                   \
+  } while (0)
+  if (splits == 1) L2Q_GEMM_F(true);
+  else L2Q_GEMM_F(false);
+#undef L2Q_GEMM_F
+#undef L2Q_GEMM
+  if (splits > 1) {
+    const long MN = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)cdiv(MN, kBlock)), dim3(kBlock), 0,
+                       st, (const T*)ws, splits, MN, N, epi, C);
+  }
+  return check_launch("l2q_gemm");
+}
+
+}  // namespace l2q
+
+using namespace l2q;
+
+extern "C" {
+
+size_t l2q_gemm_ws_bytes(int M, int N, long K, long K2) {
+  if (M <= 0 || N <= 0 || K + K2 <= 0) return 0;
+  const int splits = pick_splits(M, N, K + K2);
+  return splits == 1 ? 0 : (size_t)(splits + 1) * M * N * sizeof(double);
+}
+
+int l2q_gemm_f64(const double* A, const double* W, int M, int N, long K, const double* A2,
+                 const double* W2, long K2, const double* bias, const double* bias2,
+                 const double* coeff, double scale, int act, double* C, void* ws, size_t ws_bytes,
+                 void* stream) {
+  L2Q_REQUIRE(A && W && C, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(M > 0 && N > 0 && K > 0 && K2 >= 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(K2 == 0 || (A2 && W2), L2Q_EINVAL, "second operand pair missing");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  return gemm_launch<double>(A, W, M, N, K, A2, W2, K2, bias, bias2, coeff, scale, act, C, ws,
+                             ws_bytes, (hipStream_t)stream);
+}
+
+int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const float* A2,
+                 const float* W2, long K2, const float* bias, const float* bias2,
+                 const float* coeff, float scale, int act, float* C, void* ws, size_t ws_bytes,
+                 void* stream) {
+  L2Q_REQUIRE(A && W && C, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(M > 0 && N > 0 && K > 0 && K2 >= 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(K2 == 0 || (A2 && W2), L2Q_EINVAL, "second operand pair missing");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  return gemm_launch<float>(A, W, M, N, K, A2, W2, K2, bias, bias2, coeff, scale, act, C, ws,
+                            ws_bytes, (hipStream_t)stream);
+}
+
+int l2q_gemm_ex(const void* A, int a_trans, const void* W, int w_trans, int M, int N, long K,
+                int elem_bytes, int accumulate, void* C, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(A && W && C, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(M > 0 && N > 0 && K > 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(elem_bytes == 4 || elem_bytes == 8, L2Q_EINVAL, "elem_bytes must be 4 or 8");
+  hipStream_t st = (hipStream_t)stream;
+  if (elem_bytes == 8)
+    return gemm_launch<double>((const double*)A, (const double*)W, M, N, K, nullptr, nullptr, 0,
+                               nullptr, nullptr, nullptr, 1.0, L2Q_ACT_NONE, (double*)C, ws, ws_bytes,
+                               st, a_trans, w_trans, accumulate);
+  return gemm_launch<float>((const float*)A, (const float*)W, M, N, K, nullptr, nullptr, 0, nullptr,
+                            nullptr, nullptr, 1.0f, L2Q_ACT_NONE, (float*)C, ws, ws_bytes, st,
+                            a_trans, w_trans, accumulate);
+}
+
+int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long sw, int nb, int C,
+                               int H, int W, int k, const float* weight, int channels_last_cols,
+                               const float* bias, int cout, int act, float* out, void* stream) {
+  L2Q_REQUIRE(in && weight && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0 && cout > 0, L2Q_EINVAL,
+              "non-positive size");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  ConvGeom g;
+  g.sn = sn; g.sc = sc; g.sh = sh; g.sw = sw; g.C = C; g.H = H; g.W = W; g.k = k;
+  g.Ho = H + k - 1; g.Wo = W + k - 1; g.Kc = C * k * k;
+  g.clast = channels_last_cols ? 1 : 0;
+  g.M = (long)nb * g.Ho * g.Wo;
+  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16, L2Q_ESHAPE, "too many output pixels");
+  Epilogue<float> epi{bias, nullptr, nullptr, 1.0f, act, 0};
+  const int bn = cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
+  const dim3 grid((unsigned)cdiv(cout, bn), (unsigned)cdiv(g.M, 128)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  // 16-byte channel gathers: NHWC input, (i, j, ci) order, C % 4 == 0, aligned
+  const bool vec4 = g.clast && sc == 1 && C % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sn % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+#define L2Q_CGB(KS, BNV)                                                                          \
+  do {                                                                                            \
+    if (vec4) hipLaunchKernelGGL((conv_gemm_kernel<KS, BNV, true>), grid, block, 0, st, in, g,    \
+                                 weight, cout, epi, out);                                         \
+    else hipLaunchKernelGGL((conv_gemm_kernel<KS, BNV, false>), grid, block, 0, st, in, g,        \
+                            weight, cout, epi, out);                                              \
+  } while (0)
+#define L2Q_CG(KS)                                                     \
+  do {                                                                 \
+    if (bn == 32) L2Q_CGB(KS, 32);                                     \
+    else if (bn == 64) L2Q_CGB(KS, 64);                                \
+    else L2Q_CGB(KS, 128);                                             \
+  } while (0)
+  switch (k) {
+    case 1: L2Q_CG(1); break;
+    case 2: L2Q_CG(2); break;
+    case 3: L2Q_CG(3); break;
+    case 4: L2Q_CG(4); break;
+    case 5: L2Q_CG(5); break;
+    default: L2Q_CG(0); break;
+  }
+#undef L2Q_CG
+#undef L2Q_CGB
+  return check_launch("l2q_conv_gemm_periodic_f32");
+}
+
+size_t l2q_vnet_heads_ws_bytes(int M, long N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)M * (size_t)(cdiv(N, kHeadsBN) * 2) * sizeof(double) + 256;
+}
+
+static int heads_launch(const double* Z, int M, int K, long N, const double* Ws, const double* bs,
+                        const double* cs, double scale_s, const double* Wt, const double* bt,
+                        double scale_t, const double* Wq, const double* bq, const double* cq,
+                        double scale_q, void* v, const void* force, int is_complex, double eps,
+                        int forward, int pair, double eps2, int forward2, int flip,
+                        double* logdet, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(Z && Ws && bs && Wt && bt && Wq && bq && v && force && logdet && ws, L2Q_EINVAL,
+              "null pointer");
+  L2Q_REQUIRE(M > 0 && K > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(K % 2 == 0, L2Q_ESHAPE, "K (last hidden width) must be even");
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  L2Q_REQUIRE(al(Z) && al(Ws) && al(Wt) && al(Wq) && al(v) && al(force), L2Q_ESHAPE,
+              "operands must be 16-byte aligned");
+  const long ntile = cdiv(N, kHeadsBN), mtile = cdiv(M, 64);
+  const int ncols = (int)(ntile * 2);
+  L2Q_REQUIRE(ws_bytes >= (size_t)M * ncols * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  HeadsArgs a;
+  a.Z = Z; a.W[0] = Ws; a.W[1] = Wt; a.W[2] = Wq; a.b[0] = bs; a.b[1] = bt; a.b[2] = bq;
+  a.cs = cs; a.cq = cq; a.ss = scale_s; a.st = scale_t; a.sq = scale_q; a.eps = eps;
+  a.eps2 = eps2; a.fwd2 = forward2; a.flip = flip;
+  a.v = (double*)v; a.F = (const double*)force; a.logdet_part = (double*)ws;
+  a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncols;
+  const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
+  const int swz = tuning().xcd_swizzle;
+  const int stg = tuning().heads_stagger;
+  // partial columns of wave tiles that fall entirely beyond N are never written: clear first
+  (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * sizeof(double), st);
+  if (tuning().heads_ws && K <= 16 * BK && ntile * mtile >= 512) {
+    // producer / consumer wavefronts, one persistent workgroup per CU
+    a.ncols_part = (int)ntile;                       // one logdet partial per row and tile
+    const unsigned G = 256;
+#define L2Q_HEADS_WS(C, F, P)                                                                   \
+  do {                                                                                          \
+    static bool attr = false;                                                                   \
+    if (!attr) {                                                                                \
+      (void)hipFuncSetAttribute((const void*)fused_heads_ws_kernel<C, F, P>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kHeadsWsLds);       \
+      attr = true;                                                                              \
+    }                                                                                           \
+    hipLaunchKernelGGL((fused_heads_ws_kernel<C, F, P>), dim3(G), dim3(768), kHeadsWsLds, st, a, swz); \
+  } while (0)
+    if (pair) {
+      if (is_complex) { if (forward) L2Q_HEADS_WS(true, true, true); else L2Q_HEADS_WS(true, false, true); }
+      else { if (forward) L2Q_HEADS_WS(false, true, true); else L2Q_HEADS_WS(false, false, true); }
+    } else {
+      if (is_complex) { if (forward) L2Q_HEADS_WS(true, true, false); else L2Q_HEADS_WS(true, false, false); }
+      else { if (forward) L2Q_HEADS_WS(false, true, false); else L2Q_HEADS_WS(false, false, false); }
+    }
+#undef L2Q_HEADS_WS
+    launch_finalize((const double*)ws, logdet, M, (int)ntile, 1, 1.0, 0.0, st);
+    return check_launch("l2q_vnet_heads_vupdate_f64");
+  }
+#define L2Q_HEADS(C, F, P) \
+  hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz, stg)
+  if (pair) {
+    if (is_complex) { if (forward) L2Q_HEADS(true, true, true); else L2Q_HEADS(true, false, true); }
+    else { if (forward) L2Q_HEADS(false, true, true); else L2Q_HEADS(false, false, true); }
+  } else {
+    if (is_complex) { if (forward) L2Q_HEADS(true, true, false); else L2Q_HEADS(true, false, false); }
+    else { if (forward) L2Q_HEADS(false, true, false); else L2Q_HEADS(false, false, false); }
+  }
+#undef L2Q_HEADS
+  launch_finalize((const double*)ws, logdet, M, ncols, 1, 1.0, 0.0, st);
+  return check_launch("l2q_vnet_heads_vupdate_f64");
+}
+
+int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const double* Ws,
+                               const double* bs, const double* cs, double scale_s,
+                               const double* Wt, const double* bt, double scale_t,
+                               const double* Wq, const double* bq, const double* cq,
+                               double scale_q, void* v, const void* force, int is_complex,
+                               double eps, int forward, double* logdet, void* ws, size_t ws_bytes,
+                               void* stream) {
+  return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v,
+                      force, is_complex, eps, forward, 0, 0.0, 0, 0, logdet, ws, ws_bytes, stream);
+}
+
+int l2q_vnet_heads_vupdate_pair_f64(const double* Z, int M, int K, long N, const double* Ws,
+                                    const double* bs, const double* cs, double scale_s,
+                                    const double* Wt, const double* bt, double scale_t,
+                                    const double* Wq, const double* bq, const double* cq,
+                                    double scale_q, void* v, const void* force, int is_complex,
+                                    double eps1, int forward1, int flip_between, double eps2,
+                                    int forward2, double* logdet, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v,
+                      force, is_complex, eps1, forward1, 1, eps2, forward2, flip_between, logdet,
+                      ws, ws_bytes, stream);
+}
+
+}  // extern "C"
