@@ -346,6 +346,33 @@ def allreduce_probe(tr, dist, world, reps=5):
     return out
 
 
+def collective_probe(dist, world, n_params, reps=5):
+    """Sampling needs no collective, so the default mode would never touch RCCL; the one exchange
+    of the path is the training-gradient all-reduce (trainers/pytorch/trainer.py:246-257,
+    1296-1304 of the reference = DDP's bucketed all-reduce).  This times exactly that exchange --
+    ONE all-reduce of a flat fp64 buffer of the gradient arena's size -- outside the timed region,
+    so the driver's N = 2, 4, 8 runs also put a number on RCCL over xGMI."""
+    buf = torch.ones(n_params, dtype=torch.float64, device='cuda')
+    for _ in range(2):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    nbytes = n_params * 8
+    return {'what': 'all-reduce(sum) of a flat fp64 buffer the size of the cfg gradient arena '
+                    '(vnet parameters), untimed region', 'bytes': nbytes, 'ranks': world,
+            'ms': round(dt * 1e3, 3), 'algbw_GBps': round(nbytes / dt / 1e9, 2),
+            'busbw_GBps': round(nbytes / dt / 1e9 * 2 * (world - 1) / world, 2)}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -428,6 +455,10 @@ def main():
     acc = m['acc']
     assert torch.isfinite(acc).all() and torch.isfinite(x).all(), 'non-finite trajectory'
     ar = allreduce_probe(tr, dist, world) if train else None
+    probe = None
+    if dist is not None and not train and args.mode == 'l2hmc':
+        nparam = sum(p.numel() for p in dyn.vnet.parameters())
+        probe = collective_probe(dist, world, nparam)
 
     if rank == 0:
         V = int(np.prod(args.lattice))
@@ -515,6 +546,8 @@ def main():
             'kernels': kernels,
             'accept_prob_mean': round(float(acc.mean()), 4),
         }
+        if probe is not None:
+            out['grad_allreduce_probe'] = probe
         if train:
             out['train'] = {'params_trained': tr.arena.numel(), 'grad_allreduce': ar,
                             'micro_batch': args.micro_batch, 'loss': m.get('loss'),
