@@ -15,8 +15,8 @@
 // of mu and the j-th other direction -- four full 3x3 products on six operand matrices, the
 // right-hand factors streamed row by row (peak: three matrices + one row live) -- so the LDS
 // traffic is the minimal 54 entries per 432 FMAs AND three wavefronts fit a SIMD.  The three
-// partial staple sums of a link meet in LDS: j = 1, 2 publish, j = 0 adds them, forms U*A, TAH
-// and stores the link.
+// partial staple sums of a link meet in LDS: j = 0, 1 publish, j = 2 adds them, forms U*A (U taken
+// from the tile before the barrier), TAH and stores the link.
 //
 // Workgroup = 64 spatial sites x 4 directions x 3 planes = 12 wavefronts, sweeping t; LDS holds
 // the spatial links of the current and next slice, the t-links of the current slice and the
@@ -94,7 +94,10 @@ __device__ __forceinline__ void force_nu_sweep(const NuCtx& c) {
   M3 carry;                                           // (MU spatial, NU = t): t-direction down staple
   if (MU != 0 && NU == 0) m3_zero(carry);
   const int niter = (c.t1 - c.t0) + 1;
-  const int xpub = kNuOffX + ((J == 0 ? 0 : J - 1) * 4 + MU) * kPlaneB + c.lt * 16;
+  // the finishing wavefront of a link is j = 2: never the one that carries the t-staple (j = 0 for
+  // spatial mu), so it has 36 registers to hold its link U across the barrier
+  constexpr int JF = 2;
+  const int xpub = kNuOffX + ((J < JF ? J : J - 1) * 4 + MU) * kPlaneB + c.lt * 16;
 #pragma unroll 1
   for (int it = 0; it < niter; ++it) {
     const int tcur = (c.t0 - 1 + it + T) % T;
@@ -180,13 +183,18 @@ __device__ __forceinline__ void force_nu_sweep(const NuCtx& c) {
         }
       }
     }
-    if (J != 0 && it > 0) {
+    if (J != JF && it > 0) {
 #pragma unroll
       for (int e = 0; e < 9; ++e)
         *reinterpret_cast<double2*>(fr_lds + xpub + e * kEnt) = make_double2(acc.re[e], acc.im[e]);
     }
+    // the finisher takes its own link out of LDS now (the slot is overwritten after the barrier):
+    // U * A below then needs no trip to L2, which made this wavefront the last one at the next
+    // barrier, every slice
+    M3 u;
+    if (J == JF && it > 0) ld_m(u, oc(MU, q_sp), rs, V16);
     __syncthreads();                                  // slice tcur consumed, partial sums published
-    if (J == 0 && it > 0) {
+    if (J == JF && it > 0) {
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -202,27 +210,12 @@ __device__ __forceinline__ void force_nu_sweep(const NuCtx& c) {
     }
     cur ^= 1;
     __syncthreads();                                  // next slice in place, exchange buffer free
-    if (J == 0 && it > 0) {
-      // W = U A (U back from L2, streamed by rows), F = (W - W^H)/2 - tr(W - W^H)/6
-      // (group/su3/pytorch/group.py:92-103), formed entry by entry at the store
+    if (J == JF && it > 0) {
+      // W = U A, F = (W - W^H)/2 - tr(W - W^H)/6 (group/su3/pytorch/group.py:92-103), formed
+      // entry by entry at the store
       M3 ua;
       const int so = MU * 9 * V16 + gcur;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        double ur[3], ui[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const double2 dd = buf_ld(rs, q_sp, so + (3 * i + k) * V16); ur[k] = dd.x; ui[k] = dd.y; }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          double sr = 0.0, si = 0.0;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            sr = fma(ur[k], acc.re[3 * k + j], sr); sr = fma(-ui[k], acc.im[3 * k + j], sr);
-            si = fma(ur[k], acc.im[3 * k + j], si); si = fma(ui[k], acc.re[3 * k + j], si);
-          }
-          ua.re[3 * i + j] = sr; ua.im[3 * i + j] = si;
-        }
-      }
+      m3_mul_nn(ua, u, acc);
       const double tri = (ua.im[0] + ua.im[4] + ua.im[8]) / 3.0;     // the trace term is imaginary
 #pragma unroll
       for (int i = 0; i < 3; ++i)
