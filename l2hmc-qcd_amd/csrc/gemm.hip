@@ -86,6 +86,36 @@ __device__ __forceinline__ double exp_small(double x) {
   }
   return exp(x);
 }
+// Branch-free exp for the LDS-DMA heads kernel: x = k ln2 + r, |r| <= ln2/2, degree-12 Taylor
+// polynomial (remainder 1.7e-16 relative), ldexp.  ~19 fp64 instructions and no divergent
+// fall-back path: on gfx950 the fp64 VALU instructions of a wavefront are paid in full by the
+// fp64 MFMA stream of the other wavefront on the SIMD (tools/microbench/mfma_valu_overlap.hip).
+__device__ __forceinline__ double exp_bf(double x) {
+  const double xc = fmin(fmax(x, -708.0), 709.0);
+  const double k = __builtin_rint(xc * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, xc);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 479001600.0;
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double y = __builtin_amdgcn_ldexp(p, (int)k);
+  return (x != x) ? x : y;
+}
+__device__ __forceinline__ double tanh_bf(double x) {
+  const double c = fmin(fmax(x, -20.0), 20.0);
+  const double t = 1.0 - 2.0 * rcp_nr(exp_bf(2.0 * c) + 1.0);
+  return (x != x) ? x : t;
+}
 __device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
 
 template <typename T>
@@ -638,6 +668,318 @@ __global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_ker
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same tile (64 chains x 64 entries x 3 heads, 2 x 2 wavefronts of 32 x 32) with the operand
+// staging rebuilt for gfx950:
+//  * Z and the three W tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
+//    VGPRs, no ds_write pass, two 32 KB stages, ONE barrier per K-slab;
+//  * tile rows are 128 bytes, XOR-swizzled in 16-byte chunks (chunk ^ (row & 7)): LDS-DMA writes
+//    lane-linear, so the swizzle is applied to each lane's SOURCE address and again to the
+//    fragment reads -- ds_read_b64 fragments hit every bank pair exactly four times (the minimum);
+//  * no address arithmetic in the loop (per-lane 32-bit offsets fixed up front, the K offset is
+//    scalar): the shipped loop's ~100 VALU instructions per slab (64-bit row * K products and
+//    bounds predicates per load) are gone.  That matters more than usual on this part: a
+//    wavefront's fp64 MFMAs and ANY VALU instruction of the other wavefront on the SIMD do not
+//    overlap (tools/microbench/mfma_valu_overlap.hip: fp64 / fp32 / int VALU time adds to the
+//    MFMA time), so every VALU instruction is paid in MFMA time;
+//  * epilogue operands (v, F) are requested in batches of four, one batch ahead, and the
+//    transcendental chain is branch-free (exp_bf / tanh_bf).
+// cfg-4 (M 256, K 256, N 147456): K-loop alone 0.85 ms = 68 TFLOP/s (0.99 ms before), whole kernel
+// 1.14-1.16 ms (1.32-1.47 ms before); tools/lab/heads_lab.hip holds the A/B harness.
+// Needs K % 16 == 0 (heads_launch falls back to fused_heads_vupdate_kernel otherwise).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool CPLX, bool FWD, bool PAIR>
+__global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a, int swz) {
+  constexpr int BM = 64, BN = 64, NJ = 2;
+  constexpr int ROWB = BK * 8;                    // 128 bytes per tile row per slab
+  constexpr int STAGE = (BM + 3 * BN) * ROWB;     // 32 KB
+  using acc_t = v4f64;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const long mt = (a.M + BM - 1) / BM;
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const long m0 = (w % mt) * BM, n0 = (w / mt) * BN;
+  const long K = a.K;
+
+  // ---- loader: instruction q of this wavefront fills tile rows (4q + wave) * 8 + (lane >> 3),
+  // 16-byte position lane & 7 of the row, with source chunk (lane & 7) ^ (row & 7)
+  const char* ubase[4];
+  ubase[0] = reinterpret_cast<const char*>(a.Z) + m0 * K * 8;
+#pragma unroll
+  for (int h = 0; h < 3; ++h) ubase[h + 1] = reinterpret_cast<const char*>(a.W[h]) + n0 * K * 8;
+  unsigned voff[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int R = (4 * q + wave) * 8 + (lane >> 3);       // tile row 0..255
+    const int r = R & 63;                                  // row within the operand
+    long lim = (q < 2 ? (long)a.M - m0 : (long)a.N - n0) - 1;
+    const int rc = r <= lim ? r : (int)lim;                // clamp: edge tiles re-read a valid row
+    const int c = (lane & 7) ^ (R & 7);
+    voff[q] = (unsigned)(rc * (int)K * 8 + c * 16);
+  }
+  auto issue = [&](int stage, long k0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const char* g = ubase[q >> 1] + k0 * 8 + (unsigned long)voff[q];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (lds_ptr_t)(lds + stage * STAGE + (4 * q + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes within a stage), one per k-quad
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    const unsigned sw = ((((kq * 2) + (lane >> 5)) ^ (lane & 7)) << 4) + ((lane >> 4) & 1) * 8;
+    offA[kq] = (wm + (lane & 15)) * ROWB + sw;
+    offB[kq] = (BM + wn + (lane & 15)) * ROWB + sw;
+  }
+
+  acc_t acc[3][2][NJ];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[h][i][j] = (acc_t){0, 0, 0, 0};
+
+  issue(0, 0);
+  const int nslab = (int)(K / BK);
+  for (int s = 0; s < nslab; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nslab) issue((s + 1) & 1, (long)(s + 1) * BK);
+    const char* sb = lds + (s & 1) * STAGE;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      double fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const double*>(sb + offA[kq] + i * 16 * ROWB);
+#pragma unroll
+      for (int h = 0; h < 3; ++h) {
+        double fb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          fb[j] = *reinterpret_cast<const double*>(sb + offB[kq] + (h * BN + j * 16) * ROWB);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[h][i][j] = Mfma<double>::run(fa[i], fb[j], acc[h][i][j]);
+      }
+    }
+  }
+  // ---- epilogue: batches b = (j, i), 4 elements (r) each, operands one batch ahead
+  const double eps = a.eps, heps = 0.5 * a.eps;
+  double ld[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ld[i][r] = 0.0;
+  constexpr int NB = 2 * NJ;
+  double2 vv[2][4], ff[2][4];
+  const long mrow = m0 + wm + (lane >> 4);
+  const long ncol = n0 + wn + (lane & 15);
+  auto elem = [&](int b, int r, long& o, bool& ok) {
+    const int j = b >> 1, i = b & 1;
+    const long m = mrow + 16 * i + 4 * r, n = ncol + 16 * j;
+    ok = (m < a.M) && (n < a.N);
+    o = ok ? m * (long)a.N + n : 0;
+  };
+  auto fetch = [&](int b, int slot) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      long o; bool ok;
+      elem(b, r, o, ok);
+      if (CPLX) {
+        vv[slot][r] = reinterpret_cast<const double2*>(a.v)[o];
+        ff[slot][r] = reinterpret_cast<const double2*>(a.F)[o];
+      } else {
+        vv[slot][r] = make_double2(a.v[o], 0.0);
+        ff[slot][r] = make_double2(a.F[o], 0.0);
+      }
+    }
+  };
+  double cb[NJ][5];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long n = ncol + 16 * j;
+    const long nc = n < a.N ? n : 0;
+    cb[j][0] = a.b[0][nc]; cb[j][1] = a.b[1][nc]; cb[j][2] = a.b[2][nc];
+    cb[j][3] = a.cs ? a.cs[nc] : a.ss;
+    cb[j][4] = a.cq ? a.cq[nc] : a.sq;
+  }
+  fetch(0, 0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int slot = b & 1, j = b >> 1, i = b & 1;
+    if (b + 1 < NB) fetch(b + 1, slot ^ 1);
+    const double bs = cb[j][0], bt = cb[j][1], bq = cb[j][2], cs = cb[j][3], cq = cb[j][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      long o; bool ok;
+      elem(b, r, o, ok);
+      const double s = cs * tanh_bf(acc[0][i][j][r] + bs);
+      const double t = a.st * (acc[1][i][j][r] + bt);
+      const double q = cq * tanh_bf(acc[2][i][j][r] + bq);
+      const double lj = FWD ? heps * s : -heps * s;
+      if (ok) ld[i][r] += lj;
+      const double es = exp_bf(lj), eq = exp_bf(eps * q);
+      double vr = vv[slot][r].x, vi = vv[slot][r].y;
+      const double fr0 = ff[slot][r].x, fi0 = ff[slot][r].y;
+      {
+        const double fr = fr0 * eq + t, fi = fi0 * eq;
+        if (FWD) { vr = es * vr - heps * fr; vi = es * vi - heps * fi; }
+        else { vr = es * (vr + heps * fr); vi = es * (vi + heps * fi); }
+      }
+      if (PAIR) {
+        if (a.flip) { vr = -vr; vi = -vi; }
+        const double h2 = 0.5 * a.eps2;
+        const double lj2 = a.fwd2 ? h2 * s : -h2 * s;
+        if (ok) ld[i][r] += lj2;
+        const double es2 = exp_bf(lj2), eq2 = exp_bf(a.eps2 * q);
+        const double fr = fr0 * eq2 + t, fi = fi0 * eq2;
+        if (a.fwd2) { vr = es2 * vr - h2 * fr; vi = es2 * vi - h2 * fi; }
+        else { vr = es2 * (vr + h2 * fr); vi = es2 * (vi + h2 * fi); }
+      }
+      if (ok) {
+        if (CPLX) reinterpret_cast<double2*>(a.v)[o] = make_double2(vr, vi);
+        else a.v[o] = vr;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double x = ld[i][r];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      const long m = m0 + wm + 16 * i + Mfma<double>::row(lane, r);
+      if ((lane & 15) == 0 && m < a.M) {
+        const long col = (n0 / BN) * 2 + (wave & 1);
+        a.logdet_part[m * a.ncols_part + col] = x;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// fp64 layer with LDS-DMA operand staging (see fused_heads_dma_kernel for the scheme): 128 x 128
+// tile, 2 x 2 wavefronts of 64 x 64, two 32 KB stages of 128-byte XOR-swizzled rows, one barrier
+// per K-slab, no address arithmetic in the loop.  Serves the K-contiguous, 16-byte aligned case
+// with K, K2 and the split boundaries multiples of BK (every layer of the SU(3) vnet); everything
+// else stays on gemm_nt_kernel.  Rows past M / N re-read a valid row and are masked at the store.
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
+    const double* __restrict__ A, const double* __restrict__ W, const double* __restrict__ A2,
+    const double* __restrict__ W2, int M, int N, long K, long K2, long kchunk, Epilogue<double> epi,
+    double* __restrict__ C, double* __restrict__ part) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int ROWB = BK * 8;
+  constexpr int STAGE = (BM + BN) * ROWB;        // 32 KB
+  using T = double;
+  using acc_t = v4f64;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+  const long Kt = K + K2;
+  const long kbeg = (long)blockIdx.z * kchunk;
+  long kend = kbeg + kchunk;
+  if (kend > Kt) kend = Kt;
+
+  // loader: instruction q of this wavefront fills tile rows (4q + wave) * 8 + (lane >> 3) (rows
+  // 0..127: A, 128..255: W), 16-byte position lane & 7, source chunk (lane & 7) ^ (row & 7).
+  // Per-lane byte offsets are relative to the block's first row, once per operand pair.
+  unsigned vo1[8], vo2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int R = (4 * q + wave) * 8 + (lane >> 3);
+    const int r = R & 127;
+    const long lim = (q < 4 ? (long)M - m0 : (long)N - n0) - 1;
+    const int rc = r <= lim ? r : (int)lim;
+    const int c = (lane & 7) ^ (R & 7);
+    vo1[q] = (unsigned)(rc * K * 8 + c * 16);
+    vo2[q] = (unsigned)(rc * K2 * 8 + c * 16);
+  }
+  const char* a1 = reinterpret_cast<const char*>(A) + m0 * K * 8;
+  const char* w1 = reinterpret_cast<const char*>(W) + n0 * K * 8;
+  const char* a2 = reinterpret_cast<const char*>(A2) + m0 * K2 * 8;
+  const char* w2 = reinterpret_cast<const char*>(W2) + n0 * K2 * 8;
+  auto issue = [&](int stage, long k0) {
+    const bool second = k0 >= K;                       // wave-uniform: a slab never straddles K
+    const char* ab = second ? a2 + (k0 - K) * 8 : a1 + k0 * 8;
+    const char* wb = second ? w2 + (k0 - K) * 8 : w1 + k0 * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const char* g = (q < 4 ? ab : wb) + (unsigned long)(second ? vo2[q] : vo1[q]);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (lds_ptr_t)(lds + stage * STAGE + (4 * q + wave) * 1024), 16, 0, 0);
+    }
+  };
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    const unsigned sw = ((((kq * 2) + (lane >> 5)) ^ (lane & 7)) << 4) + ((lane >> 4) & 1) * 8;
+    offA[kq] = (wm + (lane & 15)) * ROWB + sw;
+    offB[kq] = (BM + wn + (lane & 15)) * ROWB + sw;
+  }
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
+
+  issue(0, kbeg);
+  int st = 0;
+  for (long k0 = kbeg; k0 < kend; k0 += BK, st ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k0 + BK < kend) issue(st ^ 1, k0 + BK);
+    const char* sb = lds + st * STAGE;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      T fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const T*>(sb + offA[kq] + i * 16 * ROWB);
+        fb[i] = *reinterpret_cast<const T*>(sb + offB[kq] + i * 16 * ROWB);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  T* dst = FUSED ? C : part + (long)blockIdx.z * M * N;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long n = n0 + wn + 16 * j + (lane & 15);
+    if (n >= N) continue;
+    T cs = (T)1, cb = (T)0;
+    if (FUSED) { cs = epi.colscale((int)n); cb = epi.colbias((int)n); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+        if (m < M) {
+          const T v = acc[i][j][r];
+          if (FUSED) {
+            const T y = cs * apply_act<T>(v + cb, epi.act);
+            dst[m * N + n] = epi.accumulate ? dst[m * N + n] + y : y;
+          } else {
+            dst[m * N + n] = v;
+          }
+        }
+      }
+  }
+}
+
 static int pick_splits(int M, int N, long Kt) {
   const long tiles = cdiv(M, 128) * cdiv(N, 128);
   if (tiles >= 256 || Kt <= 8 * BK) return 1;
@@ -698,7 +1040,24 @@ static int gemm_launch(const T* A, const T* W, int M, int N, long K, const T* A2
     else if (vec) L2Q_GEMM(F, true, false, false);                           \
     else L2Q_GEMM(F, false, false, false);                                   \
   } while (0)
-  if (splits == 1) L2Q_GEMM_F(true);
+  // fp64, K-contiguous, whole aligned K-slabs: LDS-DMA staged kernel
+  bool dma = false;
+  if constexpr (std::is_same<T, double>::value) {
+    dma = tuning().heads_dma && !ta && !tw && vec && K % BK == 0 && K2 % BK == 0 && kchunk % BK == 0 &&
+          128 * K * 8 < (1L << 32) && 128 * K2 * 8 < (1L << 32);
+    if (dma) {
+      const double* A2p = K2 ? A2 : A;            // never dereferenced when K2 == 0
+      const double* W2p = K2 ? W2 : W;
+      if (splits == 1)
+        hipLaunchKernelGGL((gemm_dma_f64_kernel<true>), grid, dim3(kBlock), 0, st, A, W, A2p, W2p, M, N, K,
+                           K2, kchunk, epi, C, part);
+      else
+        hipLaunchKernelGGL((gemm_dma_f64_kernel<false>), grid, dim3(kBlock), 0, st, A, W, A2p, W2p, M, N, K,
+                           K2, kchunk, epi, C, part);
+    }
+  }
+  if (dma) {
+  } else if (splits == 1) L2Q_GEMM_F(true);
   else L2Q_GEMM_F(false);
 #undef L2Q_GEMM_F
 #undef L2Q_GEMM
@@ -840,8 +1199,13 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
   const int stg = tuning().heads_stagger;
   // partial columns of wave tiles that fall entirely beyond N are never written: clear first
   (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * sizeof(double), st);
-#define L2Q_HEADS(C, F, P) \
-  hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz, stg)
+  // LDS-DMA kernel whenever the K-slabs are whole (tuning heads_dma = 0 keeps the older kernel)
+  const bool dma = tuning().heads_dma && (K % BK == 0) && K >= BK && K <= (1 << 20);
+#define L2Q_HEADS(C, F, P)                                                                      \
+  do {                                                                                          \
+    if (dma) hipLaunchKernelGGL((fused_heads_dma_kernel<C, F, P>), grid, block, 0, st, a, swz); \
+    else hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz, stg); \
+  } while (0)
   if (pair) {
     if (is_complex) { if (forward) L2Q_HEADS(true, true, true); else L2Q_HEADS(true, false, true); }
     else { if (forward) L2Q_HEADS(false, true, true); else L2Q_HEADS(false, false, true); }

@@ -1,0 +1,92 @@
+// Does fp64 VALU work of one wavefront overlap with fp64 MFMA work of another wavefront on the
+// same SIMD (gfx950)?  512-thread workgroups, 1 per CU: wavefronts 0-3 (one per SIMD) run a
+// v_mfma_f64_16x16x4_f64 loop, wavefronts 4-7 run a VALU loop of the given flavour.
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// mode bits: 1 = MFMA waves active, 2 = VALU waves active; flavour: 0 fp64 fma, 1 fp32 fma, 2 int mad
+template <int FLAV>
+__global__ __launch_bounds__(512) void k(double* out, int it_m, int it_v, int mode) {
+  const int wave = threadIdx.x >> 6;
+  double res = 0;
+  if (wave < 4) {
+    if (mode & 1) {
+      v4f64 acc[8];
+      for (int i = 0; i < 8; ++i) acc[i] = (v4f64){0, 0, 0, 0};
+      double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+      for (int it = 0; it < it_m; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+      }
+      for (int i = 0; i < 8; ++i) res += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    }
+  } else if (mode & 2) {
+    if (FLAV == 0) {
+      double acc[16];
+      for (int i = 0; i < 16; ++i) acc[i] = i;
+      double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
+      for (int it = 0; it < it_v; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fma(acc[i], a, b);
+      }
+      for (int i = 0; i < 16; ++i) res += acc[i];
+    } else if (FLAV == 1) {
+      float acc[16];
+      for (int i = 0; i < 16; ++i) acc[i] = i;
+      float a = 1.0f + threadIdx.x * 1e-6f, b = 1e-6f;
+      for (int it = 0; it < it_v; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc[i], a, b);
+      }
+      for (int i = 0; i < 16; ++i) res += acc[i];
+    } else {
+      unsigned acc[16];
+      for (int i = 0; i < 16; ++i) acc[i] = i;
+      unsigned a = 3 + threadIdx.x, b = 7;
+      for (int it = 0; it < it_v; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = acc[i] * a + b;
+      }
+      for (int i = 0; i < 16; ++i) res += acc[i];
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = res;
+}
+
+template <typename F>
+double timeit(F f) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  f(); f();
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) f();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / 5;
+}
+
+template <int FLAV>
+void run(const char* name, double* out, int it_m, int it_v) {
+  const int nb = 256;
+  double t[4];
+  for (int mode = 1; mode <= 3; ++mode)
+    t[mode] = timeit([&] { hipLaunchKernelGGL(k<FLAV>, dim3(nb), dim3(512), 0, 0, out, it_m, it_v, mode); });
+  printf("%-10s MFMA alone %.3f ms (%.1f TFLOP/s)  VALU alone %.3f ms  both %.3f ms  (sum %.3f, max %.3f)\n", name, t[1],
+         256.0 * 4 * it_m * 8 * 2048.0 / t[1] / 1e9, t[2], t[3], t[1] + t[2], t[1] > t[2] ? t[1] : t[2]);
+}
+
+int main() {
+  double* out;
+  hipMalloc(&out, 256 * 512 * sizeof(double));
+  const int it_m = 4000;
+  run<0>("fp64 fma", out, it_m, 8000);
+  run<1>("fp32 fma", out, it_m, 16000);
+  run<2>("int mad", out, it_m, 16000);
+  run<0>("fp64 fma/2", out, it_m, 4000);
+  return 0;
+}
