@@ -867,18 +867,22 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
 
 // ---------------------------------------------------------------------------------------
 // fp64 layer with LDS-DMA operand staging (see fused_heads_dma_kernel for the scheme): 128 x 128
-// tile, 2 x 2 wavefronts of 64 x 64, two 32 KB stages of 128-byte XOR-swizzled rows, one barrier
-// per K-slab, no address arithmetic in the loop.  Serves the K-contiguous, 16-byte aligned case
-// with K, K2 and the split boundaries multiples of BK (every layer of the SU(3) vnet); everything
-// else stays on gemm_nt_kernel.  Rows past M / N re-read a valid row and are masked at the store.
-template <bool FUSED>
+// tile, 2 x 2 wavefronts of 64 x 64, two 32 KB stages, one barrier per K-slab, no address
+// arithmetic in the loop.  A K-contiguous operand ([rows][K]) is staged as 128-byte XOR-swizzled
+// rows; a TRANSPOSED operand ([K][rows], the backward GEMMs dW = dY^T X, dX = dY W) is staged as
+// its own image [16 k][128 rows] -- one 1 KB LDS-DMA instruction per k, fragments are 128-byte
+// contiguous runs, no swizzle needed.  Serves 16-byte aligned operands with K, K2 and the split
+// boundaries multiples of BK (every layer of the SU(3) vnet, forward and backward); everything else
+// stays on gemm_nt_kernel.  Rows past M / N re-read valid rows and are masked at the store.
+template <bool FUSED, bool TA, bool TW>
 __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
     const double* __restrict__ A, const double* __restrict__ W, const double* __restrict__ A2,
     const double* __restrict__ W2, int M, int N, long K, long K2, long kchunk, Epilogue<double> epi,
     double* __restrict__ C, double* __restrict__ part) {
   constexpr int BM = 128, BN = 128;
   constexpr int ROWB = BK * 8;
-  constexpr int STAGE = (BM + BN) * ROWB;        // 32 KB
+  constexpr int OPB = BM * ROWB;                 // 16 KB per operand per stage
+  constexpr int STAGE = 2 * OPB;
   using T = double;
   using acc_t = v4f64;
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
@@ -891,42 +895,57 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
   long kend = kbeg + kchunk;
   if (kend > Kt) kend = Kt;
 
-  // loader: instruction q of this wavefront fills tile rows (4q + wave) * 8 + (lane >> 3) (rows
-  // 0..127: A, 128..255: W), 16-byte position lane & 7, source chunk (lane & 7) ^ (row & 7).
-  // Per-lane byte offsets are relative to the block's first row, once per operand pair.
+  // loader: this wavefront issues instructions g = 4q + wave, q = 0..7; g < 16 belongs to A, the
+  // rest to W.  K-contiguous operand: instruction fills tile rows (g & 15) * 8 + (lane >> 3),
+  // 16-byte position lane & 7, source chunk (lane & 7) ^ (row & 7); per-lane byte offsets are
+  // relative to the block's first row, one set per operand pair.  Transposed operand: instruction
+  // fills k-row g & 15 with rows 2 lane, 2 lane + 1; the per-lane offset does not depend on q.
   unsigned vo1[8], vo2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int R = (4 * q + wave) * 8 + (lane >> 3);
-    const int r = R & 127;
-    const long lim = (q < 4 ? (long)M - m0 : (long)N - n0) - 1;
-    const int rc = r <= lim ? r : (int)lim;
-    const int c = (lane & 7) ^ (R & 7);
-    vo1[q] = (unsigned)(rc * K * 8 + c * 16);
-    vo2[q] = (unsigned)(rc * K2 * 8 + c * 16);
+    const bool isA = q < 4;
+    const long lim = (isA ? (long)M - m0 : (long)N - n0) - 1;     // last valid row of this block
+    if ((isA && TA) || (!isA && TW)) {
+      long r = 2 * lane;
+      if (r + 1 > lim) r = lim - 1;                  // clamp the pair (M, N even and >= 2)
+      vo1[q] = (unsigned)(r * 8);
+      vo2[q] = vo1[q];
+    } else {
+      const int R = ((4 * q + wave) & 15) * 8 + (lane >> 3);
+      const int rc = R <= lim ? R : (int)lim;
+      const int c = (lane & 7) ^ (R & 7);
+      vo1[q] = (unsigned)(rc * K * 8 + c * 16);
+      vo2[q] = (unsigned)(rc * K2 * 8 + c * 16);
+    }
   }
-  const char* a1 = reinterpret_cast<const char*>(A) + m0 * K * 8;
-  const char* w1 = reinterpret_cast<const char*>(W) + n0 * K * 8;
-  const char* a2 = reinterpret_cast<const char*>(A2) + m0 * K2 * 8;
+  // block bases: K-contiguous operands start at row m0 / n0; transposed ones at column m0 / n0
+  const char* a1 = reinterpret_cast<const char*>(A) + (TA ? m0 * 8 : m0 * K * 8);
+  const char* w1 = reinterpret_cast<const char*>(W) + (TW ? n0 * 8 : n0 * K * 8);
+  const char* a2 = reinterpret_cast<const char*>(A2) + m0 * K2 * 8;      // K2 != 0 only without TA / TW
   const char* w2 = reinterpret_cast<const char*>(W2) + n0 * K2 * 8;
   auto issue = [&](int stage, long k0) {
     const bool second = k0 >= K;                       // wave-uniform: a slab never straddles K
-    const char* ab = second ? a2 + (k0 - K) * 8 : a1 + k0 * 8;
-    const char* wb = second ? w2 + (k0 - K) * 8 : w1 + k0 * 8;
+    const long kk = second ? k0 - K : k0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const char* g = (q < 4 ? ab : wb) + (unsigned long)(second ? vo2[q] : vo1[q]);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (lds_ptr_t)(lds + stage * STAGE + (4 * q + wave) * 1024), 16, 0, 0);
+      const int g = 4 * q + wave;
+      const char* src;
+      if (q < 4) src = TA ? a1 + (kk + (g & 15)) * (long)M * 8 : (second ? a2 : a1) + kk * 8;
+      else src = TW ? w1 + (kk + (g & 15)) * (long)N * 8 : (second ? w2 : w1) + kk * 8;
+      src += (unsigned long)(second ? vo2[q] : vo1[q]);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (lds_ptr_t)(lds + stage * STAGE + g * 1024), 16, 0, 0);
     }
   };
   unsigned offA[4], offB[4];
 #pragma unroll
   for (int kq = 0; kq < 4; ++kq) {
     const unsigned sw = ((((kq * 2) + (lane >> 5)) ^ (lane & 7)) << 4) + ((lane >> 4) & 1) * 8;
-    offA[kq] = (wm + (lane & 15)) * ROWB + sw;
-    offB[kq] = (BM + wn + (lane & 15)) * ROWB + sw;
+    const unsigned tr = (4 * kq + (lane >> 4)) * (BM * 8) + (lane & 15) * 8;
+    offA[kq] = TA ? tr + wm * 8 : (wm + (lane & 15)) * ROWB + sw;
+    offB[kq] = OPB + (TW ? tr + wn * 8 : (wn + (lane & 15)) * ROWB + sw);
   }
+  constexpr int stepA = TA ? 16 * 8 : 16 * ROWB, stepB = TW ? 16 * 8 : 16 * ROWB;
   acc_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -945,8 +964,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
       T fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const T*>(sb + offA[kq] + i * 16 * ROWB);
-        fb[i] = *reinterpret_cast<const T*>(sb + offB[kq] + i * 16 * ROWB);
+        fa[i] = *reinterpret_cast<const T*>(sb + offA[kq] + i * stepA);
+        fb[i] = *reinterpret_cast<const T*>(sb + offB[kq] + i * stepB);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1040,20 +1059,29 @@ static int gemm_launch(const T* A, const T* W, int M, int N, long K, const T* A2
     else if (vec) L2Q_GEMM(F, true, false, false);                           \
     else L2Q_GEMM(F, false, false, false);                                   \
   } while (0)
-  // fp64, K-contiguous, whole aligned K-slabs: LDS-DMA staged kernel
+  // fp64, 16-byte aligned operands, whole K-slabs: LDS-DMA staged kernel
   bool dma = false;
   if constexpr (std::is_same<T, double>::value) {
-    dma = tuning().heads_dma && !ta && !tw && vec && K % BK == 0 && K2 % BK == 0 && kchunk % BK == 0 &&
-          128 * K * 8 < (1L << 32) && 128 * K2 * 8 < (1L << 32);
+    dma = tuning().heads_dma && vec && K % BK == 0 && K2 % BK == 0 && kchunk % BK == 0 &&
+          (ta ? (M % 2 == 0 && M >= 2) : 128 * K * 8 < (1L << 32)) &&
+          (tw ? (N % 2 == 0 && N >= 2) : 128 * K * 8 < (1L << 32)) && 128 * K2 * 8 < (1L << 32);
     if (dma) {
       const double* A2p = K2 ? A2 : A;            // never dereferenced when K2 == 0
       const double* W2p = K2 ? W2 : W;
-      if (splits == 1)
-        hipLaunchKernelGGL((gemm_dma_f64_kernel<true>), grid, dim3(kBlock), 0, st, A, W, A2p, W2p, M, N, K,
-                           K2, kchunk, epi, C, part);
-      else
-        hipLaunchKernelGGL((gemm_dma_f64_kernel<false>), grid, dim3(kBlock), 0, st, A, W, A2p, W2p, M, N, K,
-                           K2, kchunk, epi, C, part);
+#define L2Q_GEMM_DMA(F, TA_, TW_)                                                                   \
+  hipLaunchKernelGGL((gemm_dma_f64_kernel<F, TA_, TW_>), grid, dim3(kBlock), 0, st, A, W, A2p, W2p, \
+                     M, N, K, K2, kchunk, epi, C, part)
+#define L2Q_GEMM_DMA_F(F)                                  \
+  do {                                                     \
+    if (ta && tw) L2Q_GEMM_DMA(F, true, true);             \
+    else if (tw) L2Q_GEMM_DMA(F, false, true);             \
+    else if (ta) L2Q_GEMM_DMA(F, true, false);             \
+    else L2Q_GEMM_DMA(F, false, false);                    \
+  } while (0)
+      if (splits == 1) L2Q_GEMM_DMA_F(true);
+      else L2Q_GEMM_DMA_F(false);
+#undef L2Q_GEMM_DMA_F
+#undef L2Q_GEMM_DMA
     }
   }
   if (dma) {
