@@ -231,9 +231,13 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
     F = ops.su3_force_n(x, beta, dyn.latvolume)
     xv = ops.su3_projsu_vec8_n(x).reshape(nb, -1)
     fv = ops.su3_projsu_vec8_n(F).reshape(nb, -1)
-    # the network sees the reference's entry order (mu, site, component)
-    s, t, q, ctx = vnet.forward_train(ops.unpack_entries(xv, V, 8), ops.unpack_entries(fv, V, 8))
-    sn, tn, qn = (ops.pack_entries(a, V, 9) for a in (s, t, q))
+    if vnet.native_active():
+        # native-order weight shadows (LeapfrogLayer.native_train_begin): no activation transposes
+        sn, tn, qn, ctx = vnet.forward_train(xv, fv)
+    else:
+        # the network sees the reference's entry order (mu, site, component)
+        s, t, q, ctx = vnet.forward_train(ops.unpack_entries(xv, V, 8), ops.unpack_entries(fv, V, 8))
+        sn, tn, qn = (ops.pack_entries(a, V, 9) for a in (s, t, q))
     v_new = v.clone()
     ld = ops.v_update_(v_new.reshape(nb, -1), F.reshape(nb, -1), sn, tn, qn, eps, forward)
     tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
@@ -467,11 +471,16 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
             if idx in pend:
                 pF, ps, pt, pq = pend.pop(idx)
                 ops.add_(dF, pF); ops.add_(dsn, ps); ops.add_(dtn, pt); ops.add_(dqn, pq)
-            ds, dt, dq = (ops.unpack_entries(a, V, 9) for a in (dsn, dtn, dqn))
-            dxr, dfr = e['net'].backward(e['ctx'], ds, dt, dq)
             dF = dF.reshape(F.shape)
-            ops.su3_projsu_vec8_bwd_(dF, F, ops.pack_entries(dfr.reshape(nb, -1), V, 8))
-            ops.su3_projsu_vec8_bwd_(gx, x, ops.pack_entries(dxr.reshape(nb, -1), V, 8))
+            if e['ctx'].get('native'):
+                dxr, dfr = e['net'].backward(e['ctx'], dsn, dtn, dqn)
+                ops.su3_projsu_vec8_bwd_(dF, F, dfr.reshape(nb, -1))
+                ops.su3_projsu_vec8_bwd_(gx, x, dxr.reshape(nb, -1))
+            else:
+                ds, dt, dq = (ops.unpack_entries(a, V, 9) for a in (dsn, dtn, dqn))
+                dxr, dfr = e['net'].backward(e['ctx'], ds, dt, dq)
+                ops.su3_projsu_vec8_bwd_(dF, F, ops.pack_entries(dfr.reshape(nb, -1), V, 8))
+                ops.su3_projsu_vec8_bwd_(gx, x, ops.pack_entries(dxr.reshape(nb, -1), V, 8))
             ops.su3_force_bwd_(gx, x, dF, beta, lat)
             gv = dv.reshape(v.shape)
             eps_acc.setdefault(('v', e['step']), []).append(deps)
@@ -544,6 +553,24 @@ def train_forward_backward_chunked(dyn, loss_fn, x: Tensor, beta, micro_batch: i
     return torch.cat(outs, 0), _cat_metrics(mets, sizes), loss
 
 
+def _native_begin(dyn) -> list:
+    """SU(3) dense vnets train on native-order weight shadows (LeapfrogLayer.native_train_begin;
+    `dyn.native_training = False` keeps the reference-order path with activation transposes)."""
+    if dyn.group != 'SU3' or not getattr(dyn, 'native_training', True):
+        return []
+    from l2hmc.network.pytorch.network import ConvStack
+    p = dyn._perms()
+    nets, seen = [], set()
+    for st in range(dyn.config.nleapfrog):
+        n = dyn._get_vnet(st)
+        if id(n) in seen or isinstance(n.input_layer.conv_stack, ConvStack):
+            continue
+        seen.add(id(n))
+        n.native_train_begin(p['in'], p['out'])
+        nets.append(n)
+    return nets
+
+
 def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1.0):
     """forward_step + calc_loss + loss.backward() of the reference's train_step for one input
     batch: returns (x_out [nb, xdim], metrics, loss).  Gradients are ACCUMULATED into the
@@ -552,10 +579,15 @@ def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1
     b = _beta(beta)
     xn = dyn._pack(x)
     vn = dyn._momentum_n(xn.shape[0])
-    x_, v_, hist, tape = trajectory_fb_train(dyn, xn, vn, b)
-    loss, gx, gv, gl = loss_and_seeds(dyn, loss_fn, xn, x_, v_, tape, hist['sumlogdet'], b)
-    if loss_weight != 1.0:
-        gx, gv, gl = gx * loss_weight, gv * loss_weight, gl * loss_weight
-    backward(dyn, tape, gx, gv, gl, b)
+    nets = _native_begin(dyn)
+    try:
+        x_, v_, hist, tape = trajectory_fb_train(dyn, xn, vn, b)
+        loss, gx, gv, gl = loss_and_seeds(dyn, loss_fn, xn, x_, v_, tape, hist['sumlogdet'], b)
+        if loss_weight != 1.0:
+            gx, gv, gl = gx * loss_weight, gv * loss_weight, gl * loss_weight
+        backward(dyn, tape, gx, gv, gl, b)
+    finally:
+        for n in nets:
+            n.native_train_end()
     xout, metrics = dyn._finish(xn, vn, x_, v_, beta, hist, with_sumlogdet=True)
     return xout, metrics, loss

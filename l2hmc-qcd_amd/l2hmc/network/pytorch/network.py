@@ -118,17 +118,21 @@ def zero_weights(m):
             nn.init.constant_(m.bias.data, 0)
 
 
-def _linear_bwd(dpre: Tensor, x: Tensor, weight: nn.Parameter, bias: Optional[nn.Parameter],
-                need_dx: bool = True, xT: Optional[Tensor] = None) -> Optional[Tensor]:
+def _linear_bwd(dpre: Tensor, x: Tensor, weight, bias,
+                need_dx: bool = True, xT: Optional[Tensor] = None,
+                wgrad: Optional[Tensor] = None, bgrad: Optional[Tensor] = None) -> Optional[Tensor]:
     """Backward of y = x W^T + b given dpre = dL/dy: W.grad += dpre^T x, b.grad += colsum(dpre),
     returns dL/dx = dpre W (MFMA GEMMs on transposed operands; accumulation into the flat
     gradient arena the parameters' .grad are views of)."""
     # both operands are read transposed in the GEMM's tile loader and the result is added into
     # the gradient arena by its epilogue: no transposed copies, no separate accumulation pass
     # (rows that are not 16-byte multiples fall back to explicit transposes inside gemm_ex)
-    ops.gemm_ex(dpre, x, a_trans=True, w_trans=True, out=weight.grad, accumulate=True)
+    # wgrad / bgrad: accumulate there instead of weight.grad / bias.grad (native-order shadows of
+    # the SU(3) vnet, LeapfrogLayer.native_train_begin)
+    ops.gemm_ex(dpre, x, a_trans=True, w_trans=True,
+                out=weight.grad if wgrad is None else wgrad, accumulate=True)
     if bias is not None:
-        ops.colsum_(bias.grad, dpre)
+        ops.colsum_(bias.grad if bgrad is None else bgrad, dpre)
     if not need_dx:
         return None
     return ops.gemm_ex(dpre, weight.detach(), w_trans=True)
@@ -587,6 +591,66 @@ class LeapfrogLayer(nn.Module):
         return z
 
 
+
+    # ---- native-order shadows for training (SU(3) vnet)
+    def native_train_begin(self, in_perm: Tensor, out_perm: Tensor) -> None:
+        """Training in the kernels' native entry order: the big matrices of this layer (input
+        columns of xlayer / vlayer, output rows of the three heads, their biases and ScaledTanh
+        coefficients) are gathered once per step into native-order shadows, forward_train /
+        backward run on the shadows (gradients accumulate in native-order buffers), and
+        native_train_end scatters the gradients back into the checkpoint-ordered .grad views.
+        Replaces the five reference <-> native transposes of the activations around every
+        network call of the tape (2 x 268 MB + 3 x 302 MB per call at cfg-4, forward and
+        backward) by one gather + one scatter of the weights per step."""
+        il = self.input_layer
+        if isinstance(il.conv_stack, ConvStack):
+            raise NotImplementedError('native-order training: dense input layers only')
+        nat = getattr(self, '_nat', None)
+        if nat is None or nat['in'] is not in_perm or nat['out'] is not out_perm:
+            nat = {'in': in_perm, 'out': out_perm, 'w': {}, 'g': {}}
+            self._nat = nat
+        src = {'wx': (il.xlayer.weight, 1, in_perm), 'wv': (il.vlayer.weight, 1, in_perm),
+               'ws': (self.scale.layer.weight, 0, out_perm), 'bs': (self.scale.layer.bias, 0, out_perm),
+               'cs': (self.scale.coeff, -1, out_perm),
+               'wt': (self.transl.weight, 0, out_perm), 'bt': (self.transl.bias, 0, out_perm),
+               'wq': (self.transf.layer.weight, 0, out_perm), 'bq': (self.transf.layer.bias, 0, out_perm),
+               'cq': (self.transf.coeff, -1, out_perm)}
+        with torch.no_grad():
+            for k, (par, dim, perm) in src.items():
+                t = par.detach()
+                if dim == -1:
+                    t = t.reshape(-1)
+                    dim = 0
+                buf = nat['w'].get(k)
+                if buf is None or buf.shape != t.shape:
+                    buf = torch.empty_like(t)
+                    nat['w'][k] = buf
+                    nat['g'][k] = torch.zeros_like(t)
+                torch.index_select(t, dim, perm, out=buf)
+                nat['g'][k].zero_()
+        nat['src'] = src
+        nat['active'] = True
+
+    def native_train_end(self) -> None:
+        """Scatter-add the native-order gradients into the parameters' .grad, leave native mode."""
+        nat = getattr(self, '_nat', None)
+        if nat is None or not nat.get('active'):
+            return
+        with torch.no_grad():
+            for k, (par, dim, perm) in nat['src'].items():
+                if par.grad is None:
+                    continue
+                g = nat['g'][k]
+                if dim == -1:
+                    par.grad.reshape(-1).index_add_(0, perm, g)
+                else:
+                    par.grad.index_add_(dim, perm, g)
+        nat['active'] = False
+
+    def native_active(self) -> bool:
+        nat = getattr(self, '_nat', None)
+        return bool(nat is not None and nat.get('active'))
+
     # ---- training path (train-mode semantics: dropout active, BatchNorm batch statistics)
     def training_needs_fresh_forward(self) -> bool:
         """True when two forward_train calls on the same input differ on purpose (fresh dropout
@@ -614,8 +678,11 @@ class LeapfrogLayer(nn.Module):
             raise NotImplementedError('training: swish inside the conv stack (its kernels fuse the '
                                       'activation with the max-pool) -- use another activation_fn')
         fused = None if swish else self.act
-        z = ops.gemm(xf, il.xlayer.weight.detach(), il.xlayer.bias.detach(), a2=vf,
-                     w2=il.vlayer.weight.detach(), bias2=il.vlayer.bias.detach(), act=fused)
+        nw_ = self._nat['w'] if self.native_active() else None     # inputs / outputs in native order
+        z = ops.gemm(xf, il.xlayer.weight.detach() if nw_ is None else nw_['wx'],
+                     il.xlayer.bias.detach(), a2=vf,
+                     w2=il.vlayer.weight.detach() if nw_ is None else nw_['wv'],
+                     bias2=il.vlayer.bias.detach(), act=fused)
         pre = [z] if swish else None
         if swish:
             z = ops.act_fwd(z, 'swish')
@@ -642,11 +709,17 @@ class LeapfrogLayer(nn.Module):
                 bn.running_var)
             bn.num_batches_tracked += 1
         ctx['z'] = z
-        s = ops.gemm(z, self.scale.layer.weight.detach(), self.scale.layer.bias.detach(),
-                     coeff=self.scale.coeff.detach().reshape(-1), scale=self.nw.s, act='tanh')
-        t = ops.gemm(z, self.transl.weight.detach(), self.transl.bias.detach(), scale=self.nw.t)
-        q = ops.gemm(z, self.transf.layer.weight.detach(), self.transf.layer.bias.detach(),
-                     coeff=self.transf.coeff.detach().reshape(-1), scale=self.nw.q, act='tanh')
+        ctx['native'] = nw_ is not None
+        if nw_ is not None:
+            s = ops.gemm(z, nw_['ws'], nw_['bs'], coeff=nw_['cs'], scale=self.nw.s, act='tanh')
+            t = ops.gemm(z, nw_['wt'], nw_['bt'], scale=self.nw.t)
+            q = ops.gemm(z, nw_['wq'], nw_['bq'], coeff=nw_['cq'], scale=self.nw.q, act='tanh')
+        else:
+            s = ops.gemm(z, self.scale.layer.weight.detach(), self.scale.layer.bias.detach(),
+                         coeff=self.scale.coeff.detach().reshape(-1), scale=self.nw.s, act='tanh')
+            t = ops.gemm(z, self.transl.weight.detach(), self.transl.bias.detach(), scale=self.nw.t)
+            q = ops.gemm(z, self.transf.layer.weight.detach(), self.transf.layer.bias.detach(),
+                         coeff=self.transf.coeff.detach().reshape(-1), scale=self.nw.q, act='tanh')
         ctx['s'], ctx['q'] = s, q
         return s, t, q, ctx
 
@@ -656,18 +729,29 @@ class LeapfrogLayer(nn.Module):
         z = ctx['z']
         zT = None            # (only the fall-back path of _linear_bwd transposes)
         dz = None
-        for head, cot, out in ((self.scale, ds, ctx['s']), (self.transl, dt, None),
-                               (self.transf, dq, ctx['q'])):
+        native = bool(ctx.get('native'))
+        if native and not self.native_active():
+            raise RuntimeError('LeapfrogLayer.backward: the tape was recorded in native order but '
+                               'native_train_end() has already run')
+        nw_ = self._nat['w'] if native else None
+        ng_ = self._nat['g'] if native else None
+        for head, cot, out, tag in ((self.scale, ds, ctx['s'], 's'), (self.transl, dt, None, 't'),
+                                    (self.transf, dq, ctx['q'], 'q')):
             if isinstance(head, ScaledTanh):
                 nw = self.nw.s if head is self.scale else self.nw.q
-                co = head.coeff.detach().reshape(-1)
-                ops.colsum_(head.coeff.grad.reshape(-1), cot, out)      # d s / d coeff = s
+                co = head.coeff.detach().reshape(-1) if not native else nw_['c' + tag]
+                cg = head.coeff.grad.reshape(-1) if not native else ng_['c' + tag]
+                ops.colsum_(cg, cot, out)                               # d s / d coeff = s
                 dpre = ops.scaled_tanh_bwd(cot, out, co, nw)
                 lin = head.layer
             else:
                 dpre = ops.scaled_tanh_bwd(cot, None, None, self.nw.t)
                 lin = head
-            d = _linear_bwd(dpre, z, lin.weight, lin.bias, xT=zT)
+            if native:
+                d = _linear_bwd(dpre, z, nw_['w' + tag], nw_['b' + tag], xT=zT,
+                                wgrad=ng_['w' + tag], bgrad=ng_['b' + tag])
+            else:
+                d = _linear_bwd(dpre, z, lin.weight, lin.bias, xT=zT)
             dz = d if dz is None else ops.add_(dz, d)
         if self.net_config.use_batch_norm:
             bn = self.batch_norm
@@ -683,8 +767,12 @@ class LeapfrogLayer(nn.Module):
             dz = _linear_bwd(dpre, acts[i], h.weight, h.bias)
         il = self.input_layer
         dpre = ops.act_bwd(dz, dact[0], self.act)
-        dxf = _linear_bwd(dpre, ctx['xf'], il.xlayer.weight, il.xlayer.bias)
-        dvf = _linear_bwd(dpre, ctx['vf'], il.vlayer.weight, il.vlayer.bias)
+        if native:
+            dxf = _linear_bwd(dpre, ctx['xf'], nw_['wx'], il.xlayer.bias, wgrad=ng_['wx'])
+            dvf = _linear_bwd(dpre, ctx['vf'], nw_['wv'], il.vlayer.bias, wgrad=ng_['wv'])
+        else:
+            dxf = _linear_bwd(dpre, ctx['xf'], il.xlayer.weight, il.xlayer.bias)
+            dvf = _linear_bwd(dpre, ctx['vf'], il.vlayer.weight, il.vlayer.bias)
         if ctx['conv'] is not None:
             dx = il.conv_stack.backward(ctx['conv'], dxf)
         else:

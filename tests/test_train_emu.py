@@ -286,7 +286,10 @@ def test_su3_micro_batched_training_host_logic(golden, monkeypatch, f64):
     for mb in (2, 3):
         for k, g in grads[None].items():
             d = float((grads[mb][k] - g).abs().max())
-            assert d <= 1e-9 * max(1.0, float(g.abs().max())), (mb, k, d)
+            # 1e-7: the gradient passes through the backward of projectSU(force), whose conditioning
+            # (~1e7, see su3_train golden) amplifies the rounding differences of a changed summation
+            # order (micro-batch GEMM shapes, native-order weight shadows)
+            assert d <= 1e-7 * max(1.0, float(g.abs().max())), (mb, k, d)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
