@@ -62,7 +62,8 @@ int l2q_version(void);
  * in {0,1}.  Returns the previous value, or L2Q_EINVAL for an unknown key/value. */
 int l2q_set_tuning(const char* key, int value);
 /* Name (template instantiation as rocprofv3 prints it, without the l2q:: prefix) of the device
- * kernel that `entry` ("l2q_su3_force", "l2q_su3_force_kick", "l2q_su3_plaq_reduce") dispatches
+ * kernel that `entry` ("l2q_su3_force", "l2q_su3_force_kick", "l2q_su3_plaq_reduce",
+ * "l2q_vnet_heads_vupdate[_pair]_f64", "l2q_gemm_f64": kernel family only) dispatches
  * for a T x X x Y x Z lattice under the current tuning; "" for entry points with a single
  * kernel.  Lets a profile (rocprofv3 --pmc) be matched to the build that is running. */
 int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, size_t buf_bytes);

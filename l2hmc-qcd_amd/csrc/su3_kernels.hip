@@ -1042,6 +1042,11 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
                kick ? 2 : 0, kick ? 1 : kLptPlain);
     else if (t.force_tile) snprintf(buf, buf_bytes, "su3_force_tile_kernel<%s, %d>", kick ? "true" : "false", t.force_occ);
     else snprintf(buf, buf_bytes, "su3_force_kernel<%s, %d>", kick ? "true" : "false", t.force_occ);
+  } else if (!strncmp(entry, "l2q_vnet_heads_vupdate", 22)) {
+    // (for shapes with whole 16-wide K-slabs, which every SU(3) vnet has)
+    snprintf(buf, buf_bytes, "%s", t.heads_dma ? "fused_heads_dma_kernel" : "fused_heads_vupdate_kernel");
+  } else if (!strcmp(entry, "l2q_gemm_f64")) {
+    snprintf(buf, buf_bytes, "%s", t.heads_dma ? "gemm_dma_f64_kernel" : "gemm_nt_kernel");
   }
   return L2Q_OK;
 }
