@@ -206,6 +206,18 @@ int l2q_vnet_heads_vupdate_pair_f64(const double* Z, int M, int K, long N, const
                                     double eps1, int forward1, int flip_between, double eps2,
                                     int forward2, double* logdet, void* ws, size_t ws_bytes,
                                     void* stream);
+/* The same pair of updates with what per-step metrics need of the state BETWEEN them
+ * (dynamics.py:865-886 evaluates the Hamiltonian after every leapfrog step): logdet1 [M] = the first
+ * update's log-Jacobian alone (logdet still receives the sum), vnorm2_mid [M] = sum |v|^2 of the
+ * momentum after the first update (before the flip, which does not change it).  Needs K % 16 == 0. */
+int l2q_vnet_heads_vupdate_pair_mid_f64(const double* Z, int M, int K, long N, const double* Ws,
+                                        const double* bs, const double* cs, double scale_s,
+                                        const double* Wt, const double* bt, double scale_t,
+                                        const double* Wq, const double* bq, const double* cq,
+                                        double scale_q, void* v, const void* force, int is_complex,
+                                        double eps1, int forward1, int flip_between, double eps2,
+                                        int forward2, double* logdet, double* logdet1,
+                                        double* vnorm2_mid, void* ws, size_t ws_bytes, void* stream);
 size_t l2q_vnet_heads_ws_bytes(int M, long N);
 /* fp32 variant on v_mfma_f32_16x16x4_f32 (U(1) networks). */
 int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const float* A2,

@@ -525,6 +525,8 @@ struct HeadsArgs {
   double* v;              // [M][N] (x2 if complex), updated in place
   const double* F;        // [M][N] (x2 if complex)
   double* logdet_part;    // [M][ncols_part]
+  double* ld1_part;       // MID kernels: log-Jacobian of the first update alone, [M][ncols_part]
+  double* ke_part;        // MID kernels: sum |v|^2 after the first update,        [M][ncols_part]
   int M, N, K, ncols_part;
 };
 
@@ -689,7 +691,12 @@ __global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_ker
 // Needs K % 16 == 0 (heads_launch falls back to fused_heads_vupdate_kernel otherwise).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <bool CPLX, bool FWD, bool PAIR>
+// MID (pair kernels): per-step metrics need the state BETWEEN the two updates -- the kernel also
+// returns the first update's log-Jacobian and sum |v|^2 of the intermediate momentum (per-row
+// partials, reduced batch by batch so that the extra accumulators do not cost registers), which
+// is all `Dynamics` needs of it (kinetic energy); verbose=True then runs 9 instead of 16 heads
+// kernels per merged nleapfrog = 4 trajectory like verbose=False.
+template <bool CPLX, bool FWD, bool PAIR, bool MID = false>
 __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a, int swz) {
   constexpr int BM = 64, BN = 64, NJ = 2;
   constexpr int ROWB = BK * 8;                    // 128 bytes per tile row per slab
@@ -817,6 +824,7 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
     const int slot = b & 1, j = b >> 1, i = b & 1;
     if (b + 1 < NB) fetch(b + 1, slot ^ 1);
     const double bs = cb[j][0], bt = cb[j][1], bq = cb[j][2], cs = cb[j][3], cq = cb[j][4];
+    double m1[4], m2[4], mk[4];                      // MID: this batch's per-row terms
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       long o; bool ok;
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
       const double t = a.st * (acc[1][i][j][r] + bt);
       const double q = cq * tanh_bf(acc[2][i][j][r] + bq);
       const double lj = FWD ? heps * s : -heps * s;
-      if (ok) ld[i][r] += lj;
+      if (!MID) { if (ok) ld[i][r] += lj; }
       const double es = exp_bf(lj), eq = exp_bf(eps * q);
       double vr = vv[slot][r].x, vi = vv[slot][r].y;
       const double fr0 = ff[slot][r].x, fi0 = ff[slot][r].y;
@@ -835,10 +843,12 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
         else { vr = es * (vr + heps * fr); vi = es * (vi + heps * fi); }
       }
       if (PAIR) {
+        if (MID) { m1[r] = ok ? lj : 0.0; mk[r] = ok ? fma(vr, vr, vi * vi) : 0.0; }
         if (a.flip) { vr = -vr; vi = -vi; }
         const double h2 = 0.5 * a.eps2;
         const double lj2 = a.fwd2 ? h2 * s : -h2 * s;
-        if (ok) ld[i][r] += lj2;
+        if (!MID) { if (ok) ld[i][r] += lj2; }
+        else m2[r] = ok ? lj + lj2 : 0.0;
         const double es2 = exp_bf(lj2), eq2 = exp_bf(a.eps2 * q);
         const double fr = fr0 * eq2 + t, fi = fi0 * eq2;
         if (a.fwd2) { vr = es2 * vr - h2 * fr; vi = es2 * vi - h2 * fi; }
@@ -849,7 +859,26 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
         else a.v[o] = vr;
       }
     }
+    if (PAIR && MID) {
+      // row partials of this batch over the 16 column lanes; partial column = (tile, wave half, j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double x1 = m1[r], x2 = m2[r], xk = mk[r];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+          x1 += __shfl_xor(x1, off, 64); x2 += __shfl_xor(x2, off, 64); xk += __shfl_xor(xk, off, 64);
+        }
+        const long m = m0 + wm + 16 * i + Mfma<double>::row(lane, r);
+        if ((lane & 15) == 0 && m < a.M) {
+          const long col = (n0 / BN) * 4 + (wave & 1) * 2 + j;
+          a.logdet_part[m * a.ncols_part + col] = x2;
+          a.ld1_part[m * a.ncols_part + col] = x1;
+          a.ke_part[m * a.ncols_part + col] = xk;
+        }
+      }
+    }
   }
+  if (PAIR && MID) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1205,7 +1234,8 @@ int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long 
 
 size_t l2q_vnet_heads_ws_bytes(int M, long N) {
   if (M <= 0 || N <= 0) return 0;
-  return (size_t)M * (size_t)(cdiv(N, kHeadsBN) * 2) * sizeof(double) + 256;
+  // (three partial arrays of 4 columns per tile for the pair kernel with mid-point outputs)
+  return (size_t)M * (size_t)(cdiv(N, kHeadsBN) * 4) * 3 * sizeof(double) + 256;
 }
 
 static int heads_launch(const double* Z, int M, int K, long N, const double* Ws, const double* bs,
@@ -1213,7 +1243,8 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
                         double scale_t, const double* Wq, const double* bq, const double* cq,
                         double scale_q, void* v, const void* force, int is_complex, double eps,
                         int forward, int pair, double eps2, int forward2, int flip,
-                        double* logdet, void* ws, size_t ws_bytes, void* stream) {
+                        double* logdet, void* ws, size_t ws_bytes, void* stream,
+                        double* logdet1 = nullptr, double* vnorm2_mid = nullptr) {
   L2Q_REQUIRE(Z && Ws && bs && Wt && bt && Wq && bq && v && force && logdet && ws, L2Q_EINVAL,
               "null pointer");
   L2Q_REQUIRE(M > 0 && K > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
@@ -1222,20 +1253,25 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
   L2Q_REQUIRE(al(Z) && al(Ws) && al(Wt) && al(Wq) && al(v) && al(force), L2Q_ESHAPE,
               "operands must be 16-byte aligned");
   const long ntile = cdiv(N, kHeadsBN), mtile = cdiv(M, 64);
-  const int ncols = (int)(ntile * 2);
-  L2Q_REQUIRE(ws_bytes >= (size_t)M * ncols * sizeof(double), L2Q_ESHAPE, "workspace too small");
+  const bool mid = logdet1 != nullptr;
+  L2Q_REQUIRE(!mid || (pair && vnorm2_mid), L2Q_EINVAL, "mid-point outputs belong to the pair kernel");
+  const int ncols = (int)(ntile * (mid ? 4 : 2));
+  L2Q_REQUIRE(ws_bytes >= (size_t)M * ncols * (mid ? 3 : 1) * sizeof(double), L2Q_ESHAPE,
+              "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   HeadsArgs a;
   a.Z = Z; a.W[0] = Ws; a.W[1] = Wt; a.W[2] = Wq; a.b[0] = bs; a.b[1] = bt; a.b[2] = bq;
   a.cs = cs; a.cq = cq; a.ss = scale_s; a.st = scale_t; a.sq = scale_q; a.eps = eps;
   a.eps2 = eps2; a.fwd2 = forward2; a.flip = flip;
   a.v = (double*)v; a.F = (const double*)force; a.logdet_part = (double*)ws;
+  a.ld1_part = (double*)ws + (size_t)M * ncols;
+  a.ke_part = (double*)ws + 2 * (size_t)M * ncols;
   a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncols;
   const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
   const int swz = tuning().xcd_swizzle;
   const int stg = tuning().heads_stagger;
   // partial columns of wave tiles that fall entirely beyond N are never written: clear first
-  (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * sizeof(double), st);
+  (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * (mid ? 3 : 1) * sizeof(double), st);
   // LDS-DMA kernel whenever the K-slabs are whole (tuning heads_dma = 0 keeps the older kernel)
   const bool dma = tuning().heads_dma && (K % BK == 0) && K >= BK && K <= (1 << 20);
 #define L2Q_HEADS(C, F, P)                                                                      \
@@ -1243,7 +1279,14 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
     if (dma) hipLaunchKernelGGL((fused_heads_dma_kernel<C, F, P>), grid, block, 0, st, a, swz); \
     else hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz, stg); \
   } while (0)
-  if (pair) {
+  if (mid) {
+    L2Q_REQUIRE(dma, L2Q_ESHAPE, "mid-point outputs need the LDS-DMA kernel (K % 16 == 0)");
+#define L2Q_HEADS_MID(C, F) \
+  hipLaunchKernelGGL((fused_heads_dma_kernel<C, F, true, true>), grid, block, 0, st, a, swz)
+    if (is_complex) { if (forward) L2Q_HEADS_MID(true, true); else L2Q_HEADS_MID(true, false); }
+    else { if (forward) L2Q_HEADS_MID(false, true); else L2Q_HEADS_MID(false, false); }
+#undef L2Q_HEADS_MID
+  } else if (pair) {
     if (is_complex) { if (forward) L2Q_HEADS(true, true, true); else L2Q_HEADS(true, false, true); }
     else { if (forward) L2Q_HEADS(false, true, true); else L2Q_HEADS(false, false, true); }
   } else {
@@ -1252,6 +1295,10 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
   }
 #undef L2Q_HEADS
   launch_finalize((const double*)ws, logdet, M, ncols, 1, 1.0, 0.0, st);
+  if (mid) {
+    launch_finalize(a.ld1_part, logdet1, M, ncols, 1, 1.0, 0.0, st);
+    launch_finalize(a.ke_part, vnorm2_mid, M, ncols, 1, 1.0, 0.0, st);
+  }
   return check_launch("l2q_vnet_heads_vupdate_f64");
 }
 
@@ -1277,6 +1324,20 @@ int l2q_vnet_heads_vupdate_pair_f64(const double* Z, int M, int K, long N, const
   return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v,
                       force, is_complex, eps1, forward1, 1, eps2, forward2, flip_between, logdet,
                       ws, ws_bytes, stream);
+}
+
+int l2q_vnet_heads_vupdate_pair_mid_f64(const double* Z, int M, int K, long N, const double* Ws,
+                                        const double* bs, const double* cs, double scale_s,
+                                        const double* Wt, const double* bt, double scale_t,
+                                        const double* Wq, const double* bq, const double* cq,
+                                        double scale_q, void* v, const void* force, int is_complex,
+                                        double eps1, int forward1, int flip_between, double eps2,
+                                        int forward2, double* logdet, double* logdet1,
+                                        double* vnorm2_mid, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(logdet1 && vnorm2_mid, L2Q_EINVAL, "null pointer");
+  return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v,
+                      force, is_complex, eps1, forward1, 1, eps2, forward2, flip_between, logdet,
+                      ws, ws_bytes, stream, logdet1, vnorm2_mid);
 }
 
 }  // extern "C"

@@ -452,6 +452,26 @@ def vnet_heads_vupdate_pair_(z: torch.Tensor, heads: dict, scales, v: torch.Tens
     return logdet
 
 
+def vnet_heads_vupdate_pair_mid_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
+                                 force: torch.Tensor, eps1: float, forward1: bool, flip: bool,
+                                 eps2: float, forward2: bool):
+    """vnet_heads_vupdate_pair_ that also returns what per-step metrics need of the momentum between
+    the two updates: (logdet_sum, logdet_first, sum |v_mid|^2), each [nb]
+    (include/l2q.h: l2q_vnet_heads_vupdate_pair_mid_f64; needs K % 16 == 0)."""
+    m, k = z.shape
+    ws_, bs, cs = heads['s']
+    wt, bt, _ = heads['t']
+    wq, bq, cq = heads['q']
+    n = ws_.shape[0]
+    out = torch.empty((3, m), dtype=torch.float64, device=z.device)
+    ws = N.workspace(int(N.load().l2q_vnet_heads_ws_bytes(m, n)), z.device)
+    N.call('l2q_vnet_heads_vupdate_pair_mid_f64', z, m, k, n, ws_, bs, cs, float(scales[0]), wt, bt,
+           float(scales[1]), wq, bq, cq, float(scales[2]), v, force, int(v.is_complex()),
+           float(eps1), int(forward1), int(flip), float(eps2), int(forward2), out[0], out[1], out[2],
+           ws, ws.numel())
+    return out[0], out[1], out[2]
+
+
 # ---------------------------------------------------------------------------- U(1)
 def u1_plaq_sums(x: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
     """[nb, 3]: sum cos(theta), sum sin(theta), sum project_angle(theta)."""

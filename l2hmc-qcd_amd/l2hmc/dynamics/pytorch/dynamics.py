@@ -227,6 +227,7 @@ class Dynamics(nn.Module):
         self._eps_cache: dict = {}
         self._masks_native: Optional[list] = None
         self._perm: dict = {}
+        self.pair_v_updates_verbose = True     # verbose=True also pairs adjacent v-updates (mid-point kernel)
 
     # ------------------------------------------------------------------ construction
     def set_net_precision(self, precision) -> None:
@@ -608,17 +609,33 @@ class Dynamics(nn.Module):
 
     def _update_v_pair_n(self, step0: int, forward0: bool, flip: bool, step1: int,
                          forward1: bool, xn: Tensor, vn: Tensor, beta,
-                         cache: Optional[dict] = None) -> Tensor:
+                         cache: Optional[dict] = None, mid: Optional[dict] = None) -> Tensor:
         """The closing v-update of one leapfrog step and the opening v-update of the next (same
         x, same network => same s, t, q), optionally with the merged trajectory's v -> -v in
-        between (dynamics.py:1001), from ONE evaluation of the heads.  Sum of both logdets."""
+        between (dynamics.py:1001), from ONE evaluation of the heads.  Sum of both logdets.
+        With `mid` (per-step metrics, verbose=True): the kernel also returns the first update's
+        logdet and the kinetic energy of the momentum between the two updates; they are left in
+        mid['ld1'] / mid['ke'] and the return value is the SECOND update's logdet alone."""
         nb = xn.shape[0]
         vnet = self._get_vnet(step1)
         fn, z, w = self._v_inputs_n(vnet, xn, beta, cache)
-        return ops.vnet_heads_vupdate_pair_(
-            z, w['heads_scaled'], (vnet.nw.s, vnet.nw.t, vnet.nw.q), vn.reshape(nb, -1),
-            fn.reshape(nb, -1), self._eps('v', step0), forward0, flip, self._eps('v', step1),
-            forward1)
+        args = (z, w['heads_scaled'], (vnet.nw.s, vnet.nw.t, vnet.nw.q), vn.reshape(nb, -1),
+                fn.reshape(nb, -1), self._eps('v', step0), forward0, flip, self._eps('v', step1),
+                forward1)
+        if mid is None:
+            return ops.vnet_heads_vupdate_pair_(*args)
+        ld, ld1, vn2 = ops.vnet_heads_vupdate_pair_mid_(*args)
+        mid['ld1'] = ld1
+        # group/su3/pytorch/group.py:125-126 as l2q_su3_kinetic_reduce evaluates it
+        mid['ke'] = 0.5 * (vn2 - 8.0 * 4.0 * self.volume)
+        return ld - ld1
+
+    def _can_pair_mid(self) -> bool:
+        """The mid-point pair kernel (LDS-DMA heads kernel) needs whole 16-wide K-slabs."""
+        if self.group != 'SU3' or not self._networks_built:
+            return False
+        return all(int(self._get_vnet(st).units[-1]) % 16 == 0
+                   for st in range(self.config.nleapfrog))
 
     def _update_x_n(self, step: int, xn: Tensor, vn: Tensor, mask: Tensor, complement: bool,
                     forward: bool, first: bool, acc: Optional[Tensor] = None) -> Optional[Tensor]:
@@ -655,12 +672,15 @@ class Dynamics(nn.Module):
         return vn.neg_()
 
     def _lf_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
-              cache: Optional[dict] = None, pend: Optional[dict] = None) -> Tensor:
+              cache: Optional[dict] = None, pend: Optional[dict] = None,
+              mid: Optional[dict] = None) -> Tensor:
         """One generalised leapfrog step in place; returns logdet [nb]
         (dynamics.py:1187-1228).  `pend` (optional, trajectory-local) enables deferral of the
         closing v-update: it is then executed together with the next step's opening v-update
         (`_update_v_pair_n`), its logdet being returned by that next call; the caller flushes
-        a last pending update with `_flush_pending_n`."""
+        a last pending update with `_flush_pending_n`.  `mid` (with `pend`, per-step metrics):
+        the deferred closing update's logdet and the kinetic energy right after it are left in
+        mid['ld1'] / mid['ke'], and the returned logdet covers THIS step's sub-updates only."""
         if forward:
             st, order = step, ((False, True), (True, False))     # (complement, first)
         else:
@@ -686,12 +706,15 @@ class Dynamics(nn.Module):
             st0, f0, flip = prev
             v0, v1 = self._get_vnet(st0), self._get_vnet(st)
             if v0 is v1 and self._can_fuse_heads(v1):
-                ld = self._update_v_pair_n(st0, f0, flip, st, forward, xn, vn, beta, cache)
+                ld = self._update_v_pair_n(st0, f0, flip, st, forward, xn, vn, beta, cache, mid)
             else:
                 ld = self._update_v_n(st0, xn, vn, beta, f0, cache)
+                if mid is not None:
+                    mid['ld1'], mid['ke'] = ld, self._kinetic_n(vn)
                 if flip:
                     self._flip_v_n(vn)
-                ld = ld + self._update_v_n(st, xn, vn, beta, forward, cache)
+                l1 = self._update_v_n(st, xn, vn, beta, forward, cache)
+                ld = l1 if mid is not None else ld + l1
         else:
             ld = self._update_v_n(st, xn, vn, beta, forward, cache)
         if self.group == 'SU3' and self.fuse_x_updates:
@@ -939,11 +962,40 @@ class Dynamics(nn.Module):
             self.update_history(m, history)
         h = h_init
         cache = {} if self.reuse_v_inputs else None
-        # per-step metrics need v between the paired updates -> pairing only when not verbose
-        pend = {} if (self.pair_v_updates and not verbose and cache is not None
-                      and self.group == 'SU3' and self._networks_built) else None
-        for step in range(self.config.nleapfrog):
-            logdet = self._lf_n(step, x_, v_, beta, True, cache, pend)
+        can_pair = (self.pair_v_updates and cache is not None and self.group == 'SU3'
+                    and self._networks_built)
+        # per-step metrics need the state between the paired updates: with verbose=True the pair
+        # kernel returns the first update's logdet and the kinetic energy after it (`mid`), and
+        # the metrics of a step are emitted once its closing update has run (one call later)
+        vpair = verbose and can_pair and self.pair_v_updates_verbose and self._can_pair_mid()
+        pend = {} if (can_pair and (not verbose or vpair)) else None
+        nlf = self.config.nleapfrog
+        deferred: Optional[dict] = None
+
+        def emit(d, ke):
+            energy = ke + d['pe']
+            if d['fwd']:
+                extras = {'sldf': sldf, 'sldb': sldb, 'sld': sumlogdet}
+            else:
+                extras = {'sldf': torch.zeros_like(sldb), 'sldb': sldb, 'sld': sumlogdet}
+            mt = {'energy': energy, 'logprob': energy - sumlogdet, 'logdet': sumlogdet}
+            mt.update(extras)
+            mt.update({'xeps': self.xeps[d['step']], 'veps': self.veps[d['step']]})
+            self.update_history(mt, history)
+            return energy
+
+        for step in range(nlf):
+            mid = {} if vpair else None
+            logdet = self._lf_n(step, x_, v_, beta, True, cache, pend, mid)
+            if vpair:
+                if deferred is not None:               # the previous step's closing update ran now
+                    sumlogdet = sumlogdet + mid['ld1']
+                    sldf = sldf + mid['ld1']
+                    emit(deferred, mid['ke'])
+                sumlogdet = sumlogdet + logdet
+                sldf = sldf + logdet
+                deferred = {'pe': self._potential_n(x_, beta), 'step': step, 'fwd': True}
+                continue
             sumlogdet = sumlogdet + logdet
             if verbose:
                 sldf = sldf + logdet
@@ -955,8 +1007,21 @@ class Dynamics(nn.Module):
             pend['p'] = (st0, f0, True)                # flip happens inside the paired kernel
         else:
             v_ = self._flip_v_n(v_)
-        for step in range(self.config.nleapfrog):
-            logdet = self._lf_n(step, x_, v_, beta, False, cache, pend)
+        for step in range(nlf):
+            mid = {} if vpair else None
+            logdet = self._lf_n(step, x_, v_, beta, False, cache, pend, mid)
+            if vpair:
+                if deferred is not None:
+                    sumlogdet = sumlogdet + mid['ld1']
+                    if deferred['fwd']:
+                        sldf = sldf + mid['ld1']
+                    else:
+                        sldb = sldb + mid['ld1']
+                    emit(deferred, mid['ke'])
+                sumlogdet = sumlogdet + logdet
+                sldb = sldb + logdet
+                deferred = {'pe': self._potential_n(x_, beta), 'step': nlf - step - 1, 'fwd': False}
+                continue
             sumlogdet = sumlogdet + logdet
             if verbose:
                 sldb = sldb + logdet
@@ -968,6 +1033,13 @@ class Dynamics(nn.Module):
         last = self._flush_pending_n(pend, x_, v_, beta, cache)
         if last is not None:
             sumlogdet = sumlogdet + last
+        if vpair and deferred is not None:
+            if last is not None:
+                if deferred['fwd']:
+                    sldf = sldf + last
+                else:
+                    sldb = sldb + last
+            h = emit(deferred, self._kinetic_n(v_))
         if not verbose or self.config.nleapfrog == 0:
             h = self._hamiltonian_n(x_, v_, beta)
         acc = self._accept_prob_n(h_init, h, sumlogdet)

@@ -352,6 +352,18 @@ def test_fused_heads_vupdate(ops, cplx, shape):
                 vb = v.clone()
                 lb = ops.vnet_heads_vupdate_pair_(z, scaled, nw, vb, f, 0.07, fwd, flip, 0.05, fwd2)
                 assert float((va - vb).abs().max()) < 1e-13 and err(host(la), host(lb)) < 1e-11
+                if k % 16 == 0:
+                    # pair kernel with the mid-point outputs per-step metrics need (verbose=True):
+                    # logdet of the first update alone, sum |v|^2 between the two updates
+                    vm = v.clone()
+                    l1 = ops.vnet_heads_vupdate_(z, scaled, nw, vm, f, 0.07, fwd)
+                    n2 = host((vm.abs() ** 2).sum(1))
+                    vc = v.clone()
+                    lc, lc1, nc2 = ops.vnet_heads_vupdate_pair_mid_(z, scaled, nw, vc, f, 0.07, fwd,
+                                                                     flip, 0.05, fwd2)
+                    assert float((va - vc).abs().max()) < 1e-13
+                    assert err(host(lc), host(la)) < 1e-11 and err(host(lc1), host(l1)) < 1e-11
+                    assert err(host(nc2), n2) < 1e-12 * max(1.0, float(np.abs(n2).max()))
 
 
 @pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
