@@ -136,6 +136,22 @@ def test_cfg4_trajectory_8x4_units256():
             assert m['energy'].shape == (2 * nlf + 1, nb)
             assert np.abs(host(m['energy']) - mo['energy']).max() < 1e-5  # |H| ~ 2.6e2
             assert np.abs(host(m['logdet']) - mo['logdet']).max() < 1e-6
+    # verbose=True with and without the mid-point pair kernel (9 vs 16 heads kernels): the same
+    # per-step history (energy, logdet, forward / backward partial sums) to rounding
+    hist = {}
+    for pv in (True, False):
+        dyn.config.verbose = True
+        dyn.pair_v_updates_verbose = pv
+        dyn._inject = {'normals': nrm, 'u': u}
+        xo_v, m_v = dyn((dev(x), torch.tensor(beta)))
+        hist[pv] = {k: host(m_v[k]) for k in ('energy', 'logprob', 'logdet', 'sldf', 'sldb', 'sld', 'acc')}
+        hist[pv]['x'] = host(xo_v)
+    dyn.pair_v_updates_verbose = True
+    dyn.config.verbose = False
+    for k, a in hist[True].items():
+        b = hist[False][k]
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), (k, np.abs(a - b).max())
     # observables of the output configuration through the slice-resident plaquette kernel
     from oracle import su3 as osu3
     met = lat.calc_metrics(xo.reshape(x.shape))
