@@ -14,7 +14,9 @@ struct Tuning {
   int plaq_occ = 2;
   int force_occ = 2;
   int xcd_swizzle = 1;
-  int plaq_sweep = 2;     // 2: slice-resident kernel (LDS + register prefetch), 1: L2 t-sweep, 0: flat
+  int plaq_sweep = 2;     // 2: slice-resident thread-per-site kernel (LDS + register prefetch), 3: slice-resident
+                          // with the six planes split over wavefronts (su3_plaq_nu.hip; measured slower),
+                          // 1: L2 t-sweep, 0: flat
   int heads_dma = 1;      // heads + v-update: LDS-DMA staged kernel (0: register-staged kernel of round 1)
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
   int force_tile = 4;     // 4: slice-resident, staples split by plane over wavefronts (su3_force_nu.hip), 3: rows

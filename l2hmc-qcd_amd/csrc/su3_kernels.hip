@@ -940,6 +940,9 @@ int force_rows_inmask(const Dims& d);
 // su3_force_nu.hip
 bool force_nu_applicable(const Dims& d);
 int force_nu_inmask(const Dims& d);
+bool plaq_nu_applicable(const Dims& d);
+long plaq_nu_per_chain(const Dims& d, int nb);
+void launch_plaq_nu(const double2* xn, Dims d, int nb, double* partial, hipStream_t st);
 void launch_force_nu(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
                      hipStream_t st);
 void launch_force_rows(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
@@ -1025,7 +1028,10 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
   const Tuning& t = tuning();
   buf[0] = 0;
   if (!strcmp(entry, "l2q_su3_plaq_reduce")) {
-    if (t.plaq_sweep == 2 && Vs % kSlice == 0)
+    const Dims dq{T, X, Y, Z, T * X * Y * Z};
+    if (t.plaq_sweep == 3 && plaq_nu_applicable(dq))
+      snprintf(buf, buf_bytes, "su3_plaq_nu_kernel<%d>", force_nu_inmask(dq));
+    else if (t.plaq_sweep >= 2 && Vs % kSlice == 0)
       snprintf(buf, buf_bytes, "su3_plaq_slice_kernel<%s>", (kSlice % (Y * Z)) == 0 ? "true" : "false");
     else if (t.plaq_sweep == 1) snprintf(buf, buf_bytes, "su3_plaq_sweep_kernel<%d>", t.plaq_occ);
     else snprintf(buf, buf_bytes, "su3_plaq_kernel<%d>", t.plaq_occ);
@@ -1065,7 +1071,16 @@ int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, doub
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)ws;
   const int swz = tuning().xcd_swizzle;
-  if (tuning().plaq_sweep == 2 && (X * Y * Z) % kSlice == 0) {
+  if (tuning().plaq_sweep == 3 && plaq_nu_applicable(d)) {
+    // six planes of a site over six wavefronts, 3 wavefronts per SIMD (su3_plaq_nu.hip)
+    const long per_chain = plaq_nu_per_chain(d, nb);
+    L2Q_REQUIRE(ws_bytes >= (size_t)nb * per_chain * 2 * sizeof(double), L2Q_ESHAPE,
+                "workspace too small");
+    launch_plaq_nu((const double2*)xn, d, nb, partial, st);
+    launch_finalize(partial, out, nb, per_chain, 2, 1.0, 0.0, st);
+    return check_launch("l2q_su3_plaq_reduce");
+  }
+  if (tuning().plaq_sweep >= 2 && (X * Y * Z) % kSlice == 0) {
     const int Vs = X * Y * Z;
     const int nsb = Vs / kSlice;
     int tsplit = (int)cdiv(1024, (long)nb * nsb);      // keep >= ~1024 workgroups
