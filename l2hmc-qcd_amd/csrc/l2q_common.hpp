@@ -19,7 +19,8 @@ struct Tuning {
                           // 1: L2 t-sweep, 0: flat
   int heads_dma = 1;      // heads + v-update: LDS-DMA staged kernel (0: register-staged kernel of round 1)
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
-  int force_tile = 4;     // 4: slice-resident, staples split by plane over wavefronts (su3_force_nu.hip), 3: rows
+  int force_tile = 5;     // 5: slice-resident thread-per-link, streamed factors, 2 workgroups / CU
+                          // (su3_force_link.hip), 4: staples split by plane over wavefronts (su3_force_nu.hip), 3: rows
                           // split over wavefronts (su3_force_rows.hip), 2: slice-resident
                           // thread-per-link, 1: LDS-tiled (64 sites x 4 mu), 0: flat
   int u1_fused_ch = 0;    // chains per workgroup of the fused U(1) kernels (0: auto; 1, 2, 4, 8)

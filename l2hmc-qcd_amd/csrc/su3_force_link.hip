@@ -9,12 +9,23 @@
 // wavefront owns direction mu of the tile's 64 sites and walks the three planes of mu itself.
 // With the right-hand factors streamed (live set: acc, t, a = three 36-VGPR matrices + one row)
 // plus the carried t-staple and the 9-entry prefetch of the thread's own link, a thread needs
-// ~210 registers: TWO wavefronts per SIMD -- what the round-1 thread-per-link kernel could not
-// reach because hipcc kept ~100 64-bit addresses alive (here: su3_force_tile.hpp addressing,
-// direction / tile residency as template parameters).  A workgroup is 64 sites x 4 directions =
+// 210-246 registers: TWO wavefronts per SIMD.  A workgroup is 64 sites x 4 directions =
 // 4 wavefronts and 63 KiB of LDS (spatial links of the current and next slice, t-links of the
 // current slice), so TWO workgroups share a CU and one runs while the other sits at its slice
 // barrier; there is no exchange buffer, no finishing wavefront and no third party to wait for.
+//
+// What makes it compile: hipcc schedules an unrolled straight-line chain of 3x3 fp64 products
+// with a live set far above what the data flow needs (this kernel spilled 146-431 VGPRs at the
+// 256-register budget; sched_barrier / memory fences between the staples change nothing).  Here
+// EVERY staple sits inside its own `if (it >= c.lo)`, where `lo` (= 1: the kernel's `it > 0`
+// test) arrives as a kernel ARGUMENT: the compiler can neither fold the conditions nor merge the
+// blocks, each block is allocated on its own, and the result is 0 spilled registers.
+// (A struct field set from a template constant does not do: it is folded after inlining.)
+//
+// MI355X, cfg-4 (8^4 x 256 chains): plain force 0.39-0.41 ms (0.37-0.39 of the 8 TB/s roofline; the
+// plane-split kernel su3_force_nu.hip: 0.43-0.45 ms), fused kick 0.51 ms (0.44; 0.61 ms);
+// 16^4 x 64 chains: 1.89 / 2.39 ms (2.11 / 2.79 ms).  Results are bit-identical to the thread-per-link
+// slice kernel (same operation order per link).
 #include "su3_force_tile.hpp"
 
 namespace l2q {
@@ -36,6 +47,7 @@ struct LkCtx {
   int V16, Vs16, tile0b, lt, t0, t1;
   int sp, px, py, pz;
   double coef;
+  int lo;        // = 1, a kernel ARGUMENT: `it >= lo` is the `it > 0` test hipcc cannot fold or merge
 };
 
 __host__ __device__ constexpr int lk_other(int mu, int j) { return j + (j >= mu ? 1 : 0); }
@@ -110,16 +122,19 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
     M3 acc;
     m3_zero(acc);
     if constexpr (MU == 0) {
-      if (it > 0) {
+      if (it >= c.lo) {
 #pragma unroll
         for (int nu = 1; nu < 4; ++nu) {
           M3 a, t;
+          if (it >= c.lo) {
           // up:   U_nu(s+t) U_t(s+nu)^H U_nu(s)^H
           ld_m(a, on(nu, q_sp), rs, V16);
           if (lk_in<INM>(nu)) mul_xh_stream<false>(t, a, oc(0, q_pp[nu]), rs, V16);
           else mul_xh_stream<false>(t, a, gco(0, q_pp[nu]), rs, V16);
           mac_stream<true>(acc, t, oc(nu, q_sp), rs, V16);
+          }
           L2Q_LK_FENCE();
+          if (it < c.lo) continue;
           // down: U_nu(s+t-nu)^H U_t(s-nu)^H U_nu(s-nu)
           if (lk_in<INM>(nu)) {
             ld_m(a, on(nu, q_pm[nu]), rs, V16);
@@ -140,7 +155,7 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
         M3 a, t;
         if (IN_MU) ld_m(a, oc(0, q_pmu), rs, V16);            // U_t(tcur, s+mu): both staples
         else ld_m(a, gco(0, q_pmu), rs, V16);
-        if (it > 0) {
+        if (it >= c.lo) {
           acc = carry;
           // up: U_t(s+mu) U_mu(s+t)^H U_t(s)^H
           mul_xh_stream<false>(t, a, on(MU, q_sp), rs, V16);
@@ -155,18 +170,21 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
           L2Q_LK_FENCE();
         }
       }
-      if (it > 0) {
+      if (it >= c.lo) {
 #pragma unroll
         for (int nu = 1; nu < 4; ++nu) {
           if (nu == MU) continue;
           M3 a, t;
+          if (it >= c.lo) {
           // up:   U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H
           if (IN_MU) ld_m(a, oc(nu, q_pmu), rs, V16);
           else ld_m(a, gco(nu, q_pmu), rs, V16);
           if (lk_in<INM>(nu)) mul_xh_stream<false>(t, a, oc(MU, q_pp[nu]), rs, V16);
           else mul_xh_stream<false>(t, a, gco(MU, q_pp[nu]), rs, V16);
           mac_stream<true>(acc, t, oc(nu, q_sp), rs, V16);
+          }
           L2Q_LK_FENCE();
+          if (it < c.lo) continue;
           // down: U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu)
           if (IN_MU && lk_in<INM>(nu)) ld_m(a, oc(nu, q_pmm[nu]), rs, V16);
           else ld_m(a, gco(nu, q_pmm[nu]), rs, V16);
@@ -182,7 +200,7 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
         }
       }
     }
-    if (it > 0) {
+    if (it >= c.lo) {
       // W = U A with U streamed by rows from the tile; F = (W - W^H)/2 - tr(W - W^H)/6
       // (group/su3/pytorch/group.py:92-103), formed entry by entry at the store
       M3 ua;
@@ -234,7 +252,7 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
 template <int MODE, int INM>
 __global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
     const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
-    double2* __restrict__ out) {
+    double2* __restrict__ out, int lo) {
   const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
   const int per_chain = nsb * tsplit;
   const long c = w / per_chain;
@@ -262,6 +280,7 @@ __global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
     k.px = q;
   }
   k.coef = coef;
+  k.lo = lo;
   switch (wv) {
     case 0: force_link_sweep<MODE, 0, INM>(k); break;
     case 1: force_link_sweep<MODE, 1, INM>(k); break;
@@ -280,7 +299,7 @@ static void launch_link_variant(const double2* xn, Dims d, int nb, int nsb, int 
     attr_set = true;
   }
   hipLaunchKernelGGL((su3_force_link_kernel<MODE, INM>), dim3((unsigned)((long)nb * nsb * tsplit)),
-                     dim3(kLkThreads), kLkLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, out);
+                     dim3(kLkThreads), kLkLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, out, 1);
 }
 
 int force_link_inmask(const Dims& d) {

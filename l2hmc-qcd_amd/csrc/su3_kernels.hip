@@ -947,6 +947,11 @@ void launch_force_nu(bool kick, const double2* xn, Dims d, int nb, double coef, 
                      hipStream_t st);
 void launch_force_rows(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
                        hipStream_t st);
+// su3_force_link.hip
+bool force_link_applicable(const Dims& d);
+int force_link_inmask(const Dims& d);
+void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
+                       hipStream_t st);
 }  // namespace l2q
 
 using namespace l2q;
@@ -969,7 +974,11 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
   constexpr int kFS = KICK ? kFSKick : kFSPlain;
   constexpr int kVar = KICK ? 2 : 0;
   constexpr int kLpt = KICK ? 1 : kLptPlain;
-  if (tuning().force_tile == 4 && force_nu_applicable(d) && nu_preferred<KICK>(d)) {
+  if (tuning().force_tile == 5 && force_link_applicable(d)) {
+    launch_force_link(KICK, xn, d, nb, coef, out, st);
+    return;
+  }
+  if (tuning().force_tile >= 4 && force_nu_applicable(d) && nu_preferred<KICK>(d)) {
     launch_force_nu(KICK, xn, d, nb, coef, out, st);
     return;
   }
@@ -1039,7 +1048,9 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
     const bool kick = !strcmp(entry, "l2q_su3_force_kick");
     const int fs = kick ? kFSKick : kFSPlain;
     const Dims dd{T, X, Y, Z, T * X * Y * Z};
-    if (t.force_tile == 4 && force_nu_applicable(dd) && (kick ? nu_preferred<true>(dd) : nu_preferred<false>(dd)))
+    if (t.force_tile == 5 && force_link_applicable(dd))
+      snprintf(buf, buf_bytes, "su3_force_link_kernel<%d, %d>", kick ? 1 : 0, force_link_inmask(dd));
+    else if (t.force_tile >= 4 && force_nu_applicable(dd) && (kick ? nu_preferred<true>(dd) : nu_preferred<false>(dd)))
       snprintf(buf, buf_bytes, "su3_force_nu_kernel<%d, %d>", kick ? 1 : 0, force_nu_inmask(dd));
     else if (t.force_tile == 3 && Vs % 64 == 0)
       snprintf(buf, buf_bytes, "su3_force_rows_kernel<%d, %d>", kick ? 1 : 0, force_rows_inmask(Dims{T, X, Y, Z, T * X * Y * Z}));

@@ -111,20 +111,22 @@ def test_su3_stencils_vs_oracle(ops, L):
     from l2hmc import native
     # every kernel variant (register budget, flat vs t-sweep plaquette, flat vs LDS-tiled
     # force, with / without the XCD remap) must give the same numbers
-    # (force_tile 3 = rows split over wavefronts, su3_force_rows.hip: the lattices above cover its
+    # (force_tile 5 = thread per link with streamed factors, su3_force_link.hip; plaq_sweep 3 = planes
+    # over wavefronts, su3_plaq_nu.hip;
+    # force_tile 3 = rows split over wavefronts, su3_force_rows.hip: the lattices above cover its
     # four tile-residency specialisations -- Z | 64, Y Z | 64, X Y Z | 64, none -- and T = 1)
     for occ in (2, 3, 4):
-        for variant in (0, 1, 2, 3, 4):
+        for variant in (0, 1, 2, 3, 4, 5):
             for swz in (0, 1):
                 native.set_tuning('force_occ', occ); native.set_tuning('plaq_occ', occ)
-                native.set_tuning('plaq_sweep', min(variant, 2)); native.set_tuning('force_tile', variant)
+                native.set_tuning('plaq_sweep', min(variant, 3)); native.set_tuning('force_tile', variant)
                 native.set_tuning('xcd_swizzle', swz)
                 assert err(host(ops.su3_plaq_sums_n(xn, L)), s) < 1e-10
                 assert err(host(ops.su3_unpack(ops.su3_force_n(xn, 5.7, L), L)), f) < 1e-13
                 v = xn.clone()
                 ops.su3_force_kick_n(xn, 5.7, -0.3, v, L)
                 assert err(host(ops.su3_unpack(v, L)), x - 0.3 * f) < 1e-12
-    for k, val in (('force_occ', 2), ('plaq_occ', 2), ('plaq_sweep', 2), ('force_tile', 4),
+    for k, val in (('force_occ', 2), ('plaq_occ', 2), ('plaq_sweep', 2), ('force_tile', 5),
                    ('xcd_swizzle', 1)):
         native.set_tuning(k, val)
 

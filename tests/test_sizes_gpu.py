@@ -164,17 +164,17 @@ def test_cfg4_trajectory_8x4_units256():
     f_ref = osu3.grad_action(x, beta)
     from l2hmc import native
     try:
-        for ft in (4, 3, 2, 1, 0):
+        for ft in (5, 4, 3, 2, 1, 0):
             native.set_tuning('force_tile', ft)
             f = ops.su3_unpack(ops.su3_force_n(xn, beta, L), L)
             assert np.abs(host(f) - f_ref).max() < 1e-12, ft
-        for ps in (2, 1, 0):
+        for ps in (3, 2, 1, 0):
             native.set_tuning('plaq_sweep', ps)
             s = host(ops.su3_plaq_sums_n(xn, L))
             re, im = osu3.plaq_sums(x)
             assert np.abs(s - np.stack([re, im], 1)).max() < 1e-8, ps
     finally:
-        native.set_tuning('force_tile', 4)
+        native.set_tuning('force_tile', 5)
         native.set_tuning('plaq_sweep', 2)
 
 
