@@ -32,7 +32,11 @@ namespace l2q {
 
 // keeps hipcc from starting the next staple's operand loads before the current staple's
 // arithmetic has retired its matrices (unfenced it software-pipelines across staples and spills)
+#ifdef L2Q_LK_NOFENCE
+#define L2Q_LK_FENCE() do { } while (0)
+#else
 #define L2Q_LK_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 constexpr int kLkThreads = kRS * 4;
 constexpr int kLkOffS0 = 0, kLkOffS1 = 3 * kPlaneB, kLkOffT = 6 * kPlaneB;

@@ -12,12 +12,13 @@ import sys
 ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'su3_plaq_slice_kernel': 'l2q_su3_plaq_reduce', 'su3_plaq_kernel': None, 'su3_plaq_sweep_kernel': None,
     'su3_force_slice_kernel<false': 'l2q_su3_force', 'su3_force_tile_kernel<false': None,
-    'su3_force_kernel<false': None, 'su3_force_rows_kernel<0': None, 'su3_force_nu_kernel<0': 'l2q_su3_force', 'su3_force_nu_kernel<1': 'l2q_su3_force_kick',
+    'su3_force_kernel<false': None, 'su3_force_rows_kernel<0': None, 'su3_force_nu_kernel<0': None, 'su3_force_nu_kernel<1': None,
+    'su3_force_link_kernel<0': 'l2q_su3_force', 'su3_force_link_kernel<1': 'l2q_su3_force_kick',
     'su3_force_rows_kernel<1': None,
     'su3_force_slice_kernel<true': 'l2q_su3_force_kick',
     'su3_expm_mul_kernel<true, true>': 'l2q_su3_expm_mul2_vec8',
-    'fused_heads_dma_kernel<true, true, true>': 'l2q_vnet_heads_vupdate_pair_f64',
-    'fused_heads_dma_kernel<true, true, false>': 'l2q_vnet_heads_vupdate_f64',
+    'fused_heads_dma_kernel<true, true, true, false>': 'l2q_vnet_heads_vupdate_pair_f64',
+    'fused_heads_dma_kernel<true, true, false, false>': 'l2q_vnet_heads_vupdate_f64',
     'gemm_dma_f64_kernel<false, false, false>': 'l2q_gemm_f64',
     'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_expm_mul_kernel<true, false>': 'l2q_su3_expm_mul2',
     'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
