@@ -17,7 +17,7 @@ namespace l2q {
 // forward (l2q_su3_expm_mul): x' = keep (.) x + expm(eps v) @ ((1 - keep) (.) x)
 //   g_x = keep (.) g + (1 - keep) (.) (E^H g);   g_E = g y^H,  y = (1 - keep) (.) x
 //   g_A = L_exp((eps v)^H)[g_E];  g_v += eps g_A;  d eps = sum Re tr(g_A^H v)
-__global__ __launch_bounds__(kBlock) void su3_expm_mul_bwd_kernel(
+__global__ __launch_bounds__(kBlock, 2) void su3_expm_mul_bwd_kernel(
     const double2* __restrict__ xn, const double2* __restrict__ vn, double eps,
     const float* __restrict__ mask, int complement, const double2* __restrict__ gxn, double2* gx,
     double2* gv, int V, long nblk, double* __restrict__ partial) {
@@ -27,44 +27,58 @@ __global__ __launch_bounds__(kBlock) void su3_expm_mul_bwd_kernel(
   const int mu = (int)(f & 3);
   double de = 0.0;
   if (s < V) {
-    M3 x, v, g;
-    load_link(x, xn + f * 9L * V, V, s);
-    load_link(v, vn + f * 9L * V, V, s);
-    load_link(g, gxn + f * 9L * V, V, s);
-    double keep[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    // Register budget: the Frechet derivative keeps six 3x3 matrices live (216 VGPRs); x, v, g and
+    // the mask are therefore NOT carried across it but read again afterwards (L2 hits) -- two
+    // wavefronts per SIMD instead of one.
+    auto keep_of = [&](int i) -> double {
       double k = 0.0;
       if (mask != nullptr) {
         k = (double)mask[(mu * 9 + i) * (long)V + s];
         if (complement) k = 1.0 - k;
       }
-      keep[i] = k;
-    }
-    M3 y, gE, B;
+      return k;
+    };
+    M3 gE, B;
+    {
+      M3 x, g;
+      load_link(x, xn + f * 9L * V, V, s);
+      load_link(g, gxn + f * 9L * V, V, s);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      y.re[i] = (1.0 - keep[i]) * x.re[i]; y.im[i] = (1.0 - keep[i]) * x.im[i];
-    }
-    m3_mul_na(gE, g, y);                               // g y^H
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {                    // B = (eps v)^H
-        B.re[3 * i + j] = eps * v.re[3 * j + i]; B.im[3 * i + j] = -eps * v.im[3 * j + i];
+      for (int i = 0; i < 9; ++i) {
+        const double k1 = 1.0 - keep_of(i);
+        x.re[i] *= k1; x.im[i] *= k1;                    // y = (1 - keep) (.) x
       }
+      m3_mul_na(gE, g, x);                               // g y^H
+    }
+    {
+      M3 v;
+      load_link(v, vn + f * 9L * V, V, s);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                    // B = (eps v)^H
+          B.re[3 * i + j] = eps * v.re[3 * j + i]; B.im[3 * i + j] = -eps * v.im[3 * j + i];
+        }
+    }
     M3 EB, gA;
     m3_expm_frechet(EB, gA, B, gE);                    // EB = expm(eps v)^H
-    M3 gy;
-    m3_mul_nn(gy, EB, g);                              // E^H g
-    M3 out;
+    {
+      M3 g, gy;
+      load_link(g, gxn + f * 9L * V, V, s);
+      m3_mul_nn(gy, EB, g);                              // E^H g
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      out.re[i] = keep[i] * g.re[i] + (1.0 - keep[i]) * gy.re[i];
-      out.im[i] = keep[i] * g.im[i] + (1.0 - keep[i]) * gy.im[i];
+      for (int i = 0; i < 9; ++i) {
+        const double k = keep_of(i);
+        gy.re[i] = k * g.re[i] + (1.0 - k) * gy.re[i];
+        gy.im[i] = k * g.im[i] + (1.0 - k) * gy.im[i];
+      }
+      store_link(gx + f * 9L * V, V, s, gy);
     }
-    store_link(gx + f * 9L * V, V, s, out);
-    de = m3_inner(gA, v);
+    {
+      M3 v;
+      load_link(v, vn + f * 9L * V, V, s);
+      de = m3_inner(gA, v);
+    }
     double2* gvf = gv + f * 9L * V;
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void su3_expm_mul_bwd_kernel(
 }
 
 // ------------------------------------------------------------------ projectSU -> vec8 VJP
-__global__ __launch_bounds__(kBlock) void su3_projsu_vec8_bwd_kernel(
+__global__ __launch_bounds__(kBlock, 3) void su3_projsu_vec8_bwd_kernel(
     const double2* __restrict__ in, const double* __restrict__ gvec, double2* gm, int V,
     long nblk) {
   const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;

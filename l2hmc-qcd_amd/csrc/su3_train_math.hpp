@@ -50,17 +50,46 @@ __device__ __forceinline__ void m3_expm_frechet(M3& E, M3& L, const M3& B, const
   double f = 1.0;
 #pragma unroll 1
   for (int n = 1; n <= 13; ++n) {
-    M3 t;
-    m3_mul_nn(t, M, X);
-    m3_mac_nn(t, P, Gs);
-    M = t;
-    m3_mul_nn(t, P, X);
-    P = t;
+    // M <- M X + P Gs and P <- P X, row by row IN PLACE: row i of either result depends on row i
+    // of M and P only, so a three-entry temporary replaces a full scratch matrix (six live
+    // matrices instead of seven: what takes the reverse x-update kernel from one to two
+    // wavefronts per SIMD)
     f /= (double)n;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      E.re[i] = fma(f, P.re[i], E.re[i]); E.im[i] = fma(f, P.im[i], E.im[i]);
-      L.re[i] = fma(f, M.re[i], L.re[i]); L.im[i] = fma(f, M.im[i], L.im[i]);
+    for (int i = 0; i < 3; ++i) {
+      double tr[3], ti[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          sr = fma(M.re[3 * i + k], X.re[3 * k + j], sr); sr = fma(-M.im[3 * i + k], X.im[3 * k + j], sr);
+          si = fma(M.re[3 * i + k], X.im[3 * k + j], si); si = fma(M.im[3 * i + k], X.re[3 * k + j], si);
+          sr = fma(P.re[3 * i + k], Gs.re[3 * k + j], sr); sr = fma(-P.im[3 * i + k], Gs.im[3 * k + j], sr);
+          si = fma(P.re[3 * i + k], Gs.im[3 * k + j], si); si = fma(P.im[3 * i + k], Gs.re[3 * k + j], si);
+        }
+        tr[j] = sr; ti[j] = si;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        M.re[3 * i + j] = tr[j]; M.im[3 * i + j] = ti[j];
+        L.re[3 * i + j] = fma(f, tr[j], L.re[3 * i + j]); L.im[3 * i + j] = fma(f, ti[j], L.im[3 * i + j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          sr = fma(P.re[3 * i + k], X.re[3 * k + j], sr); sr = fma(-P.im[3 * i + k], X.im[3 * k + j], sr);
+          si = fma(P.re[3 * i + k], X.im[3 * k + j], si); si = fma(P.im[3 * i + k], X.re[3 * k + j], si);
+        }
+        tr[j] = sr; ti[j] = si;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        P.re[3 * i + j] = tr[j]; P.im[3 * i + j] = ti[j];
+        E.re[3 * i + j] = fma(f, tr[j], E.re[3 * i + j]); E.im[3 * i + j] = fma(f, ti[j], E.im[3 * i + j]);
+      }
     }
   }
 #pragma unroll 1
