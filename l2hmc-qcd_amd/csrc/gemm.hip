@@ -1019,6 +1019,19 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
     if (n >= N) continue;
     T cs = (T)1, cb = (T)0;
     if (FUSED) { cs = epi.colscale((int)n); cb = epi.colbias((int)n); }
+    // accumulate (dW += ...): all sixteen previous values of this column first -- C is read and
+    // written through one pointer, element by element the loads would each wait for the
+    // previous element's store (64 dependent HBM round trips per lane)
+    T prev[4][4];
+    if (FUSED && epi.accumulate) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long m = m0 + wm + 16 * i + Mfma<T>::row(lane, r);
+          prev[i][r] = m < M ? dst[m * N + n] : (T)0;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1028,7 +1041,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
           const T v = acc[i][j][r];
           if (FUSED) {
             const T y = cs * apply_act<T>(v + cb, epi.act);
-            dst[m * N + n] = epi.accumulate ? dst[m * N + n] + y : y;
+            dst[m * N + n] = epi.accumulate ? prev[i][r] + y : y;
           } else {
             dst[m * N + n] = v;
           }

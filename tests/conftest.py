@@ -32,6 +32,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _restore_torch_state():
+    """Tests (and the Trainer, like the reference's) switch torch's default dtype and the library's
+    tuning table; put both back so that no test depends on what ran before it."""
+    import torch
+    old = torch.get_default_dtype()
+    yield
+    torch.set_default_dtype(old)
+
+
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np
