@@ -110,6 +110,46 @@ def test_su3_l2hmc_subupdates(golden):
     assert err(host(ld), g['lf_fwd_logdet']) < 1e-7
 
 
+def test_su3_native_output_cache(golden):
+    """A sampler loop feeds the returned x straight back: the second transition then starts from
+    the native original it still holds (no reference -> native transpose).  Same result as from a
+    copy of x (cache miss) and with the cache off; an in-place edit of x invalidates the entry."""
+    torch.set_default_dtype(torch.float64)
+    g = golden('su3_l2hmc')
+    dyn, lat = build_su3_dynamics(g)
+    dyn.config.verbose = False
+    beta = torch.tensor(float(g['beta']))
+
+    def two_steps(mode):
+        dyn._xcache = None
+        dyn.cache_native_output = mode != 'off'
+        dyn._inject = {'normals': g['normals'], 'u': g['u']}
+        x1, _ = dyn((dev(g['x']), beta))
+        if mode == 'copy':
+            x1 = x1.clone()
+        elif mode == 'edit':
+            x1.mul_(1.0)                                  # bumps the version counter
+        hit = dyn._xcache is not None and dyn._xcache[0] is x1 and dyn._xcache[1] == x1._version
+        dyn._inject = {'normals': g['normals'], 'u': g['u']}
+        x2, m2 = dyn((x1, beta))
+        return host(x2), host(m2['acc']), hit
+
+    ref = two_steps('hit')
+    assert ref[2]
+    for mode in ('copy', 'edit', 'off'):
+        out = two_steps(mode)
+        assert mode == 'off' or not out[2]
+        assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]), mode
+    dyn.cache_native_output = True
+    # the lazily selected output momentum equals the eager selection
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    xo, m = dyn((dev(g['x']), beta))
+    mc = m['mc_states']
+    ma = host(m['acc_mask'])[:, None]
+    want = ma * host(mc.proposed.v).reshape(ma.shape[0], -1) + (1 - ma) * host(mc.init.v).reshape(ma.shape[0], -1)
+    assert err(host(mc.out.v).reshape(ma.shape[0], -1), want) == 0.0
+
+
 def test_su3_l2hmc_trajectory(golden):
     torch.set_default_dtype(torch.float64)
     g = golden('su3_l2hmc')
