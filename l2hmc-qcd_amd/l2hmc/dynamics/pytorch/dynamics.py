@@ -915,7 +915,8 @@ class Dynamics(nn.Module):
     def _kernel_hmc_n(self, xn, vn, beta, eps=None, nleapfrog=None):
         """(dynamics.py:915-954) in place on clones; returns (x', v', history)."""
         nb = xn.shape[0]
-        x_, v_ = xn.clone(), vn.clone()
+        v_ = vn.clone()
+        x_ = None                                   # cloned below unless the first x-update can write a fresh tensor
         sumlogdet = self._zeros_nb(nb)
         history: dict = {}
         h_init = self._hamiltonian_n(xn, vn, beta)
@@ -934,16 +935,26 @@ class Dynamics(nn.Module):
             # v - (eps/2) F - (eps/2) F == v - eps F up to one rounding of v, so one force pass
             # serves both.  nleapfrog + 1 force evaluations instead of 2 nleapfrog.  Only
             # without per-step metrics (they need v at the step boundary).
-            self._kick_n(x_, v_, beta, -0.5 * eps)
+            if self.group == 'SU3':
+                # the opening kick only reads x and the first x-update writes a fresh tensor: the
+                # input configuration is never copied
+                self._kick_n(xn, v_, beta, -0.5 * eps)
+                x_ = ops.su3_expm_mul_n(xn, v_, eps)
+            else:
+                x_ = xn.clone()
+                self._kick_n(x_, v_, beta, -0.5 * eps)
+                ops.axpy_(x_.reshape(nb, -1), v_, eps)
             for i in range(nleapfrog):
-                if self.group == 'SU3':
-                    ops.su3_expm_mul_n(x_, v_, eps, out=x_)
-                else:
-                    ops.axpy_(x_.reshape(nb, -1), v_, eps)
+                if i > 0:
+                    if self.group == 'SU3':
+                        ops.su3_expm_mul_n(x_, v_, eps, out=x_)
+                    else:
+                        ops.axpy_(x_.reshape(nb, -1), v_, eps)
                 self._kick_n(x_, v_, beta, -eps if i + 1 < nleapfrog else -0.5 * eps)
             nleapfrog_done = True
         else:
             nleapfrog_done = False
+            x_ = xn.clone()
         for _ in range(0 if nleapfrog_done else nleapfrog):
             self._leapfrog_hmc_n(x_, v_, beta, eps)
             if self.config.verbose:
