@@ -686,14 +686,16 @@ class Dynamics(nn.Module):
 
     def _lf_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
               cache: Optional[dict] = None, pend: Optional[dict] = None,
-              mid: Optional[dict] = None) -> Tensor:
+              mid: Optional[dict] = None, x_src: Optional[Tensor] = None) -> Tensor:
         """One generalised leapfrog step in place; returns logdet [nb]
         (dynamics.py:1187-1228).  `pend` (optional, trajectory-local) enables deferral of the
         closing v-update: it is then executed together with the next step's opening v-update
         (`_update_v_pair_n`), its logdet being returned by that next call; the caller flushes
         a last pending update with `_flush_pending_n`.  `mid` (with `pend`, per-step metrics):
         the deferred closing update's logdet and the kinetic energy right after it are left in
-        mid['ld1'] / mid['ke'], and the returned logdet covers THIS step's sub-updates only."""
+        mid['ld1'] / mid['ke'], and the returned logdet covers THIS step's sub-updates only.
+        `x_src` (first step of a trajectory, SU(3)): the configuration is READ from x_src and the
+        x-update writes it into xn, so the trajectory never copies its input."""
         if forward:
             st, order = step, ((False, True), (True, False))     # (complement, first)
         else:
@@ -715,32 +717,35 @@ class Dynamics(nn.Module):
                 ops.u1_vstep_(xn, vn, b, ev, forward, self.latvolume, fv, ld)
                 return ld
         prev = pend.pop('p', None) if pend is not None else None
+        xr = xn if x_src is None else x_src              # where this step reads x before its x-update
         if prev is not None:
             st0, f0, flip = prev
             v0, v1 = self._get_vnet(st0), self._get_vnet(st)
             if v0 is v1 and self._can_fuse_heads(v1):
-                ld = self._update_v_pair_n(st0, f0, flip, st, forward, xn, vn, beta, cache, mid)
+                ld = self._update_v_pair_n(st0, f0, flip, st, forward, xr, vn, beta, cache, mid)
             else:
-                ld = self._update_v_n(st0, xn, vn, beta, f0, cache)
+                ld = self._update_v_n(st0, xr, vn, beta, f0, cache)
                 if mid is not None:
                     mid['ld1'], mid['ke'] = ld, self._kinetic_n(vn)
                 if flip:
                     self._flip_v_n(vn)
-                l1 = self._update_v_n(st, xn, vn, beta, forward, cache)
+                l1 = self._update_v_n(st, xr, vn, beta, forward, cache)
                 ld = l1 if mid is not None else ld + l1
         else:
-            ld = self._update_v_n(st, xn, vn, beta, forward, cache)
+            ld = self._update_v_n(st, xr, vn, beta, forward, cache)
         if self.group == 'SU3' and self.fuse_x_updates:
             # both half-updates share expm(eps v): one kernel, one pass over x
             eps = self._eps('x', st)
             if (cache is not None and self.fuse_x_vec8 and self.reuse_v_inputs
                     and self._can_fuse_heads(self._get_vnet(st))):
-                _, xv = ops.su3_expm_mul2_vec8_n(xn, vn, eps if forward else -eps, m, not forward,
+                _, xv = ops.su3_expm_mul2_vec8_n(xr, vn, eps if forward else -eps, m, not forward,
                                                  out=xn)
                 cache['xv_pre'] = xv.reshape(xn.shape[0], -1)
             else:
-                ops.su3_expm_mul2_n(xn, vn, eps if forward else -eps, m, not forward, out=xn)
+                ops.su3_expm_mul2_n(xr, vn, eps if forward else -eps, m, not forward, out=xn)
         else:
+            if x_src is not None:
+                xn.copy_(x_src)
             for comp, first in order:
                 l = self._update_x_n(st, xn, vn, m, comp, forward, first)
                 if l is not None:
@@ -972,7 +977,10 @@ class Dynamics(nn.Module):
     def _kernel_fb_n(self, xn, vn, beta):
         """Merged forward + backward trajectory (dynamics.py:956-1029)."""
         nb = xn.shape[0]
-        x_, v_ = xn.clone(), vn.clone()
+        v_ = vn.clone()
+        # SU(3): the first leapfrog step reads the input configuration and writes x_ (x_src below)
+        lazy_x = self.group == 'SU3' and self.config.nleapfrog > 0 and self._networks_built
+        x_ = torch.empty_like(xn) if lazy_x else xn.clone()
         sumlogdet = self._zeros_nb(nb)
         sldf = torch.zeros_like(sumlogdet)
         sldb = torch.zeros_like(sumlogdet)
@@ -1010,7 +1018,8 @@ class Dynamics(nn.Module):
 
         for step in range(nlf):
             mid = {} if vpair else None
-            logdet = self._lf_n(step, x_, v_, beta, True, cache, pend, mid)
+            logdet = self._lf_n(step, x_, v_, beta, True, cache, pend, mid,
+                                x_src=xn if (lazy_x and step == 0) else None)
             if vpair:
                 if deferred is not None:               # the previous step's closing update ran now
                     sumlogdet = sumlogdet + mid['ld1']
