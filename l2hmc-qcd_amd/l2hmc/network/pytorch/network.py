@@ -637,14 +637,22 @@ class LeapfrogLayer(nn.Module):
         if nat is None or not nat.get('active'):
             return
         with torch.no_grad():
+            inv = nat.setdefault('inv', {})
             for k, (par, dim, perm) in nat['src'].items():
                 if par.grad is None:
                     continue
                 g = nat['g'][k]
+                # perm is a bijection: grad[perm] += g  ==  grad += g[perm^-1]  (a gather and an
+                # add instead of index_add_'s atomics: 0.25 instead of 0.8 ms per 302 MB matrix)
+                ip = inv.get(id(perm))
+                if ip is None:
+                    ip = torch.empty_like(perm)
+                    ip[perm] = torch.arange(perm.numel(), device=perm.device, dtype=perm.dtype)
+                    inv[id(perm)] = ip
                 if dim == -1:
-                    par.grad.reshape(-1).index_add_(0, perm, g)
+                    par.grad.reshape(-1).add_(torch.index_select(g, 0, ip))
                 else:
-                    par.grad.index_add_(dim, perm, g)
+                    par.grad.add_(torch.index_select(g, dim, ip))
         nat['active'] = False
 
     def native_active(self) -> bool:
