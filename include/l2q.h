@@ -157,6 +157,12 @@ int l2q_su3_check_su(const void* xn, int nb, long V, double* out, void* ws, size
 int l2q_v_update(void* v, const void* force, const void* s, const void* t, const void* q,
                  double eps, int forward, int is_complex, int elem_bytes, int nb, long n,
                  void* logdet, void* ws, size_t ws_bytes, void* stream);
+/* The same update out of place: v_out = update(v_in) (v_in is not written; v_out == v_in is the
+ * in-place call).  The training tape keeps the momentum BEFORE every update for its reverse sweep:
+ * this saves the copy. */
+int l2q_v_update_to(const void* v_in, void* v_out, const void* force, const void* s, const void* t,
+                    const void* q, double eps, int forward, int is_complex, int elem_bytes, int nb,
+                    long n, void* logdet, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- accept / reject */
 /* acc = exp(min(0, h_init - h_prop + sumlogdet)); mask = (acc > u) as float32 0/1

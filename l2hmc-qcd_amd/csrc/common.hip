@@ -87,7 +87,7 @@ static int launch_transpose(const void* in, void* out, long batch, int rows, int
 // ------------------------------------------------------------------ v update
 // T = double/float; CPLX: v, F are (re, im) pairs, heads are real.
 template <typename T, bool CPLX, bool FWD>
-__global__ __launch_bounds__(kBlock) void v_update_kernel(T* v, const T* __restrict__ force,
+__global__ __launch_bounds__(kBlock) void v_update_kernel(const T* vin, T* v, const T* __restrict__ force,
                                                           const T* __restrict__ s,
                                                           const T* __restrict__ t,
                                                           const T* __restrict__ q, T eps, long n,
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void v_update_kernel(T* v, const T* __restr
     const T es = exp(lj);
     const T eq = exp(eps * qj);
     if (CPLX) {
-      const T vr = v[2 * o], vi = v[2 * o + 1];
+      const T vr = vin[2 * o], vi = vin[2 * o + 1];
       const T fr = force[2 * o] * eq + tj, fi = force[2 * o + 1] * eq;
       if (FWD) {
         v[2 * o] = es * vr - half * eps * fr;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void v_update_kernel(T* v, const T* __restr
       }
     } else {
       const T f = force[o] * eq + tj;
-      v[o] = FWD ? (es * v[o] - half * eps * f) : (es * (v[o] + half * eps * f));
+      v[o] = FWD ? (es * vin[o] - half * eps * f) : (es * (vin[o] + half * eps * f));
     }
   }
   const double r = block_sum(ld, lds);
@@ -223,10 +223,10 @@ int l2q_su3_unpack(const void* x_nat, void* x_ref, int nb, long V, void* stream)
   return l2q_transpose(x_nat, x_ref, (long)nb * 4, 9, (int)V, 16, stream);
 }
 
-int l2q_v_update(void* v, const void* force, const void* s, const void* t, const void* q,
-                 double eps, int forward, int is_complex, int elem_bytes, int nb, long n,
-                 void* logdet, void* ws, size_t ws_bytes, void* stream) {
-  L2Q_REQUIRE(v && force && s && t && q && logdet && ws, L2Q_EINVAL, "null pointer");
+static int v_update_launch(const void* vin, void* v, const void* force, const void* s, const void* t,
+                           const void* q, double eps, int forward, int is_complex, int elem_bytes,
+                           int nb, long n, void* logdet, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(vin && v && force && s && t && q && logdet && ws, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
   L2Q_REQUIRE(elem_bytes == 8 || elem_bytes == 4, L2Q_EINVAL, "elem_bytes must be 4 or 8");
   const long nblk = cdiv(n, kBlock);
@@ -236,7 +236,7 @@ int l2q_v_update(void* v, const void* force, const void* s, const void* t, const
   double* partial = (double*)ws;
   const dim3 grid((unsigned)(nb * nblk)), block(kBlock);
 #define L2Q_VUPD(T, C, F)                                                                   \
-  hipLaunchKernelGGL((v_update_kernel<T, C, F>), grid, block, 0, st, (T*)v, (const T*)force, \
+  hipLaunchKernelGGL((v_update_kernel<T, C, F>), grid, block, 0, st, (const T*)vin, (T*)v, (const T*)force, \
                      (const T*)s, (const T*)t, (const T*)q, (T)eps, n, nblk, partial)
   if (elem_bytes == 8) {
     if (is_complex) { if (forward) L2Q_VUPD(double, true, true); else L2Q_VUPD(double, true, false); }
@@ -252,6 +252,20 @@ int l2q_v_update(void* v, const void* force, const void* s, const void* t, const
   }
 #undef L2Q_VUPD
   return check_launch("l2q_v_update");
+}
+
+int l2q_v_update(void* v, const void* force, const void* s, const void* t, const void* q,
+                 double eps, int forward, int is_complex, int elem_bytes, int nb, long n,
+                 void* logdet, void* ws, size_t ws_bytes, void* stream) {
+  return v_update_launch(v, v, force, s, t, q, eps, forward, is_complex, elem_bytes, nb, n, logdet,
+                         ws, ws_bytes, stream);
+}
+
+int l2q_v_update_to(const void* v_in, void* v_out, const void* force, const void* s, const void* t,
+                    const void* q, double eps, int forward, int is_complex, int elem_bytes, int nb,
+                    long n, void* logdet, void* ws, size_t ws_bytes, void* stream) {
+  return v_update_launch(v_in, v_out, force, s, t, q, eps, forward, is_complex, elem_bytes, nb, n,
+                         logdet, ws, ws_bytes, stream);
 }
 
 int l2q_accept(const void* h_init, const void* h_prop, const void* sumlogdet, const void* u,

@@ -239,6 +239,19 @@ def v_update_(v: torch.Tensor, force: torch.Tensor, s: torch.Tensor, t: torch.Te
     return logdet
 
 
+def v_update(v: torch.Tensor, force: torch.Tensor, s: torch.Tensor, t: torch.Tensor,
+             q: torch.Tensor, eps: float, forward: bool):
+    """Out-of-place generalised momentum update: (v', logdet [nb]); v is not written."""
+    nb = v.shape[0]
+    n = v.numel() // nb
+    out = torch.empty_like(v)
+    logdet = torch.empty(nb, dtype=s.dtype, device=v.device)
+    ws = _ws(nb, n, v.device)
+    N.call('l2q_v_update_to', v, out, force, s, t, q, float(eps), int(forward), int(v.is_complex()),
+           s.element_size(), nb, n, logdet, ws, ws.numel())
+    return out, logdet
+
+
 def accept(h_init: torch.Tensor, h_prop: torch.Tensor, sumlogdet: torch.Tensor,
            u: torch.Tensor):
     nb = h_init.shape[0]

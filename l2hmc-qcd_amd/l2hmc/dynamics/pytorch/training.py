@@ -179,8 +179,7 @@ def _v_step(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, forward
     vnet = dyn._get_vnet(st)
     F = ops.u1_force(x, beta, dyn.latvolume)
     s, t, q, ctx = vnet.forward_train(x, F)
-    v_new = v.clone()
-    ld = ops.v_update_(v_new, F.reshape(nb, -1), s, t, q, eps, forward)
+    v_new, ld = ops.v_update(v, F.reshape(nb, -1), s, t, q, eps, forward)
     tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
                          's': s, 't': t, 'q': q, 'ctx': ctx, 'net': vnet, 'eps': eps})
     return v_new, ld
@@ -222,8 +221,7 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
            and not vnet.training_needs_fresh_forward())
     if hit:
         F, sn, tn, qn = share['F'], share['s'], share['t'], share['q']
-        v_new = v.clone()
-        ld = ops.v_update_(v_new.reshape(nb, -1), F.reshape(nb, -1), sn, tn, qn, eps, forward)
+        v_new, ld = ops.v_update(v, F.reshape(nb, -1), sn, tn, qn, eps, forward)
         tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
                              's': sn, 't': tn, 'q': qn, 'ctx': None, 'net': vnet, 'eps': eps,
                              'primary': share['idx']})
@@ -238,8 +236,7 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
         # the network sees the reference's entry order (mu, site, component)
         s, t, q, ctx = vnet.forward_train(ops.unpack_entries(xv, V, 8), ops.unpack_entries(fv, V, 8))
         sn, tn, qn = (ops.pack_entries(a, V, 9) for a in (s, t, q))
-    v_new = v.clone()
-    ld = ops.v_update_(v_new.reshape(nb, -1), F.reshape(nb, -1), sn, tn, qn, eps, forward)
+    v_new, ld = ops.v_update(v, F.reshape(nb, -1), sn, tn, qn, eps, forward)
     tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
                          's': sn, 't': tn, 'q': qn, 'ctx': ctx, 'net': vnet, 'eps': eps})
     if share is not None:

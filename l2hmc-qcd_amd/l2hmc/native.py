@@ -46,6 +46,7 @@ SIGNATURES = {
     'l2q_su3_assemble_tah': (I, [P, P, L, L, P]),
     'l2q_su3_check_su': (I, [P, I, L, P, P, Z, P]),
     'l2q_v_update': (I, [P, P, P, P, P, D, I, I, I, I, L, P, P, Z, P]),
+    'l2q_v_update_to': (I, [P, P, P, P, P, P, D, I, I, I, I, L, P, P, Z, P]),
     'l2q_accept': (I, [P, P, P, P, P, P, I, I, P]),
     'l2q_select_rows': (I, [P, P, P, P, I, L, P]),
     'l2q_scale_f64': (I, [P, D, P, L, P]),

@@ -599,6 +599,11 @@ def l2q_v_update(v, force, s, t, q, eps, forward, cplx, esz, nb, n, logdet, ws, 
     logdet.copy_(ld)
 
 
+def l2q_v_update_to(vin, vout, force, s, t, q, eps, forward, cplx, esz, nb, n, logdet, ws, wsn):
+    vout.copy_(vin)
+    return l2q_v_update(vout, force, s, t, q, eps, forward, cplx, esz, nb, n, logdet, ws, wsn)
+
+
 # ---- SU(3) training entry points
 def l2q_su3_expm_mul_bwd(xn, vn, eps, mask_n, complement, gxnew, gx, gv, deps, nb, V, ws, wsn):
     keep = _keep_n(mask_n, complement, nb, V)
