@@ -1170,7 +1170,9 @@ class Dynamics(nn.Module):
             out = State(x=xout, v=lambda: self._unpack(ops.select_rows(
                 v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)).reshape(nb, -1),
                 beta=beta, xshape=xout.shape)
-            self._xcache = (xout, xout._version, xo_n)
+            # (kept only while it is small next to the HBM: the 16^4 shard would pin 9.7 GB)
+            big = xo_n.numel() * xo_n.element_size() > (4 << 30)
+            self._xcache = None if big else (xout, xout._version, xo_n)
         else:
             vo_n = ops.select_rows(v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)
             out = State(x=xout, v=vo_n.reshape(nb, -1), beta=beta)

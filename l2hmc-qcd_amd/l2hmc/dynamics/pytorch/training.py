@@ -527,6 +527,7 @@ def train_forward_backward_chunked(dyn, loss_fn, x: Tensor, beta, micro_batch: i
     nb = x.shape[0]
     outs, mets, sizes, loss = [], [], [], 0.0
     inj = dyn._inject
+    nets = _native_begin(dyn, min(nb, micro_batch))     # one gather / scatter for all micro-batches
     try:
         for lo in range(0, nb, micro_batch):
             hi = min(nb, lo + micro_batch)
@@ -547,12 +548,20 @@ def train_forward_backward_chunked(dyn, loss_fn, x: Tensor, beta, micro_batch: i
             loss = loss + l * ((hi - lo) / nb)
     finally:
         dyn._inject = inj
+        for n in nets:
+            n.native_train_end()
     return torch.cat(outs, 0), _cat_metrics(mets, sizes), loss
 
 
-def _native_begin(dyn) -> list:
+def _native_begin(dyn, nb: Optional[int] = None) -> list:
     """SU(3) dense vnets train on native-order weight shadows (LeapfrogLayer.native_train_begin;
-    `dyn.native_training = False` keeps the reference-order path with activation transposes)."""
+    `dyn.native_training = False` keeps the reference-order path with activation transposes).
+    Returns the networks this call switched (the caller ends them); networks that are already in
+    native mode (a chunked step begins once for all its micro-batches) are left alone.
+    The shadows cost one gather + one scatter of the big matrices (and twice their bytes of HBM) per
+    step, the transposes they replace 18 x 2 passes over the activations of `nb` chains: with few
+    chains per pass on a large lattice (the 16^4 shard in micro-batches of 16: 23 GB of weights)
+    the transposes are the cheaper side and stay."""
     if dyn.group != 'SU3' or not getattr(dyn, 'native_training', True):
         return []
     from l2hmc.network.pytorch.network import ConvStack
@@ -560,9 +569,17 @@ def _native_begin(dyn) -> list:
     nets, seen = [], set()
     for st in range(dyn.config.nleapfrog):
         n = dyn._get_vnet(st)
-        if id(n) in seen or isinstance(n.input_layer.conv_stack, ConvStack):
+        if id(n) in seen or isinstance(n.input_layer.conv_stack, ConvStack) or n.native_active():
             continue
         seen.add(id(n))
+        if nb is not None:
+            il = n.input_layer
+            wbytes = sum(t.numel() * t.element_size() for t in (
+                il.xlayer.weight, il.vlayer.weight, n.scale.layer.weight, n.transl.weight,
+                n.transf.layer.weight))
+            abytes = nb * (2 * 32 + 3 * 36) * dyn.volume * il.xlayer.weight.element_size()
+            if 2 * wbytes > 18 * abytes:
+                continue
         n.native_train_begin(p['in'], p['out'])
         nets.append(n)
     return nets
@@ -576,7 +593,7 @@ def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1
     b = _beta(beta)
     xn = dyn._pack(x)
     vn = dyn._momentum_n(xn.shape[0])
-    nets = _native_begin(dyn)
+    nets = _native_begin(dyn, xn.shape[0])
     try:
         x_, v_, hist, tape = trajectory_fb_train(dyn, xn, vn, b)
         loss, gx, gv, gl = loss_and_seeds(dyn, loss_fn, xn, x_, v_, tape, hist['sumlogdet'], b)
