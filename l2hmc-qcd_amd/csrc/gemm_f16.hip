@@ -504,6 +504,31 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[h][i][j] = (v4f32){0, 0, 0, 0};
 
+  // The lattice operands of the update (a = v or x, b = force or v) do not depend on the K-loop, and
+  // the update is in place: once the first tile has been stored, hipcc keeps every later load of
+  // `a` behind that store.  They are therefore requested up front, by ROW tile i: a wavefront's
+  // 16 x 32 sub-tile is one whole 128-byte line per row when both column halves (j = 0, 1) are
+  // requested together (requested a K-loop apart, each half pulled the full line from HBM again:
+  // this kernel moves 805 MB per launch at cfg-3 for 103 GFLOP and is HBM-bound).  Row tiles 0, 1
+  // travel during the K-loop, 2, 3 are requested before the first store of the epilogue.
+  const bool vec4 = (a.N & 3) == 0;
+  float4 pav[MI][2], pbv[MI][2];
+  auto fetch_ab = [&](int i) {
+    const long m = m0 + wm + 16 * i + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
+      const bool ok = nb4 < a.N && m < a.M;
+      const long o = ok ? m * (long)a.N + nb4 : 0;
+      pav[i][j] = *reinterpret_cast<const float4*>(a.a + o);
+      pbv[i][j] = *reinterpret_cast<const float4*>(a.bsrc + o);
+    }
+  };
+  if (vec4) {
+#pragma unroll
+    for (int i = 0; i < MI / 2; ++i) fetch_ab(i);
+  }
+
   TileH<HT, HT, BM> lz;
   TileH<HT, HT, BN> l0, l1, l2;
   lz.fetch(Z, Z, m0, a.M, 0, K, 0, K, vec);
@@ -548,37 +573,39 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   // lane holds chain m = lane & 15 of tile i and the four consecutive entries
   // n = 16 j + 4 (lane >> 4) + r of tile j: 16-byte accesses to v / x / force / mask / biases.
   const float eps = a.eps;
-  const bool vec4 = (a.N & 3) == 0;
+  if (vec4) {
+#pragma unroll
+    for (int i = MI / 2; i < MI; ++i) fetch_ab(i);       // before any store of the epilogue
+  }
   float* __restrict__ pa = a.a;
   const float* __restrict__ pb = a.bsrc;
   float ld[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) ld[i] = 0.f;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
-    if (nb4 >= a.N) continue;
-    float bs[4], bt[4], bq[4], cs[4], cq[4], keep[4];
+  for (int i = 0; i < MI; ++i) {
+    const long m = m0 + wm + 16 * i + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long n = nb4 + r < a.N ? nb4 + r : a.N - 1;
-      bs[r] = a.b[0][n]; bt[r] = a.b[1][n]; bq[r] = a.b[2][n];
-      cs[r] = a.cs[n]; cq[r] = a.cq[n];
-      keep[r] = 0.f;
-      if (XUPD) {
-        keep[r] = a.mask[n];
-        if (a.complement) keep[r] = 1.f - keep[r];
+    for (int j = 0; j < 2; ++j) {
+      const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
+      if (nb4 >= a.N || m >= a.M) continue;
+      float bs[4], bt[4], bq[4], cs[4], cq[4], keep[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long n = nb4 + r < a.N ? nb4 + r : a.N - 1;
+        bs[r] = a.b[0][n]; bt[r] = a.b[1][n]; bq[r] = a.b[2][n];
+        cs[r] = a.cs[n]; cq[r] = a.cq[n];
+        keep[r] = 0.f;
+        if (XUPD) {
+          keep[r] = a.mask[n];
+          if (a.complement) keep[r] = 1.f - keep[r];
+        }
       }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const long m = m0 + wm + 16 * i + (lane & 15);
-      if (m >= a.M) continue;
       const long o = m * (long)a.N + nb4;
       float av[4], bv[4], out[4];
       if (vec4) {
-        const float4 t0 = *reinterpret_cast<const float4*>(pa + o);
-        const float4 t1 = *reinterpret_cast<const float4*>(pb + o);
+        const float4 t0 = pav[i][j];
+        const float4 t1 = pbv[i][j];
         av[0] = t0.x; av[1] = t0.y; av[2] = t0.z; av[3] = t0.w;
         bv[0] = t1.x; bv[1] = t1.y; bv[2] = t1.z; bv[3] = t1.w;
       } else {
