@@ -506,11 +506,13 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
 
   // The lattice operands of the update (a = v or x, b = force or v) do not depend on the K-loop, and
   // the update is in place: once the first tile has been stored, hipcc keeps every later load of
-  // `a` behind that store.  They are therefore requested up front, by ROW tile i: a wavefront's
-  // 16 x 32 sub-tile is one whole 128-byte line per row when both column halves (j = 0, 1) are
-  // requested together (requested a K-loop apart, each half pulled the full line from HBM again:
-  // this kernel moves 805 MB per launch at cfg-3 for 103 GFLOP and is HBM-bound).  Row tiles 0, 1
-  // travel during the K-loop, 2, 3 are requested before the first store of the epilogue.
+  // `a` behind that store.  They are therefore requested up front, by ROW tile i (a wavefront's
+  // 16 x 32 sub-tile is one whole 128-byte line per row when both column halves j = 0, 1 are
+  // requested together): row tiles 0, 1 travel during the K-loop, 2, 3 are requested before the
+  // first store of the epilogue.  Measured neutral at cfg-3 (508 vs 513 us per launch): with
+  // K = units[-1] = 256 the kernel is bound by the four dependent global -> register -> LDS
+  // round trips of its K-loop (one head as a plain gemm_h takes 250 us for 34 GFLOP), not by
+  // the epilogue -- the open item for this family is an LDS-DMA K-loop as in gemm.hip.
   const bool vec4 = (a.N & 3) == 0;
   float4 pav[MI][2], pbv[MI][2];
   auto fetch_ab = [&](int i) {
