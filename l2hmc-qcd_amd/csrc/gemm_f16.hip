@@ -509,10 +509,10 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   // `a` behind that store.  They are therefore requested up front, by ROW tile i (a wavefront's
   // 16 x 32 sub-tile is one whole 128-byte line per row when both column halves j = 0, 1 are
   // requested together): row tiles 0, 1 travel during the K-loop, 2, 3 are requested before the
-  // first store of the epilogue.  Measured neutral at cfg-3 (508 vs 513 us per launch): with
-  // K = units[-1] = 256 the kernel is bound by the four dependent global -> register -> LDS
-  // round trips of its K-loop (one head as a plain gemm_h takes 250 us for 34 GFLOP), not by
-  // the epilogue -- the open item for this family is an LDS-DMA K-loop as in gemm.hip.
+  // first store of the epilogue.  Measured neutral at cfg-3 (508 vs 513 us per launch), and so was
+  // an LDS-DMA K-loop on 64-chain tiles (506 vs 494 us, same box; not kept): neither the operand
+  // latency of the epilogue nor the four global -> register -> LDS round trips of the K = 256
+  // loop is what bounds this kernel at 3x its HBM time (805 MB per launch).
   const bool vec4 = (a.N & 3) == 0;
   float4 pav[MI][2], pbv[MI][2];
   auto fetch_ab = [&](int i) {
