@@ -320,6 +320,10 @@ def test_graphed_transition_follows_model_changes(golden):
     gt = dyn.make_graphed(x, beta)
     xo0 = gt(x)[0].clone()
     assert gt.captures == 1
+    if native._WS.buf is None:                       # (nothing before this test needed scratch)
+        native.workspace(1 << 16, x.device)
+        gt = dyn.make_graphed(x, beta)
+        xo0 = gt(x)[0].clone()
     ws0 = native._WS.buf
     # (1) a larger workspace request: the block the graph points at must stay alive and intact
     big = native.workspace(ws0.numel() * 4 + (1 << 20), x.device)

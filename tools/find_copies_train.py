@@ -18,7 +18,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 seen = collections.Counter(); tot = collections.Counter()
 for ev in prof.events():
-    if ev.device_time_total > 100 and ev.name in ('aten::copy_', 'aten::clone', 'aten::contiguous', 'aten::index_select', 'aten::index_add_', 'aten::add_', 'aten::mul', 'aten::zero_', 'aten::fill_', 'aten::add', 'aten::sum'):
+    if ev.device_time_total > 50 and ('Memcpy' in ev.name or ev.name in ('aten::copy_', 'aten::clone', 'aten::contiguous', 'aten::index_select', 'aten::index_add_', 'aten::add_', 'aten::mul', 'aten::zero_', 'aten::fill_', 'aten::add', 'aten::sum')):
         st = [f for f in (ev.stack or []) if 'l2hmc' in f][:2]
         k = (ev.name, ' <- '.join(x.split('/')[-1] for x in st))
         seen[k] += 1; tot[k] += ev.device_time_total
