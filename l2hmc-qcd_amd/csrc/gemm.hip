@@ -849,7 +849,12 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
         const double lj2 = a.fwd2 ? h2 * s : -h2 * s;
         if (!MID) { if (ok) ld[i][r] += lj2; }
         else m2[r] = ok ? lj + lj2 : 0.0;
-        const double es2 = exp_bf(lj2), eq2 = exp_bf(a.eps2 * q);
+        // same step size and direction (adjacent updates of an un-trained or eps_fixed model, i.e.
+        // six of the seven pairs of a merged nleapfrog = 4 trajectory): lj2 == lj bit for bit, the
+        // two exponentials are the first update's (wave-uniform branch; pair 1.21 -> 1.15 ms)
+        double es2, eq2;
+        if (a.eps2 == a.eps && a.fwd2 == (int)FWD) { es2 = es; eq2 = eq; }
+        else { es2 = exp_bf(lj2); eq2 = exp_bf(a.eps2 * q); }
         const double fr = fr0 * eq2 + t, fi = fi0 * eq2;
         if (a.fwd2) { vr = es2 * vr - h2 * fr; vi = es2 * vi - h2 * fi; }
         else { vr = es2 * (vr + h2 * fr); vi = es2 * (vi + h2 * fi); }
