@@ -206,7 +206,9 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
     }
     if (it >= c.lo) {
       // W = U A with U streamed by rows from the tile; F = (W - W^H)/2 - tr(W - W^H)/6
-      // (group/su3/pytorch/group.py:92-103), formed entry by entry at the store
+      // (group/su3/pytorch/group.py:92-103), formed entry by entry at the store.  The output (and
+      // the momentum read by the kick) is touched once: streaming (nt) accesses keep it from
+      // evicting the links the neighbouring tiles are about to re-read from L2 (-4 % measured)
       M3 ua;
       const Opnd<true> uo = oc(MU, q_sp);
 #pragma unroll
@@ -236,10 +238,10 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
           if (i == j) fi -= tri;
           double2 v2 = make_double2(c.coef * fr, c.coef * fi);
           if (MODE == 1) {
-            const double2 o = buf_ld(ro, q_sp, so + e * V16);
+            const double2 o = buf_ld_nt(ro, q_sp, so + e * V16);
             v2.x += o.x; v2.y += o.y;
           }
-          buf_st(ro, q_sp, so + e * V16, v2);
+          buf_st_nt(ro, q_sp, so + e * V16, v2);
         }
     }
     __syncthreads();                                  // slice tcur consumed

@@ -26,6 +26,19 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t rs, int voff, int 
   __builtin_amdgcn_raw_buffer_store_b128(c.u, rs, voff, soff, 0);
 }
 
+// streaming store (nt): the written line is not kept in L2 / MALL ahead of data that is re-read
+__device__ __forceinline__ void buf_st_nt(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double2 v) {
+  union { v4u u; double2 d; } c;
+  c.d = v;
+  __builtin_amdgcn_raw_buffer_store_b128(c.u, rs, voff, soff, 2);
+}
+
+__device__ __forceinline__ double2 buf_ld_nt(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  union { v4u u; double2 d; } c;
+  c.u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 2);
+  return c.d;
+}
+
 struct R3 {
   double re[3], im[3];
 };
