@@ -105,6 +105,11 @@ int l2q_su3_force(const void* xn, double beta, void* fn, int nb, int T, int X, i
  * coef = -eps/2); F is never materialised. */
 int l2q_su3_force_kick(const void* xn, double beta, double coef, void* vn, int nb, int T,
                        int X, int Y, int Z, void* stream);
+/* The same kick out of place: v_out = v_in + coef * (beta/3) TAH(U A)  (v_in == v_out is the call
+ * above).  The first kick of a plain-HMC trajectory uses it to leave the momentum it was handed
+ * untouched without copying it. */
+int l2q_su3_force_kick_to(const void* xn, double beta, double coef, const void* v_in, void* v_out,
+                          int nb, int T, int X, int Y, int Z, void* stream);
 /* out = keep (.) x + expm(eps * v) @ ((1 - keep) (.) x), element-wise 0/1 mask on matrix
  * entries.  mask_n: float32 [36 V] in native order or NULL (keep = 0 everywhere: the plain
  * `update_gauge`, group/su3/pytorch/group.py:45-50).  keep = mask if !complement else 1-mask.
@@ -200,6 +205,16 @@ int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const doub
                                double scale_q, void* v, const void* force, int is_complex,
                                double eps, int forward, double* logdet, void* ws,
                                size_t ws_bytes, void* stream);
+/* The same update out of place: the momentum is read from v_in and written to v_out (v_in == v_out
+ * is the in-place call; any other overlap is undefined).  A trajectory's first update uses it to
+ * leave the momentum it was handed untouched without copying it. */
+int l2q_vnet_heads_vupdate_to_f64(const double* Z, int M, int K, long N, const double* Ws,
+                                  const double* bs, const double* cs, double scale_s,
+                                  const double* Wt, const double* bt, double scale_t,
+                                  const double* Wq, const double* bq, const double* cq,
+                                  double scale_q, const void* v_in, void* v_out, const void* force,
+                                  int is_complex, double eps, int forward, double* logdet, void* ws,
+                                  size_t ws_bytes, void* stream);
 /* Two consecutive v-updates on the SAME x (closing update of leapfrog step k, opening update
  * of step k+1; optionally the merged trajectory's momentum flip v -> -v in between,
  * dynamics.py:1001) from ONE evaluation of the heads: update (eps1, forward1), [flip],

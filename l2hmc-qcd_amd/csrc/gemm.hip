@@ -522,7 +522,8 @@ struct HeadsArgs {
   double eps;
   double eps2;            // second update of a pair (PAIR kernels)
   int fwd2, flip;         // its direction; v -> -v between the two updates
-  double* v;              // [M][N] (x2 if complex), updated in place
+  double* v;              // [M][N] (x2 if complex): the updated momentum
+  const double* vin;      // the momentum read (= v for the in-place update)
   const double* F;        // [M][N] (x2 if complex)
   double* logdet_part;    // [M][ncols_part]
   double* ld1_part;       // MID kernels: log-Jacobian of the first update alone, [M][ncols_part]
@@ -629,11 +630,11 @@ __global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_ker
         const long o = m * (long)a.N + n;
         double vr, vi = 0.0, fr0, fi0 = 0.0;
         if (CPLX) {
-          const double2 vv = reinterpret_cast<const double2*>(a.v)[o];
+          const double2 vv = reinterpret_cast<const double2*>(a.vin)[o];
           const double2 ff = reinterpret_cast<const double2*>(a.F)[o];
           vr = vv.x; vi = vv.y; fr0 = ff.x; fi0 = ff.y;
         } else {
-          vr = a.v[o]; fr0 = a.F[o];
+          vr = a.vin[o]; fr0 = a.F[o];
         }
         {
           const double fr = fr0 * eq + t, fi = fi0 * eq;
@@ -801,10 +802,10 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
       long o; bool ok;
       elem(b, r, o, ok);
       if (CPLX) {
-        vv[slot][r] = reinterpret_cast<const double2*>(a.v)[o];
+        vv[slot][r] = reinterpret_cast<const double2*>(a.vin)[o];
         ff[slot][r] = reinterpret_cast<const double2*>(a.F)[o];
       } else {
-        vv[slot][r] = make_double2(a.v[o], 0.0);
+        vv[slot][r] = make_double2(a.vin[o], 0.0);
         ff[slot][r] = make_double2(a.F[o], 0.0);
       }
     }
@@ -1262,7 +1263,8 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
                         double scale_q, void* v, const void* force, int is_complex, double eps,
                         int forward, int pair, double eps2, int forward2, int flip,
                         double* logdet, void* ws, size_t ws_bytes, void* stream,
-                        double* logdet1 = nullptr, double* vnorm2_mid = nullptr) {
+                        double* logdet1 = nullptr, double* vnorm2_mid = nullptr,
+                        const void* v_in = nullptr) {
   L2Q_REQUIRE(Z && Ws && bs && Wt && bt && Wq && bq && v && force && logdet && ws, L2Q_EINVAL,
               "null pointer");
   L2Q_REQUIRE(M > 0 && K > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
@@ -1281,7 +1283,9 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
   a.Z = Z; a.W[0] = Ws; a.W[1] = Wt; a.W[2] = Wq; a.b[0] = bs; a.b[1] = bt; a.b[2] = bq;
   a.cs = cs; a.cq = cq; a.ss = scale_s; a.st = scale_t; a.sq = scale_q; a.eps = eps;
   a.eps2 = eps2; a.fwd2 = forward2; a.flip = flip;
-  a.v = (double*)v; a.F = (const double*)force; a.logdet_part = (double*)ws;
+  a.v = (double*)v; a.vin = v_in ? (const double*)v_in : (const double*)v;
+  L2Q_REQUIRE(al(a.vin), L2Q_ESHAPE, "operands must be 16-byte aligned");
+  a.F = (const double*)force; a.logdet_part = (double*)ws;
   a.ld1_part = (double*)ws + (size_t)M * ncols;
   a.ke_part = (double*)ws + 2 * (size_t)M * ncols;
   a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncols;
@@ -1329,6 +1333,19 @@ int l2q_vnet_heads_vupdate_f64(const double* Z, int M, int K, long N, const doub
                                void* stream) {
   return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v,
                       force, is_complex, eps, forward, 0, 0.0, 0, 0, logdet, ws, ws_bytes, stream);
+}
+
+int l2q_vnet_heads_vupdate_to_f64(const double* Z, int M, int K, long N, const double* Ws,
+                                  const double* bs, const double* cs, double scale_s,
+                                  const double* Wt, const double* bt, double scale_t,
+                                  const double* Wq, const double* bq, const double* cq,
+                                  double scale_q, const void* v_in, void* v_out, const void* force,
+                                  int is_complex, double eps, int forward, double* logdet, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(v_in, L2Q_EINVAL, "null pointer");
+  return heads_launch(Z, M, K, N, Ws, bs, cs, scale_s, Wt, bt, scale_t, Wq, bq, cq, scale_q, v_out,
+                      force, is_complex, eps, forward, 0, 0.0, 0, 0, logdet, ws, ws_bytes, stream,
+                      nullptr, nullptr, v_in);
 }
 
 int l2q_vnet_heads_vupdate_pair_f64(const double* Z, int M, int K, long N, const double* Ws,

@@ -46,7 +46,7 @@ template <int INM>
 __device__ __forceinline__ constexpr bool lk_in(int dir) { return dir == 0 ? true : ((INM >> (dir - 1)) & 1) != 0; }
 
 struct LkCtx {
-  __amdgpu_buffer_rsrc_t rs, ro;
+  __amdgpu_buffer_rsrc_t rs, ro, rv;   // links, output, the momentum the kick reads (MODE 1)
   Dims d;
   int V16, Vs16, tile0b, lt, t0, t1;
   int sp, px, py, pz;
@@ -56,13 +56,13 @@ struct LkCtx {
 
 __host__ __device__ constexpr int lk_other(int mu, int j) { return j + (j >= mu ? 1 : 0); }
 
-// MODE 0: out = coef * F;  MODE 1: out += coef * F
+// MODE 0: out = coef * F;  MODE 1: out = vin + coef * F  (vin == out: the in-place kick)
 template <int MODE, int MU, int INM>
 __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
   constexpr bool IN_MU = lk_in<INM>(MU);
   const Dims& d = c.d;
   const int T = d.T, V16 = c.V16, Vs16 = c.Vs16;
-  const __amdgpu_buffer_rsrc_t rs = c.rs, ro = c.ro;
+  const __amdgpu_buffer_rsrc_t rs = c.rs, ro = c.ro, rv = c.rv;
   const int q_sp = c.sp * 16;
   int q_pmu = q_sp, mx = c.px, my = c.py, mz = c.pz;          // s + mu (spatial MU)
   if (MU != 0) {
@@ -238,7 +238,7 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
           if (i == j) fi -= tri;
           double2 v2 = make_double2(c.coef * fr, c.coef * fi);
           if (MODE == 1) {
-            const double2 o = buf_ld_nt(ro, q_sp, so + e * V16);
+            const double2 o = buf_ld_nt(rv, q_sp, so + e * V16);
             v2.x += o.x; v2.y += o.y;
           }
           buf_st_nt(ro, q_sp, so + e * V16, v2);
@@ -258,7 +258,7 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
 template <int MODE, int INM>
 __global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
     const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
-    double2* __restrict__ out, int lo) {
+    const double2* vin, double2* out, int lo) {
   const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
   const int per_chain = nsb * tsplit;
   const long c = w / per_chain;
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
   const int chain_bytes = 36 * k.V16;
   k.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + c * 36L * V), 0, chain_bytes, 0x00020000);
   k.ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + c * 36L * V), 0, chain_bytes, 0x00020000);
+  k.rv = __builtin_amdgcn_make_buffer_rsrc((void*)((MODE == 1 ? vin : out) + c * 36L * V), 0, chain_bytes, 0x00020000);
   k.sp = sb * kRS + k.lt;
   {
     int q = k.sp;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
 
 template <int MODE, int INM>
 static void launch_link_variant(const double2* xn, Dims d, int nb, int nsb, int tsplit, double coef,
-                                double2* out, hipStream_t st) {
+                                const double2* vin, double2* out, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)su3_force_link_kernel<MODE, INM>,
@@ -305,7 +306,7 @@ static void launch_link_variant(const double2* xn, Dims d, int nb, int nsb, int 
     attr_set = true;
   }
   hipLaunchKernelGGL((su3_force_link_kernel<MODE, INM>), dim3((unsigned)((long)nb * nsb * tsplit)),
-                     dim3(kLkThreads), kLkLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, out, 1);
+                     dim3(kLkThreads), kLkLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, vin, out, 1);
 }
 
 int force_link_inmask(const Dims& d) {
@@ -320,8 +321,10 @@ bool force_link_applicable(const Dims& d) {
   return (d.X * d.Y * d.Z) % kRS == 0 && 36.0 * d.V * 16.0 < 2.0e9;
 }
 
+// kick: out = vin + coef * F (vin == nullptr or out: in place)
 void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
-                       hipStream_t st) {
+                       hipStream_t st, const double2* vin) {
+  if (vin == nullptr) vin = out;
   const int Vs = d.X * d.Y * d.Z;
   const int nsb = Vs / kRS;
   int tsplit = (int)cdiv(1024, (long)nb * nsb);        // >= ~2 resident rounds of 2 x 256 workgroups
@@ -331,16 +334,16 @@ void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef
   tsplit = (int)cdiv(d.T, tlen);
 #define L2Q_LK_CASE(M)                                                                    \
   case M:                                                                                 \
-    if (kick) launch_link_variant<1, M>(xn, d, nb, nsb, tsplit, coef, out, st);           \
-    else launch_link_variant<0, M>(xn, d, nb, nsb, tsplit, coef, out, st);                \
+    if (kick) launch_link_variant<1, M>(xn, d, nb, nsb, tsplit, coef, vin, out, st);           \
+    else launch_link_variant<0, M>(xn, d, nb, nsb, tsplit, coef, vin, out, st);                \
     break;
   switch (force_link_inmask(d)) {
     L2Q_LK_CASE(7)
     L2Q_LK_CASE(6)
     L2Q_LK_CASE(4)
     default:
-      if (kick) launch_link_variant<1, 0>(xn, d, nb, nsb, tsplit, coef, out, st);
-      else launch_link_variant<0, 0>(xn, d, nb, nsb, tsplit, coef, out, st);
+      if (kick) launch_link_variant<1, 0>(xn, d, nb, nsb, tsplit, coef, vin, out, st);
+      else launch_link_variant<0, 0>(xn, d, nb, nsb, tsplit, coef, vin, out, st);
   }
 #undef L2Q_LK_CASE
 }

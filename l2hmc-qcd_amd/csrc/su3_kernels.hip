@@ -951,7 +951,7 @@ void launch_force_rows(bool kick, const double2* xn, Dims d, int nb, double coef
 bool force_link_applicable(const Dims& d);
 int force_link_inmask(const Dims& d);
 void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
-                       hipStream_t st);
+                       hipStream_t st, const double2* vin = nullptr);
 }  // namespace l2q
 
 using namespace l2q;
@@ -1189,6 +1189,23 @@ int l2q_su3_force_kick(const void* xn, double beta, double coef, void* vn, int n
   const long nblk = cdiv(d.V, kBlock);
   launch_force<true>((const double2*)xn, d, nb, nblk, coef * beta / 3.0, (double2*)vn, (hipStream_t)stream);
   return check_launch("l2q_su3_force_kick");
+}
+
+int l2q_su3_force_kick_to(const void* xn, double beta, double coef, const void* v_in, void* v_out,
+                          int nb, int T, int X, int Y, int Z, void* stream) {
+  L2Q_REQUIRE(xn && v_in && v_out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  hipStream_t st = (hipStream_t)stream;
+  if (v_in != v_out && tuning().force_tile == 5 && force_link_applicable(d)) {
+    launch_force_link(true, (const double2*)xn, d, nb, coef * beta / 3.0, (double2*)v_out, st,
+                      (const double2*)v_in);
+    return check_launch("l2q_su3_force_kick_to");
+  }
+  // the other kernels of the family update in place: copy first
+  if (v_in != v_out)
+    (void)hipMemcpyAsync(v_out, v_in, (size_t)nb * 36 * d.V * sizeof(double2), hipMemcpyDeviceToDevice, st);
+  return l2q_su3_force_kick(xn, beta, coef, v_out, nb, T, X, Y, Z, stream);
 }
 
 int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* mask_n,

@@ -122,9 +122,13 @@ def su3_force_n(xn: torch.Tensor, beta: float, lat: Sequence[int]) -> torch.Tens
 
 
 def su3_force_kick_n(xn: torch.Tensor, beta: float, coef: float, vn: torch.Tensor,
-                     lat: Sequence[int]) -> torch.Tensor:
-    """vn += coef * F(xn) in place."""
+                     lat: Sequence[int], v_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """vn += coef * F(xn) in place; with v_src: vn = v_src + coef * F(xn) (vn only written)."""
     T, X, Y, Z = (int(i) for i in lat)
+    if v_src is not None:
+        assert v_src.shape == vn.shape and v_src.dtype == vn.dtype and v_src.is_contiguous()
+        N.call('l2q_su3_force_kick_to', xn, float(beta), float(coef), v_src, vn, xn.shape[0], T, X, Y, Z)
+        return vn
     N.call('l2q_su3_force_kick', xn, float(beta), float(coef), vn, xn.shape[0], T, X, Y, Z)
     return vn
 
@@ -428,10 +432,12 @@ def u1_heads_update_h_(z: torch.Tensor, heads: dict, scale_t: float, a: torch.Te
 
 
 def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
-                        force: torch.Tensor, eps: float, forward: bool) -> torch.Tensor:
+                        force: torch.Tensor, eps: float, forward: bool,
+                        v_src: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused (s, t, q) heads + generalised momentum update, v in place; returns logdet [nb].
     heads: {'s': (W, b, colscale|None), 't': (W, b, None), 'q': (W, b, colscale|None)};
-    scales = (nw.s, nw.t, nw.q) used where no per-column scale is given."""
+    scales = (nw.s, nw.t, nw.q) used where no per-column scale is given.
+    v_src: read the momentum from there instead (v is then only written)."""
     m, k = z.shape
     ws_, bs, cs = heads['s']
     wt, bt, _ = heads['t']
@@ -440,6 +446,12 @@ def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
     logdet = torch.empty(m, dtype=torch.float64, device=z.device)
     nbytes = int(N.load().l2q_vnet_heads_ws_bytes(m, n))
     ws = N.workspace(nbytes, z.device)
+    if v_src is not None:
+        assert v_src.shape == v.shape and v_src.dtype == v.dtype and v_src.is_contiguous()
+        N.call('l2q_vnet_heads_vupdate_to_f64', z, m, k, n, ws_, bs, cs, float(scales[0]), wt, bt,
+               float(scales[1]), wq, bq, cq, float(scales[2]), v_src, v, force,
+               int(v.is_complex()), float(eps), int(forward), logdet, ws, ws.numel())
+        return logdet
     N.call('l2q_vnet_heads_vupdate_f64', z, m, k, n, ws_, bs, cs, float(scales[0]), wt, bt,
            float(scales[1]), wq, bq, cq, float(scales[2]), v, force, int(v.is_complex()),
            float(eps), int(forward), logdet, ws, ws.numel())

@@ -451,11 +451,14 @@ class Dynamics(nn.Module):
             return ops.su3_force_n(xn, _beta(beta), self.latvolume)
         return ops.u1_force(xn, _beta(beta), self.latvolume)
 
-    def _kick_n(self, xn: Tensor, vn: Tensor, beta, coef: float) -> None:
-        """vn += coef * F(xn), F never materialised."""
+    def _kick_n(self, xn: Tensor, vn: Tensor, beta, coef: float,
+                v_src: Optional[Tensor] = None) -> None:
+        """vn += coef * F(xn), F never materialised (v_src: vn = v_src + coef * F(xn))."""
         if self.group == 'SU3':
-            ops.su3_force_kick_n(xn, _beta(beta), coef, vn, self.latvolume)
+            ops.su3_force_kick_n(xn, _beta(beta), coef, vn, self.latvolume, v_src)
         else:
+            if v_src is not None:
+                vn.copy_(v_src)
             ops.u1_force_kick_(xn, _beta(beta), coef, vn, self.latvolume)
 
     def _potential_n(self, xn: Tensor, beta) -> Tensor:
@@ -594,12 +597,17 @@ class Dynamics(nn.Module):
                 and getattr(net, 'half_dtype', None) is not None)
 
     def _update_v_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
-                    cache: Optional[dict] = None, acc: Optional[Tensor] = None) -> Tensor:
+                    cache: Optional[dict] = None, acc: Optional[Tensor] = None,
+                    v_src: Optional[Tensor] = None) -> Tensor:
         """v-update in place (dynamics.py:1266-1297); returns logdet [nb] (the fused U(1) kernel
-        adds it into `acc` when given)."""
+        adds it into `acc` when given).  `v_src`: the momentum is read from there and only
+        written to vn (the heads kernel does that itself; the other paths copy first)."""
         eps = self._eps('v', step)
         nb = xn.shape[0]
         vnet = self._get_vnet(step)
+        if v_src is not None and not (self.group == 'SU3' and self._can_fuse_heads(vnet)):
+            vn.copy_(v_src)
+            v_src = None
         fw = self._fused_u1(vnet)
         if fw is not None:            # force + vnet + update in one launch
             return ops.u1_vstep_(xn, vn, _beta(beta), eps, forward, self.latvolume, fw, acc)
@@ -616,7 +624,10 @@ class Dynamics(nn.Module):
         if z is not None:
             # heads + momentum update in one kernel: s, t, q never reach HBM
             return ops.vnet_heads_vupdate_(z, w['heads_scaled'], (vnet.nw.s, vnet.nw.t, vnet.nw.q),
-                                           vn.reshape(nb, -1), fn.reshape(nb, -1), eps, forward)
+                                           vn.reshape(nb, -1), fn.reshape(nb, -1), eps, forward,
+                                           None if v_src is None else v_src.reshape(nb, -1))
+        if v_src is not None:
+            vn.copy_(v_src)
         s, t, q = self._vnet_n(step, xn, fn)
         return ops.v_update_(vn.reshape(nb, -1), fn.reshape(nb, -1), s, t, q, eps, forward)
 
@@ -686,7 +697,8 @@ class Dynamics(nn.Module):
 
     def _lf_n(self, step: int, xn: Tensor, vn: Tensor, beta, forward: bool,
               cache: Optional[dict] = None, pend: Optional[dict] = None,
-              mid: Optional[dict] = None, x_src: Optional[Tensor] = None) -> Tensor:
+              mid: Optional[dict] = None, x_src: Optional[Tensor] = None,
+              v_src: Optional[Tensor] = None) -> Tensor:
         """One generalised leapfrog step in place; returns logdet [nb]
         (dynamics.py:1187-1228).  `pend` (optional, trajectory-local) enables deferral of the
         closing v-update: it is then executed together with the next step's opening v-update
@@ -695,7 +707,8 @@ class Dynamics(nn.Module):
         the deferred closing update's logdet and the kinetic energy right after it are left in
         mid['ld1'] / mid['ke'], and the returned logdet covers THIS step's sub-updates only.
         `x_src` (first step of a trajectory, SU(3)): the configuration is READ from x_src and the
-        x-update writes it into xn, so the trajectory never copies its input."""
+        x-update writes it into xn, so the trajectory never copies its input; `v_src` likewise for
+        the momentum of the step's opening v-update."""
         if forward:
             st, order = step, ((False, True), (True, False))     # (complement, first)
         else:
@@ -718,6 +731,9 @@ class Dynamics(nn.Module):
                 return ld
         prev = pend.pop('p', None) if pend is not None else None
         xr = xn if x_src is None else x_src              # where this step reads x before its x-update
+        if v_src is not None and prev is not None:
+            vn.copy_(v_src)
+            v_src = None
         if prev is not None:
             st0, f0, flip = prev
             v0, v1 = self._get_vnet(st0), self._get_vnet(st)
@@ -732,7 +748,7 @@ class Dynamics(nn.Module):
                 l1 = self._update_v_n(st, xr, vn, beta, forward, cache)
                 ld = l1 if mid is not None else ld + l1
         else:
-            ld = self._update_v_n(st, xr, vn, beta, forward, cache)
+            ld = self._update_v_n(st, xr, vn, beta, forward, cache, v_src=v_src)
         if self.group == 'SU3' and self.fuse_x_updates:
             # both half-updates share expm(eps v): one kernel, one pass over x
             eps = self._eps('x', st)
@@ -920,7 +936,7 @@ class Dynamics(nn.Module):
     def _kernel_hmc_n(self, xn, vn, beta, eps=None, nleapfrog=None):
         """(dynamics.py:915-954) in place on clones; returns (x', v', history)."""
         nb = xn.shape[0]
-        v_ = vn.clone()
+        v_ = None                                   # cloned below unless the first kick can write a fresh tensor
         x_ = None                                   # cloned below unless the first x-update can write a fresh tensor
         sumlogdet = self._zeros_nb(nb)
         history: dict = {}
@@ -941,12 +957,13 @@ class Dynamics(nn.Module):
             # serves both.  nleapfrog + 1 force evaluations instead of 2 nleapfrog.  Only
             # without per-step metrics (they need v at the step boundary).
             if self.group == 'SU3':
-                # the opening kick only reads x and the first x-update writes a fresh tensor: the
-                # input configuration is never copied
-                self._kick_n(xn, v_, beta, -0.5 * eps)
+                # the opening kick only reads x and v, the first x-update writes a fresh tensor:
+                # neither the input configuration nor the momentum is copied
+                v_ = torch.empty_like(vn)
+                self._kick_n(xn, v_, beta, -0.5 * eps, v_src=vn)
                 x_ = ops.su3_expm_mul_n(xn, v_, eps)
             else:
-                x_ = xn.clone()
+                x_, v_ = xn.clone(), vn.clone()
                 self._kick_n(x_, v_, beta, -0.5 * eps)
                 ops.axpy_(x_.reshape(nb, -1), v_, eps)
             for i in range(nleapfrog):
@@ -959,7 +976,7 @@ class Dynamics(nn.Module):
             nleapfrog_done = True
         else:
             nleapfrog_done = False
-            x_ = xn.clone()
+            x_, v_ = xn.clone(), vn.clone()
         for _ in range(0 if nleapfrog_done else nleapfrog):
             self._leapfrog_hmc_n(x_, v_, beta, eps)
             if self.config.verbose:
@@ -977,10 +994,11 @@ class Dynamics(nn.Module):
     def _kernel_fb_n(self, xn, vn, beta):
         """Merged forward + backward trajectory (dynamics.py:956-1029)."""
         nb = xn.shape[0]
-        v_ = vn.clone()
-        # SU(3): the first leapfrog step reads the input configuration and writes x_ (x_src below)
+        # SU(3): the first leapfrog step reads the input configuration and momentum and writes
+        # x_ / v_ (x_src, v_src below): no copy of either
         lazy_x = self.group == 'SU3' and self.config.nleapfrog > 0 and self._networks_built
         x_ = torch.empty_like(xn) if lazy_x else xn.clone()
+        v_ = torch.empty_like(vn) if lazy_x else vn.clone()
         sumlogdet = self._zeros_nb(nb)
         sldf = torch.zeros_like(sumlogdet)
         sldb = torch.zeros_like(sumlogdet)
@@ -1019,7 +1037,8 @@ class Dynamics(nn.Module):
         for step in range(nlf):
             mid = {} if vpair else None
             logdet = self._lf_n(step, x_, v_, beta, True, cache, pend, mid,
-                                x_src=xn if (lazy_x and step == 0) else None)
+                                x_src=xn if (lazy_x and step == 0) else None,
+                                v_src=vn if (lazy_x and step == 0) else None)
             if vpair:
                 if deferred is not None:               # the previous step's closing update ran now
                     sumlogdet = sumlogdet + mid['ld1']

@@ -34,6 +34,7 @@ SIGNATURES = {
     'l2q_diff_norm2_reduce': (I, [P, P, I, L, P, P, Z, P]),
     'l2q_su3_force': (I, [P, D, P, I, I, I, I, I, P]),
     'l2q_su3_force_kick': (I, [P, D, D, P, I, I, I, I, I, P]),
+    'l2q_su3_force_kick_to': (I, [P, D, D, P, P, I, I, I, I, I, P]),
     'l2q_su3_expm_mul': (I, [P, P, D, P, I, P, I, L, P]),
     'l2q_su3_expm_mul2': (I, [P, P, D, P, I, P, I, L, P]),
     'l2q_su3_expm_mul2_vec8': (I, [P, P, D, P, I, P, P, I, L, P]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'l2q_gemm_f64': (I, [P, P, I, I, L, P, P, L, P, P, P, D, I, P, P, Z, P]),
     'l2q_gemm_ws_bytes': (Z, [I, I, L, L]),
     'l2q_vnet_heads_vupdate_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, I, D, I, P, P, Z, P]),
+    'l2q_vnet_heads_vupdate_to_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, P, I, D, I, P, P, Z, P]),
     'l2q_vnet_heads_vupdate_pair_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, I, D, I, I, D, I, P, P, Z, P]),
     'l2q_vnet_heads_vupdate_pair_mid_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, I, D, I, I, D, I, P, P, P, P, Z, P]),
     'l2q_vnet_heads_ws_bytes': (Z, [I, L]),

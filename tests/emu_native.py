@@ -538,6 +538,11 @@ def l2q_su3_force_kick(xn, beta, coef, vn, nb, T, X, Y, Z):
     vn.add_(coef * _native(_su3_force(x, beta).reshape(nb, 4, -1, 3, 3)).reshape(vn.shape))
 
 
+def l2q_su3_force_kick_to(xn, beta, coef, vin, vout, nb, T, X, Y, Z):
+    vout.copy_(vin)
+    l2q_su3_force_kick(xn, beta, coef, vout, nb, T, X, Y, Z)
+
+
 def l2q_su3_expm_mul(xn, vn, eps, mask_n, complement, out, nb, V):
     keep = _keep_n(mask_n, complement, nb, V)
     out.copy_(_expm_mul(xn.reshape(nb, 4, 9, V), vn.reshape(nb, 4, 9, V), eps, keep).reshape(out.shape))

@@ -126,6 +126,10 @@ def test_su3_stencils_vs_oracle(ops, L):
                 v = xn.clone()
                 ops.su3_force_kick_n(xn, 5.7, -0.3, v, L)
                 assert err(host(ops.su3_unpack(v, L)), x - 0.3 * f) < 1e-12
+                # out of place (l2q_su3_force_kick_to): the same bits, the source untouched
+                src = xn.clone(); v2 = torch.full_like(xn, float('nan'))
+                ops.su3_force_kick_n(xn, 5.7, -0.3, v2, L, v_src=src)
+                assert torch.equal(v2, v) and torch.equal(src, xn)
     for k, val in (('force_occ', 2), ('plaq_occ', 2), ('plaq_sweep', 2), ('force_tile', 5),
                    ('xcd_swizzle', 1)):
         native.set_tuning(k, val)
@@ -343,6 +347,10 @@ def test_fused_heads_vupdate(ops, cplx, shape):
         fn = host(f) * np.exp(0.07 * qn) + tn
         want = np.exp(lj) * host(v) - 0.035 * fn if fwd else np.exp(lj) * (host(v) + 0.035 * fn)
         assert err(host(v2), want) < 1e-12 and err(host(ld2), lj.sum(1)) < 1e-11
+        # out of place (l2q_vnet_heads_vupdate_to_f64): the same bits, the source untouched
+        v0 = v.clone(); v3 = torch.full_like(v, float('nan'))
+        ld3 = ops.vnet_heads_vupdate_(z, scaled, nw, v3, f, 0.07, fwd, v_src=v0)
+        assert torch.equal(v3, v2) and torch.equal(ld3, ld2) and torch.equal(v0, v)
         # paired updates (optionally with the momentum flip in between) == two single calls
         for flip in (False, True):
             for fwd2 in (True, False):

@@ -233,7 +233,10 @@ def test_cfg5_kernels_16x4_256chains():
     vk = vn.clone()
     ops.su3_force_kick_n(xn, beta, -0.5 * eps, vk, L)
     assert _maxdiff_tiled(vk, vn2 - 0.5 * eps * f_ref) < 1e-12
-    del vk
+    vk2 = torch.empty_like(vn)                     # out of place: same bits
+    ops.su3_force_kick_n(xn, beta, -0.5 * eps, vk2, L, v_src=vn)
+    assert torch.equal(vk2, vk)
+    del vk, vk2
     # su3_to_vec(projectSU(.)) of links and of the force
     xv = ops.su3_projsu_vec8_n(xn)
     xv_ref = dev(osu3.group_to_vec(x2))                                   # [2,4,T,X,Y,Z,8]

@@ -66,3 +66,20 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 print(f'pair, 20 launches in a row:   {e0.elapsed_time(e1) / 20:.4f} ms')
+
+# sustained load: do the clocks hold?  Blocks of 100 launches, with the SMI's view of the clocks and
+# the power draw sampled from the host while the queue drains.
+if '--sustained' in sys.argv:
+    import subprocess
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+    evs[0].record()
+    for b in range(20):
+        for _ in range(100):
+            pair()
+        evs[b + 1].record()
+    smi = subprocess.run('rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|mclk|Power" | head -6',
+                         shell=True, capture_output=True, text=True).stdout
+    torch.cuda.synchronize()
+    print('pair, 20 blocks of 100 launches (ms per launch):',
+          ' '.join(f'{evs[b].elapsed_time(evs[b + 1]) / 100:.3f}' for b in range(20)))
+    print(smi)
