@@ -290,6 +290,14 @@ def secondary(dyn, x, beta, args, nlf_exec):
         dyn.config.verbose = False
         res['hmc'] = rate(lambda: dyn.apply_transition_hmc((x, beta), eps=0.01,
                                                            nleapfrog=nlf_exec))
+        # the headline trajectory replayed from a HIP graph (Dynamics.make_graphed): what the
+        # host-side launch gaps cost
+        try:
+            g = dyn.make_graphed(x, beta=float(beta))
+            res['l2hmc_hip_graph'] = rate(lambda: g(x))
+            del g
+        except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
+            res['l2hmc_hip_graph'] = f'failed: {type(e).__name__}: {e}'[:200]
     finally:
         dyn.config.verbose = old
     res['unit'] = 'chain*leapfrog-steps/s'
