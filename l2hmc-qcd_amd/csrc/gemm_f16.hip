@@ -13,70 +13,10 @@
 // scale are applied in fp32 (torch promotes fp32 tensor x fp16 tensor to fp32).  The input
 // layer's two products share one accumulator here (autocast rounds xlayer(x) and vlayer(v)
 // separately before adding: one rounding fewer, <= 2^-11 relative).
-#include "l2q_common.hpp"
+#include "half_common.hpp"
 #include "u1_math.hpp"
 
 namespace l2q {
-
-typedef float v4f32 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int HBK = 64;            // K-slab: two MFMA K-steps of 32
-constexpr int HLD = HBK + 8;       // row stride 144 B: conflict-free ds_read_b128 fragments
-
-template <typename HT> struct MfmaH;
-typedef float v16f32 __attribute__((ext_vector_type(16)));
-template <> struct MfmaH<_Float16> {
-  using vec_t = f16x8;
-  static __device__ __forceinline__ v4f32 run(vec_t a, vec_t b, v4f32 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-  // 32x32x16: A lane l holds row l & 31, k = 8 (l >> 5) .. +7; D col = l & 31,
-  // row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).  Half the LDS fragment reads per flop of 16x16x32.
-  static __device__ __forceinline__ v16f32 run32(vec_t a, vec_t b, v16f32 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct MfmaH<__bf16> {
-  using vec_t = bf16x8;
-  static __device__ __forceinline__ v4f32 run(vec_t a, vec_t b, v4f32 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ v16f32 run32(vec_t a, vec_t b, v16f32 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-
-template <typename HT> __device__ __forceinline__ float rnd(float x) { return (float)(HT)x; }
-
-__device__ __forceinline__ float act_h(float z, int act) {
-  switch (act) {
-    case L2Q_ACT_TANH: return tanhf(z);
-    case L2Q_ACT_RELU: return z > 0.f ? z : 0.f;
-    case L2Q_ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
-    case L2Q_ACT_ELU: return z > 0.f ? z : expm1f(z);
-    case L2Q_ACT_SWISH: return z / (1.f + expf(-z));
-    default: return z;
-  }
-}
-
-struct EpiH {
-  const float* bias;
-  const float* bias2;
-  const float* coeff;
-  float scale;
-  int act;
-};
-
-// y = scale * exp(coeff[n]) * r16(act(r16(acc + bias)))   (see the header of this file)
-template <typename HT>
-__device__ __forceinline__ float epilogue_h(float acc, float cb, float cs, bool has_coeff, int act) {
-  float y = rnd<HT>(acc + cb);
-  if (act != L2Q_ACT_NONE) y = rnd<HT>(act_h(y, act));
-  y *= cs;
-  return has_coeff ? y : rnd<HT>(y);
-}
 
 // ROWS x HBK tile of the virtual K-concatenated matrix [P | P2] -> registers -> LDS (as HT).
 // S: element type in HBM (HT or float).  vec: every 16-byte vector is aligned and inside one
@@ -370,7 +310,6 @@ static int pick_config_h(int M, int N, long Kt, bool* wide) {
   return (int)(s < 1 ? 1 : s);
 }
 
-static bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename HT, typename AS, typename CT>
 static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, const void* A2_,
@@ -683,13 +622,6 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
 // consecutive input channels with ONE 16-byte load (VEC8); the first layer reads the fp32 NCHW
 // lattice data ([cos, sin] of the links) element-wise and rounds it while staging.
 // Output: NHWC 16-bit, r16(acc + bias) then r16(act(.)) -- autocast's rounding points.
-struct ConvGeomH {
-  long sn, sc, sh, sw;
-  int C, H, W, k, Ho, Wo, Kc;
-  int clast;            // K order: 0 (ci, i, j) -- nn.Conv2d's flatten order, 1 (i, j, ci)
-  long M;
-};
-
 template <typename HT, typename IT, int KS, int BN, bool VEC8>
 __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __restrict__ in,
                                                                 ConvGeomH g,
@@ -883,6 +815,11 @@ __global__ __launch_bounds__(kBlock) void nchw_to_nhwc_pad_h_kernel(const float*
   for (int c = 0; c < CP; ++c) dst[c] = c < C ? (HT)src[c * HW] : (HT)0.f;
 }
 
+// conv_patch_f16.hip: LDS-patch kernel when the layer fits it; false -> use the gather kernel here
+template <typename HT>
+bool conv_patch_launch(const void* in, const ConvGeomH& g, const void* w, const float* bias,
+                       int cout, int act, void* out, hipStream_t st);
+
 template <typename HT, typename IT>
 static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const float* bias, int cout,
                          int act, void* out_, hipStream_t st) {
@@ -894,6 +831,8 @@ static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const flo
   // 16-byte channel gathers: 16-bit NHWC input, (i, j, ci) order, C % 8 == 0, aligned
   const bool vec8 = sizeof(IT) == 2 && g.clast && g.sc == 1 && g.C % 8 == 0 && g.sw % 8 == 0 &&
                     g.sh % 8 == 0 && g.sn % 8 == 0 && al16(in);
+  if (vec8 && tuning().conv_patch && conv_patch_launch<HT>(in_, g, w_, bias, cout, act, out_, st))
+    return check_launch("l2q_conv_gemm_periodic_h");
 #define L2Q_CHB(KS, BNV)                                                                         \
   do {                                                                                           \
     if (vec8)                                                                                    \

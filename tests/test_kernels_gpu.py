@@ -502,7 +502,7 @@ def test_u1_heads_update_h(hd, dims):
 @pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
 @pytest.mark.parametrize('dims', [(3, 4, 4, 6, 5, 8), (2, 8, 6, 6, 3, 16), (5, 16, 7, 5, 3, 32),
                                   (2, 64, 4, 4, 2, 128), (130, 4, 8, 8, 3, 3), (1, 3, 2, 3, 3, 5),
-                                  (3, 32, 9, 9, 3, 64)])
+                                  (3, 32, 9, 9, 3, 64), (3, 8, 30, 34, 5, 8), (2, 8, 40, 24, 3, 16)])
 def test_conv_gemm_periodic_h(hd, layout, dims):
     """l2q_conv_gemm_periodic_h (+ l2q_maxpool_act_nhwc_h) against the emulator's restatement
     (16-bit rounded operands, fp32 accumulation, autocast rounding points) -- fp32 NCHW input
@@ -527,6 +527,14 @@ def test_conv_gemm_periodic_h(hd, layout, dims):
         if Ho // pool == 0 or Wo // pool == 0:
             continue
         got = ops.conv2d_periodic_gemm_h(xin.cuda(), layout, w16.cuda(), b.cuda(), pool, act)
+        # the LDS-patch kernel (conv_patch_f16.hip; 2: wherever it fits) and the gather kernel (0)
+        # accumulate the same products in the same order: identical bits
+        from l2hmc import native
+        for cp in (2, 0):
+            native.set_tuning('conv_patch', cp)
+            alt = ops.conv2d_periodic_gemm_h(xin.cuda(), layout, w16.cuda(), b.cuda(), pool, act)
+            assert torch.equal(alt, got), (cp, float((alt.float() - got.float()).abs().max()))
+        native.set_tuning('conv_patch', 1)
         y = torch.empty(nb * Ho * Wo, cout, dtype=hd)
         emu_native.l2q_conv_gemm_periodic_h(ops.HALF_TYPES[hd], xin, int(layout == 'nchw'), *strides,
                                             nb, C, H, W, k, w16.reshape(cout, -1),
