@@ -502,7 +502,9 @@ def test_u1_heads_update_h(hd, dims):
 @pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
 @pytest.mark.parametrize('dims', [(3, 4, 4, 6, 5, 8), (2, 8, 6, 6, 3, 16), (5, 16, 7, 5, 3, 32),
                                   (2, 64, 4, 4, 2, 128), (130, 4, 8, 8, 3, 3), (1, 3, 2, 3, 3, 5),
-                                  (3, 32, 9, 9, 3, 64), (3, 8, 30, 34, 5, 8), (2, 8, 40, 24, 3, 16)])
+                                  (3, 32, 9, 9, 3, 64), (3, 8, 30, 34, 5, 8), (2, 8, 40, 24, 3, 16),
+                                  # a patch larger than what travels through registers (5632 vectors)
+                                  (1, 64, 20, 40, 3, 16)])
 def test_conv_gemm_periodic_h(hd, layout, dims):
     """l2q_conv_gemm_periodic_h (+ l2q_maxpool_act_nhwc_h) against the emulator's restatement
     (16-bit rounded operands, fp32 accumulation, autocast rounding points) -- fp32 NCHW input
