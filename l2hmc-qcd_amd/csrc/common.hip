@@ -188,6 +188,7 @@ int l2q_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "force_tile")) { slot = &t.force_tile; ok = value >= 0 && value <= 5; }
   else if (!strcmp(key, "gemm_h_wide_fused")) { slot = &t.gemm_h_wide_fused; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "conv_patch")) { slot = &t.conv_patch; ok = value >= 0 && value <= 2; }
+  else if (!strcmp(key, "gemm_h_dma")) { slot = &t.gemm_h_dma; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "gemm_h_patch")) { slot = &t.gemm_h_patch; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "heads_h_bm")) { slot = &t.heads_h_bm; ok = value == 64 || value == 128; }
   else if (!strcmp(key, "heads_h_order")) { slot = &t.heads_h_order; ok = value == 0 || value == 1; }

@@ -1,0 +1,166 @@
+// gemm_f16_dma.hip -- the large half-precision Linear layers on LDS-DMA staging (gfx950):
+//
+//   C[M][N] = epi( A[M][K] . W[N][K]^T + bias )      A, W 16-bit, K-contiguous, fp32 accumulate
+//
+// for M, N multiples of 256 and K a multiple of 64 -- the conv stack's Linear of the U(1) networks
+// (network.py:283-326; 8192 x 8192 x 51 200 at BASELINE cfg-3) and the other big dense layers.
+// Same rounding points as gemm_nt_h_kernel (half_common.hpp); the accumulation order over K differs
+// from the register-staged kernel only in that there is no split-K here.
+//
+// 256 x 256 tile, 512 threads = 8 wavefronts (2 x 4), wavefront tile 128 x 64 on
+// v_mfma_f32_16x16x32_{f16,bf16}: 32 accumulator tiles.  A K-slab is 64 halves = ONE 128-byte row
+// per tile row: global_load_lds_dwordx4 writes it into LDS with the 16-byte chunks XOR-swizzled by
+// (row >> 1) & 7 (applied to the SOURCE address; 16 consecutive rows of a fragment read then hit 16
+// different bank groups), two 64 KB stages, one barrier per K-slab, no address arithmetic in the
+// loop.  Blocks are ordered so that the 32 tiles an XCD runs at a time form an 8 x 4 patch: 12 operand
+// panels per K-slab through its L2 instead of 64.
+//
+// MI355X, 8192 x 8192 x 51 200 fp16 (6.87 TFLOP): 5.3-5.5 ms = 1.25-1.29 PFLOP/s (0.50-0.52 of the 2.5 PFLOP/s
+// dense peak); the register-staged 128 x 256 kernel: 8.7 ms (0.31).  178 VGPRs, no spills, two
+// wavefronts per SIMD; per K-slab a CU reads 192 KB of fragments from LDS and the DMA writes 64 KB
+// (~2000 of the slab's ~3900 cycles of LDS time): wider wavefront tiles are the next step.
+#include "half_common.hpp"
+
+namespace l2q {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+extern __shared__ __attribute__((aligned(1024))) char hd_lds[];
+
+constexpr int kHdThreads = 512;
+constexpr int kHdBM = 256, kHdBN = 256, kHdBK = 64;
+constexpr int kHdOp = kHdBM * 128;                 // bytes of one operand tile per stage
+constexpr int kHdStage = 2 * kHdOp;
+
+template <typename HT, typename CT>
+__global__ __launch_bounds__(kHdThreads, 2) void gemm_h_dma_kernel(const HT* __restrict__ A,
+                                                                   const HT* __restrict__ W, int M, int N,
+                                                                   long K, EpiH epi, CT* __restrict__ C,
+                                                                   int patched) {
+  using vec_t = typename MfmaH<HT>::vec_t;
+  constexpr int MI = 8, NI = 4;
+  const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const long tm = M / kHdBM, tn = N / kHdBN, total = tm * tn;
+  long w = xcd_swizzle(blockIdx.x, total, 1);
+  long bm, bn;
+  if (patched) {                                   // 8 x 4 patches of tiles, m fastest inside a patch
+    const long patch = w >> 5, in = w & 31, ppr = tm >> 3;
+    bm = (patch % ppr) * 8 + (in & 7);
+    bn = (patch / ppr) * 4 + (in >> 3);
+  } else {
+    bm = w % tm; bn = w / tm;
+  }
+  const long m0 = bm * kHdBM, n0 = bn * kHdBN;
+  // loader: wavefront instruction g = 8 q + wave (q < 4: A, else W) fills tile rows (g & 31) * 8 +
+  // (lane >> 3), 16-byte position lane & 7 with source chunk (lane & 7) ^ ((row >> 1) & 7)
+  unsigned vo[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int R = ((8 * q + wave) & 31) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    vo[q] = (unsigned)(R * K * 2 + c * 16);
+  }
+  const char* a1 = reinterpret_cast<const char*>(A) + m0 * K * 2;
+  const char* w1 = reinterpret_cast<const char*>(W) + n0 * K * 2;
+  auto issue = [&](int stage, long k0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int g = 8 * q + wave;
+      const char* src = (q < 4 ? a1 : w1) + k0 * 2 + (unsigned long)vo[q];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (lds_ptr_t)(hd_lds + stage * kHdStage + g * 1024), 16, 0, 0);
+    }
+  };
+  unsigned offA[2], offB[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const unsigned sw = (unsigned)(((4 * s + grp) ^ ((l15 >> 1) & 7)) << 4);
+    offA[s] = (wm + l15) * 128 + sw;
+    offB[s] = kHdOp + (wn + l15) * 128 + sw;
+  }
+  v4f32 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (v4f32){0, 0, 0, 0};
+
+  issue(0, 0);
+  int st = 0;
+  for (long k0 = 0; k0 < K; k0 += kHdBK, st ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k0 + kHdBK < K) issue(st ^ 1, k0 + kHdBK);
+    const char* sb = hd_lds + st * kHdStage;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      vec_t fb[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const vec_t*>(sb + offB[s] + j * 2048);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const vec_t fa = *reinterpret_cast<const vec_t*>(sb + offA[s] + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = MfmaH<HT>::run(fb[j], fa, acc[i][j]);
+      }
+    }
+  }
+  // W was the MFMA row operand: lane owns chain m = l15 of tile i, outputs 4 grp + r of tile j
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const long nb4 = n0 + wn + 16 * j + 4 * grp;
+    float cs[4], cb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long n = nb4 + r;
+      cs[r] = epi.coeff ? epi.scale * expf(epi.coeff[n]) : epi.scale;
+      cb[r] = 0.f;
+      if (epi.bias) cb[r] += epi.bias[n];
+      if (epi.bias2) cb[r] += epi.bias2[n];
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const long m = m0 + wm + 16 * i + l15;
+      typedef CT cv __attribute__((ext_vector_type(4)));
+      cv o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (CT)epilogue_h<HT>(acc[i][j][r], cb[r], cs[r], epi.coeff != nullptr, epi.act);
+      *reinterpret_cast<cv*>(C + m * N + nb4) = o;
+    }
+  }
+}
+
+// true: launched.  false: the shape does not fit (the caller uses gemm_nt_h_kernel)
+template <typename HT>
+bool gemm_h_dma_launch(const void* A, const void* W, int M, int N, long K, const EpiH& epi, void* C,
+                       int c_is_f32, hipStream_t st) {
+  if (M % kHdBM || N % kHdBN || K % kHdBK || K < 4 * kHdBK) return false;
+  if ((long)(M / kHdBM) * (N / kHdBN) < 128) return false;  // few tiles: the split-K kernels fill the chip
+  if (!al16(A) || !al16(W) || !al16(C) || (double)kHdBM * K * 2.0 >= 4.0e9) return false;
+  const long tm = M / kHdBM, tn = N / kHdBN;
+  const int patched = (tm % 8 == 0 && tn % 4 == 0) ? 1 : 0;     // (row-major tile order: 5.72 instead of 5.46 ms)
+  const dim3 grid((unsigned)(tm * tn)), block(kHdThreads);
+  const size_t lds = 2 * kHdStage;
+#define L2Q_HD(CTV)                                                                                  \
+  do {                                                                                               \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_h_dma_kernel<HT, CTV>,                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    hipLaunchKernelGGL((gemm_h_dma_kernel<HT, CTV>), grid, block, lds, st, (const HT*)A, (const HT*)W, M, \
+                       N, K, epi, (CTV*)C, patched);                                                 \
+  } while (0)
+  if (c_is_f32) L2Q_HD(float);
+  else L2Q_HD(HT);
+#undef L2Q_HD
+  return true;
+}
+
+template bool gemm_h_dma_launch<_Float16>(const void*, const void*, int, int, long, const EpiH&, void*, int,
+                                          hipStream_t);
+template bool gemm_h_dma_launch<__bf16>(const void*, const void*, int, int, long, const EpiH&, void*, int,
+                                        hipStream_t);
+
+}  // namespace l2q

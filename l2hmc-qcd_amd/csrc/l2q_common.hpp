@@ -27,6 +27,7 @@ struct Tuning {
   int gemm_h_wide_fused = 0;  // large half GEMMs: 128 x 256 tile with 512 threads (measured slower)
   int conv_patch = 1;         // half conv: input patch staged in LDS by persistent workgroups for layers with
                               // <= 16 output channels (2: every layer it fits, 0: gather kernel only)
+  int gemm_h_dma = 1;         // big half GEMMs (M, N % 256 == 0, K % 64 == 0): LDS-DMA 256 x 256 kernel (0: off)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
   int heads_h_bm = 128;   // chains per workgroup of the half-precision heads+update kernel (64 | 128)
   int heads_h_order = 0;  // half-precision heads+update kernel: 0 m-tiles fastest, 1 n-tiles fastest

@@ -450,6 +450,41 @@ N_ACT = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'leaky_relu': 3, 'elu': 4, 's
 
 
 @pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(1024, 1024, 320), (2048, 1024, 256), (1024, 1280, 832)])
+def test_gemm_h_dma(hd, shape):
+    """The 256 x 256 LDS-DMA kernel of the big half-precision layers (gemm_f16_dma.hip; M, N % 256 == 0,
+    K % 64 == 0, 16-bit activations) against the emulator's restatement and against the
+    register-staged kernel (tuning gemm_h_dma = 0): same rounding points, K accumulated in one pass
+    instead of split-K partials."""
+    import emu_native
+    from l2hmc import _ops as ops, native
+    m, n, k = shape
+    g = torch.Generator().manual_seed(19)
+    a = torch.randn(m, k, generator=g).to(hd)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd)
+    b = torch.randn(n, generator=g).to(hd).float()
+    co = 0.3 * torch.randn(n, generator=g)
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    for act, coeff, odt in ((None, None, hd), ('tanh', co, torch.float32), ('leaky_relu', None, torch.float32),
+                            ('relu', None, hd)):
+        native.set_tuning('gemm_h_dma', 1)
+        got = ops.gemm_h(a.cuda(), w.cuda(), b.cuda(), coeff=None if coeff is None else coeff.cuda(),
+                         scale=0.7, act=act, out_dtype=odt)
+        native.set_tuning('gemm_h_dma', 0)
+        old = ops.gemm_h(a.cuda(), w.cuda(), b.cuda(), coeff=None if coeff is None else coeff.cuda(),
+                         scale=0.7, act=act, out_dtype=odt)
+        native.set_tuning('gemm_h_dma', 1)
+        want = torch.empty(m, n, dtype=odt)
+        emu_native.l2q_gemm_h(ops.HALF_TYPES[hd], a, 0, w, m, n, k, None, None, 0, b, None, coeff,
+                              0.7, N_ACT[act], want, int(odt == torch.float32), None, 0)
+        for other in (want, old.cpu()):
+            d = (got.cpu().float() - other.float()).abs()
+            tol = 2.5 * ulp * other.float().abs().clamp(min=1.0)
+            assert bool((d <= tol).all()), (act, shape, float((d / tol).max()))
+            assert float((d > 0).float().mean()) < 0.2, (act, shape)
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('dims', [(5, 16, 40), (130, 64, 200), (256, 256, 512), (37, 24, 130),
                                   (3, 7, 9)])
 def test_u1_heads_update_h(hd, dims):
