@@ -7,7 +7,7 @@
 // Same rounding points as gemm_nt_h_kernel (half_common.hpp); the accumulation order over K differs
 // from the register-staged kernel only in that there is no split-K here.
 //
-// 256 x 256 tile, 512 threads = 8 wavefronts (2 x 4), wavefront tile 128 x 64 on
+// 256 x 256 tile, 512 threads = 8 wavefronts (4 x 2), wavefront tile 64 x 128 on
 // v_mfma_f32_16x16x32_{f16,bf16}: 32 accumulator tiles.  A K-slab is 64 halves = ONE 128-byte row
 // per tile row: global_load_lds_dwordx4 writes it into LDS with the 16-byte chunks XOR-swizzled by
 // (row >> 1) & 7 (applied to the SOURCE address; 16 consecutive rows of a fragment read then hit 16
@@ -15,7 +15,7 @@
 // loop.  Blocks are ordered so that the 32 tiles an XCD runs at a time form an 8 x 4 patch: 12 operand
 // panels per K-slab through its L2 instead of 64.
 //
-// MI355X, 8192 x 8192 x 51 200 fp16 (6.87 TFLOP): 5.3-5.5 ms = 1.25-1.29 PFLOP/s (0.50-0.52 of the 2.5 PFLOP/s
+// MI355X, 8192 x 8192 x 51 200 fp16 (6.87 TFLOP): 5.3-5.4 ms = 1.27-1.30 PFLOP/s (0.51-0.52 of the 2.5 PFLOP/s
 // dense peak); the register-staged 128 x 256 kernel: 8.7 ms (0.31).  178 VGPRs, no spills, two
 // wavefronts per SIMD; per K-slab a CU reads 192 KB of fragments from LDS and the DMA writes 64 KB
 // (~2000 of the slab's ~3900 cycles of LDS time): wider wavefront tiles are the next step.
@@ -26,21 +26,24 @@ namespace l2q {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 extern __shared__ __attribute__((aligned(1024))) char hd_lds[];
 
-constexpr int kHdThreads = 512;
 constexpr int kHdBM = 256, kHdBN = 256, kHdBK = 64;
 constexpr int kHdOp = kHdBM * 128;                 // bytes of one operand tile per stage
 constexpr int kHdStage = 2 * kHdOp;
 
+// wavefront grid over the tile: 4 x 2 (wavefront tile 64 x 128) 5.30 ms, 2 x 4 5.43 ms; 2 x 2 with the
+// 256 accumulator registers in AGPRs and one wavefront per SIMD: 34 ms (nothing hides the LDS latency)
+constexpr int kHdWM = 4, kHdWN = 2, kHdWaves = kHdWM * kHdWN;
+
 template <typename HT, typename CT>
-__global__ __launch_bounds__(kHdThreads, 2) void gemm_h_dma_kernel(const HT* __restrict__ A,
+__global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel(const HT* __restrict__ A,
                                                                    const HT* __restrict__ W, int M, int N,
                                                                    long K, EpiH epi, CT* __restrict__ C,
                                                                    int patched) {
   using vec_t = typename MfmaH<HT>::vec_t;
-  constexpr int MI = 8, NI = 4;
+  constexpr int MI = kHdBM / (16 * kHdWM), NI = kHdBN / (16 * kHdWN), LQ = 64 / kHdWaves;
   const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int wm = (wave / kHdWN) * (16 * MI), wn = (wave % kHdWN) * (16 * NI);
   const long tm = M / kHdBM, tn = N / kHdBN, total = tm * tn;
   long w = xcd_swizzle(blockIdx.x, total, 1);
   long bm, bn;
@@ -54,10 +57,10 @@ __global__ __launch_bounds__(kHdThreads, 2) void gemm_h_dma_kernel(const HT* __r
   const long m0 = bm * kHdBM, n0 = bn * kHdBN;
   // loader: wavefront instruction g = 8 q + wave (q < 4: A, else W) fills tile rows (g & 31) * 8 +
   // (lane >> 3), 16-byte position lane & 7 with source chunk (lane & 7) ^ ((row >> 1) & 7)
-  unsigned vo[8];
+  unsigned vo[LQ];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int R = ((8 * q + wave) & 31) * 8 + (lane >> 3);
+  for (int q = 0; q < LQ; ++q) {
+    const int R = ((kHdWaves * q + wave) & 31) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((R >> 1) & 7);
     vo[q] = (unsigned)(R * K * 2 + c * 16);
   }
@@ -65,9 +68,9 @@ __global__ __launch_bounds__(kHdThreads, 2) void gemm_h_dma_kernel(const HT* __r
   const char* w1 = reinterpret_cast<const char*>(W) + n0 * K * 2;
   auto issue = [&](int stage, long k0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int g = 8 * q + wave;
-      const char* src = (q < 4 ? a1 : w1) + k0 * 2 + (unsigned long)vo[q];
+    for (int q = 0; q < LQ; ++q) {
+      const int g = kHdWaves * q + wave;
+      const char* src = (q < LQ / 2 ? a1 : w1) + k0 * 2 + (unsigned long)vo[q];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (lds_ptr_t)(hd_lds + stage * kHdStage + g * 1024), 16, 0, 0);
     }
@@ -139,7 +142,7 @@ bool gemm_h_dma_launch(const void* A, const void* W, int M, int N, long K, const
   if (!al16(A) || !al16(W) || !al16(C) || (double)kHdBM * K * 2.0 >= 4.0e9) return false;
   const long tm = M / kHdBM, tn = N / kHdBN;
   const int patched = (tm % 8 == 0 && tn % 4 == 0) ? 1 : 0;     // (row-major tile order: 5.72 instead of 5.46 ms)
-  const dim3 grid((unsigned)(tm * tn)), block(kHdThreads);
+  const dim3 grid((unsigned)(tm * tn)), block(64 * kHdWaves);
   const size_t lds = 2 * kHdStage;
 #define L2Q_HD(CTV)                                                                                  \
   do {                                                                                               \
