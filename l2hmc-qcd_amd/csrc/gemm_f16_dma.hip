@@ -18,7 +18,11 @@
 // MI355X, 8192 x 8192 x 51 200 fp16 (6.87 TFLOP): 5.3-5.4 ms = 1.27-1.30 PFLOP/s (0.51-0.52 of the 2.5 PFLOP/s
 // dense peak); the register-staged 128 x 256 kernel: 8.7 ms (0.31).  178 VGPRs, no spills, two
 // wavefronts per SIMD; per K-slab a CU reads 192 KB of fragments from LDS and the DMA writes 64 KB
-// (~2000 of the slab's ~3900 cycles of LDS time): wider wavefront tiles are the next step.
+// (~2000 of the slab's ~3900 cycles of LDS time): wider wavefront tiles are the next step.  hipcc batches the
+// fragment reads in front of each group of 16 MFMAs behind an s_waitcnt lgkmcnt(0) (four exposed LDS
+// latencies per slab, covered only by the SIMD's other wavefront); requesting both K-steps' fragments up
+// front (sched_barrier) ends in ONE lgkmcnt(0) in front of all 64 MFMAs -- it does not emit the partial
+// count -- so that variant was not kept.
 #include "half_common.hpp"
 
 namespace l2q {
