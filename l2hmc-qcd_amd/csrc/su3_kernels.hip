@@ -740,25 +740,39 @@ __global__ __launch_bounds__(4 * kFS / LPT, (kFS == 64 || LPT == 2) ? 1 : 2) voi
 // applied back to back with ONE expm(eps v) and one pass over x -- both are local to a link.
 // VEC8: additionally emit su3_to_vec(projectSU(x')) (the vnet input of the next v-update,
 // group/su3/pytorch/group.py:138-147) while x' is in registers -- saves the pass that re-reads it.
+#ifndef XU_OCC
+#define XU_OCC 3        // wavefronts per SIMD the x-update is compiled for (A/B builds override)
+#endif
 template <bool TWO, bool VEC8>
-__global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
+__global__ __launch_bounds__(kBlock, XU_OCC) void su3_expm_mul_kernel(const double2* xn,
                                                               const double2* __restrict__ vn,
                                                               double eps,
                                                               const float* __restrict__ mask,
                                                               int complement, double2* out,
                                                               double* __restrict__ out_vec,
-                                                              int V, long nblk) {
+                                                              int V, long nblk, int lo) {
   const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;     // f = chain*4 + mu
   const int s = (int)blk * kBlock + threadIdx.x;
   if (s >= V) return;
   const int mu = (int)(f & 3);
-  M3 x, a, e;
-  load_link(x, xn + f * 9L * V, V, s);
-  load_link(a, vn + f * 9L * V, V, s);
+  // The three stages below sit in run-time conditionals that are always taken (`lo` = 0 is a kernel
+  // ARGUMENT): hipcc then allocates each stage on its own instead of scheduling the exponential, the
+  // masked products and the projection as one straight line with all their temporaries live
+  // (218 VGPRs, two wavefronts per SIMD; capped at 168 it spilled 52).  Staged, with the masked copies of
+  // x formed inside the product: 182 VGPRs uncapped, 168 with 10 spilled at three wavefronts per SIMD,
+  // x-update 0.423 -> 0.402 ms at cfg-4 (the same staging at two wavefronts per SIMD: 0.443 ms).
+  M3 x, e;
+  load_link(e, vn + f * 9L * V, V, s);
+  if (s >= lo) {
+    M3 a;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { a.re[i] *= eps; a.im[i] *= eps; }
-  m3_expm(e, a);
-  M3 r;
+    for (int i = 0; i < 9; ++i) { a.re[i] = e.re[i] * eps; a.im[i] = e.im[i] * eps; }
+    m3_expm(e, a);
+  }
+  // (the link is requested only now: it would otherwise be live across the exponential; the other
+  // wavefronts of the SIMD cover its latency)
+  load_link(x, xn + f * 9L * V, V, s);
+  M3 r = x;
   if (mask != nullptr) {
     const float* mk = mask + mu * 9 * V;
     double keep[9];
@@ -767,30 +781,46 @@ __global__ __launch_bounds__(kBlock) void su3_expm_mul_kernel(const double2* xn,
       const double k = (double)mk[i * V + s];
       keep[i] = complement ? 1.0 - k : k;
     }
-#pragma unroll 1
-    for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
-      M3 kept, moved;
+    // r = keep (.) x + e @ ((1 - keep) (.) x) with the two masked copies of x formed entry by entry
+    // inside the product (they would be two more live matrices); each half-update in its own
+    // run-time conditional
+    auto half = [&](M3& dst, const M3& src, bool flip) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        const double k = pass == 0 ? keep[i] : 1.0 - keep[i];
-        kept.re[i] = k * x.re[i]; kept.im[i] = k * x.im[i];
-        moved.re[i] = (1.0 - k) * x.re[i]; moved.im[i] = (1.0 - k) * x.im[i];
-      }
-      m3_mul_nn(r, e, moved);
-      m3_add(r, kept);
-      x = r;
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          double sr = 0.0, si = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const double kq = flip ? 1.0 - keep[3 * kk + j] : keep[3 * kk + j];
+            const double mr = (1.0 - kq) * src.re[3 * kk + j], mi = (1.0 - kq) * src.im[3 * kk + j];
+            const double ar = e.re[3 * i + kk], ai = e.im[3 * i + kk];
+            sr = fma(ar, mr, sr); sr = fma(-ai, mi, sr);
+            si = fma(ar, mi, si); si = fma(ai, mr, si);
+          }
+          const double kq = flip ? 1.0 - keep[3 * i + j] : keep[3 * i + j];
+          dst.re[3 * i + j] = fma(kq, src.re[3 * i + j], sr);
+          dst.im[3 * i + j] = fma(kq, src.im[3 * i + j], si);
+        }
+    };
+    if (s >= lo) half(r, x, false);
+    if (TWO) {
+      if (s >= lo) half(x, r, true);
+      r = x;
     }
   } else {
-    m3_mul_nn(r, e, x);
+    if (s >= lo) m3_mul_nn(r, e, x);
   }
   store_link(out + f * 9L * V, V, s, r);
   if constexpr (VEC8) {
-    M3 p;
-    m3_project_su(p, r);
-    double w[8];
-    m3_to_vec8(w, p);
+    if (s >= lo) {
+      M3 p;
+      m3_project_su(p, r);
+      double w[8];
+      m3_to_vec8(w, p);
 #pragma unroll
-    for (int a = 0; a < 8; ++a) out_vec[(f * 8 + a) * (long)V + s] = w[a];
+      for (int a = 0; a < 8; ++a) out_vec[(f * 8 + a) * (long)V + s] = w[a];
+    }
   }
 }
 
@@ -1215,7 +1245,7 @@ int l2q_su3_expm_mul(const void* xn, const void* vn, double eps, const float* ma
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL((su3_expm_mul_kernel<false, false>), dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
                      0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
-                     complement, (double2*)out, (double*)nullptr, (int)V, nblk);
+                     complement, (double2*)out, (double*)nullptr, (int)V, nblk, 0);
   return check_launch("l2q_su3_expm_mul");
 }
 
@@ -1226,7 +1256,7 @@ int l2q_su3_expm_mul2(const void* xn, const void* vn, double eps, const float* m
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL((su3_expm_mul_kernel<true, false>), dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
                      0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
-                     complement_first, (double2*)out, (double*)nullptr, (int)V, nblk);
+                     complement_first, (double2*)out, (double*)nullptr, (int)V, nblk, 0);
   return check_launch("l2q_su3_expm_mul2");
 }
 
@@ -1238,7 +1268,7 @@ int l2q_su3_expm_mul2_vec8(const void* xn, const void* vn, double eps, const flo
   const long nblk = cdiv(V, kBlock);
   hipLaunchKernelGGL((su3_expm_mul_kernel<true, true>), dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock),
                      0, (hipStream_t)stream, (const double2*)xn, (const double2*)vn, eps, mask_n,
-                     complement_first, (double2*)out, vec, (int)V, nblk);
+                     complement_first, (double2*)out, vec, (int)V, nblk, 0);
   return check_launch("l2q_su3_expm_mul2_vec8");
 }
 
