@@ -775,11 +775,11 @@ __global__ __launch_bounds__(kBlock, XU_OCC) void su3_expm_mul_kernel(const doub
   M3 r = x;
   if (mask != nullptr) {
     const float* mk = mask + mu * 9 * V;
-    double keep[9];
+    float keep[9];                           // 0 / 1 masks: exact in fp32, half the registers
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      const double k = (double)mk[i * V + s];
-      keep[i] = complement ? 1.0 - k : k;
+      const float k = mk[i * V + s];
+      keep[i] = complement ? 1.0f - k : k;
     }
     // r = keep (.) x + e @ ((1 - keep) (.) x) with the two masked copies of x formed entry by entry
     // inside the product (they would be two more live matrices); each half-update in its own
@@ -792,13 +792,13 @@ __global__ __launch_bounds__(kBlock, XU_OCC) void su3_expm_mul_kernel(const doub
           double sr = 0.0, si = 0.0;
 #pragma unroll
           for (int kk = 0; kk < 3; ++kk) {
-            const double kq = flip ? 1.0 - keep[3 * kk + j] : keep[3 * kk + j];
+            const double kq = flip ? 1.0 - (double)keep[3 * kk + j] : (double)keep[3 * kk + j];
             const double mr = (1.0 - kq) * src.re[3 * kk + j], mi = (1.0 - kq) * src.im[3 * kk + j];
             const double ar = e.re[3 * i + kk], ai = e.im[3 * i + kk];
             sr = fma(ar, mr, sr); sr = fma(-ai, mi, sr);
             si = fma(ar, mi, si); si = fma(ai, mr, si);
           }
-          const double kq = flip ? 1.0 - keep[3 * i + j] : keep[3 * i + j];
+          const double kq = flip ? 1.0 - (double)keep[3 * i + j] : (double)keep[3 * i + j];
           dst.re[3 * i + j] = fma(kq, src.re[3 * i + j], sr);
           dst.im[3 * i + j] = fma(kq, src.im[3 * i + j], si);
         }
