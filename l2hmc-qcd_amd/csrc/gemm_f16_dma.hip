@@ -26,7 +26,9 @@
 // L2 hit rate 0.81 (10.1 GB through the fabric for 1.68 GB of operands), 48 % of the wavefront cycles
 // waiting and only 3 % of them on LDS: the wait is the vmcnt(0) + barrier for the NEXT slab, one slab
 // (~1.7 us) being a short prefetch distance for the fifth of the requests that miss L2.  A third stage
-// needs a smaller stage (256 x 128 tiles or 32-wide K-slabs): the next step.
+// needs a smaller stage.  Measured (HD_BN = 128, HD_STAGES = 3: 256 x 128 tiles, three 48 KB stages, two
+// slabs in flight): 6.75 ms against 5.19 ms -- the 1.5x operand traffic and the doubled barrier rate cost more
+// than the longer prefetch distance buys; 32-wide K-slabs with four stages are the variant left to try.
 #include "half_common.hpp"
 
 namespace l2q {
@@ -34,9 +36,13 @@ namespace l2q {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 extern __shared__ __attribute__((aligned(1024))) char hd_lds[];
 
-constexpr int kHdBM = 256, kHdBN = 256, kHdBK = 64;
-constexpr int kHdOp = kHdBM * 128;                 // bytes of one operand tile per stage
-constexpr int kHdStage = 2 * kHdOp;
+#ifndef HD_BN
+#define HD_BN 256          // N-tile width and ring depth (A/B builds: tools/ab_build.sh ... -DHD_BN=128 -DHD_STAGES=3)
+#define HD_STAGES 2
+#endif
+constexpr int kHdBM = 256, kHdBN = HD_BN, kHdBK = 64, kHdStages = HD_STAGES;
+constexpr int kHdOp = kHdBM * 128;                 // bytes of the A tile per stage (W tile: kHdBN * 128)
+constexpr int kHdStage = kHdOp + kHdBN * 128;
 
 // wavefront grid over the tile: 4 x 2 (wavefront tile 64 x 128) 5.30 ms, 2 x 4 5.43 ms; 2 x 2 with the
 // 256 accumulator registers in AGPRs and one wavefront per SIMD: 34 ms (nothing hides the LDS latency)
@@ -48,7 +54,8 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
                                                                    long K, EpiH epi, CT* __restrict__ C,
                                                                    int patched) {
   using vec_t = typename MfmaH<HT>::vec_t;
-  constexpr int MI = kHdBM / (16 * kHdWM), NI = kHdBN / (16 * kHdWN), LQ = 64 / kHdWaves;
+  constexpr int MI = kHdBM / (16 * kHdWM), NI = kHdBN / (16 * kHdWN);
+  constexpr int GA = kHdBM / 8, GW = kHdBN / 8, LQ = (GA + GW) / kHdWaves, LQA = GA / kHdWaves;   // loader instructions
   const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave / kHdWN) * (16 * MI), wn = (wave % kHdWN) * (16 * NI);
@@ -68,7 +75,8 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
   unsigned vo[LQ];
 #pragma unroll
   for (int q = 0; q < LQ; ++q) {
-    const int R = ((kHdWaves * q + wave) & 31) * 8 + (lane >> 3);
+    const int gq = kHdWaves * q + wave;
+    const int R = (gq < GA ? gq : gq - GA) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((R >> 1) & 7);
     vo[q] = (unsigned)(R * K * 2 + c * 16);
   }
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
 #pragma unroll
     for (int q = 0; q < LQ; ++q) {
       const int g = kHdWaves * q + wave;
-      const char* src = (q < LQ / 2 ? a1 : w1) + k0 * 2 + (unsigned long)vo[q];
+      const char* src = (q < LQA ? a1 : w1) + k0 * 2 + (unsigned long)vo[q];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (lds_ptr_t)(hd_lds + stage * kHdStage + g * 1024), 16, 0, 0);
     }
@@ -96,12 +104,23 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (v4f32){0, 0, 0, 0};
 
-  issue(0, 0);
+  // ring of kHdStages stages: slabs k + 1 .. k + kHdStages - 1 are in flight while slab k is computed
+  const long nslab = K / kHdBK;
+#pragma unroll
+  for (int p = 0; p < kHdStages - 1; ++p)
+    if (p < nslab) issue(p, (long)p * kHdBK);
   int st = 0;
-  for (long k0 = 0; k0 < K; k0 += kHdBK, st ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (long ks = 0; ks < nslab; ++ks) {
+    // slab ks has landed when at most the younger slabs' requests are outstanding
+    if (kHdStages == 3 && ks + 1 < nslab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LQ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (k0 + kHdBK < K) issue(st ^ 1, k0 + kHdBK);
+    {
+      const long kn = ks + kHdStages - 1;
+      int sn = st + kHdStages - 1;
+      if (sn >= kHdStages) sn -= kHdStages;
+      if (kn < nslab) issue(sn, kn * kHdBK);
+    }
     const char* sb = hd_lds + st * kHdStage;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -115,6 +134,7 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
         for (int j = 0; j < NI; ++j) acc[i][j] = MfmaH<HT>::run(fb[j], fa, acc[i][j]);
       }
     }
+    if (++st == kHdStages) st = 0;
   }
   // W was the MFMA row operand: lane owns chain m = l15 of tile i, outputs 4 grp + r of tile j
 #pragma unroll
@@ -151,7 +171,7 @@ bool gemm_h_dma_launch(const void* A, const void* W, int M, int N, long K, const
   const long tm = M / kHdBM, tn = N / kHdBN;
   const int patched = (tm % 8 == 0 && tn % 4 == 0) ? 1 : 0;     // (row-major tile order: 5.72 instead of 5.46 ms)
   const dim3 grid((unsigned)(tm * tn)), block(64 * kHdWaves);
-  const size_t lds = 2 * kHdStage;
+  const size_t lds = (size_t)kHdStages * kHdStage;
 #define L2Q_HD(CTV)                                                                                  \
   do {                                                                                               \
     static bool attr_set = false;                                                                    \
