@@ -28,7 +28,9 @@
 // (~1.7 us) being a short prefetch distance for the fifth of the requests that miss L2.  A third stage
 // needs a smaller stage.  Measured (HD_BN = 128, HD_STAGES = 3: 256 x 128 tiles, three 48 KB stages, two
 // slabs in flight): 6.75 ms against 5.19 ms -- the 1.5x operand traffic and the doubled barrier rate cost more
-// than the longer prefetch distance buys; 32-wide K-slabs with four stages are the variant left to try.
+// than the longer prefetch distance buys; 32-wide K-slabs in a four-deep ring (HD_BK = 32, HD_STAGES = 4: three
+// slabs in flight, 64-byte rows swizzled by (row >> 2) & 3): 6.42 ms.  Both deeper rings lose to the doubled
+// barrier rate: 64-wide slabs, two stages it is.
 #include "half_common.hpp"
 
 namespace l2q {
@@ -40,9 +42,16 @@ extern __shared__ __attribute__((aligned(1024))) char hd_lds[];
 #define HD_BN 256          // N-tile width and ring depth (A/B builds: tools/ab_build.sh ... -DHD_BN=128 -DHD_STAGES=3)
 #define HD_STAGES 2
 #endif
-constexpr int kHdBM = 256, kHdBN = HD_BN, kHdBK = 64, kHdStages = HD_STAGES;
-constexpr int kHdOp = kHdBM * 128;                 // bytes of the A tile per stage (W tile: kHdBN * 128)
-constexpr int kHdStage = kHdOp + kHdBN * 128;
+#ifndef HD_BK
+#define HD_BK 64           // K-slab in halves: 64 (128-byte rows, 8 chunks) or 32 (64-byte rows, 4 chunks)
+#endif
+constexpr int kHdBM = 256, kHdBN = HD_BN, kHdBK = HD_BK, kHdStages = HD_STAGES;
+constexpr int kHdRow = kHdBK * 2;                  // bytes of a tile row in LDS
+constexpr int kHdRpi = 1024 / kHdRow;              // tile rows one wavefront DMA instruction fills
+constexpr int kHdOp = kHdBM * kHdRow;              // bytes of the A tile per stage
+constexpr int kHdStage = kHdOp + kHdBN * kHdRow;
+// chunk swizzle key of a row: 16 consecutive rows of a fragment read must cover 16 bank groups
+__host__ __device__ constexpr int hd_key(int row) { return kHdBK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
 // wavefront grid over the tile: 4 x 2 (wavefront tile 64 x 128) 5.30 ms, 2 x 4 5.43 ms; 2 x 2 with the
 // 256 accumulator registers in AGPRs and one wavefront per SIMD: 34 ms (nothing hides the LDS latency)
@@ -55,7 +64,8 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
                                                                    int patched) {
   using vec_t = typename MfmaH<HT>::vec_t;
   constexpr int MI = kHdBM / (16 * kHdWM), NI = kHdBN / (16 * kHdWN);
-  constexpr int GA = kHdBM / 8, GW = kHdBN / 8, LQ = (GA + GW) / kHdWaves, LQA = GA / kHdWaves;   // loader instructions
+  constexpr int GA = kHdBM / kHdRpi, GW = kHdBN / kHdRpi, LQ = (GA + GW) / kHdWaves, LQA = GA / kHdWaves;   // loader instructions
+  constexpr int CPR = kHdRow / 16, KS = kHdBK / 32;             // 16-byte chunks per row, MFMA K-steps per slab
   const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave / kHdWN) * (16 * MI), wn = (wave % kHdWN) * (16 * NI);
@@ -76,8 +86,8 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
 #pragma unroll
   for (int q = 0; q < LQ; ++q) {
     const int gq = kHdWaves * q + wave;
-    const int R = (gq < GA ? gq : gq - GA) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    const int R = (gq < GA ? gq : gq - GA) * kHdRpi + lane / CPR;
+    const int c = (lane % CPR) ^ hd_key(R);
     vo[q] = (unsigned)(R * K * 2 + c * 16);
   }
   const char* a1 = reinterpret_cast<const char*>(A) + m0 * K * 2;
@@ -91,12 +101,12 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
                                        (lds_ptr_t)(hd_lds + stage * kHdStage + g * 1024), 16, 0, 0);
     }
   };
-  unsigned offA[2], offB[2];
+  unsigned offA[KS], offB[KS];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const unsigned sw = (unsigned)(((4 * s + grp) ^ ((l15 >> 1) & 7)) << 4);
-    offA[s] = (wm + l15) * 128 + sw;
-    offB[s] = kHdOp + (wn + l15) * 128 + sw;
+  for (int s = 0; s < KS; ++s) {
+    const unsigned sw = (unsigned)(((4 * s + grp) ^ hd_key(l15)) << 4);
+    offA[s] = (wm + l15) * kHdRow + sw;
+    offB[s] = kHdOp + (wn + l15) * kHdRow + sw;
   }
   v4f32 acc[MI][NI];
 #pragma unroll
@@ -112,8 +122,10 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
   int st = 0;
   for (long ks = 0; ks < nslab; ++ks) {
     // slab ks has landed when at most the younger slabs' requests are outstanding
-    if (kHdStages == 3 && ks + 1 < nslab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LQ) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kHdStages > 2 && ks + kHdStages - 2 < nslab)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kHdStages - 2) * LQ) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
       const long kn = ks + kHdStages - 1;
@@ -123,13 +135,13 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
     }
     const char* sb = hd_lds + st * kHdStage;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KS; ++s) {
       vec_t fb[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const vec_t*>(sb + offB[s] + j * 2048);
+      for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const vec_t*>(sb + offB[s] + j * 16 * kHdRow);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const vec_t fa = *reinterpret_cast<const vec_t*>(sb + offA[s] + i * 2048);
+        const vec_t fa = *reinterpret_cast<const vec_t*>(sb + offA[s] + i * 16 * kHdRow);
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = MfmaH<HT>::run(fb[j], fa, acc[i][j]);
       }
