@@ -70,6 +70,8 @@ def parse():
                     help='train mode: chains per tape micro-batch (needed at 16^4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-spot-check', action='store_true')
+    ap.add_argument('--no-comm-probe', action='store_true')
+    ap.add_argument('--no-u1', action='store_true', help='skip the untimed U(1) cfg-2 / cfg-3 block')
     ap.add_argument('--cpu-chains', type=int, default=32)
     return ap.parse_args()
 
@@ -304,6 +306,127 @@ def secondary(dyn, x, beta, args, nlf_exec):
     return res
 
 
+FP16_MFMA_PEAK_TF = 2500.0      # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
+FP32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_16x16x4_f32
+
+
+def _u1_flops(name, a):
+    """MFMA flops of one launch of a U(1) network entry point from its C-ABI arguments."""
+    if name == 'l2q_gemm_h':
+        return 2.0 * a[4] * a[5] * (a[6] + a[9])
+    if name == 'l2q_gemm_h_u1x':
+        return 2.0 * a[5] * a[6] * (2 * a[7] + a[10])
+    if name == 'l2q_u1_heads_update_h':
+        return 6.0 * a[2] * a[3] * a[4]
+    if name == 'l2q_conv_gemm_periodic_h':
+        nb, C, H, W, k, cout = a[6], a[7], a[8], a[9], a[10], a[14]
+        return 2.0 * nb * (H + k - 1) * (W + k - 1) * cout * C * k * k
+    if name == 'l2q_conv_gemm_periodic_f32':
+        nb, C, H, W, k, cout = a[5], a[6], a[7], a[8], a[9], a[13]
+        return 2.0 * nb * (H + k - 1) * (W + k - 1) * cout * C * k * k
+    if name == 'l2q_gemm_f32':
+        return 2.0 * a[2] * a[3] * (a[4] + a[7])
+    return 0.0
+
+
+def secondary_u1(steps=3):
+    """Untimed-region block (rank 0, N = 1): the other two single-GPU BASELINE configs run as
+    themselves -- cfg-2 (2D U(1) 16x16, beta 4, 2048 chains, nleapfrog 8, fp32) and cfg-3 (64x64,
+    beta 6, 8192 chains, nleapfrog 8, fp16 nets / fp32 action), each with the reference's default
+    network (conf/network + conf/conv defaults: conv [8,16,32,64,128] + units [16]*4) and with a
+    dense one -- `steps` merged trajectories after one warm-up, x fed through compat_proj like the
+    reference's eval loop.  Reports chain*LF/s and, from HIP events around every C-ABI call, the
+    dominant kernel with its share and (MFMA entry points) its fraction of the dense peak.
+    Parity of exactly these shapes: tests/test_sizes_gpu.py::test_cfg2_* / test_cfg3_*."""
+    import gc
+    import l2hmc.configs as cfgs
+    from l2hmc import native
+    import l2hmc._ops as ops
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+    old_dtype = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)
+    conv_default = dict(filters=[8, 16, 32, 64, 128], sizes=[5, 3, 3, 3, 2], pool=[2, 2, 2, 2, 2])
+    cases = [('cfg2_default_net_fp32', [16, 16], 2048, 4.0, [16, 16, 16, 16], True, None),
+             ('cfg2_dense_fp32', [16, 16], 2048, 4.0, [16, 16, 16, 16], False, None),
+             ('cfg3_dense256_fp16', [64, 64], 8192, 6.0, [256, 256], False, 'fp16'),
+             ('cfg3_default_net_fp16', [64, 64], 8192, 6.0, [16, 16, 16, 16], True, 'fp16')]
+    out = {}
+    orig_native, orig_ops = native.call, ops.N.call
+    for tag, L, nb, beta, units, conv, prec in cases:
+        try:
+            torch.manual_seed(9992)
+            np.random.seed(9992)
+            nlf = 8
+            dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=nlf, eps=0.1,
+                                     eps_hmc=0.1, verbose=False)
+            nc = cfgs.NetworkConfig(units=units, activation_fn='leaky_relu', dropout_prob=0.2,
+                                    use_batch_norm=True)
+            cc = cfgs.ConvolutionConfig(**conv_default) if conv else cfgs.ConvolutionConfig()
+            spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [dc.xdim, 2], 'v': [dc.xdim]},
+                                  vnet={'x': [dc.xdim], 'v': [dc.xdim]})
+            lat = LatticeU1(nb, L)
+            dyn = Dynamics(lat.action, dc, NetworkFactory(spec, nc, cc)).eval()
+            dyn.set_net_precision(prec)
+            x = lat.random()
+            bt = torch.tensor(beta)
+            xo, m = dyn((x, bt))                                   # warm-up (weight copies, pool)
+            x = dyn.g.compat_proj(xo.reshape(x.shape))
+            torch.cuda.synchronize()
+            recs = []
+
+            def timed(name, *a):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig_native(name, *a)
+                e1.record()
+                recs.append((name, _u1_flops(name, a), e0, e1))
+            native.call = timed
+            ops.N.call = timed
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                xo, m = dyn((x, bt))
+                x = dyn.g.compat_proj(xo.reshape(x.shape))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            native.call, ops.N.call = orig_native, orig_ops
+            assert bool(torch.isfinite(x).all())
+            agg = {}
+            for name, fl, e0, e1 in recs:
+                d = agg.setdefault(name, [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += e0.elapsed_time(e1) * 1e-3
+                d[2] += fl
+            tot = sum(v[1] for v in agg.values())
+            name, (cnt, tt, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+            dom = {'kernel': name, 'share_of_kernel_time': round(tt / tot, 4),
+                   'launches_per_trajectory': cnt // steps, 'avg_ms': round(tt / cnt * 1e3, 4)}
+            if fl > 0:
+                peak = FP32_MFMA_PEAK_TF if name.endswith('f32') else FP16_MFMA_PEAK_TF
+                dom.update({'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': peak,
+                            'unit': 'TFLOP/s', 'frac': round(fl / tt / 1e12 / peak, 4)})
+            out[tag] = {'workload': f'2D U(1) {L[0]}x{L[1]}, beta={beta}, {nb} chains, nleapfrog={nlf} '
+                                    f'({2 * nlf} LF steps/trajectory), '
+                                    f'{"default conv stack + " if conv else ""}units {units}, '
+                                    f'{prec or "fp32"} nets / fp32 action',
+                        'ms_per_trajectory': round(dt * 1e3, 3),
+                        'value': round(nb * 2 * nlf / dt, 1), 'unit': 'chain*leapfrog-steps/s',
+                        'steps': steps, 'accept_prob_mean': round(float(m['acc'].mean()), 4),
+                        'kernel_time_fraction_of_wall': round(tot / (dt * steps), 4),
+                        'dominant_kernel': dom}
+        except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
+            out[tag] = f'failed: {type(e).__name__}: {e}'[:300]
+        finally:
+            native.call, ops.N.call = orig_native, orig_ops
+            dyn = lat = x = xo = m = None
+            gc.collect()
+            torch.cuda.empty_cache()
+    torch.set_default_dtype(old_dtype)
+    return out
+
+
 def load_traffic(args):
     """profiles/pmc_traffic.json: HBM/fabric bytes per launch from separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes (tools/pmc_collect.sh).  An entry is used only if it was
@@ -381,6 +504,33 @@ def collective_probe(dist, world, n_params, reps=5):
             'busbw_GBps': round(nbytes / dt / 1e9 * 2 * (world - 1) / world, 2)}
 
 
+def native_comm_probe(dist, world, n_params, reps=3):
+    """The same exchange through the C ABI (l2q_comm_init / l2q_allreduce_grads, librccl resolved at
+    run time) -- also with ONE rank, so that a 1-GPU run proves librccl loads and that one flat
+    buffer of the gradient arena's size goes through on the launch stream (untimed region; never
+    fatal for the headline)."""
+    try:
+        from l2hmc.utils.dist import NativeComm
+        c = NativeComm(rank=0 if dist is None else dist.get_rank(), world_size=world)
+        buf = torch.ones(n_params, dtype=torch.float64, device='cuda')
+        c.all_reduce_(buf)
+        torch.cuda.synchronize()
+        ok = bool((buf == float(world)).all())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            c.all_reduce_(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        c.close()
+        return {'route': 'l2q_allreduce_grads (C ABI -> librccl)', 'ranks': world,
+                'bytes': n_params * 8, 'ms': round(ms, 3), 'sum_correct': ok,
+                'algbw_GBps': round(n_params * 8 / ms / 1e6, 2)}
+    except Exception as e:  # noqa: BLE001
+        return {'route': 'l2q_allreduce_grads', 'error': f'{type(e).__name__}: {e}'[:300]}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -414,11 +564,17 @@ def main():
         dyn, lat = tr.dynamics, tr.lattice
     else:
         dyn, lat = build(args, seed)
-    x = hot_start(args, seed=seed * (rank + 1))
+    cseed = seed + 1_000_003 * (rank + 1)          # chain streams: distinct from the model seed on every rank
+    x = hot_start(args, seed=cseed)
+    # sampler-loop conveniences, named in config.workload: the transition keeps the native-layout
+    # original of the x it returned and reuses it when that very tensor comes straight back (the
+    # reference's eval_step does compat_proj first: one 0.2 ms pack more), and mc_states.out.v is
+    # selected on first access (nothing in a sampler loop reads it)
+    dyn.cache_native_output = True
     if train:
         # per-rank stream for momenta / accept uniforms (chains differ, the model does not)
-        torch.manual_seed(seed * (rank + 1))
-        torch.cuda.manual_seed(seed * (rank + 1))
+        torch.manual_seed(cseed)
+        torch.cuda.manual_seed(cseed)
     beta = torch.tensor(args.beta)
     nlf_exec = 2 * args.nleapfrog
 
@@ -464,9 +620,12 @@ def main():
     assert torch.isfinite(acc).all() and torch.isfinite(x).all(), 'non-finite trajectory'
     ar = allreduce_probe(tr, dist, world) if train else None
     probe = None
-    if dist is not None and not train and args.mode == 'l2hmc':
+    nprobe = None
+    if not train and args.mode == 'l2hmc' and not args.no_comm_probe:
         nparam = sum(p.numel() for p in dyn.vnet.parameters())
-        probe = collective_probe(dist, world, nparam)
+        if dist is not None:
+            probe = collective_probe(dist, world, nparam)
+        nprobe = native_comm_probe(dist, world, nparam)
 
     if rank == 0:
         V = int(np.prod(args.lattice))
@@ -545,9 +704,15 @@ def main():
             'config': {'workload': f'4D SU(3) {"x".join(map(str, args.lattice))}, beta={args.beta}, '
                                    f'{args.nchains} chains/GPU, complex128/fp64, {what}, '
                                    f'nleapfrog={args.nleapfrog} ({nlf_exec} LF steps/trajectory), '
-                                   f'vnet units {args.units}, verbose=False',
+                                   f'vnet units {args.units}, verbose=False; sampler-loop conveniences on: '
+                                   f'native-output cache (x_out fed straight back skips one pack), '
+                                   f'mc_states.out.v selected lazily',
                        'global_chains': world * args.nchains, 'parallelism': f'chains sharded x{world}'},
-            'rccl_ranks': world if (dist is not None and backend == 'nccl') else (0 if dist is None else f'{world} ({backend})'),
+            # ranks of the RCCL communicator that executed in this run (N = 1: the one-rank
+            # communicator of the native probe, if it ran)
+            'rccl_ranks': (world if (dist is not None and backend == 'nccl')
+                           else (f'{world} ({backend})' if dist is not None
+                                 else (1 if (nprobe or {}).get('sum_correct') else 0))),
             'roofline': roofline,
             'rooflines': rooflines,
             'kernel_time_fraction_of_wall': round(total_k / dt, 4),
@@ -556,6 +721,8 @@ def main():
         }
         if probe is not None:
             out['grad_allreduce_probe'] = probe
+        if nprobe is not None:
+            out['grad_allreduce_probe_native'] = nprobe
         if train:
             out['train'] = {'params_trained': tr.arena.numel(), 'grad_allreduce': ar,
                             'micro_batch': args.micro_batch, 'loss': m.get('loss'),
@@ -566,6 +733,10 @@ def main():
             if not args.no_cpu_baseline:
                 out['secondary'] = secondary(dyn, x, beta, args, nlf_exec)
                 out['cpu_baseline'] = cpu_baseline(dyn, args)
+            if not args.no_u1:
+                del dyn, lat, x, m
+                torch.cuda.empty_cache()
+                out['secondary_u1'] = secondary_u1()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

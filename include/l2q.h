@@ -67,6 +67,27 @@ int l2q_set_tuning(const char* key, int value);
  * for a T x X x Y x Z lattice under the current tuning; "" for entry points with a single
  * kernel.  Lets a profile (rocprofv3 --pmc) be matched to the build that is running. */
 int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, size_t buf_bytes);
+/* Select and check the device this process drives (one process per GPU): hipSetDevice(device),
+ * refuses anything that is not gfx950, touches the device's knob table.  Returns `device` or a
+ * negative error.  Optional -- every entry point works on the caller's current HIP device; this is
+ * the explicit per-device handle SURVEY.md section 8(b)(ii) lists. */
+int l2q_init(int device);
+
+/* ---------------------------------------------------------------- the one collective of the path
+ * Sum of the flat training-gradient buffer over ranks: the reference wraps the dynamics in
+ * DistributedDataParallel (trainers/pytorch/trainer.py:246-257; bucketed all-reduce during
+ * loss.backward(), :1296-1304) on the process group of utils/dist.py:126-144.  Thin wrapper over
+ * RCCL (xGMI within a node); librccl is resolved at run time, so the library loads without it.
+ * Bootstrap like NCCL: rank 0 calls l2q_comm_unique_id, the L2Q_COMM_ID_BYTES bytes reach the other
+ * ranks out of band (a torch.distributed / file / env broadcast), every rank calls l2q_comm_init
+ * with its HIP device current.  l2q_allreduce_grads is in place, enqueued on `stream`, elem_bytes
+ * 8 = fp64, 4 = fp32 (one call per dtype group of the gradient arena).  Sampling never calls it. */
+#define L2Q_COMM_ID_BYTES 128
+int l2q_comm_unique_id(void* id_out);
+int l2q_comm_init(const void* id, int nranks, int rank, void** comm_out);
+int l2q_allreduce_grads(void* comm, void* grad, long n, int elem_bytes, void* stream);
+int l2q_comm_destroy(void* comm);
+
 /* bytes of scratch the reductions need for `nb` chains of `n_per_chain` work items */
 size_t l2q_reduce_ws_bytes(int nb, long n_per_chain);
 

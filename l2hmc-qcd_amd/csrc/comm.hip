@@ -1,0 +1,132 @@
+// comm.hip -- per-device initialisation and the ONE collective of the path: the sum of the flat
+// training-gradient buffer over ranks (RCCL over xGMI).  The reference's counterpart is the DDP
+// wrap of the dynamics (trainers/pytorch/trainer.py:246-257, bucketed all-reduce in
+// loss.backward(), :1296-1304) on the process group of utils/dist.py:126-144.  Sampling needs no
+// collective: chains are independent and sharded over ranks.
+//
+// librccl is resolved at run time (dlopen of the soname): libl2q.so itself has no link-time
+// dependency on it, and inside a PyTorch process the copy PyTorch already loaded is the one used.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "l2q_common.hpp"
+
+namespace l2q {
+namespace {
+
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+Rccl& rccl() {
+  static Rccl r;
+  if (r.ok || r.h) return r;
+  for (const char* name : {"librccl.so.1", "librccl.so"}) {
+    r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.h) break;
+  }
+  if (!r.h) {
+    set_error("librccl.so.1 not found (%s)", dlerror());
+    return r;
+  }
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+  r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+  r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy && r.GetErrorString;
+  if (!r.ok) set_error("librccl: missing symbols");
+  return r;
+}
+
+int rccl_fail(const char* what, ncclResult_t e) {
+  set_error("%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(e) : "rccl error");
+  return L2Q_EHIP;
+}
+
+}  // namespace
+}  // namespace l2q
+
+using namespace l2q;
+
+extern "C" {
+
+static_assert(sizeof(ncclUniqueId) == L2Q_COMM_ID_BYTES, "ncclUniqueId size");
+
+int l2q_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("l2q_init: no HIP device visible");
+    return L2Q_EHIP;
+  }
+  L2Q_REQUIRE(device >= 0 && device < n && device < 16, L2Q_EINVAL, "device index out of range");
+  if (hipSetDevice(device) != hipSuccess) {
+    set_error("l2q_init: hipSetDevice(%d) failed", device);
+    return L2Q_EHIP;
+  }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return L2Q_EHIP;
+  if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+    set_error("l2q_init: device %d is %s; libl2q.so carries gfx950 code only", device, p.gcnArchName);
+    return L2Q_EHIP;
+  }
+  (void)tuning();          // this device's knob table (defaults on first touch)
+  return device;
+}
+
+int l2q_comm_unique_id(void* id_out) {
+  L2Q_REQUIRE(id_out, L2Q_EINVAL, "null pointer");
+  Rccl& r = rccl();
+  if (!r.ok) return L2Q_EHIP;
+  ncclUniqueId id;
+  ncclResult_t e = r.GetUniqueId(&id);
+  if (e != ncclSuccess) return rccl_fail("ncclGetUniqueId", e);
+  memcpy(id_out, &id, sizeof id);
+  return L2Q_OK;
+}
+
+int l2q_comm_init(const void* id, int nranks, int rank, void** comm_out) {
+  L2Q_REQUIRE(id && comm_out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, L2Q_EINVAL, "bad rank / nranks");
+  Rccl& r = rccl();
+  if (!r.ok) return L2Q_EHIP;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  ncclComm_t c = nullptr;
+  ncclResult_t e = r.CommInitRank(&c, nranks, uid, rank);
+  if (e != ncclSuccess) return rccl_fail("ncclCommInitRank", e);
+  *comm_out = (void*)c;
+  return L2Q_OK;
+}
+
+int l2q_allreduce_grads(void* comm, void* grad, long n, int elem_bytes, void* stream) {
+  L2Q_REQUIRE(comm && grad, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(n > 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(elem_bytes == 4 || elem_bytes == 8, L2Q_EINVAL, "elem_bytes must be 4 (fp32) or 8 (fp64)");
+  Rccl& r = rccl();
+  if (!r.ok) return L2Q_EHIP;
+  ncclResult_t e = r.AllReduce(grad, grad, (size_t)n, elem_bytes == 8 ? ncclFloat64 : ncclFloat32, ncclSum,
+                               (ncclComm_t)comm, (hipStream_t)stream);
+  if (e != ncclSuccess) return rccl_fail("ncclAllReduce", e);
+  return L2Q_OK;
+}
+
+int l2q_comm_destroy(void* comm) {
+  L2Q_REQUIRE(comm, L2Q_EINVAL, "null pointer");
+  Rccl& r = rccl();
+  if (!r.ok) return L2Q_EHIP;
+  ncclResult_t e = r.CommDestroy((ncclComm_t)comm);
+  if (e != ncclSuccess) return rccl_fail("ncclCommDestroy", e);
+  return L2Q_OK;
+}
+
+}  // extern "C"

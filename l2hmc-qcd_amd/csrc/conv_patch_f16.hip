@@ -240,11 +240,10 @@ bool conv_patch_launch(const void* in, const ConvGeomH& g, const void* w, const 
   const long nwg = a.ntiles < 256L * per_cu ? a.ntiles : 256L * per_cu;
 #define L2Q_CP(BNV, MIV)                                                                            \
   do {                                                                                           \
-    static bool attr_set = false;                                                                \
-    if (!attr_set) {                                                                             \
+    static PerDeviceOnce attr_once;                                                              \
+    if (attr_once.first()) {                                                                             \
       (void)hipFuncSetAttribute((const void*)conv_patch_h_kernel<HT, BNV, MIV>,                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);         \
-      attr_set = true;                                                                           \
     }                                                                                            \
     hipLaunchKernelGGL((conv_patch_h_kernel<HT, BNV, MIV>), dim3((unsigned)nwg), dim3(kBlock), lds, st, a); \
   } while (0)

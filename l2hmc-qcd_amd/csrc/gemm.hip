@@ -1295,14 +1295,17 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
   // partial columns of wave tiles that fall entirely beyond N are never written: clear first
   (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * (mid ? 3 : 1) * sizeof(double), st);
   // LDS-DMA kernel whenever the K-slabs are whole (tuning heads_dma = 0 keeps the older kernel)
-  const bool dma = tuning().heads_dma && (K % BK == 0) && K >= BK && K <= (1 << 20);
+  const bool dma_ok = (K % BK == 0) && K >= BK && K <= (1 << 20);
+  const bool dma = tuning().heads_dma && dma_ok;
 #define L2Q_HEADS(C, F, P)                                                                      \
   do {                                                                                          \
     if (dma) hipLaunchKernelGGL((fused_heads_dma_kernel<C, F, P>), grid, block, 0, st, a, swz); \
     else hipLaunchKernelGGL((fused_heads_vupdate_kernel<C, F, P>), grid, block, 0, st, a, swz, stg); \
   } while (0)
   if (mid) {
-    L2Q_REQUIRE(dma, L2Q_ESHAPE, "mid-point outputs need the LDS-DMA kernel (K % 16 == 0)");
+    // (only the LDS-DMA kernel has the mid-point variant: it runs whatever `heads_dma` says --
+    // results never depend on the knobs)
+    L2Q_REQUIRE(dma_ok, L2Q_ESHAPE, "mid-point outputs need the LDS-DMA kernel (K % 16 == 0)");
 #define L2Q_HEADS_MID(C, F) \
   hipLaunchKernelGGL((fused_heads_dma_kernel<C, F, true, true>), grid, block, 0, st, a, swz)
     if (is_complex) { if (forward) L2Q_HEADS_MID(true, true); else L2Q_HEADS_MID(true, false); }

@@ -186,11 +186,10 @@ bool gemm_h_dma_launch(const void* A, const void* W, int M, int N, long K, const
   const size_t lds = (size_t)kHdStages * kHdStage;
 #define L2Q_HD(CTV)                                                                                  \
   do {                                                                                               \
-    static bool attr_set = false;                                                                    \
-    if (!attr_set) {                                                                                 \
+    static PerDeviceOnce attr_once;                                                                  \
+    if (attr_once.first()) {                                                                                 \
       (void)hipFuncSetAttribute((const void*)gemm_h_dma_kernel<HT, CTV>,                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-      attr_set = true;                                                                               \
     }                                                                                                \
     hipLaunchKernelGGL((gemm_h_dma_kernel<HT, CTV>), grid, block, lds, st, (const HT*)A, (const HT*)W, M, \
                        N, K, epi, (CTV*)C, patched);                                                 \

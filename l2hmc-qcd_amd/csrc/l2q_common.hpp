@@ -34,6 +34,19 @@ struct Tuning {
 };
 Tuning& tuning();
 
+// One-time per-DEVICE set-up of a kernel (hipFuncSetAttribute is a property of the function on
+// the current device): `static PerDeviceOnce once; if (once.first()) { ... }`.
+struct PerDeviceOnce {
+  bool done[16] = {};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

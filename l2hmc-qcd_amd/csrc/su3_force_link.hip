@@ -299,11 +299,10 @@ __global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
 template <int MODE, int INM>
 static void launch_link_variant(const double2* xn, Dims d, int nb, int nsb, int tsplit, double coef,
                                 const double2* vin, double2* out, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)su3_force_link_kernel<MODE, INM>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((su3_force_link_kernel<MODE, INM>), dim3((unsigned)((long)nb * nsb * tsplit)),
                      dim3(kLkThreads), kLkLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, vin, out, 1);

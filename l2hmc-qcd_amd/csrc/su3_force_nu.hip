@@ -288,11 +288,10 @@ __global__ __launch_bounds__(kNuThreads) void su3_force_nu_kernel(
 template <int MODE, int INM>
 static void launch_nu_variant(const double2* xn, Dims d, int nb, int nsb, int tsplit, double coef,
                               double2* out, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)su3_force_nu_kernel<MODE, INM>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kNuLds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((su3_force_nu_kernel<MODE, INM>), dim3((unsigned)((long)nb * nsb * tsplit)),
                      dim3(kNuThreads), kNuLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, out);

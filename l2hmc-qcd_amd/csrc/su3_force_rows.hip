@@ -407,11 +407,10 @@ bool force_rows_applicable(const Dims& d) {
 template <int MODE, int INM>
 static void launch_rows_variant(const double2* xn, Dims d, int nb, int nsb, int tsplit, double coef,
                                 double2* out, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)su3_force_rows_kernel<MODE, INM>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (INM & 8) ? kRowsLdsHalo : kRowsLds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((su3_force_rows_kernel<MODE, INM>), dim3((unsigned)((long)nb * nsb * tsplit)),
                      dim3(kRowsThreads), (INM & 8) ? kRowsLdsHalo : kRowsLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, out);

@@ -1024,11 +1024,10 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
     const int tlen = (int)cdiv(d.T, tsplit);
     tsplit = (int)cdiv(d.T, tlen);
     const size_t lds = 2ul * 4 * 9 * kFS * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
       (void)hipFuncSetAttribute((const void*)su3_force_slice_kernel<KICK, kFS, kVar, kLpt>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
     }
     hipLaunchKernelGGL((su3_force_slice_kernel<KICK, kFS, kVar, kLpt>),
                        dim3((unsigned)((long)nb * nsb * tsplit)), dim3(4 * kFS / kLpt), lds, st, xn, d, nsb,

@@ -172,11 +172,10 @@ __global__ __launch_bounds__(kPqThreads, 3) void su3_plaq_nu_kernel(
 template <int INM>
 static void launch_pq_variant(const double2* xn, Dims d, int nb, int nsb, int tsplit, double* partial,
                               hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)su3_plaq_nu_kernel<INM>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kPqLds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((su3_plaq_nu_kernel<INM>), dim3((unsigned)((long)nb * nsb * tsplit)),
                      dim3(kPqThreads), kPqLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, partial, 0);

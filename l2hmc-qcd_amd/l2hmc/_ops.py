@@ -703,11 +703,17 @@ def act_fwd(x: torch.Tensor, act: Optional[str]) -> torch.Tensor:
     return y
 
 
-def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: Optional[str]) -> torch.Tensor:
-    """dy * act'(z) from the activation output y -- for swish from the pre-activation z -- in
-    place on dy."""
+def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: Optional[str],
+            from_preact: bool = False) -> torch.Tensor:
+    """dy * act'(z) in place on dy.  `y` is the activation OUTPUT for every activation whose
+    derivative can be written in terms of it; swish needs the PRE-activation z, and the caller must
+    say so (`from_preact=True`) -- a post-activation passed for swish would give a silently wrong
+    gradient, so that combination raises."""
     if N.ACT[act] == 0:
         return dy
+    if (act == 'swish') != bool(from_preact):
+        raise ValueError("act_bwd: swish differentiates from the pre-activation (from_preact=True), "
+                         "every other activation from its output")
     N.call('l2q_act_bwd', dy, y, N.ACT[act], dy.numel(), dy.element_size(), dy)
     return dy
 
@@ -855,6 +861,9 @@ def conv2d_periodic_gemm_bwd(ctx: dict, dout: torch.Tensor, w: torch.Tensor, dw:
     nb, C, H, W, k, cout = ctx['dims']
     Ho, Wo, Kc = H + k - 1, W + k - 1, C * k * k
     pool, act = ctx['pool'], ctx['act']
+    if act == 'swish':
+        # the fused conv kernels keep the activation OUTPUT only; swish' needs the pre-activation
+        raise NotImplementedError('conv backward with swish: the conv tape holds post-activations')
     dout = dout.contiguous()
     if pool > 1:
         dy = torch.empty_like(ctx['y'])

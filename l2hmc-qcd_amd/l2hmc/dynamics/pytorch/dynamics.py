@@ -228,7 +228,10 @@ class Dynamics(nn.Module):
         self._masks_native: Optional[list] = None
         self._perm: dict = {}
         self._xcache = None                    # (returned x_out, its version, native original)
-        self.cache_native_output = True
+        # opt-in (a sampler loop / bench.py that feeds the returned tensor straight back): the entry
+        # is validated by tensor identity + torch's version counter only, which writes through raw
+        # pointers (the library's own in-place kernels, .data edits) do not bump
+        self.cache_native_output = False
         self.pair_v_updates_verbose = True     # verbose=True also pairs adjacent v-updates (mid-point kernel)
 
     # ------------------------------------------------------------------ construction
@@ -434,7 +437,7 @@ class Dynamics(nn.Module):
         transition returned straight back (`x, _ = dynamics((x, beta))`): its native-layout
         original is still at hand, so the 0.24 ms reference -> native transpose is skipped when
         the caller passes that very tensor, unmodified (the transitions never write their input)."""
-        c = self._xcache
+        c, self._xcache = self._xcache, None         # one use: a miss drops the entry
         if (c is not None and self.group == 'SU3' and x is c[0] and x._version == c[1]
                 and self.cache_native_output):
             return c[2]
@@ -1190,8 +1193,9 @@ class Dynamics(nn.Module):
                 v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)).reshape(nb, -1),
                 beta=beta, xshape=xout.shape)
             # (kept only while it is small next to the HBM: the 16^4 shard would pin 9.7 GB)
-            big = xo_n.numel() * xo_n.element_size() > (4 << 30)
-            self._xcache = None if big else (xout, xout._version, xo_n)
+            keep = (self.cache_native_output
+                    and xo_n.numel() * xo_n.element_size() <= (1 << 30))
+            self._xcache = (xout, xout._version, xo_n) if keep else None
         else:
             vo_n = ops.select_rows(v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)
             out = State(x=xout, v=vo_n.reshape(nb, -1), beta=beta)

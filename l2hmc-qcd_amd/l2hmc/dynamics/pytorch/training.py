@@ -89,11 +89,22 @@ class ParamArena:
         """number of trained parameters (without the alignment padding of the flat buffers)"""
         return sum(p.numel() for g in self.groups.values() for p in g['params'])
 
-    def all_reduce(self) -> float:
+    def all_reduce(self, comm=None, force: bool = False) -> float:
         """Sum the flat gradients over ranks (RCCL over xGMI: one collective per dtype);
-        returns the 1/world factor to fold into the optimiser step (DDP averages)."""
+        returns the 1/world factor to fold into the optimiser step (DDP averages).
+        `comm`: a `utils.dist.NativeComm` (l2q_allreduce_grads through the C ABI) instead of the
+        torch.distributed group; `force`: run the collective even with a single rank (the RCCL
+        smoke test / bench probe of a 1-GPU box)."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if comm is not None:
+            if comm.world_size == 1 and not force:
+                return 1.0
+            for g in self.groups.values():
+                comm.all_reduce_(g['grad'])
+            return 1.0 / comm.world_size
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1.0
+        if dist.get_world_size() == 1 and not force:
             return 1.0
         for g in self.groups.values():
             dist.all_reduce(g['grad'], op=dist.ReduceOp.SUM)

@@ -25,6 +25,11 @@ SIGNATURES = {
     'l2q_version': (I, []),
     'l2q_set_tuning': (I, [C.c_char_p, I]),
     'l2q_kernel_name': (I, [C.c_char_p, I, I, I, I, C.c_char_p, Z]),
+    'l2q_init': (I, [I]),
+    'l2q_comm_unique_id': (I, [P]),
+    'l2q_comm_init': (I, [P, I, I, C.POINTER(P)]),
+    'l2q_allreduce_grads': (I, [P, P, L, I, P]),
+    'l2q_comm_destroy': (I, [P]),
     'l2q_reduce_ws_bytes': (Z, [I, L]),
     'l2q_transpose': (I, [P, P, L, I, I, I, P]),
     'l2q_su3_pack': (I, [P, P, I, L, P]),

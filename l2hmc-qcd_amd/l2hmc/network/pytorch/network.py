@@ -327,6 +327,8 @@ class ConvStack(nn.Module):
     def backward(self, ctx: dict, dy: Tensor) -> Tensor:
         """Accumulates the layers' .grad; returns dL/dx [nb, C, T, X]."""
         lin = self.layers[self.linear_index]
+        if self.act == 'swish':
+            raise NotImplementedError('ConvStack.backward with swish: the tape holds post-activations')
         dpre = ops.act_bwd(dy.contiguous().clone(), ctx['y'], self.act)
         d = _linear_bwd(dpre, ctx['flat'], lin.weight, lin.bias)
         nb = d.shape[0]
@@ -768,13 +770,14 @@ class LeapfrogLayer(nn.Module):
         if 'drop' in ctx:
             dz = ops.mul(dz, ctx['drop'], 1.0 / (1.0 - float(self.net_config.dropout_prob)))
         acts = ctx['acts']
-        dact = ctx['pre'] if ctx.get('pre') is not None else acts   # swish: from the pre-activation
+        pre = ctx.get('pre') is not None
+        dact = ctx['pre'] if pre else acts                          # swish: from the pre-activation
         for i in range(len(self.hidden_layers) - 1, -1, -1):
             h = self.hidden_layers[i]
-            dpre = ops.act_bwd(dz, dact[i + 1], self.act)
+            dpre = ops.act_bwd(dz, dact[i + 1], self.act, from_preact=pre)
             dz = _linear_bwd(dpre, acts[i], h.weight, h.bias)
         il = self.input_layer
-        dpre = ops.act_bwd(dz, dact[0], self.act)
+        dpre = ops.act_bwd(dz, dact[0], self.act, from_preact=pre)
         if native:
             dxf = _linear_bwd(dpre, ctx['xf'], nw_['wx'], il.xlayer.bias, wgrad=ng_['wx'])
             dvf = _linear_bwd(dpre, ctx['vf'], nw_['wv'], il.vlayer.bias, wgrad=ng_['wv'])

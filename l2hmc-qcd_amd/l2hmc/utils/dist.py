@@ -60,8 +60,11 @@ def setup_torch(seed: int, backend: Optional[str] = None, port: str = '2345') ->
 
 
 def chain_seed(seed: int, rank: Optional[int] = None) -> int:
+    """Seed of this rank's chain streams (initial configurations, momenta, accept uniforms):
+    distinct from the model seed on EVERY rank -- `seed * (rank + 1)` would replay on rank 0 the
+    very stream that drew the weights and masks, and give all ranks the same chains for seed 0."""
     rank = query_environment()['rank'] if rank is None else rank
-    return int(seed) * (rank + 1)
+    return (int(seed) + 1_000_003 * (rank + 1)) % (2 ** 32 - 1)      # numpy wants < 2^32
 
 
 def shard_chains(nchains_global: int, rank: Optional[int] = None,
@@ -142,6 +145,54 @@ def sync_model(dynamics, src: int = 0) -> None:
         dynamics.set_masks([stacked[i].cpu().numpy() for i in range(stacked.shape[0])])
     from l2hmc import _ops as ops
     ops.PARAM_GENERATION[0] += 1          # cached kernel-order weight copies are stale now
+
+
+class NativeComm:
+    """RCCL communicator behind the C ABI (``l2q_comm_init`` / ``l2q_allreduce_grads``,
+    include/l2q.h): the gradient all-reduce without PyTorch's process group on the data path.
+    The 128-byte unique id is drawn on rank 0 and reaches the other ranks through the already
+    initialised ``torch.distributed`` group (any backend; only the bootstrap uses it).  With
+    ``world_size == 1`` nothing else is needed -- which is also how a single-GPU box proves that
+    librccl loads and that the collective orders with the kernels on the launch stream."""
+
+    def __init__(self, rank: Optional[int] = None, world_size: Optional[int] = None):
+        import ctypes as C
+        from l2hmc import native
+        env = query_environment()
+        if dist.is_available() and dist.is_initialized():
+            rank = dist.get_rank() if rank is None else rank
+            world_size = dist.get_world_size() if world_size is None else world_size
+        self.rank = env['rank'] if rank is None else rank
+        self.world_size = env['world_size'] if world_size is None else world_size
+        lib = native.load()
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            rc = lib.l2q_comm_unique_id(ident)
+            if rc != 0:
+                raise native.L2QError(f'l2q_comm_unique_id failed ({rc}): {lib.l2q_last_error().decode()}')
+        if self.world_size > 1:
+            box = [ident.raw if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ident = C.create_string_buffer(box[0], 128)
+        comm = C.c_void_p()
+        rc = lib.l2q_comm_init(ident, self.world_size, self.rank, C.byref(comm))
+        if rc != 0:
+            raise native.L2QError(f'l2q_comm_init failed ({rc}): {lib.l2q_last_error().decode()}')
+        self._comm = comm
+
+    def all_reduce_(self, flat: torch.Tensor) -> torch.Tensor:
+        """in-place sum of a contiguous fp32 / fp64 device buffer over ranks, on the current stream"""
+        from l2hmc import native
+        if flat.dtype not in (torch.float32, torch.float64):
+            raise TypeError(f'all_reduce_: {flat.dtype} (fp32 / fp64 gradient buffers only)')
+        native.call('l2q_allreduce_grads', self._comm, flat, flat.numel(), flat.element_size())
+        return flat
+
+    def close(self) -> None:
+        from l2hmc import native
+        if self._comm is not None and self._comm.value:
+            native.load().l2q_comm_destroy(self._comm)
+        self._comm = None
 
 
 def cleanup() -> None:

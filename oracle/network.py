@@ -45,11 +45,12 @@ def conv2d_valid(x, w, b):
     nb, c, h, wd = x.shape
     f, _, kh, kw = w.shape
     ho, wo = h - kh + 1, wd - kw + 1
-    out = np.zeros((nb, f, ho, wo), dtype=x.dtype)
+    xt = np.ascontiguousarray(x.transpose(0, 2, 3, 1))             # [nb, H, W, C]
+    out = np.zeros((nb, ho, wo, f), dtype=x.dtype)
     for i in range(kh):
         for j in range(kw):
-            out += np.einsum('bchw,fc->bfhw', x[:, :, i:i + ho, j:j + wo], w[:, :, i, j])
-    return out + b[None, :, None, None]
+            out += xt[:, i:i + ho, j:j + wo, :] @ w[:, :, i, j].T    # channel sum on BLAS
+    return out.transpose(0, 3, 1, 2) + b[None, :, None, None]
 
 
 def maxpool2d(x, p):

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""bf16 golden for BASELINE cfg-3 ("fp16 nets / fp32 action"): the REAL reference's U(1)
-``Dynamics`` run under ``torch.autocast('cpu', dtype=torch.bfloat16)`` -- the context manager the
-reference's trainer wraps around the forward step (trainers/pytorch/trainer.py:211-219,
-1276-1280; it enables it on CUDA only, the CPU device type is what can be run here).
+"""16-bit goldens for BASELINE cfg-3 ("fp16 nets / fp32 action"): the REAL reference's U(1)
+``Dynamics`` run under ``torch.autocast('cpu', dtype=torch.bfloat16 | torch.float16)`` -- the
+context manager the reference's trainer wraps around the forward step
+(trainers/pytorch/trainer.py:211-219, 1276-1280; it enables it on CUDA only, the CPU device type
+is what can be run here).
 
     bash tests/golden/setup_reference_env.sh
-    PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_bf16.py
+    PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_bf16.py [bf16|fp16]
 
+(default bf16 -> u1_bf16*.npz; ``fp16`` -> u1_fp16*.npz, cfg-3's stated dtype.)
 Stores inputs (weights, masks, x, draws) and the reference's network outputs, sub-updates and
-merged-trajectory results; tests/test_dynamics_gpu.py::test_u1_bf16_reference_golden compares
-``Dynamics.set_net_precision('bf16')`` with them.
+merged-trajectory results; tests/test_dynamics_gpu.py::test_u1_half_reference_golden compares
+``Dynamics.set_net_precision('bf16' | 'fp16')`` with them.
 """
 import os
 import sys
@@ -17,6 +19,8 @@ import sys
 import numpy as np
 import torch
 
+HD = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+HDT = {'bf16': torch.bfloat16, 'fp16': torch.float16}[HD]
 sys.argv = [sys.argv[0], 'u1']
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import make_golden as G  # noqa: E402  (imports the reference, float32 default)
@@ -35,7 +39,7 @@ def case(name, L, nb, nlf, units, act, beta, seed, conv=None):
     for _ in range(30):       # thermalise in fp32 with the reference's own HMC
         x, _m = dyn.apply_transition_hmc((x, bt), eps=0.2, nleapfrog=5)
         x = dyn.g.compat_proj(dyn.unflatten(x)).detach()
-    ac = torch.autocast('cpu', dtype=torch.bfloat16)
+    ac = torch.autocast('cpu', dtype=HDT)
     best = None
     for sd in range(seed + 3, seed + 103):       # draw with the widest accept margin
         G.seed_all(sd)
@@ -67,7 +71,7 @@ def case(name, L, nb, nlf, units, act, beta, seed, conv=None):
         sx, tx, qx = dyn._call_xnet(0, (xm, v), first=True)
         st_x, ld_x = dyn._update_x_fwd(0, st, m0, first=True)
         st_xb, ld_xb = dyn._update_x_bwd(0, st, mb0, first=False)
-    # the same trajectory in fp32 (how far bf16 moves the result: scale for the tolerances)
+    # the same trajectory in fp32 (how far the 16-bit type moves the result: scale for the tolerances)
     G.seed_all(best[1])
     xo32, m32 = dyn((x, bt))
     f32 = lambda t: npy(t.float())
@@ -90,7 +94,7 @@ def case(name, L, nb, nlf, units, act, beta, seed, conv=None):
 
 
 if __name__ == '__main__':
-    case('u1_bf16', (8, 8), 32, 2, [32, 32], 'leaky_relu', beta=2.0, seed=300)
-    case('u1_bf16_tanh', (8, 16), 12, 2, [24], 'tanh', beta=3.0, seed=320)
-    case('u1_bf16_conv', (8, 8), 6, 2, [8, 8], 'relu', beta=2.0, seed=340,
+    case(f'u1_{HD}', (8, 8), 32, 2, [32, 32], 'leaky_relu', beta=2.0, seed=300)
+    case(f'u1_{HD}_tanh', (8, 16), 12, 2, [24], 'tanh', beta=3.0, seed=320)
+    case(f'u1_{HD}_conv', (8, 8), 6, 2, [8, 8], 'relu', beta=2.0, seed=340,
          conv={'filters': [2, 4], 'sizes': [3, 2], 'pool': [2, 2]})

@@ -117,6 +117,70 @@ def build_u1_dynamics(g, verbose=True):
     return dyn, lat
 
 
+def build_u1_seeded_dynamics(g, nb, device=None):
+    """Product Dynamics configured like a tests/golden/u1_cfg*.npz fixture (make_golden_sizes.py)
+    with ``nb`` chains: the weights are the counter-based numbers of tests/golden/seeded.py (the
+    same ones the generator loaded into the reference), step sizes and masks from the fixture."""
+    import os
+    import sys
+    import torch
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1
+    from l2hmc.network.pytorch.network import NetworkFactory
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    if gd not in sys.path:
+        sys.path.insert(0, gd)
+    import seeded
+    L = [int(i) for i in g['latvolume']]
+    nlf = int(g['nleapfrog'])
+    dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=nlf,
+                             eps=float(g['eps']), eps_hmc=float(g['eps']), use_ncp=True,
+                             verbose=True, use_split_xnets=bool(g['use_split_xnets']),
+                             use_separate_networks=bool(g['use_separate_networks']),
+                             merge_directions=True)
+    kw = u1_net_kwargs(g)
+    nc = cfgs.NetworkConfig(units=[int(i) for i in g['units']], activation_fn=kw['activation'],
+                            dropout_prob=0.2, use_batch_norm=kw['use_batch_norm'])
+    cc = cfgs.ConvolutionConfig(**kw['conv']) if kw['conv'] else cfgs.ConvolutionConfig()
+    xdim = dc.xdim
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), xnet={'x': [xdim, 2], 'v': [xdim]},
+                          vnet={'x': [xdim], 'v': [xdim]})
+    lat = LatticeU1(nb, L)
+    dyn = Dynamics(potential_fn=lat.action, config=dc,
+                   network_factory=NetworkFactory(input_spec=spec, network_config=nc, conv_config=cc))
+    sd = dyn.state_dict()
+    dev_ = device if device is not None else next(dyn.parameters()).device
+    seeded.fill_state_dict(sd, int(g['weight_seed']), float(g['head_scale']), torch_device=dev_)
+    with torch.no_grad():
+        for i in range(nlf):
+            dyn.xeps[i].copy_(torch.tensor(float(g['xeps'][i])))
+            dyn.veps[i].copy_(torch.tensor(float(g['veps'][i])))
+    dyn._eps_cache = {}
+    dyn.set_masks(g['masks'])
+    dyn.eval()
+    return dyn, lat
+
+
+def u1_seeded_oracle(g, dyn, dtype=np.float32):
+    """DynamicsOracle driven by the state_dict of a build_u1_seeded_dynamics product."""
+    sd = {k: v.detach().cpu().numpy() for k, v in dyn.state_dict().items()
+          if not k.startswith('networks.')}
+    kw = u1_net_kwargs(g)
+    nlf = int(g['nleapfrog'])
+
+    def vnet(step, x, f):
+        return onet.leapfrog_layer(x, f, sub(sd, f'vnet.{step}.'), **kw)
+
+    def xnet(step, first, x, v):
+        which = 'first' if first else 'second'
+        return onet.leapfrog_layer(x, v, sub(sd, f'xnet.{step}.{which}.'), **kw)
+    L = tuple(int(i) for i in g['latvolume'])
+    return DynamicsOracle('U1', L, nlf, [sd[f'xeps.{i}'] for i in range(nlf)],
+                          [sd[f'veps.{i}'] for i in range(nlf)], g['masks'], vnet=vnet, xnet=xnet,
+                          dtype=dtype)
+
+
 def build_u1_train_dynamics(g, dropout=0.0):
     """Product Dynamics + LatticeLoss configured like a u1_train_* golden file (train mode).
     Call under the default dtype the fixture was generated with."""

@@ -149,3 +149,18 @@ def test_flat_configs_and_history(tmp_path):
     assert z['energy'].shape == (4, 3, 6) and z['plaqs_mean'].shape == (6,)
     rows = (tmp_path / 'eval_avgs.csv').read_text().strip().splitlines()
     assert len(rows) == 7 and rows[0].split(',')[0] == 'acc'
+
+
+def test_comm_entry_points_validate_without_gpu():
+    """l2q_init / l2q_comm_* / l2q_allreduce_grads (the thin RCCL wrapper of SURVEY 8(b)(ii)):
+    exported, argument checks come before any RCCL / HIP call."""
+    import torch
+    from l2hmc import native
+    lib = native.load()
+    assert lib.l2q_allreduce_grads(None, None, 4, 8, None) == -1
+    assert b'null pointer' in lib.l2q_last_error()
+    assert lib.l2q_comm_init(None, 1, 0, None) == -1
+    assert lib.l2q_comm_unique_id(None) == -1
+    assert lib.l2q_comm_destroy(None) == -1
+    if not torch.cuda.is_available():
+        assert lib.l2q_init(0) == -3                       # L2Q_EHIP: no device visible

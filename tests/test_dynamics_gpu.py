@@ -639,16 +639,16 @@ def test_u1_half_precision_networks(hd, lat, nb, units, act, bn):
     assert bool(torch.isfinite(out[hd][0][0]).all())
 
 
-def _bf16_golden_check(g, dyn, fused: bool, has_conv: bool):
-    """Compare Dynamics.set_net_precision('bf16') with the REAL reference run under
-    torch.autocast('cpu', dtype=torch.bfloat16) (tests/golden/make_golden_bf16.py).  Tolerances in
-    bf16 ulps (2^-7 relative to the largest magnitude): the 16-bit layers round after every Linear
+def _half_golden_check(g, dyn, fused: bool, has_conv: bool, hd: str = 'bf16'):
+    """Compare Dynamics.set_net_precision('bf16' | 'fp16') with the REAL reference run under
+    torch.autocast('cpu', dtype=torch.bfloat16 | torch.float16) (tests/golden/make_golden_bf16.py).
+    Tolerances in ulps of the 16-bit type (2^-7 resp. 2^-10 relative to the largest magnitude): the 16-bit layers round after every Linear
     and activation like autocast does; the one structural difference is that the input layer's two
     Linears share one fp32 accumulator here (one rounding) while autocast rounds each and their
     sum (three roundings), so outputs agree to ~1-2 ulp with about half of the entries bit-equal."""
     from l2hmc.dynamics.pytorch.dynamics import State
-    ulp = 2.0 ** -7
-    dyn.set_net_precision('bf16')
+    ulp = 2.0 ** -7 if hd == 'bf16' else 2.0 ** -10
+    dyn.set_net_precision(hd)
     dyn.fuse_half_heads = fused
     x = torch.from_numpy(g['x']).to(dyn.device)
     beta = torch.tensor(float(g['beta']))
@@ -701,7 +701,18 @@ def test_u1_bf16_reference_golden(golden, name, fused):
     torch.set_default_dtype(torch.float32)
     g = golden(name)
     dyn, lat = build_u1_dynamics(g)
-    _bf16_golden_check(g, dyn, fused, has_conv=bool(g['conv_filters'].size))
+    _half_golden_check(g, dyn, fused, has_conv=bool(g['conv_filters'].size), hd='bf16')
+
+
+@pytest.mark.parametrize('name', ['u1_fp16', 'u1_fp16_tanh', 'u1_fp16_conv'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_u1_fp16_reference_golden(golden, name, fused):
+    """BASELINE cfg-3's stated dtype -- fp16 nets / fp32 action -- pinned to the reference itself
+    (the same generator with torch.float16)."""
+    torch.set_default_dtype(torch.float32)
+    g = golden(name)
+    dyn, lat = build_u1_dynamics(g)
+    _half_golden_check(g, dyn, fused, has_conv=bool(g['conv_filters'].size), hd='fp16')
 
 
 def test_su3_improved_action_c1(golden):

@@ -210,3 +210,29 @@ def test_torch_cpu_oracle_trajectories(golden):
     assert np.array_equal(m['acc_mask'].numpy(), g['acc_mask'])
     close(m['sumlogdet'].numpy(), g['sumlogdet'], 1e-6)
     close(xo.numpy().reshape(g['x_out'].shape), g['x_out'], 1e-7)
+
+
+@pytest.mark.parametrize('name', ['u1_cfg2_dense', 'u1_cfg2_conv'])
+def test_u1_cfg2_shape_oracle_vs_reference(golden, name, monkeypatch):
+    """BASELINE cfg-2's own shape (16 x 16, beta 4, nleapfrog 8, separate + split networks, default
+    conv stack resp. dense units): the oracle against the reference's merged trajectory
+    (tests/golden/make_golden_sizes.py).  The weights are the counter-based numbers of
+    tests/golden/seeded.py written into the PRODUCT's state_dict (host logic only, no kernels), so
+    this also pins that the product's parameter names / shapes are the reference's."""
+    import emu_native
+    import helpers
+    import torch
+    emu_native.install(monkeypatch)
+    torch.set_default_dtype(torch.float32)
+    g = golden(name)
+    dyn, lat = helpers.build_u1_seeded_dynamics(g, 2, device='cpu')
+    d = helpers.u1_seeded_oracle(g, dyn)
+    x, beta = g['x'], float(g['beta'])
+    xo, m = d.apply_transition_fb(x, beta, g['normals'], g['u'], history=True)
+    close(m['energy'], g['energy'], 2e-2)                 # |H| ~ 4e2, 16 leapfrog steps in fp32
+    close(m['acc'], g['acc'], 5e-3)
+    assert np.array_equal(m['acc_mask'], g['acc_mask']) and g['acc_mask'].tolist() == [0.0, 1.0]
+    dx = np.abs(np.angle(np.exp(1j * (xo - g['x_out'].reshape(2, -1)))))
+    assert dx.max() < 1e-3, dx.max()
+    dx = np.abs(np.angle(np.exp(1j * (m['x_prop'].reshape(2, -1) - g['x_prop'].reshape(2, -1)))))
+    assert dx.max() < 1e-3, dx.max()

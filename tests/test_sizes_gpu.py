@@ -13,6 +13,12 @@ N = 147 456 / 2 359 296 -- against the numpy oracle on the same seeded inputs:
   the oracle's result for its base chain -- so an index that wraps anywhere in the allocation
   shows up.  Kernels, a plain-HMC transition and one merged L2HMC trajectory (nleapfrog = 1,
   units [256]: 23 GB of fp64 weights).
+* cfg-2 / cfg-3: U(1) 16 x 16, beta 4, **2048 chains**, nleapfrog 8, fp32 and
+  64 x 64, beta 6, **8192 chains**, fp16 nets / fp32 action, each with the reference's default conv
+  network and a dense one, against fixtures the REAL reference produced at those shapes on two
+  chains (tests/golden/make_golden_sizes.py; the weights -- up to 2.3e9 numbers -- are the
+  counter-based ones of tests/golden/seeded.py, regenerated here on the device).  The chains are
+  copies of the fixture's two; every chain is compared on the device, accept masks bit-exact.
 """
 import gc
 
@@ -185,6 +191,7 @@ NB16 = 256
 
 def _tile(a2, nb=NB16):
     """[2, ...] device tensor -> [nb, ...] with chain c = a2[c % 2]"""
+    assert a2.shape[0] == 2
     return a2.repeat(nb // 2, *([1] * (a2.dim() - 1))).contiguous()
 
 
@@ -338,3 +345,104 @@ def test_cfg5_l2hmc_trajectory_16x4_256chains():
     assert torch.equal(m['acc_mask'].cpu(), torch.from_numpy(mo['acc_mask']).repeat(nb // 2))
     assert _maxdiff_tiled(xo, dev(xo_ref.reshape(2, -1))) < 1e-7
     assert _maxdiff_tiled(m['sumlogdet'], dev(mo['acc_mask'] * mo['sumlogdet'])) < 1e-6
+
+
+# --------------------------------------------------------------------------- cfg-2 / cfg-3 shapes
+def _wrap(d):
+    return torch.remainder(d + np.pi, 2 * np.pi) - np.pi
+
+
+def _angle_diff_tiled(out, ref2):
+    """max |wrap(out[c] - ref2[c % 2])| over all chains, on the device"""
+    ref2 = ref2.to(out.device).reshape(1, 2, -1)
+    worst = 0.0
+    for c0 in range(0, out.shape[0], 512):
+        blk = out[c0:c0 + 512]
+        worst = max(worst, float(_wrap(blk.reshape(blk.shape[0] // 2, 2, -1) - ref2).abs().max()))
+    return worst
+
+
+def _u1_full_size(golden, name, nb, tol_x, tol_acc, tol_h, fused_variants=(True,)):
+    import helpers
+    torch.set_default_dtype(torch.float32)
+    g = golden(name)
+    prec = str(g['precision'])
+    dyn, lat = helpers.build_u1_seeded_dynamics(g, nb)
+    if prec != 'fp32':
+        dyn.set_net_precision(prec)
+    L = [int(i) for i in g['latvolume']]
+    assert nb % 2 == 0 and g['x'].shape[0] == 2
+    x = _tile(dev(g['x']), nb)
+    nrm = _tile(dev(g['normals']), nb)
+    u = dev(g['u']).repeat(nb // 2)
+    beta = torch.tensor(float(g['beta']))
+    want_mask = torch.from_numpy(g['acc_mask']).repeat(nb // 2)
+    assert g['acc_mask'].tolist() == [0.0, 1.0] and float(np.abs(g['acc'] - g['u']).min()) > 0.05
+    res = {}
+    for verbose in (False, True):
+        for fused in fused_variants:
+            dyn.config.verbose = verbose
+            dyn.fuse_u1_steps = fused
+            dyn._inject = {'normals': nrm, 'u': u}
+            xo, m = dyn((x, beta))
+            dyn._inject = None
+            mc = m['mc_states']
+            assert torch.equal(m['acc_mask'].cpu(), want_mask), (name, verbose, fused)   # bit-exact
+            assert _maxdiff_tiled(m['acc'], dev(g['acc'])) < tol_acc, (name, verbose, fused)
+            assert _angle_diff_tiled(mc.proposed.x, dev(g['x_prop'])) < tol_x, (name, verbose, fused)
+            sc = float(np.abs(g['v_prop']).max())
+            assert _maxdiff_tiled(mc.proposed.v, dev(g['v_prop'])) < tol_x * max(1.0, sc)
+            assert _angle_diff_tiled(xo, dev(g['x_out'])) < tol_x
+            assert _maxdiff_tiled(m['sumlogdet'], dev(g['sumlogdet'])) < tol_h
+            if verbose:
+                e = m['energy']                                   # [2 nlf + 1, nb]
+                assert e.shape == (2 * int(g['nleapfrog']) + 1, nb)
+                d = (e.reshape(e.shape[0], nb // 2, 2) - dev(g['energy']).reshape(-1, 1, 2)).abs().max()
+                assert float(d) < tol_h, (name, float(d))
+                d = (m['logdet'].reshape(e.shape[0], nb // 2, 2)
+                     - dev(g['logdet']).reshape(-1, 1, 2)).abs().max()
+                assert float(d) < tol_h, (name, float(d))
+            res[(verbose, fused)] = float(m['acc'].mean())
+    # observables of the output configuration at this chain count
+    from oracle import u1 as ou1
+    xo2 = g['x_out'].reshape(2, 2, *L)
+    met = lat.calc_metrics(xo.reshape(nb, 2, *L))
+    assert _maxdiff_tiled(met['plaqs'], dev(ou1.plaqs(xo2).astype(np.float32))) < 1e-5
+    assert _maxdiff_tiled(met['intQ'], dev(ou1.int_charges(xo2).astype(np.float32))) < 2e-2
+    return g, dyn
+
+
+def test_cfg2_dense_16x16_2048chains(golden):
+    """BASELINE cfg-2 as itself: 16 x 16, beta 4, 2048 chains, nleapfrog 8, fp32, units [16]*4
+    (the fused one-launch-per-sub-update kernels and the multi-kernel path)."""
+    _u1_full_size(golden, 'u1_cfg2_dense', 2048, tol_x=2e-4, tol_acc=2e-3, tol_h=5e-3,
+                  fused_variants=(True, False))
+
+
+def test_cfg2_conv_16x16_2048chains(golden):
+    """cfg-2 with the reference's default network (conv [8,16,32,64,128] + units [16]*4)."""
+    _u1_full_size(golden, 'u1_cfg2_conv', 2048, tol_x=2e-4, tol_acc=2e-3, tol_h=5e-3)
+
+
+def test_cfg3_dense_fp16_64x64_8192chains(golden):
+    """BASELINE cfg-3 as itself: 64 x 64, beta 6, 8192 chains, nleapfrog 8, fp16 nets / fp32 action,
+    units [256, 256]: M = 8192 row tiles of gemm_h / u1_heads_update_h, 256 MiB fields.  The fixture
+    is the reference under torch.autocast('cpu', float16); tolerances are multiples of the
+    reference's own fp16-vs-fp32 distance (stored in the fixture)."""
+    g = golden('u1_cfg3_fp16_dense')
+    yard = float(np.abs(g['acc'] - g['acc_fp32']).max())
+    _u1_full_size(golden, 'u1_cfg3_fp16_dense', 8192, tol_x=5e-3, tol_acc=max(3 * yard, 5e-3),
+                  tol_h=0.1)
+
+
+def test_cfg3_conv_fp16_64x64_8192chains(golden):
+    """cfg-3 with the reference's default conv network at its real shapes: the
+    8192 x 8192 x 51 200 Linear on gemm_h_dma_kernel, the LDS-patch and gather conv kernels on
+    8192 x 64 x 64 images, 16-bit max-pool (nleapfrog 2: six networks of 1.7 GB each)."""
+    free, total = torch.cuda.mem_get_info()
+    if total < 100 * 2 ** 30:
+        pytest.skip('needs > 100 GB of HBM')
+    g = golden('u1_cfg3_fp16_conv')
+    yard = float(np.abs(g['acc'] - g['acc_fp32']).max())
+    _u1_full_size(golden, 'u1_cfg3_fp16_conv', 8192, tol_x=5e-3, tol_acc=max(3 * yard, 5e-3),
+                  tol_h=0.1)

@@ -293,7 +293,7 @@ def test_su3_micro_batched_training_host_logic(golden, monkeypatch, f64):
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
-@pytest.mark.parametrize('name', ['u1_bf16', 'u1_bf16_tanh'])
+@pytest.mark.parametrize('name', ['u1_bf16', 'u1_bf16_tanh', 'u1_fp16', 'u1_fp16_tanh'])
 def test_bf16_rounding_points_vs_reference_autocast(name, golden, monkeypatch):
     """The emulator's restatement of where the 16-bit layers round (tests/emu_native.py,
     l2q_gemm_h) against the REAL reference run under torch.autocast('cpu', bfloat16)
@@ -302,13 +302,14 @@ def test_bf16_rounding_points_vs_reference_autocast(name, golden, monkeypatch):
     g = golden(name)
     emu_native.install(monkeypatch)
     dyn, lat = helpers.build_u1_dynamics(g)
-    dyn.set_net_precision('bf16')
+    hd = 'fp16' if 'fp16' in name else 'bf16'
+    dyn.set_net_precision(hd)
     dyn.fuse_half_heads = False           # gemm_h + fp32 update kernels (the emulated set)
     x = torch.from_numpy(g['x'])
     beta = torch.tensor(float(g['beta']))
     nb = x.shape[0]
     f = dyn.grad_potential(x, beta)
-    ulp = 2.0 ** -7
+    ulp = 2.0 ** -7 if hd == 'bf16' else 2.0 ** -10
     for a, k in zip(dyn._call_vnet(0, (x, f)), ('vnet_s', 'vnet_t', 'vnet_q')):
         ref = g[k]
         d = np.abs(a.numpy() - ref)
