@@ -310,6 +310,15 @@ FP16_MFMA_PEAK_TF = 2500.0      # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md; n
 FP32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_16x16x4_f32
 
 
+def _u1_bytes(name, a):
+    """algorithmic HBM bytes of one launch of the fused half-precision heads + update kernel: the
+    fp32 field it updates in place (read + write), the second fp32 operand, Z and the 3 heads' W"""
+    if name == 'l2q_u1_heads_update_h':
+        M, K, N = a[2], a[3], a[4]
+        return 3.0 * M * N * 4 + 2.0 * M * K + 3.0 * 2.0 * N * K
+    return 0.0
+
+
 def _u1_flops(name, a):
     """MFMA flops of one launch of a U(1) network entry point from its C-ABI arguments."""
     if name == 'l2q_gemm_h':
@@ -319,7 +328,7 @@ def _u1_flops(name, a):
     if name == 'l2q_u1_heads_update_h':
         return 6.0 * a[2] * a[3] * a[4]
     if name == 'l2q_conv_gemm_periodic_h':
-        nb, C, H, W, k, cout = a[6], a[7], a[8], a[9], a[10], a[14]
+        nb, C, H, W, k, cout = a[7], a[8], a[9], a[10], a[11], a[15]
         return 2.0 * nb * (H + k - 1) * (W + k - 1) * cout * C * k * k
     if name == 'l2q_conv_gemm_periodic_f32':
         nb, C, H, W, k, cout = a[5], a[6], a[7], a[8], a[9], a[13]
@@ -382,7 +391,7 @@ def secondary_u1(steps=3):
                 e0.record()
                 orig_native(name, *a)
                 e1.record()
-                recs.append((name, _u1_flops(name, a), e0, e1))
+                recs.append((name, _u1_flops(name, a), e0, e1, _u1_bytes(name, a)))
             native.call = timed
             ops.N.call = timed
             t0 = time.perf_counter()
@@ -394,19 +403,27 @@ def secondary_u1(steps=3):
             native.call, ops.N.call = orig_native, orig_ops
             assert bool(torch.isfinite(x).all())
             agg = {}
-            for name, fl, e0, e1 in recs:
-                d = agg.setdefault(name, [0, 0.0, 0.0])
+            for name, fl, e0, e1, by in recs:
+                d = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
                 d[0] += 1
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += fl
+                d[3] += by
             tot = sum(v[1] for v in agg.values())
-            name, (cnt, tt, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+            name, (cnt, tt, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
             dom = {'kernel': name, 'share_of_kernel_time': round(tt / tot, 4),
                    'launches_per_trajectory': cnt // steps, 'avg_ms': round(tt / cnt * 1e3, 4)}
             if fl > 0:
                 peak = FP32_MFMA_PEAK_TF if name.endswith('f32') else FP16_MFMA_PEAK_TF
-                dom.update({'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': peak,
-                            'unit': 'TFLOP/s', 'frac': round(fl / tt / 1e12 / peak, 4)})
+                f_mfma = fl / tt / 1e12 / peak
+                f_hbm = by / tt / 1e9 / HBM_PEAK_GBS
+                if f_hbm > f_mfma:       # the roofline that binds is the one closer to its peak
+                    dom.update({'bound': 'hbm', 'achieved': round(by / tt / 1e9, 1),
+                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(f_hbm, 4),
+                                'mfma_frac': round(f_mfma, 4)})
+                else:
+                    dom.update({'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': peak,
+                                'unit': 'TFLOP/s', 'frac': round(f_mfma, 4)})
             out[tag] = {'workload': f'2D U(1) {L[0]}x{L[1]}, beta={beta}, {nb} chains, nleapfrog={nlf} '
                                     f'({2 * nlf} LF steps/trajectory), '
                                     f'{"default conv stack + " if conv else ""}units {units}, '
@@ -417,7 +434,8 @@ def secondary_u1(steps=3):
                         'kernel_time_fraction_of_wall': round(tot / (dt * steps), 4),
                         'dominant_kernel': dom}
         except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
-            out[tag] = f'failed: {type(e).__name__}: {e}'[:300]
+            import traceback
+            out[tag] = f'failed: {type(e).__name__}: {e} | ' + traceback.format_exc()[-400:]
         finally:
             native.call, ops.N.call = orig_native, orig_ops
             dyn = lat = x = xo = m = None
@@ -438,7 +456,7 @@ def load_traffic(args):
     L = [int(i) for i in args.lattice]
 
     def traffic(name):
-        t = pmc.get(name)
+        t = pmc.get(f'{name}@{"x".join(map(str, L))}x{args.nchains}', pmc.get(name))
         if t is None:
             return None, 'no PMC pass recorded for this entry point'
         if t.get('lattice') != L or t.get('nchains') != args.nchains:

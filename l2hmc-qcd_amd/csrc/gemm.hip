@@ -487,14 +487,36 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __res
 #undef L2Q_CONV_FETCH_A
 }
 
+// Fixed-order reduction of the split-K partials + epilogue.  A workgroup owns 64 consecutive
+// outputs; its four wavefronts each sum a contiguous quarter of the splits (eight loads in flight
+// per lane), the quarters meet in LDS and are added in order 0..3 -- the same order every run.
+// (One thread per output summing all 128 partials of the SU(3) input layer one after the other was
+// a 128-deep chain of dependent HBM round trips: 43 us per call.)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const T* __restrict__ part,
                                                                int splits, long MN, int N,
                                                                Epilogue<T> epi, T* __restrict__ C) {
-  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= MN) return;
+  __shared__ T quarter[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + o;
+  const int per = (splits + 3) / 4;
+  const int z0 = g * per, z1 = min(splits, z0 + per);
   T s = (T)0;
-  for (int z = 0; z < splits; ++z) s += part[(long)z * MN + i];     // fixed order
+  if (i < MN) {
+    int z = z0;
+    for (; z + 8 <= z1; z += 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(z + u) * MN + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < z1; ++z) s += part[(long)z * MN + i];
+  }
+  quarter[g][o] = s;
+  __syncthreads();
+  if (g != 0 || i >= MN) return;
+  s = ((quarter[0][o] + quarter[1][o]) + quarter[2][o]) + quarter[3][o];
   const int n = (int)(i % N);
   const T y = epi.colscale(n) * apply_act<T>(s + epi.colbias(n), epi.act);
   C[i] = epi.accumulate ? C[i] + y : y;
@@ -691,6 +713,15 @@ __global__ __launch_bounds__(kBlock, L2Q_HEADS_OCC) void fused_heads_vupdate_ker
 // 1.14-1.16 ms (1.32-1.47 ms before); tools/lab/heads_lab.hip holds the A/B harness.
 // Needs K % 16 == 0 (heads_launch falls back to fused_heads_vupdate_kernel otherwise).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// 16-byte chunk swizzle of the 128-byte LDS rows: position = chunk ^ L2Q_SWZ(row).  A ds_read_b64
+// fragment read takes 32 lanes per LDS cycle (rows 0..15 x the two 8-byte halves of one chunk);
+// the bank group of a row is 32 (row & 1) + 4 position, so the swizzle must separate the eight
+// rows of equal parity: (row >> 1) & 7.  (row & 7, the first version, put rows r and r + 8 on
+// the same banks: SQ_LDS_BANK_CONFLICT = 47 % of SQ_LDS_IDX_ACTIVE, tools/microbench/
+// lds_b64_conflict.hip modes 2 and 5.)
+#ifndef L2Q_SWZ
+#define L2Q_SWZ(r) (((r) >> 1) & 7)
+#endif
 
 // MID (pair kernels): per-step metrics need the state BETWEEN the two updates -- the kernel also
 // returns the first update's log-Jacobian and sum |v|^2 of the intermediate momentum (per-row
@@ -725,7 +756,7 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
     const int r = R & 63;                                  // row within the operand
     long lim = (q < 2 ? (long)a.M - m0 : (long)a.N - n0) - 1;
     const int rc = r <= lim ? r : (int)lim;                // clamp: edge tiles re-read a valid row
-    const int c = (lane & 7) ^ (R & 7);
+    const int c = (lane & 7) ^ L2Q_SWZ(R);
     voff[q] = (unsigned)(rc * (int)K * 8 + c * 16);
   }
   auto issue = [&](int stage, long k0) {
@@ -741,7 +772,7 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
   unsigned offA[4], offB[4];
 #pragma unroll
   for (int kq = 0; kq < 4; ++kq) {
-    const unsigned sw = ((((kq * 2) + (lane >> 5)) ^ (lane & 7)) << 4) + ((lane >> 4) & 1) * 8;
+    const unsigned sw = ((((kq * 2) + (lane >> 5)) ^ L2Q_SWZ(lane)) << 4) + ((lane >> 4) & 1) * 8;
     offA[kq] = (wm + (lane & 15)) * ROWB + sw;
     offB[kq] = (BM + wn + (lane & 15)) * ROWB + sw;
   }
@@ -957,7 +988,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
     } else {
       const int R = ((4 * q + wave) & 15) * 8 + (lane >> 3);
       const int rc = R <= lim ? R : (int)lim;
-      const int c = (lane & 7) ^ (R & 7);
+      const int c = (lane & 7) ^ L2Q_SWZ(R);
       vo1[q] = (unsigned)(rc * K * 8 + c * 16);
       vo2[q] = (unsigned)(rc * K2 * 8 + c * 16);
     }
@@ -984,7 +1015,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
   unsigned offA[4], offB[4];
 #pragma unroll
   for (int kq = 0; kq < 4; ++kq) {
-    const unsigned sw = ((((kq * 2) + (lane >> 5)) ^ (lane & 7)) << 4) + ((lane >> 4) & 1) * 8;
+    const unsigned sw = ((((kq * 2) + (lane >> 5)) ^ L2Q_SWZ(lane)) << 4) + ((lane >> 4) & 1) * 8;
     const unsigned tr = (4 * kq + (lane >> 4)) * (BM * 8) + (lane & 15) * 8;
     offA[kq] = TA ? tr + wm * 8 : (wm + (lane & 15)) * ROWB + sw;
     offB[kq] = OPB + (TW ? tr + wn * 8 : (wn + (lane & 15)) * ROWB + sw);
@@ -1148,7 +1179,7 @@ static int gemm_launch(const T* A, const T* W, int M, int N, long K, const T* A2
 #undef L2Q_GEMM
   if (splits > 1) {
     const long MN = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)cdiv(MN, kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)cdiv(MN, 64)), dim3(kBlock), 0,
                        st, (const T*)ws, splits, MN, N, epi, C);
   }
   return check_launch("l2q_gemm");

@@ -772,7 +772,6 @@ __global__ __launch_bounds__(kBlock, XU_OCC) void su3_expm_mul_kernel(const doub
   // (the link is requested only now: it would otherwise be live across the exponential; the other
   // wavefronts of the SIMD cover its latency)
   load_link(x, xn + f * 9L * V, V, s);
-  M3 r = x;
   if (mask != nullptr) {
     const float* mk = mask + mu * 9 * V;
     float keep[9];                           // 0 / 1 masks: exact in fp32, half the registers
@@ -781,36 +780,51 @@ __global__ __launch_bounds__(kBlock, XU_OCC) void su3_expm_mul_kernel(const doub
       const float k = mk[i * V + s];
       keep[i] = complement ? 1.0f - k : k;
     }
-    // r = keep (.) x + e @ ((1 - keep) (.) x) with the two masked copies of x formed entry by entry
-    // inside the product (they would be two more live matrices); each half-update in its own
-    // run-time conditional
-    auto half = [&](M3& dst, const M3& src, bool flip) {
+    // m <- keep (.) m + e @ ((1 - keep) (.) m), IN PLACE and column by column: entry (i, j) of the
+    // result needs column j of m only, so a column is read (masked copy formed on the fly), its
+    // three results are formed and written back before the next column is touched -- the live set
+    // is e, m, the masks and one column (no second and third copy of the link: that is what took
+    // the staged kernel over the 168-register budget of three wavefronts per SIMD, 10 spilled).
+    // Same products in the same order as the two-copy form: identical bits.
+    auto half = [&](M3& m, bool flip) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double cr[3], ci[3], ki[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int kk = 0; kk < 3; ++kk) {
+          const double kq = flip ? 1.0 - (double)keep[3 * kk + j] : (double)keep[3 * kk + j];
+          cr[kk] = (1.0 - kq) * m.re[3 * kk + j]; ci[kk] = (1.0 - kq) * m.im[3 * kk + j];
+          ki[kk] = kq;
+        }
+        double orr[3], oi[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
           double sr = 0.0, si = 0.0;
 #pragma unroll
           for (int kk = 0; kk < 3; ++kk) {
-            const double kq = flip ? 1.0 - (double)keep[3 * kk + j] : (double)keep[3 * kk + j];
-            const double mr = (1.0 - kq) * src.re[3 * kk + j], mi = (1.0 - kq) * src.im[3 * kk + j];
             const double ar = e.re[3 * i + kk], ai = e.im[3 * i + kk];
-            sr = fma(ar, mr, sr); sr = fma(-ai, mi, sr);
-            si = fma(ar, mi, si); si = fma(ai, mr, si);
+            sr = fma(ar, cr[kk], sr); sr = fma(-ai, ci[kk], sr);
+            si = fma(ar, ci[kk], si); si = fma(ai, cr[kk], si);
           }
-          const double kq = flip ? 1.0 - (double)keep[3 * i + j] : (double)keep[3 * i + j];
-          dst.re[3 * i + j] = fma(kq, src.re[3 * i + j], sr);
-          dst.im[3 * i + j] = fma(kq, src.im[3 * i + j], si);
+          orr[i] = fma(ki[i], m.re[3 * i + j], sr);
+          oi[i] = fma(ki[i], m.im[3 * i + j], si);
         }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { m.re[3 * i + j] = orr[i]; m.im[3 * i + j] = oi[i]; }
+      }
     };
-    if (s >= lo) half(r, x, false);
+    if (s >= lo) half(x, false);
     if (TWO) {
-      if (s >= lo) half(x, r, true);
-      r = x;
+      if (s >= lo) half(x, true);
     }
   } else {
-    if (s >= lo) m3_mul_nn(r, e, x);
+    if (s >= lo) {
+      M3 r;
+      m3_mul_nn(r, e, x);
+      x = r;
+    }
   }
+  M3& r = x;
   store_link(out + f * 9L * V, V, s, r);
   if constexpr (VEC8) {
     if (s >= lo) {

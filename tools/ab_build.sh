@@ -8,5 +8,5 @@ name="$1"; stem="$2"; shift 2
 mkdir -p obj_ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $stem.hip -o obj_ab/${stem}_$name.o
 objs=$(ls obj/*.o | grep -v "obj/$stem.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../l2hmc/_lib/libl2q_$name.so $objs obj_ab/${stem}_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../l2hmc/_lib/libl2q_$name.so $objs obj_ab/${stem}_$name.o -ldl
 echo " -> libl2q_$name.so"

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run each hot kernel a few times at the cfg-4 size -- the target of rocprofv3 --pmc passes."""
+"""Run each hot kernel a few times at the cfg-4 size (or, with L2Q_KPROF_LATTICE="16 16 16 16"
+L2Q_KPROF_NB=256, at the cfg-5 per-GPU shard) -- the target of rocprofv3 --pmc passes."""
 import os
 import sys
 
@@ -9,8 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
 from l2hmc import _ops as ops, native  # noqa: E402
 
-nb, L = 256, (8, 8, 8, 8)
-V = 4096
+L = tuple(int(i) for i in os.environ.get('L2Q_KPROF_LATTICE', '8 8 8 8').split())
+nb = int(os.environ.get('L2Q_KPROF_NB', 256))
+V = L[0] * L[1] * L[2] * L[3]
 torch.manual_seed(0)
 xn = ops.su3_project_su_n(torch.randn(nb, 4, 9, V, dtype=torch.complex128, device='cuda'))
 vn = ops.su3_assemble_tah_n(torch.randn(8, nb, 4, V, dtype=torch.float64, device='cuda'))
@@ -30,6 +32,8 @@ wv = torch.randn(h, K, dtype=torch.float64, device='cuda') / K ** 0.5
 bx = torch.randn(h, dtype=torch.float64, device='cuda')
 for _ in range(3):
     ops.su3_plaq_sums_n(xn, L)
+    native.call('l2q_su3_force_kick', xn, 6.0, -0.005, vn, nb, *L)
+    ops.su3_expm_mul2_vec8_n(xn, vn, 0.01, mask, False)
     native.call('l2q_su3_force', xn, 6.0, f, nb, *L)
     ops.su3_expm_mul_n(xn, vn, 0.01)
     ops.su3_projsu_vec8_n(xn)

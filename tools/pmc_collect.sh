@@ -5,7 +5,7 @@
 #   bash tools/pmc_collect.sh rNN      -> gpurun_out/pmc_rNN/{FETCH_SIZE,WRITE_SIZE,...}/
 #                                         profiles/rNN_pmc_counters.txt, profiles/pmc_traffic.json
 set -u
-tag="${1:-r02}"
+tag="${1:-r03}"      # L2Q_KPROF_LATTICE="16 16 16 16" L2Q_KPROF_NB=256 for the cfg-5 shard
 cd "$(dirname "$0")/.."
 root="$PWD"
 out="$root/gpurun_out/pmc_$tag"

@@ -6,14 +6,19 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+LAT = [int(i) for i in os.environ.get('L2Q_KPROF_LATTICE', '8 8 8 8').split()]
+NB = int(os.environ.get('L2Q_KPROF_NB', 256))
 
 ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'su3_plaq_slice_kernel': 'l2q_su3_plaq_reduce', 'su3_plaq_kernel': None, 'su3_plaq_sweep_kernel': None,
     'su3_force_slice_kernel<false': 'l2q_su3_force', 'su3_force_tile_kernel<false': None,
     'su3_force_kernel<false': None, 'su3_force_rows_kernel<0': None, 'su3_force_nu_kernel<0': None, 'su3_force_nu_kernel<1': None,
     'su3_force_link_kernel<0': 'l2q_su3_force', 'su3_force_link_kernel<1': 'l2q_su3_force_kick',
+    'su3_force_brick_kernel<0': 'l2q_su3_force', 'su3_force_brick_kernel<1': 'l2q_su3_force_kick',
     'su3_force_rows_kernel<1': None,
     'su3_force_slice_kernel<true': 'l2q_su3_force_kick',
     'su3_expm_mul_kernel<true, true>': 'l2q_su3_expm_mul2_vec8',
@@ -36,7 +41,7 @@ def main():
         for r in csv.DictReader(open(f)):
             agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     lines = ['# rocprofv3 --pmc passes (separate runs per counter group) of tools/kprof.py:',
-             '# SU(3) 8^4, 256 chains, fp64.  FETCH_SIZE / WRITE_SIZE in KiB as reported; on gfx950',
+             f'# SU(3) {"x".join(map(str, LAT))}, {NB} chains, fp64.  FETCH_SIZE / WRITE_SIZE in KiB as reported; on gfx950',
              '# FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM',
              '# section) -> read bytes = 2 * FETCH_SIZE * 1024.  Means over the launches of a run.', '']
     traffic = {}
@@ -53,14 +58,19 @@ def main():
                          f'+ write {wr / 1e6:.1f} MB = {(rd + wr) / 1e6:.1f} MB')
             for frag, entry in ENTRY.items():
                 if entry and frag in k:
-                    traffic[entry] = {'read_bytes': rd, 'write_bytes': wr, 'total_bytes': rd + wr,
-                                      'kernel': k.replace('l2q::', ''), 'lattice': [8, 8, 8, 8],
-                                      'nchains': 256, 'source': f'{sys.argv[2]} ({k})'}
+                    key = f'{entry}@{"x".join(map(str, LAT))}x{NB}'
+                    traffic[key] = {'read_bytes': rd, 'write_bytes': wr, 'total_bytes': rd + wr,
+                                    'kernel': k.replace('l2q::', ''), 'lattice': LAT,
+                                    'nchains': NB, 'source': f'{sys.argv[2]} ({k})'}
         if 'TCC_HIT_sum' in v:
             h, m = sum(v['TCC_HIT_sum']), sum(v['TCC_MISS_sum'])
             lines.append(f'    -> L2 hit rate {h / (h + m):.3f}')
     open(sys.argv[2], 'w').write('\n'.join(lines) + '\n')
-    json.dump(traffic, open(sys.argv[3], 'w'), indent=1)
+    # one entry per (entry point, lattice, chains): passes at another shape are kept
+    old = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
+    old = {k: v for k, v in old.items() if '@' in k}
+    old.update(traffic)
+    json.dump(old, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
     print('\n'.join(l for l in lines if '->' in l or (l and not l.startswith(' '))))
 
 
