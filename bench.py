@@ -411,6 +411,9 @@ def secondary_u1(steps=3):
                 d[3] += by
             tot = sum(v[1] for v in agg.values())
             name, (cnt, tt, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
+            top = {k: {'share': round(v[1] / tot, 4), 'launches_per_trajectory': v[0] // steps,
+                       'avg_ms': round(v[1] / v[0] * 1e3, 4)}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:6]}
             dom = {'kernel': name, 'share_of_kernel_time': round(tt / tot, 4),
                    'launches_per_trajectory': cnt // steps, 'avg_ms': round(tt / cnt * 1e3, 4)}
             if fl > 0:
@@ -432,7 +435,7 @@ def secondary_u1(steps=3):
                         'value': round(nb * 2 * nlf / dt, 1), 'unit': 'chain*leapfrog-steps/s',
                         'steps': steps, 'accept_prob_mean': round(float(m['acc'].mean()), 4),
                         'kernel_time_fraction_of_wall': round(tot / (dt * steps), 4),
-                        'dominant_kernel': dom}
+                        'dominant_kernel': dom, 'kernels': top}
         except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
             import traceback
             out[tag] = f'failed: {type(e).__name__}: {e} | ' + traceback.format_exc()[-400:]
@@ -643,7 +646,10 @@ def main():
         nparam = sum(p.numel() for p in dyn.vnet.parameters())
         if dist is not None:
             probe = collective_probe(dist, world, nparam)
-        nprobe = native_comm_probe(dist, world, nparam)
+        # the C-ABI route: always with one rank (cannot hang); with N > 1 only on request -- a second
+        # communicator next to torch's is not something to discover in the driver's scaling run
+        if dist is None or os.environ.get('L2Q_BENCH_NATIVE_COMM') == '1':
+            nprobe = native_comm_probe(dist, world, nparam)
 
     if rank == 0:
         V = int(np.prod(args.lattice))

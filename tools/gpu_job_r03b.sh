@@ -18,8 +18,9 @@ python tools/force_bench.py --big > "$o/force_variants_ab.txt" 2>&1
 bash tools/pmc_collect.sh "${tag}" > "$o/pmc_8x4.log" 2>&1
 L2Q_KPROF_LATTICE="16 16 16 16" L2Q_KPROF_NB=256 bash tools/pmc_collect.sh "${tag}_16x4" > "$o/pmc_16x4.log" 2>&1
 cp profiles/${tag}_pmc_counters.txt profiles/${tag}_16x4_pmc_counters.txt profiles/pmc_traffic.json "$o/" 2>/dev/null
+mkdir -p tools/bin; hipcc --offload-arch=gfx950 -O3 tools/microbench/lds_b64_conflict.hip -o tools/bin/lds_b64_conflict 2>/dev/null
 d="$o/lds_micro"; mkdir -p "$d"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT -d "$OLDPWD/$d" -o p --output-format csv -- "$OLDPWD/tools/bin/lds_b64_conflict" 4000 > "$OLDPWD/$d/stdout.log" 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d "$OLDPWD/$d" -o p --output-format csv -- "$OLDPWD/tools/bin/lds_b64_conflict" 4000 > "$OLDPWD/$d/stdout.log" 2>&1)
 python - "$d" > "$o/lds_b64_conflict.txt" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(dict)
