@@ -13,6 +13,7 @@
 // scale are applied in fp32 (torch promotes fp32 tensor x fp16 tensor to fp32).  The input
 // layer's two products share one accumulator here (autocast rounds xlayer(x) and vlayer(v)
 // separately before adding: one rounding fewer, <= 2^-11 relative).
+#include <type_traits>
 #include "half_common.hpp"
 #include "u1_math.hpp"
 
@@ -395,8 +396,15 @@ static int gemm_h_dispatch(const void* A, int a_f32, const void* W, int M, int N
 // because the epilogue (not the K = units[-1] MFMA loop) is the long part of this kernel.
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_tanh_h(float x) {
-  return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f);      // saturates to +-1
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);      // saturates to +-1; v_rcp_f32 (1 ulp),
+                                                                       // not the 10-instruction IEEE division
 }
+
+// timing-only builds of u1_heads_update_h_kernel (tools/ab_build.sh -DL2Q_HH_SKIP=n): 1 no K-loop,
+// 2 no epilogue math, 4 no field traffic.  0 in the product.
+#ifndef L2Q_HH_SKIP
+#define L2Q_HH_SKIP 0
+#endif
 
 struct HeadsHArgs {
   const void* Z;          // [M][K]  16 bit
@@ -414,11 +422,53 @@ struct HeadsHArgs {
   int M, N, K, ncols_part;
 };
 
+// One entry of the half-precision heads + update epilogue (the arithmetic both kernels below share):
+// head pre-activations (fp32 accumulators) -> s, t, q with autocast's rounding points -> v- or x-update.
+// Returns the new field value; `ldterm` is the entry's contribution to the chain's log-Jacobian.
+template <typename HT, bool XUPD, bool FWD, bool NCP>
+__device__ __forceinline__ float hh_element(float as, float at, float aq, float bs, float bt, float bq,
+                                            float cs, float cq, float st, float eps, float a0, float b0,
+                                            float keep, float& ldterm) {
+  const float s = cs * rnd<HT>(fast_tanh_h(rnd<HT>(as + bs)));
+  const float t = rnd<HT>(st * rnd<HT>(at + bt));
+  const float q = cq * rnd<HT>(fast_tanh_h(rnd<HT>(aq + bq)));
+  if (!XUPD) {
+    const float lj = FWD ? (eps * s * 0.5f) : (-eps * s * 0.5f);
+    ldterm = lj;
+    const float es = fast_exp(lj), eq = fast_exp(eps * q);
+    const float f = b0 * eq + t;
+    return FWD ? (es * a0 - 0.5f * eps * f) : (es * (a0 + 0.5f * eps * f));
+  }
+  const float xj = a0, mb = 1.f - keep;
+  const float sj = FWD ? eps * s : -eps * s;
+  const float es = fast_exp(sj), eq = fast_exp(eps * q);
+  const float tr = b0 * eq + t;
+  float xp, l;
+  if (NCP) {
+    const float hx = xj * 0.5f;                    // |hx| <= pi/2 (x is wrapped)
+    const float ch = __cosf(hx), sh = es * __sinf(hx);
+    const float x1 = 2.f * atan2f(sh, ch);         // = 2 atan(tan(hx) es), no division
+    xp = FWD ? (x1 + eps * tr) : (x1 - es * eps * tr);
+    l = sj - __logf(ch * ch + sh * sh);            // log(es / (ch^2 + sh^2))
+  } else {
+    xp = FWD ? (xj * es + eps * tr) : (es * (xj - eps * tr));
+    l = sj;
+  }
+  ldterm = mb * l;
+  return wrap_angle<float>(keep * xj + mb * xp);
+}
+
 template <typename HT, bool XUPD, bool FWD, bool NCP, int BM>
 __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_kernel(HeadsHArgs a, int swz,
-                                                                      int nfast) {
+                                                                      int nfast, int stagger) {
   constexpr int BN = 64, MI = BM / 32;        // MI: 16-row MFMA tiles per wavefront along m
   using vec_t = typename MfmaH<HT>::vec_t;
+  // tuning `heads_h_stagger` (A/B only): the g-th workgroup placed on a CU starts g * stagger * ~3.5 us
+  // late, so that co-resident workgroups are in different phases (staging / MFMA / epilogue)
+  if (stagger > 0 && blockIdx.x < 1024) {
+    const int gen = blockIdx.x >> 8;
+    for (int i = 0; i < gen * stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   __shared__ __attribute__((aligned(16))) HT Zs[BM][HLD];
   __shared__ __attribute__((aligned(16))) HT Ws[3][BN][HLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -455,6 +505,11 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   const bool vec4 = (a.N & 3) == 0;
   float4 pav[MI][2], pbv[MI][2];
   auto fetch_ab = [&](int i) {
+    if (L2Q_HH_SKIP & 4) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { pav[i][j] = make_float4(1.f, 2.f, 3.f, 4.f); pbv[i][j] = pav[i][j]; }
+      return;
+    }
     const long m = m0 + wm + 16 * i + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -476,7 +531,7 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   l0.fetch(W0, W0, n0, a.N, 0, K, 0, K, vec);
   l1.fetch(W1, W1, n0, a.N, 0, K, 0, K, vec);
   l2.fetch(W2, W2, n0, a.N, 0, K, 0, K, vec);
-  for (long k0 = 0; k0 < K; k0 += HBK) {
+  for (long k0 = 0; k0 < ((L2Q_HH_SKIP & 1) ? 0 : K); k0 += HBK) {
     __syncthreads();
     lz.store(Zs);
     l0.store(Ws[0]);
@@ -523,6 +578,46 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   float ld[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) ld[i] = 0.f;
+  // Per-column parameters (biases, exp(coeff) scales, mask) of this wavefront's two 16-column groups:
+  // they depend on j only, so they are fetched ONCE, as one 16-byte load per array and group -- 10-12
+  // loads per wavefront.  (Fetched per element inside the row loop they were 160 scalar gathers per
+  // wavefront and tile against 24 loads / stores of actual field traffic: the texture addresser, not
+  // HBM, was what the epilogue waited for.)
+  float pbs[2][4], pbt[2][4], pbq[2][4], pcs[2][4], pcq[2][4], pkeep[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
+    if (vec4 && nb4 < a.N) {
+      const float4 v0 = *reinterpret_cast<const float4*>(a.b[0] + nb4);
+      const float4 v1 = *reinterpret_cast<const float4*>(a.b[1] + nb4);
+      const float4 v2 = *reinterpret_cast<const float4*>(a.b[2] + nb4);
+      const float4 v3 = *reinterpret_cast<const float4*>(a.cs + nb4);
+      const float4 v4 = *reinterpret_cast<const float4*>(a.cq + nb4);
+      pbs[j][0] = v0.x; pbs[j][1] = v0.y; pbs[j][2] = v0.z; pbs[j][3] = v0.w;
+      pbt[j][0] = v1.x; pbt[j][1] = v1.y; pbt[j][2] = v1.z; pbt[j][3] = v1.w;
+      pbq[j][0] = v2.x; pbq[j][1] = v2.y; pbq[j][2] = v2.z; pbq[j][3] = v2.w;
+      pcs[j][0] = v3.x; pcs[j][1] = v3.y; pcs[j][2] = v3.z; pcs[j][3] = v3.w;
+      pcq[j][0] = v4.x; pcq[j][1] = v4.y; pcq[j][2] = v4.z; pcq[j][3] = v4.w;
+      if (XUPD) {
+        const float4 v5 = *reinterpret_cast<const float4*>(a.mask + nb4);
+        pkeep[j][0] = v5.x; pkeep[j][1] = v5.y; pkeep[j][2] = v5.z; pkeep[j][3] = v5.w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        long n = nb4 + r < a.N ? nb4 + r : a.N - 1;
+        if (n < 0) n = 0;
+        pbs[j][r] = a.b[0][n]; pbt[j][r] = a.b[1][n]; pbq[j][r] = a.b[2][n];
+        pcs[j][r] = a.cs[n]; pcq[j][r] = a.cq[n];
+        if (XUPD) pkeep[j][r] = a.mask[n];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!XUPD) pkeep[j][r] = 0.f;
+      else if (a.complement) pkeep[j][r] = 1.f - pkeep[j][r];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const long m = m0 + wm + 16 * i + (lane & 15);
@@ -533,14 +628,8 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
       float bs[4], bt[4], bq[4], cs[4], cq[4], keep[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long n = nb4 + r < a.N ? nb4 + r : a.N - 1;
-        bs[r] = a.b[0][n]; bt[r] = a.b[1][n]; bq[r] = a.b[2][n];
-        cs[r] = a.cs[n]; cq[r] = a.cq[n];
-        keep[r] = 0.f;
-        if (XUPD) {
-          keep[r] = a.mask[n];
-          if (a.complement) keep[r] = 1.f - keep[r];
-        }
+        bs[r] = pbs[j][r]; bt[r] = pbt[j][r]; bq[r] = pbq[j][r];
+        cs[r] = pcs[j][r]; cq[r] = pcq[j][r]; keep[r] = pkeep[j][r];
       }
       const long o = m * (long)a.N + nb4;
       float av[4], bv[4], out[4];
@@ -559,37 +648,17 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s = cs[r] * rnd<HT>(fast_tanh_h(rnd<HT>(acc[0][i][j][r] + bs[r])));
-        const float t = rnd<HT>(a.st * rnd<HT>(acc[1][i][j][r] + bt[r]));
-        const float q = cq[r] * rnd<HT>(fast_tanh_h(rnd<HT>(acc[2][i][j][r] + bq[r])));
-        const bool in = nb4 + r < a.N;
-        const float a0 = av[r], b0 = bv[r];
-        if (!XUPD) {
-          const float lj = FWD ? (eps * s * 0.5f) : (-eps * s * 0.5f);
-          if (in) ld[i] += lj;
-          const float es = fast_exp(lj), eq = fast_exp(eps * q);
-          const float f = b0 * eq + t;
-          out[r] = FWD ? (es * a0 - 0.5f * eps * f) : (es * (a0 + 0.5f * eps * f));
-        } else {
-          const float xj = a0, mb = 1.f - keep[r];
-          const float sj = FWD ? eps * s : -eps * s;
-          const float es = fast_exp(sj), eq = fast_exp(eps * q);
-          const float tr = b0 * eq + t;
-          float xp, l;
-          if (NCP) {
-            const float hx = xj * 0.5f;                    // |hx| <= pi/2 (x is wrapped)
-            const float ch = __cosf(hx), sh = es * __sinf(hx);
-            const float x1 = 2.f * atan2f(sh, ch);         // = 2 atan(tan(hx) es), no division
-            xp = FWD ? (x1 + eps * tr) : (x1 - es * eps * tr);
-            l = sj - __logf(ch * ch + sh * sh);            // log(es / (ch^2 + sh^2))
-          } else {
-            xp = FWD ? (xj * es + eps * tr) : (es * (xj - eps * tr));
-            l = sj;
-          }
-          if (in) ld[i] += mb * l;
-          out[r] = wrap_angle<float>(keep[r] * xj + mb * xp);
+        if (L2Q_HH_SKIP & 2) {
+          out[r] = av[r] + bv[r] + acc[0][i][j][r] + acc[1][i][j][r] + acc[2][i][j][r] + bs[r] + cq[r] + keep[r];
+          continue;
         }
+        const bool in = nb4 + r < a.N;
+        float ldt;
+        out[r] = hh_element<HT, XUPD, FWD, NCP>(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], bs[r], bt[r],
+                                                bq[r], cs[r], cq[r], a.st, eps, av[r], bv[r], keep[r], ldt);
+        if (in) ld[i] += ldt;
       }
+      if ((L2Q_HH_SKIP & 4) && out[0] + out[1] + out[2] + out[3] != 12345.678f) continue;
       if (vec4) {
         *reinterpret_cast<float4*>(pa + o) = make_float4(out[0], out[1], out[2], out[3]);
       } else {
@@ -613,6 +682,236 @@ __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_k
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The same operation as u1_heads_update_h_kernel, organised as a STREAM over the chains with the
+// weights stationary (round 3).  Same-box decomposition of the tile kernel at cfg-3 (8192 chains x
+// 8192 entries, K = 256; tools/probe_heads_h3.py on -DL2Q_HH_SKIP builds): whole kernel 0.41 ms =
+// staging + MFMA 0.20 ms (every 128 x 64 tile stages 160 KB of Z and W through registers into LDS in
+// four dependent round trips) + field traffic 0.16-0.25 ms (805 MB) + epilogue arithmetic 0.06-0.09 ms,
+// and the first two do not overlap.  Here
+//  * a workgroup owns 64 entries (columns) and a range of chains; each of its four wavefronts keeps the
+//    three heads' weights of ITS 16 columns in registers for the whole sweep (3 x K / 32 MFMA operand
+//    fragments = 96 VGPRs at K = 256; W is read once per workgroup) together with the per-column
+//    biases / scales / mask;
+//  * the chains stream by in steps of 32 rows: their Z rows (32 x K 16-bit = 16 KB, four 16-byte chunks
+//    per thread) and the fp32 field operands (a, b) of the NEXT step are requested while the current
+//    step's epilogue runs; Z goes registers -> LDS (two stages, one barrier per step, chunk-swizzled so
+//    that the ds_read_b128 fragments are conflict-free).  (An LDS-DMA version was written first: hipcc
+//    cannot tell its vmcnt traffic from the operand prefetches and drains vmcnt to 0 around every
+//    global_load_lds, which serialises the step; plain loads keep its scoreboard exact.)
+//  * per step a wavefront issues 6 K / 32 MFMAs (32 rows x its 16 columns x 3 heads), runs the shared
+//    hh_element arithmetic on 2 x 4 entries per lane and stores two float4.
+// Same MFMA instruction, operand roles and k order as the tile kernel: identical accumulators; the fp32
+// epilogue is contracted differently by hipcc in the two kernels (rare 1-ulp16 flips of a head); the
+// per-chain log-det is summed in a different (fixed) order.
+// Needs K in {32, 64, 128, 256}, N % 4 == 0 and 16-byte aligned operands (heads_h_launch falls back).
+// MEASURED (cfg-3, same box, four rotating operand sets): 0.475 ms (v) / 0.56 ms (x) against the tile
+// kernel's 0.420 / 0.48 ms -- with one step of prefetch the operand latency of every 32-row step is still
+// exposed (hipcc waits vmcnt(0) at the top of a step; a second prefetch stage does not fit the 256
+// registers next to the 96 of the stationary weights).  Kept as tuning `heads_h_stream = 1`, off by default.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <typename HT, bool XUPD, bool FWD, bool NCP>
+__global__ __launch_bounds__(kBlock, 2) void u1_heads_stream_h_kernel(HeadsHArgs a, int swz, int rows_per_wg) {
+  constexpr int KS_MAX = 8;                       // K <= 256
+  constexpr int ROWS = 32;                        // chains per step
+  constexpr int STAGE = ROWS * 512;               // bytes (K = 256); smaller K uses a prefix
+  using vec_t = typename MfmaH<HT>::vec_t;
+  __shared__ __attribute__((aligned(1024))) char zs[2 * STAGE];
+  __shared__ float red[2][4][ROWS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K;
+  const int ksteps = K >> 5;                      // MFMA k-steps of 32
+  const int cpr = K >> 3;                         // 16-byte chunks per Z row
+  const int rowb = K * 2;                         // bytes per Z row
+  const int swm = (cpr < 16 ? cpr : 16) - 1;      // chunk swizzle mask
+  const long ntiles = (a.N + 63) / 64;
+  const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
+  const long n0 = (w % ntiles) * 64;              // n-tiles fastest: neighbours walk the same rows
+  const long mbeg = (w / ntiles) * rows_per_wg;
+  long mend = mbeg + rows_per_wg;
+  if (mend > a.M) mend = a.M;
+  if (mbeg >= a.M) return;
+  const int nstep = (int)((mend - mbeg + ROWS - 1) / ROWS);
+
+  // ---- stationary operands of this wavefront: columns nw0 .. nw0 + 15
+  const long nw0 = n0 + 16 * wave;
+  const long ncol = nw0 + (lane & 15);            // W row this lane's fragments come from
+  const long nrow = ncol < a.N ? ncol : a.N - 1;
+  vec_t wf[3][KS_MAX];
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    const HT* W = (const HT*)a.W[h] + nrow * (long)K + 8 * (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < KS_MAX; ++kk) {
+      // unconditional (k-steps past K re-read the last one and are never used): a load behind a branch
+      // makes hipcc guard every later use with s_waitcnt vmcnt(0), which would drain the prefetches
+      const int ko = kk < ksteps ? 32 * kk : K - 32;
+      wf[h][kk] = *reinterpret_cast<const vec_t*>(W + ko);
+    }
+  }
+  const long nb4 = nw0 + 4 * (lane >> 4);         // this lane's four consecutive entries
+  const bool ncok = nb4 < a.N;                    // (N % 4 == 0: all four or none)
+  const long nq = ncok ? nb4 : 0;
+  float bs[4], bt[4], bq[4], cs[4], cq[4], keep[4];
+  {
+    const float4 v0 = *reinterpret_cast<const float4*>(a.b[0] + nq);
+    const float4 v1 = *reinterpret_cast<const float4*>(a.b[1] + nq);
+    const float4 v2 = *reinterpret_cast<const float4*>(a.b[2] + nq);
+    const float4 v3 = *reinterpret_cast<const float4*>(a.cs + nq);
+    const float4 v4 = *reinterpret_cast<const float4*>(a.cq + nq);
+    bs[0] = v0.x; bs[1] = v0.y; bs[2] = v0.z; bs[3] = v0.w;
+    bt[0] = v1.x; bt[1] = v1.y; bt[2] = v1.z; bt[3] = v1.w;
+    bq[0] = v2.x; bq[1] = v2.y; bq[2] = v2.z; bq[3] = v2.w;
+    cs[0] = v3.x; cs[1] = v3.y; cs[2] = v3.z; cs[3] = v3.w;
+    cq[0] = v4.x; cq[1] = v4.y; cq[2] = v4.z; cq[3] = v4.w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keep[r] = 0.f;
+    if (XUPD) {
+      const float4 v5 = *reinterpret_cast<const float4*>(a.mask + nq);
+      keep[0] = v5.x; keep[1] = v5.y; keep[2] = v5.z; keep[3] = v5.w;
+      if (a.complement) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = 1.f - keep[r];
+      }
+    }
+  }
+
+  // ---- Z stream: a step's 32 rows are 32 * cpr 16-byte chunks; thread t carries chunks t, t + 256, ...
+  // (at most four) in registers for one step and writes them to the stage when their turn comes.
+  // Chunk c of row r sits at slot c ^ (r & swm) of its row: the ds_read_b128 fragments below (16 rows, one
+  // chunk index) then touch 16 different bank groups.
+  const int nchunk = ROWS * cpr;                  // 1024 (K = 256) .. 128 (K = 32)
+  const char* zbase = reinterpret_cast<const char*>(a.Z);
+  uint4 zr[4];
+  auto zfetch = [&](long r0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int p = tid + 256 * q;
+      if (p >= nchunk) p = nchunk - 1;            // unconditional loads (a load behind a branch is waited for
+                                                  // on the spot); the surplus copies are never stored
+      const int row = p / cpr, c = p - row * cpr;
+      long m = r0 + row;
+      if (m >= a.M) m = a.M - 1;                  // rows past the end re-read a valid one (masked later)
+      zr[q] = *reinterpret_cast<const uint4*>(zbase + m * (long)rowb + (c << 4));
+    }
+  };
+  auto zstore = [&](int st) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = tid + 256 * q;
+      if (p < nchunk) {
+        const int row = p / cpr, c = p - row * cpr;
+        *reinterpret_cast<uint4*>(zs + st * STAGE + row * rowb + ((c ^ (row & swm)) << 4)) = zr[q];
+      }
+    }
+  };
+  // fragment read offsets of this lane: row (lane & 15) [+ 16 i], chunk 4 kk + (lane >> 4)
+  const int frow = lane & 15;
+  const int fsw = frow & swm;                     // (row + 16 i) & swm == row & swm (swm <= 15)
+
+  // ---- field operands: lane holds chain 16 i + (lane & 15) of the step and entries nb4 .. nb4 + 3
+  float* __restrict__ pa = a.a;
+  const float* __restrict__ pb = a.bsrc;
+  float4 av[2][2], bv[2][2];                      // [slot][i]
+  auto fetch = [&](int slot, long r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long m = r0 + 16 * i + (lane & 15);
+      const bool ok = ncok && m < mend;
+      const long o = ok ? m * (long)a.N + nb4 : 0;
+      av[slot][i] = *reinterpret_cast<const float4*>(pa + o);
+      bv[slot][i] = *reinterpret_cast<const float4*>(pb + o);
+    }
+  };
+  const float eps = a.eps;
+  zfetch(mbeg);
+  fetch(0, mbeg);
+  auto step = [&](auto CUR, int s) {
+    constexpr int cur = decltype(CUR)::value;      // stage / operand slot of this step (compile time)
+    const long r0 = mbeg + (long)s * ROWS;
+    zstore(cur);                                   // stage `cur` was last read two steps ago
+    __syncthreads();
+    // previous step's row sums of the log-det: the four wavefronts' partials meet here
+    if (s > 0 && tid < ROWS) {
+      const long m = r0 - ROWS + tid;
+      if (m < mend) {
+        const int pr = (s - 1) & 1;
+        const double x = ((double)red[pr][0][tid] + (double)red[pr][1][tid]) +
+                         ((double)red[pr][2][tid] + (double)red[pr][3][tid]);
+        a.logdet_part[m * a.ncols_part + (n0 >> 6)] = x;
+      }
+    }
+    v4f32 acc[3][2];
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[h][i] = (v4f32){0, 0, 0, 0};
+    const char* sb = zs + cur * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KS_MAX; ++kk) {
+      if (kk < ksteps) {
+        vec_t fa[2];
+        const int chunk = (4 * kk + (lane >> 4)) ^ fsw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          fa[i] = *reinterpret_cast<const vec_t*>(sb + (frow + 16 * i) * rowb + (chunk << 4));
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[h][i] = MfmaH<HT>::run(wf[h][kk], fa[i], acc[h][i]);
+      }
+    }
+    // next step's operands (Z rows into registers, field values into the other slot): in flight during
+    // this step's epilogue, consumed one step later
+    if (s + 1 < nstep) {
+      zfetch(r0 + ROWS);
+      fetch(cur ^ 1, r0 + ROWS);
+    }
+    float ld[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long m = r0 + 16 * i + (lane & 15);
+      const bool ok = ncok && m < mend;
+      const float4 ta = av[cur][i];
+      const float4 tb = bv[cur][i];
+      const float a4[4] = {ta.x, ta.y, ta.z, ta.w}, b4[4] = {tb.x, tb.y, tb.z, tb.w};
+      float out[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float ldt;
+        out[r] = hh_element<HT, XUPD, FWD, NCP>(acc[0][i][r], acc[1][i][r], acc[2][i][r], bs[r], bt[r], bq[r],
+                                                cs[r], cq[r], a.st, eps, a4[r], b4[r], keep[r], ldt);
+        if (ok) ld[i] += ldt;
+      }
+      if (ok) *reinterpret_cast<float4*>(pa + m * (long)a.N + nb4) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+    // row sums over this wavefront's 16 columns (four lane groups of 4 entries)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float x = ld[i];
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      if (lane < 16) red[cur][wave][16 * i + lane] = x;
+    }
+  };
+  for (int s = 0; s < nstep; s += 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < nstep) step(std::integral_constant<int, 1>{}, s + 1);
+  }
+  __syncthreads();
+  if (tid < ROWS) {
+    const long m = mbeg + (long)(nstep - 1) * ROWS + tid;
+    if (m < mend) {
+      const int pr = (nstep - 1) & 1;
+      const double x = ((double)red[pr][0][tid] + (double)red[pr][1][tid]) +
+                       ((double)red[pr][2][tid] + (double)red[pr][3][tid]);
+      a.logdet_part[m * a.ncols_part + (n0 >> 6)] = x;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------
 // Periodic conv layer of the U(1) ConvStack in half precision (autocast runs nn.Conv2d in 16
@@ -878,18 +1177,44 @@ static int heads_h_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, floa
   const dim3 grid((unsigned)(ntile * mtile)), block(kBlock);
   const int swz = tuning().xcd_swizzle;
   const int nfast = tuning().heads_h_order;
+  const int stg = tuning().heads_stagger;
   double* part = (double*)ws;
   double* tmp = part + (size_t)a.M * a.ncols_part;
   a.logdet_part = part;
   (void)hipMemsetAsync(part, 0, (size_t)a.M * a.ncols_part * sizeof(double), st);
+  // weights-stationary stream kernel wherever its shape conditions hold (tuning heads_h_stream = 0: tile kernel)
+  const bool stream = tuning().heads_h_stream && (a.K == 32 || a.K == 64 || a.K == 128 || a.K == 256) &&
+                      (a.N & 3) == 0 && al16(a.a) && al16(a.bsrc) && al16(a.b[0]) && al16(a.b[1]) &&
+                      al16(a.b[2]) && al16(a.cs) && al16(a.cq) && (!xupd || al16(a.mask)) && al16(a.Z) &&
+                      al16(a.W[0]) && al16(a.W[1]) && al16(a.W[2]);
+  if (stream) {
+    const long nt = cdiv(a.N, 64);
+    long msplit = cdiv(768, nt);
+    const long maxsplit = cdiv(a.M, 32);
+    if (msplit > maxsplit) msplit = maxsplit;
+    if (msplit < 1) msplit = 1;
+    const int rows_per_wg = (int)(cdiv(cdiv(a.M, msplit), 32) * 32);
+    msplit = cdiv(a.M, rows_per_wg);
+    const dim3 sgrid((unsigned)(nt * msplit));
+#define L2Q_HS(X, F, C) \
+  hipLaunchKernelGGL((u1_heads_stream_h_kernel<HT, X, F, C>), sgrid, block, 0, st, a, swz, rows_per_wg)
+    if (!xupd) { if (forward) L2Q_HS(false, true, false); else L2Q_HS(false, false, false); }
+    else if (use_ncp) { if (forward) L2Q_HS(true, true, true); else L2Q_HS(true, false, true); }
+    else { if (forward) L2Q_HS(true, true, false); else L2Q_HS(true, false, false); }
+#undef L2Q_HS
+    launch_finalize(part, tmp, a.M, a.ncols_part, 1, 1.0, 0.0, st);
+    hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)cdiv(a.M, 64)), dim3(64), 0, st, tmp, logdet,
+                       a.M, accumulate);
+    return check_launch("l2q_u1_heads_update_h");
+  }
 #define L2Q_HH(X, F, C)                                                                          \
   do {                                                                                           \
     if (bm == 128)                                                                               \
       hipLaunchKernelGGL((u1_heads_update_h_kernel<HT, X, F, C, 128>), grid, block, 0, st, a,    \
-                         swz, nfast);                                                       \
+                         swz, nfast, stg);                                                  \
     else                                                                                         \
       hipLaunchKernelGGL((u1_heads_update_h_kernel<HT, X, F, C, 64>), grid, block, 0, st, a,     \
-                         swz, nfast);                                                       \
+                         swz, nfast, stg);                                                  \
   } while (0)
   if (!xupd) { if (forward) L2Q_HH(false, true, false); else L2Q_HH(false, false, false); }
   else if (use_ncp) { if (forward) L2Q_HH(true, true, true); else L2Q_HH(true, false, true); }

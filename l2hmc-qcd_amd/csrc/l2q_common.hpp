@@ -29,8 +29,11 @@ struct Tuning {
                               // <= 16 output channels (2: every layer it fits, 0: gather kernel only)
   int gemm_h_dma = 1;         // big half GEMMs (M, N % 256 == 0, K % 64 == 0): LDS-DMA 256 x 256 kernel (0: off)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
+  int heads_h_stream = 0; // half-precision heads+update: 1 = weights-stationary stream kernel (measured slower at
+                          // cfg-3: 0.475 vs 0.420 ms, see u1_heads_stream_h_kernel), 0 = tile kernel
   int heads_h_bm = 128;   // chains per workgroup of the half-precision heads+update kernel (64 | 128)
-  int heads_h_order = 0;  // half-precision heads+update kernel: 0 m-tiles fastest, 1 n-tiles fastest
+  int heads_h_order = 1;  // half-precision heads+update kernel: 0 m-tiles fastest, 1 n-tiles fastest (consecutive
+                          // workgroups walk along the rows of the fp32 field: 0.50 -> 0.41 ms at cfg-3)
 };
 Tuning& tuning();
 

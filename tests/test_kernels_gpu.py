@@ -673,3 +673,49 @@ def test_lattice_edge_shapes_vs_oracle():
             xh = host(x).astype(np.float64)
             assert err(host(lat.action(x, b)), ou1.action(xh, 2.5)) < 2e-5, L
             assert err(host(lat.grad_action(x, b)).reshape(xh.shape), ou1.grad_action(xh, 2.5)) < 1e-5, L
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('dims', [(37, 64, 128), (200, 256, 512), (64, 32, 64), (33, 128, 260)])
+def test_u1_heads_update_h_stream_equals_tile(hd, dims):
+    """Tuning `heads_h_stream` (the weights-stationary form of l2q_u1_heads_update_h, off by default):
+    same MFMA operands and k order as the tile kernel, so the accumulators are identical and the updated
+    field agrees to within a rare 16-bit rounding flip; the per-chain log-det is summed in a different
+    fixed order (fp32 rounding)."""
+    from l2hmc import _ops as ops, native
+    m, k, n = dims
+    g = torch.Generator().manual_seed(29)
+    z = torch.randn(m, k, generator=g).to(hd).cuda()
+    heads = {}
+    for nm in 'stq':
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd).cuda()
+        b = (0.1 * torch.randn(n, generator=g)).cuda()
+        c = None if nm == 't' else (0.7 * torch.exp(0.3 * torch.randn(n, generator=g))).cuda()
+        heads[nm] = (w, b, c)
+    mask = (torch.rand(n, generator=g) < 0.5).float().cuda()
+    try:
+        for xupd in (False, True):
+            for forward in (True, False):
+                a0 = (torch.randn(m, n, generator=g) if not xupd
+                      else (2 * np.pi * torch.rand(m, n, generator=g) - np.pi)).cuda()
+                b0 = torch.randn(m, n, generator=g).cuda()
+                res = {}
+                for stream in (0, 1):
+                    assert native.set_tuning('heads_h_stream', stream) >= 0
+                    a = a0.clone()
+                    ld = ops.u1_heads_update_h_(z, heads, 0.9, a, b0, 0.17, forward,
+                                                mask=mask if xupd else None, complement=False)
+                    res[stream] = (a, ld)
+                # same accumulators; hipcc contracts the fp32 epilogue differently in the two kernels, so a
+                # 16-bit rounding of a head can flip where its argument sits on a tie: rare, 1 ulp16
+                d = res[0][0] - res[1][0]
+                if xupd:
+                    d = torch.remainder(d + np.pi, 2 * np.pi) - np.pi
+                ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+                scale = max(1.0, float(res[0][0].abs().max()))
+                assert float(d.abs().max()) < 2 * ulp * scale, (xupd, forward, float(d.abs().max()))
+                assert float((d != 0).float().mean()) < 0.05, (xupd, forward)
+                dl = float((res[0][1] - res[1][1]).abs().max())
+                assert dl < (1e-5 * max(1.0, float(res[0][1].abs().max())) + 2 * ulp * 0.17) * n ** 0.5, dl
+    finally:
+        native.set_tuning('heads_h_stream', 0)
