@@ -323,6 +323,14 @@ int l2q_conv_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long 
                              long sw, int nb, int C, int H, int W, int k, const void* weight,
                              int channels_last_cols, const float* bias, int cout, int act,
                              void* out, void* stream);
+/* l2q_conv_gemm_periodic_h followed by MaxPool2d(2) (floor mode) and the activation, in one kernel
+ * (network.py:283-326: Conv2d -> MaxPool2d -> act of the pooled ConvStack layers): out is the pooled
+ * NHWC image [nb][Ho / 2][Wo / 2][cout] = r16(act(max_window r16(conv + bias))); the un-pooled image
+ * is never written.  Same bits as l2q_conv_gemm_periodic_h (act none) + l2q_maxpool_act_nhwc_h(2). */
+int l2q_conv_pool_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long sn, long sc,
+                                  long sh, long sw, int nb, int C, int H, int W, int k,
+                                  const void* weight, int channels_last_cols, const float* bias,
+                                  int cout, int act, void* out, void* stream);
 int l2q_maxpool_act_nhwc_h(int half_type, const void* in, int nb, int H, int W, int C, int pool,
                            int act, void* out, void* stream);
 /* out[b][h][w][c] = c < C ? r16(in[b][c][h][w]) : 0 for c < cpad: the fp32 NCHW lattice input of

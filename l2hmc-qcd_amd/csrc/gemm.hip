@@ -395,10 +395,13 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __res
     long base = -1;
     int r0 = 0, c0 = 0;
     if (m < g.M) {
-      const int wo = (int)(m % g.Wo);
-      const long t = m / g.Wo;
-      const int ho = (int)(t % g.Ho);
-      base = (t / g.Ho) * g.sn;
+      // 32-bit index arithmetic (M < 2^31, checked at launch): a 64-bit division is ~100 instructions
+      const unsigned mu = (unsigned)m;
+      const unsigned t = mu / (unsigned)g.Wo;
+      const int wo = (int)(mu - t * (unsigned)g.Wo);
+      const unsigned bq = t / (unsigned)g.Ho;
+      const int ho = (int)(t - bq * (unsigned)g.Ho);
+      base = (long)bq * g.sn;
       r0 = (ho - (k - 1)) % g.H; if (r0 < 0) r0 += g.H;
       c0 = (wo - (k - 1)) % g.W; if (c0 < 0) c0 += g.W;
     }
@@ -419,11 +422,13 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_kernel(const float* __res
 // gather this thread's K column(s) (kk = K0 + kq ..) for its SNP rows of the tile
 #define L2Q_CONV_FETCH_A(K0)                                                            \
   do {                                                                                  \
-    const long kk_ = (K0) + kq;                                                         \
-    const bool kin_ = kk_ < g.Kc;                                                       \
+    const unsigned kk_ = (unsigned)(K0) + (unsigned)kq;      /* 32-bit: Kc = C k k is small */ \
+    const bool kin_ = kk_ < (unsigned)g.Kc;                                             \
     int j_, i_, ci_;                                                                    \
-    if (g.clast) { ci_ = (int)(kk_ % g.C); const int ij_ = (int)(kk_ / g.C); j_ = ij_ % k; i_ = ij_ / k; } \
-    else { j_ = (int)(kk_ % k); const int ij_ = (int)(kk_ / k); i_ = ij_ % k; ci_ = ij_ / k; }   \
+    if (g.clast) { const unsigned ij_ = kk_ / (unsigned)g.C; ci_ = (int)(kk_ - ij_ * (unsigned)g.C); \
+                   i_ = (int)(ij_ / (unsigned)k); j_ = (int)(ij_ - (unsigned)i_ * (unsigned)k); }    \
+    else { const unsigned ij_ = kk_ / (unsigned)k; j_ = (int)(kk_ - ij_ * (unsigned)k);               \
+           ci_ = (int)(ij_ / (unsigned)k); i_ = (int)(ij_ - (unsigned)ci_ * (unsigned)k); }           \
     const long coff_ = (long)ci_ * g.sc;                                                \
     _Pragma("unroll") for (int p = 0; p < SNP; ++p) {                                   \
       const int row_ = rq + p * SRPP;                                                   \
@@ -1248,7 +1253,7 @@ int l2q_conv_gemm_periodic_f32(const float* in, long sn, long sc, long sh, long 
   g.Ho = H + k - 1; g.Wo = W + k - 1; g.Kc = C * k * k;
   g.clast = channels_last_cols ? 1 : 0;
   g.M = (long)nb * g.Ho * g.Wo;
-  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16, L2Q_ESHAPE, "too many output pixels");
+  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16 && g.M < (1L << 31), L2Q_ESHAPE, "too many output pixels");
   Epilogue<float> epi{bias, nullptr, nullptr, 1.0f, act, 0};
   const int bn = cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
   const dim3 grid((unsigned)cdiv(cout, bn), (unsigned)cdiv(g.M, 128)), block(kBlock);

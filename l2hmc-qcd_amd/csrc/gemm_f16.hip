@@ -921,8 +921,21 @@ __global__ __launch_bounds__(kBlock, 2) void u1_heads_stream_h_kernel(HeadsHArgs
 // consecutive input channels with ONE 16-byte load (VEC8); the first layer reads the fp32 NCHW
 // lattice data ([cos, sin] of the links) element-wise and rounds it while staging.
 // Output: NHWC 16-bit, r16(acc + bias) then r16(act(.)) -- autocast's rounding points.
-template <typename HT, typename IT, int KS, int BN, bool VEC8>
-__global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __restrict__ in,
+// POOL (round 3): MaxPool2d(2) and the activation fused.  The GEMM row index then runs over (pooled
+// pixel, window position): row m = 4 P + 2 dy + dx is conv pixel (2 hp + dy, 2 wp + dx) of pooled pixel
+// P = (b, hp, wp), so the four pixels of a window are four neighbouring rows of one MFMA tile = four
+// neighbouring lanes of the accumulator layout; the window maximum is two quad shuffles, and only the
+// pooled, activated tile (a quarter of the pixels, contiguous in memory) is written.  The un-pooled
+// intermediate -- 3.2 GB at cfg-3's 128-channel layer, written at ~1 TB/s and read back by the pool
+// kernel -- never exists; pixels the floor-mode pool drops are not computed.  Rounding points as in the
+// two-kernel path: r16(acc + bias) -> max -> r16(act(.)) (max commutes with the monotone rounding).
+// wavefronts per SIMD the latency-bound variants are compiled for (pooled: the output tile in LDS is a
+// quarter; <= 64 channels: 44 KB of LDS): 2 -> 3 took the pooled 128-channel layer of cfg-3 from 3.3 to 2.6 ms
+#ifndef L2Q_CONV_POOL_OCC
+#define L2Q_CONV_POOL_OCC 3
+#endif
+template <typename HT, typename IT, int KS, int BN, bool VEC8, bool POOL = false>
+__global__ __launch_bounds__(kBlock, (POOL || BN <= 64) ? L2Q_CONV_POOL_OCC : 2) void conv_gemm_h_kernel(const IT* __restrict__ in,
                                                                 ConvGeomH g,
                                                                 const HT* __restrict__ Wt, int N,
                                                                 const float* __restrict__ bias,
@@ -935,7 +948,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   __shared__ __attribute__((aligned(16))) HT Ws[BN][HLD];
   __shared__ long rbase[BM];
   __shared__ int rr0[BM], rc0[BM];
-  __shared__ __attribute__((aligned(16))) HT Cs[BM * BN];      // output tile, row stride N <= BN
+  __shared__ __attribute__((aligned(16))) HT Cs[(POOL ? BM / 4 : BM) * BN];   // output tile, row stride N <= BN
   const int k = KS > 0 ? KS : g.k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
@@ -945,10 +958,26 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
     long base = -1;
     int r0 = 0, c0 = 0;
     if (m < g.M) {
-      const int wo = (int)(m % g.Wo);
-      const long t = m / g.Wo;
-      const int ho = (int)(t % g.Ho);
-      base = (t / g.Ho) * g.sn;
+      int wo, ho;
+      long bidx;
+      // 32-bit index arithmetic (M < 2^31, checked at launch): a 64-bit division is ~100 instructions
+      const unsigned mu = (unsigned)m;
+      if (POOL) {
+        const unsigned P = mu >> 2, d = mu & 3;
+        const unsigned t = P / (unsigned)g.Wp;
+        const unsigned wp = P - t * (unsigned)g.Wp;
+        const unsigned bq = t / (unsigned)g.Hp;
+        ho = 2 * (int)(t - bq * (unsigned)g.Hp) + (int)(d >> 1);
+        wo = 2 * (int)wp + (int)(d & 1);
+        bidx = bq;
+      } else {
+        const unsigned t = mu / (unsigned)g.Wo;
+        wo = (int)(mu - t * (unsigned)g.Wo);
+        const unsigned bq = t / (unsigned)g.Ho;
+        ho = (int)(t - bq * (unsigned)g.Ho);
+        bidx = bq;
+      }
+      base = bidx * g.sn;
       r0 = (ho - (k - 1)) % g.H; if (r0 < 0) r0 += g.H;
       c0 = (wo - (k - 1)) % g.W; if (c0 < 0) c0 += g.W;
     }
@@ -970,11 +999,13 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   const int akv = (tid % (HBK / AV)) * AV, arq = tid / (HBK / AV);
 #define L2Q_CONVH_FETCH_A(K0)                                                           \
   do {                                                                                  \
-    const long kk_ = (K0) + akv;                                                        \
-    const bool kin_ = kk_ < g.Kc;                                                       \
+    const unsigned kk_ = (unsigned)(K0) + (unsigned)akv;     /* 32-bit: Kc = C k k is small */ \
+    const bool kin_ = kk_ < (unsigned)g.Kc;                                             \
     int j_, i_, ci_;                                                                    \
-    if (g.clast) { ci_ = (int)(kk_ % g.C); const int ij_ = (int)(kk_ / g.C); j_ = ij_ % k; i_ = ij_ / k; } \
-    else { j_ = (int)(kk_ % k); const int ij_ = (int)(kk_ / k); i_ = ij_ % k; ci_ = ij_ / k; }   \
+    if (g.clast) { const unsigned ij_ = kk_ / (unsigned)g.C; ci_ = (int)(kk_ - ij_ * (unsigned)g.C); \
+                   i_ = (int)(ij_ / (unsigned)k); j_ = (int)(ij_ - (unsigned)i_ * (unsigned)k); }    \
+    else { const unsigned ij_ = kk_ / (unsigned)k; j_ = (int)(kk_ - ij_ * (unsigned)k);               \
+           ci_ = (int)(ij_ / (unsigned)k); i_ = (int)(ij_ - (unsigned)ci_ * (unsigned)k); }           \
     const long coff_ = (long)ci_ * g.sc;                                                \
     _Pragma("unroll") for (int p = 0; p < ANP; ++p) {                                   \
       const int row_ = arq + p * ARPP;                                                  \
@@ -1027,23 +1058,46 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   // C[m0 .. m0+127][0 .. N) is ONE contiguous range of memory.  The lanes' 4-channel pieces
   // (8 bytes, 32-byte runs per wavefront store: ~1.2 TB/s measured) are therefore assembled in
   // LDS and written as a flat 16-byte-per-lane stream.
-  const bool staged = BN == 128 && gridDim.x == 1 && (N % 8) == 0;   // narrower tiles: no gain measured
+  const bool staged = (POOL || BN == 128) && gridDim.x == 1 && (N % 8) == 0;   // (un-pooled narrower tiles: no gain measured)
   const bool vecc = (N % 4) == 0;
   if (staged) __syncthreads();                       // all fragment reads of As / Ws are done
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const long nb4 = n0 + wn + 16 * j + 4 * (lane >> 4);
-    if (nb4 >= N) continue;
+    if (!POOL && nb4 >= N) continue;
     float cb[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cb[r] = bias ? bias[nb4 + r < N ? nb4 + r : N - 1] : 0.f;
+    for (int r = 0; r < 4; ++r) cb[r] = (bias && nb4 < N) ? bias[nb4 + r < N ? nb4 + r : N - 1] : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int ml = wm + 16 * i + (lane & 15);
       const long m = m0 + ml;
-      if (m >= g.M) continue;
       typedef HT cv __attribute__((ext_vector_type(4)));
       cv o;
+      if (POOL) {
+        // every lane takes part in the quad shuffles; rows past M hold bias only and are never stored
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = rnd<HT>(acc[i][j][r] + cb[r]);
+          v = fmaxf(v, __shfl_xor(v, 1, 64));
+          v = fmaxf(v, __shfl_xor(v, 2, 64));
+          o[r] = (HT)(act != L2Q_ACT_NONE ? act_h(v, act) : v);
+        }
+        if ((lane & 3) != 0 || m >= g.M || nb4 >= N) continue;
+        const int pl = ml >> 2;                       // pooled pixel within the tile
+        if (staged) {
+          *reinterpret_cast<cv*>(&Cs[(long)pl * N + nb4]) = o;
+          continue;
+        }
+        HT* dst = C + ((m0 >> 2) + pl) * N + nb4;
+        if (vecc) *reinterpret_cast<cv*>(dst) = o;
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (nb4 + r < N) dst[r] = o[r];
+        }
+        continue;
+      }
+      if (m >= g.M) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (HT)epilogue_h<HT>(acc[i][j][r], cb[r], 1.f, false, act);
       if (staged) {
@@ -1060,10 +1114,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_gemm_h_kernel(const IT* __rest
   }
   if (staged) {
     __syncthreads();
-    const long rows = g.M - m0 < BM ? g.M - m0 : BM;
+    long rows = g.M - m0 < BM ? g.M - m0 : BM;
+    long row0 = m0;
+    if (POOL) { rows >>= 2; row0 >>= 2; }             // pooled pixels of this tile: contiguous in memory
     const long total = rows * N;                      // halves, multiple of 8
     typedef HT v8 __attribute__((ext_vector_type(8)));
-    HT* dst = C + m0 * N;
+    HT* dst = C + row0 * N;
     for (long idx = (long)tid * 8; idx < total; idx += (long)kBlock * 8)
       *reinterpret_cast<v8*>(dst + idx) = *reinterpret_cast<const v8*>(&Cs[idx]);
   }
@@ -1124,6 +1180,11 @@ template <typename HT>
 bool conv_patch_launch(const void* in, const ConvGeomH& g, const void* w, const float* bias,
                        int cout, int act, void* out, hipStream_t st);
 
+// conv_stream_f16.hip: persistent whole-K kernel when the layer fits it; false -> the gather kernel here
+template <typename HT>
+bool conv_stream_launch(const void* in, const ConvGeomH& g, const void* w, const float* bias, int cout,
+                        int act, void* out, hipStream_t st);
+
 template <typename HT, typename IT>
 static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const float* bias, int cout,
                          int act, void* out_, hipStream_t st) {
@@ -1135,11 +1196,21 @@ static int conv_h_launch(const void* in_, ConvGeomH g, const void* w_, const flo
   // 16-byte channel gathers: 16-bit NHWC input, (i, j, ci) order, C % 8 == 0, aligned
   const bool vec8 = sizeof(IT) == 2 && g.clast && g.sc == 1 && g.C % 8 == 0 && g.sw % 8 == 0 &&
                     g.sh % 8 == 0 && g.sn % 8 == 0 && al16(in);
-  if (vec8 && tuning().conv_patch && conv_patch_launch<HT>(in_, g, w_, bias, cout, act, out_, st))
+  if (g.pool != 2 && vec8 && tuning().conv_patch &&
+      conv_patch_launch<HT>(in_, g, w_, bias, cout, act, out_, st))
+    return check_launch("l2q_conv_gemm_periodic_h");
+  if (vec8 && tuning().conv_stream && cout > (g.pool == 2 ? 0 : 16) &&
+      conv_stream_launch<HT>(in_, g, w_, bias, cout, act, out_, st))
     return check_launch("l2q_conv_gemm_periodic_h");
 #define L2Q_CHB(KS, BNV)                                                                         \
   do {                                                                                           \
-    if (vec8)                                                                                    \
+    if (g.pool == 2 && vec8)                                                                     \
+      hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, sizeof(IT) == 2, true>), grid,     \
+                         block, 0, st, in, g, weight, cout, bias, act, out);                     \
+    else if (g.pool == 2)                                                                        \
+      hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, false, true>), grid, block, 0, st, \
+                         in, g, weight, cout, bias, act, out);                                   \
+    else if (vec8)                                                                               \
       hipLaunchKernelGGL((conv_gemm_h_kernel<HT, IT, KS, BNV, sizeof(IT) == 2>), grid, block, 0, \
                          st, in, g, weight, cout, bias, act, out);                               \
     else                                                                                         \
@@ -1328,7 +1399,33 @@ int l2q_conv_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long 
   g.Ho = H + k - 1; g.Wo = W + k - 1; g.Kc = C * k * k;
   g.clast = channels_last_cols ? 1 : 0;
   g.M = (long)nb * g.Ho * g.Wo;
-  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16, L2Q_ESHAPE, "too many output pixels");
+  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16 && g.M < (1L << 31), L2Q_ESHAPE, "too many output pixels");
+  const hipStream_t st = (hipStream_t)stream;
+  if (half_type == L2Q_HALF_F16) {
+    return in_is_f32 ? conv_h_launch<_Float16, float>(in, g, weight, bias, cout, act, out, st)
+                     : conv_h_launch<_Float16, _Float16>(in, g, weight, bias, cout, act, out, st);
+  }
+  return in_is_f32 ? conv_h_launch<__bf16, float>(in, g, weight, bias, cout, act, out, st)
+                   : conv_h_launch<__bf16, __bf16>(in, g, weight, bias, cout, act, out, st);
+}
+
+int l2q_conv_pool_gemm_periodic_h(int half_type, const void* in, int in_is_f32, long sn, long sc,
+                                  long sh, long sw, int nb, int C, int H, int W, int k,
+                                  const void* weight, int channels_last_cols, const float* bias,
+                                  int cout, int act, void* out, void* stream) {
+  L2Q_REQUIRE(in && weight && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && C > 0 && H > 0 && W > 0 && k > 0 && cout > 0, L2Q_EINVAL,
+              "non-positive size");
+  L2Q_REQUIRE(act >= L2Q_ACT_NONE && act <= L2Q_ACT_SWISH, L2Q_EINVAL, "bad activation");
+  L2Q_REQUIRE(half_type == L2Q_HALF_F16 || half_type == L2Q_HALF_BF16, L2Q_EINVAL, "bad half type");
+  ConvGeomH g;
+  g.sn = sn; g.sc = sc; g.sh = sh; g.sw = sw; g.C = C; g.H = H; g.W = W; g.k = k;
+  g.Ho = H + k - 1; g.Wo = W + k - 1; g.Kc = C * k * k;
+  g.clast = channels_last_cols ? 1 : 0;
+  g.pool = 2; g.Hp = g.Ho / 2; g.Wp = g.Wo / 2;
+  L2Q_REQUIRE(g.Hp > 0 && g.Wp > 0, L2Q_ESHAPE, "image smaller than the pooling window");
+  g.M = 4L * nb * g.Hp * g.Wp;
+  L2Q_REQUIRE(cdiv(g.M, 128) < 65536L * 16 && g.M < (1L << 31), L2Q_ESHAPE, "too many output pixels");
   const hipStream_t st = (hipStream_t)stream;
   if (half_type == L2Q_HALF_F16) {
     return in_is_f32 ? conv_h_launch<_Float16, float>(in, g, weight, bias, cout, act, out, st)

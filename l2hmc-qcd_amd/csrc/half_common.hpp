@@ -72,7 +72,9 @@ struct ConvGeomH {
   long sn, sc, sh, sw;
   int C, H, W, k, Ho, Wo, Kc;
   int clast;            // K order: 0 (ci, i, j) -- nn.Conv2d's flatten order, 1 (i, j, ci)
-  long M;
+  long M;               // GEMM rows: output pixels, or (pool == 2) 4 x pooled pixels
+  int pool = 1;         // 2: MaxPool2d(2) fused -- row m is window position m & 3 of pooled pixel m >> 2
+  int Hp = 0, Wp = 0;   // pooled extent (Ho / 2, Wo / 2)
 };
 
 }  // namespace l2q

@@ -27,6 +27,8 @@ struct Tuning {
   int gemm_h_wide_fused = 0;  // large half GEMMs: 128 x 256 tile with 512 threads (measured slower)
   int conv_patch = 1;         // half conv: input patch staged in LDS by persistent workgroups for layers with
                               // <= 16 output channels (2: every layer it fits, 0: gather kernel only)
+  int conv_stream = 0;        // half conv: 1 = persistent whole-K kernel (conv_stream_f16.hip; measured slower at cfg-3:
+                              // 3.7 / 1.8 ms against the gather kernel's 2.6 / 1.2 ms), 0 = gather kernel
   int gemm_h_dma = 1;         // big half GEMMs (M, N % 256 == 0, K % 64 == 0): LDS-DMA 256 x 256 kernel (0: off)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
   int heads_h_stream = 0; // half-precision heads+update: 1 = weights-stationary stream kernel (measured slower at

@@ -618,6 +618,9 @@ def nchw_to_nhwc_pad_h(x: torch.Tensor, hd: torch.dtype, cpad: int = 8) -> torch
     return out
 
 
+FUSE_CONV_POOL_H = [True]      # switch for A/B and the equality test (same bits either way)
+
+
 def conv2d_periodic_gemm_h(x: torch.Tensor, layout: str, w16: torch.Tensor, b: torch.Tensor,
                            pool: int = 1, act: Optional[str] = None) -> torch.Tensor:
     """Half-precision PeriodicPadding(k-1) -> Conv2d(k) -> [MaxPool2d] -> [act] (include/l2q.h:
@@ -638,6 +641,13 @@ def conv2d_periodic_gemm_h(x: torch.Tensor, layout: str, w16: torch.Tensor, b: t
         raise N.L2QError(f'conv2d_periodic_gemm_h: x {tuple(x.shape)} {x.dtype}, w {tuple(w16.shape)} {hd}')
     Ho, Wo = H + k - 1, W + k - 1
     pool = max(int(pool), 1)
+    if pool == 2 and FUSE_CONV_POOL_H[0] and Ho >= 2 and Wo >= 2:
+        # conv + MaxPool2d(2) + activation in one kernel: the un-pooled image never reaches HBM
+        out = torch.empty((nb, Ho // 2, Wo // 2, cout), dtype=hd, device=x.device)
+        N.call('l2q_conv_pool_gemm_periodic_h', HALF_TYPES[hd], x, int(x.dtype == torch.float32), sn,
+               sc, sh, sw, nb, C, H, W, k, w16.reshape(cout, -1).contiguous(), int(layout != 'nchw'),
+               b.contiguous(), cout, N.ACT[act], out)
+        return out
     y = torch.empty((nb * Ho * Wo, cout), dtype=hd, device=x.device)
     N.call('l2q_conv_gemm_periodic_h', HALF_TYPES[hd], x, int(x.dtype == torch.float32), sn, sc, sh,
            sw, nb, C, H, W, k, w16.reshape(cout, -1).contiguous(), int(layout != 'nchw'),

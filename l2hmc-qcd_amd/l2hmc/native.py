@@ -72,6 +72,7 @@ SIGNATURES = {
                                   I, P, Z, P]),
     'l2q_u1_heads_update_h_ws_bytes': (Z, [I, L]),
     'l2q_conv_gemm_periodic_h': (I, [I, P, I, L, L, L, L, I, I, I, I, I, P, I, P, I, I, P, P]),
+    'l2q_conv_pool_gemm_periodic_h': (I, [I, P, I, L, L, L, L, I, I, I, I, I, P, I, P, I, I, P, P]),
     'l2q_maxpool_act_nhwc_h': (I, [I, P, I, I, I, I, I, I, P, P]),
     'l2q_nchw_to_nhwc_pad_h': (I, [I, P, I, I, I, I, I, P, P]),
     'l2q_u1_plaq_reduce': (I, [P, I, I, I, I, P, P]),

@@ -718,6 +718,15 @@ def l2q_conv_gemm_periodic_h(ht, x, x32, sn, sc, sh, sw, nb, C, H, W, k, w, clas
     out.copy_(y.reshape(out.shape).to(out.dtype))
 
 
+def l2q_conv_pool_gemm_periodic_h(ht, x, x32, sn, sc, sh, sw, nb, C, H, W, k, w, clast, b, cout, act, out):
+    """conv (no activation) -> MaxPool2d(2) -> activation: the two entry points it replaces, composed"""
+    hd = torch.float16 if ht == 0 else torch.bfloat16
+    Ho, Wo = H + k - 1, W + k - 1
+    y = torch.empty(nb * Ho * Wo, cout, dtype=hd)
+    l2q_conv_gemm_periodic_h(ht, x, x32, sn, sc, sh, sw, nb, C, H, W, k, w, clast, b, cout, 0, y)
+    l2q_maxpool_act_nhwc_h(ht, y, nb, Ho, Wo, cout, 2, act, out)
+
+
 def l2q_nchw_to_nhwc_pad_f32(x, nb, C, H, W, cpad, out):
     out.zero_()
     out.reshape(nb, H, W, cpad)[..., :C] = x.reshape(nb, C, H, W).permute(0, 2, 3, 1)

@@ -572,6 +572,21 @@ def test_conv_gemm_periodic_h(hd, layout, dims):
             alt = ops.conv2d_periodic_gemm_h(xin.cuda(), layout, w16.cuda(), b.cuda(), pool, act)
             assert torch.equal(alt, got), (cp, float((alt.float() - got.float()).abs().max()))
         native.set_tuning('conv_patch', 1)
+        # the persistent whole-K kernel (conv_stream_f16.hip, off by default): same products, same order
+        native.set_tuning('conv_stream', 1)
+        try:
+            alt = ops.conv2d_periodic_gemm_h(xin.cuda(), layout, w16.cuda(), b.cuda(), pool, act)
+        finally:
+            native.set_tuning('conv_stream', 0)
+        assert torch.equal(alt, got), ('conv_stream', float((alt.float() - got.float()).abs().max()))
+        if pool == 2:
+            # conv + MaxPool2d(2) + act in one kernel (the default) == conv, then the pool kernel
+            ops.FUSE_CONV_POOL_H[0] = False
+            try:
+                two = ops.conv2d_periodic_gemm_h(xin.cuda(), layout, w16.cuda(), b.cuda(), pool, act)
+            finally:
+                ops.FUSE_CONV_POOL_H[0] = True
+            assert torch.equal(two, got), float((two.float() - got.float()).abs().max())
         y = torch.empty(nb * Ho * Wo, cout, dtype=hd)
         emu_native.l2q_conv_gemm_periodic_h(ops.HALF_TYPES[hd], xin, int(layout == 'nchw'), *strides,
                                             nb, C, H, W, k, w16.reshape(cout, -1),
