@@ -261,6 +261,27 @@ int l2q_vnet_heads_vupdate_pair_mid_f64(const double* Z, int M, int K, long N, c
                                         int forward2, double* logdet, double* logdet1,
                                         double* vnorm2_mid, void* ws, size_t ws_bytes, void* stream);
 size_t l2q_vnet_heads_ws_bytes(int M, long N);
+/* The same heads + momentum update with the fp64 products rebuilt from exact int8 x int8 -> int32 slice
+ * products on v_mfma_i32_16x16x64_i8 (error-free slicing, csrc/heads_sliced.hip): an
+ * inference path for K = 256 (the reference's default width of the last hidden layer of the SU(3) nets).
+ * l2q_heads_sliced_build turns the three weight matrices [N][K] into the int8 slice image + per-entry
+ * power-of-two scales (sliced: l2q_heads_sliced_bytes(K, N) bytes, 256-byte aligned; rebuild when the
+ * weights change); *usable = 0 when a weight vector's dynamic range is too wide for the 54-bit fixed
+ * point (mean |w| below 2^-6 of the largest): keep the fp64 kernel then.  The call synchronises the
+ * stream.  l2q_vnet_heads_vupdate_sliced_f64 is the four fp64 entry points in one: v_in NULL = in
+ * place; pair = 0 ignores flip_between / eps2 / forward2; logdet1 / vnorm2_mid non-NULL (pair only) =
+ * the mid-point outputs.  Results agree with the fp64 kernels to fp64 rounding (not bit for bit). */
+size_t l2q_heads_sliced_bytes(int K, long N);
+int l2q_heads_sliced_build(const double* Ws, const double* Wt, const double* Wq, int K, long N, void* sliced,
+                           size_t sliced_bytes, int* usable, void* stream);
+size_t l2q_vnet_heads_sliced_ws_bytes(int M, long N);
+int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, const void* sliced,
+                                      const double* bs, const double* cs, double scale_s, const double* bt,
+                                      double scale_t, const double* bq, const double* cq, double scale_q,
+                                      const void* v_in, void* v, const void* force, int is_complex, double eps1,
+                                      int forward1, int pair, int flip_between, double eps2, int forward2,
+                                      double* logdet, double* logdet1, double* vnorm2_mid, void* ws,
+                                      size_t ws_bytes, void* stream);
 /* fp32 variant on v_mfma_f32_16x16x4_f32 (U(1) networks). */
 int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const float* A2,
                  const float* W2, long K2, const float* bias, const float* bias2,

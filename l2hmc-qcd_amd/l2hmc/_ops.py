@@ -431,6 +431,49 @@ def u1_heads_update_h_(z: torch.Tensor, heads: dict, scale_t: float, a: torch.Te
     return logdet
 
 
+# int8-sliced heads (csrc/heads_sliced.hip): [True] = use the slice image when the network offers one
+# (`heads['sliced']`, built by network.kernel_weights for fp64 heads with K = 256 outside training)
+USE_SLICED_HEADS = [True]
+SLICED_K = 256
+
+
+def heads_sliced_build(heads: dict):
+    """int8 slice image of the three head weight matrices (include/l2q.h: l2q_heads_sliced_build).
+    Returns the uint8 device buffer, or None when the weights do not qualify (dtype, K, dynamic range)."""
+    import ctypes
+    ws_, wt, wq = heads['s'][0], heads['t'][0], heads['q'][0]
+    n, k = ws_.shape
+    if ws_.dtype != torch.float64 or k != SLICED_K or not ws_.is_cuda:
+        return None
+    nbytes = int(N.load().l2q_heads_sliced_bytes(k, n))
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=ws_.device)
+    usable = ctypes.c_int(0)
+    N.call('l2q_heads_sliced_build', ws_, wt, wq, k, n, buf, nbytes, ctypes.byref(usable))
+    return buf if usable.value else None
+
+
+def _sliced_call(z, heads, scales, v, force, eps1, forward1, pair, flip, eps2, forward2, v_src=None,
+                 mid=False):
+    m, k = z.shape
+    _, bs, cs = heads['s']
+    _, bt, _ = heads['t']
+    wq, bq, cq = heads['q']
+    n = wq.shape[0]
+    out = torch.empty((3 if mid else 1, m), dtype=torch.float64, device=z.device)
+    nbytes = int(N.load().l2q_vnet_heads_sliced_ws_bytes(m, n))
+    ws = N.workspace(nbytes, z.device)
+    N.call('l2q_vnet_heads_vupdate_sliced_f64', z, m, k, n, heads['sliced'], bs, cs, float(scales[0]), bt,
+           float(scales[1]), bq, cq, float(scales[2]), v_src, v, force, int(v.is_complex()), float(eps1),
+           int(forward1), int(pair), int(flip), float(eps2), int(forward2), out[0],
+           out[1] if mid else None, out[2] if mid else None, ws, ws.numel())
+    return out
+
+
+def _use_sliced(z, heads) -> bool:
+    return (USE_SLICED_HEADS[0] and heads.get('sliced') is not None and z.dtype == torch.float64
+            and z.shape[1] == SLICED_K)
+
+
 def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
                         force: torch.Tensor, eps: float, forward: bool,
                         v_src: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -443,6 +486,10 @@ def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
     wt, bt, _ = heads['t']
     wq, bq, cq = heads['q']
     n = ws_.shape[0]
+    if _use_sliced(z, heads):
+        if v_src is not None:
+            assert v_src.shape == v.shape and v_src.dtype == v.dtype and v_src.is_contiguous()
+        return _sliced_call(z, heads, scales, v, force, eps, forward, False, False, 0.0, False, v_src)[0]
     logdet = torch.empty(m, dtype=torch.float64, device=z.device)
     nbytes = int(N.load().l2q_vnet_heads_ws_bytes(m, n))
     ws = N.workspace(nbytes, z.device)
@@ -468,6 +515,8 @@ def vnet_heads_vupdate_pair_(z: torch.Tensor, heads: dict, scales, v: torch.Tens
     wt, bt, _ = heads['t']
     wq, bq, cq = heads['q']
     n = ws_.shape[0]
+    if _use_sliced(z, heads):
+        return _sliced_call(z, heads, scales, v, force, eps1, forward1, True, flip, eps2, forward2)[0]
     logdet = torch.empty(m, dtype=torch.float64, device=z.device)
     ws = N.workspace(int(N.load().l2q_vnet_heads_ws_bytes(m, n)), z.device)
     N.call('l2q_vnet_heads_vupdate_pair_f64', z, m, k, n, ws_, bs, cs, float(scales[0]), wt, bt,
@@ -488,6 +537,9 @@ def vnet_heads_vupdate_pair_mid_(z: torch.Tensor, heads: dict, scales, v: torch.
     wt, bt, _ = heads['t']
     wq, bq, cq = heads['q']
     n = ws_.shape[0]
+    if _use_sliced(z, heads):
+        out = _sliced_call(z, heads, scales, v, force, eps1, forward1, True, flip, eps2, forward2, mid=True)
+        return out[0], out[1], out[2]
     out = torch.empty((3, m), dtype=torch.float64, device=z.device)
     ws = N.workspace(int(N.load().l2q_vnet_heads_ws_bytes(m, n)), z.device)
     N.call('l2q_vnet_heads_vupdate_pair_mid_f64', z, m, k, n, ws_, bs, cs, float(scales[0]), wt, bt,

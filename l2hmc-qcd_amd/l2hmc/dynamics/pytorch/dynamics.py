@@ -233,6 +233,9 @@ class Dynamics(nn.Module):
         # pointers (the library's own in-place kernels, .data edits) do not bump
         self.cache_native_output = False
         self.pair_v_updates_verbose = True     # verbose=True also pairs adjacent v-updates (mid-point kernel)
+        # fp64 heads with K = 256 outside the training tape: products rebuilt from exact int8 slice
+        # products on the int8 matrix cores (csrc/heads_sliced.hip; same values to fp64 rounding)
+        self.sliced_heads = True
 
     # ------------------------------------------------------------------ construction
     def set_net_precision(self, precision) -> None:
@@ -568,6 +571,12 @@ class Dynamics(nn.Module):
             return fn, None, None
         p = self._perms()
         w = vnet.kernel_weights(p['in'], p['out'])
+        hs = w['heads_scaled']
+        if 'sliced' not in hs:
+            # int8 slice image of the head weights (csrc/heads_sliced.hip); lives in the
+            # version-keyed weight cache, so it is rebuilt whenever a parameter changes
+            hs['sliced'] = (ops.heads_sliced_build(hs)
+                            if self.sliced_heads and ops.USE_SLICED_HEADS[0] else None)
         zkey = ('z', id(vnet))
         if cache is not None and zkey in cache:
             return fn, cache[zkey], w

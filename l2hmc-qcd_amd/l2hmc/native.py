@@ -63,6 +63,11 @@ SIGNATURES = {
     'l2q_vnet_heads_vupdate_pair_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, I, D, I, I, D, I, P, P, Z, P]),
     'l2q_vnet_heads_vupdate_pair_mid_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, I, D, I, I, D, I, P, P, P, P, Z, P]),
     'l2q_vnet_heads_ws_bytes': (Z, [I, L]),
+    'l2q_heads_sliced_bytes': (Z, [I, L]),
+    'l2q_heads_sliced_build': (I, [P, P, P, I, L, P, Z, P, P]),
+    'l2q_vnet_heads_sliced_ws_bytes': (Z, [I, L]),
+    'l2q_vnet_heads_vupdate_sliced_f64': (I, [P, I, I, L, P, P, P, D, P, D, P, P, D, P, P, P, I, D, I, I, I, D,
+                                              I, P, P, P, P, Z, P]),
     'l2q_gemm_f32': (I, [P, P, I, I, L, P, P, L, P, P, P, F, I, P, P, Z, P]),
     'l2q_gemm_ex': (I, [P, I, P, I, I, I, L, I, I, P, P, Z, P]),
     'l2q_gemm_h': (I, [I, P, I, P, I, I, L, P, P, L, P, P, P, F, I, P, I, P, Z, P]),

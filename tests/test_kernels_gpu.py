@@ -310,6 +310,124 @@ def test_accept_select(ops):
 
 
 @pytest.mark.parametrize('cplx', [True, False])
+@pytest.mark.parametrize('shape', [(64, 48), (37, 50), (130, 16), (256, 8200), (300, 1000),
+                                   # 32 row groups (cfg-2-like chain counts), and more row groups than
+                                   # fit the chip at once
+                                   (2048, 160), (4160, 64)])
+def test_heads_sliced(ops, cplx, shape):
+    """The int8-sliced heads + momentum-update kernel (csrc/heads_sliced.hip: fp64 products rebuilt from
+    exact int8 slice products on v_mfma_i32_16x16x64_i8) against the fp64 MFMA kernel and against a
+    long-double evaluation: as accurate as the fp64 kernel, every variant (in place, out of place, pair,
+    pair with mid-point outputs), deterministic."""
+    m, n = shape
+    k = 256
+    rng = np.random.default_rng(5)
+    z = dev(np.maximum(rng.normal(size=(m, k)), 0.0))          # relu activations (exact zeros included)
+    scaled = {}
+    for nm in 'stq':
+        w = dev(rng.uniform(-1, 1, size=(n, k)) / 16); b = dev(0.1 * rng.normal(size=n))
+        c = None if nm == 't' else dev(np.exp(0.3 * rng.normal(size=n)))
+        scaled[nm] = (w, b, c)
+    nw = (0.9, 1.1, 0.8)
+    if cplx:
+        v = dev(rng.normal(size=(m, n)) + 1j * rng.normal(size=(m, n)))
+        f = dev(rng.normal(size=(m, n)) + 1j * rng.normal(size=(m, n)))
+    else:
+        v = dev(rng.normal(size=(m, n))); f = dev(rng.normal(size=(m, n)))
+    sl = dict(scaled)
+    sl['sliced'] = ops.heads_sliced_build(scaled)
+    assert sl['sliced'] is not None
+    assert ops.USE_SLICED_HEADS[0]
+    L = np.longdouble
+    for fwd in (True, False):
+        va = v.clone(); la = ops.vnet_heads_vupdate_(z, scaled, nw, va, f, 0.07, fwd)      # fp64 MFMA
+        vb = v.clone(); lb = ops.vnet_heads_vupdate_(z, sl, nw, vb, f, 0.07, fwd)          # sliced
+        assert float((va - vb).abs().max()) < 2e-14
+        assert err(host(la), host(lb)) < 1e-12
+        vb2 = v.clone(); lb2 = ops.vnet_heads_vupdate_(z, sl, nw, vb2, f, 0.07, fwd)
+        assert torch.equal(vb, vb2) and torch.equal(lb, lb2)                               # deterministic
+        if m * n <= 4096:
+            # long-double reference of the whole update: the sliced kernel is as close to it as the fp64 one
+            zz = host(z).astype(L)
+            y = {nm: zz @ host(scaled[nm][0]).astype(L).T + host(scaled[nm][1]).astype(L) for nm in 'stq'}
+            s = host(scaled['s'][2]).astype(L) * np.tanh(y['s'])
+            q = host(scaled['q'][2]).astype(L) * np.tanh(y['q'])
+            t = L(nw[1]) * y['t']
+            h = L(0.035)
+            es = np.exp(h * s if fwd else -h * s); eq = np.exp(L(0.07) * q)
+            hv, hf = host(v), host(f)
+            comps = [(hv.real.astype(L), hf.real.astype(L), t)]
+            if cplx:
+                comps.append((hv.imag.astype(L), hf.imag.astype(L), L(0) * t))
+            for ci, (vc, fc, tc) in enumerate(comps):
+                want = es * vc - h * (fc * eq + tc) if fwd else es * (vc + h * (fc * eq + tc))
+                ga = host(va).real if ci == 0 else host(va).imag
+                gb = host(vb).real if ci == 0 else host(vb).imag
+                ea = float(np.abs(ga.astype(L) - want).max()); eb = float(np.abs(gb.astype(L) - want).max())
+                assert eb < 2.0 * ea + 1e-15, (ea, eb)
+        # out of place: the same bits, the source untouched
+        v0 = v.clone(); v3 = torch.full_like(v, float('nan'))
+        l3 = ops.vnet_heads_vupdate_(z, sl, nw, v3, f, 0.07, fwd, v_src=v0)
+        assert torch.equal(v3, vb) and torch.equal(l3, lb) and torch.equal(v0, v)
+        for flip in (False, True):
+            for fwd2, eps2 in ((True, 0.05), (False, 0.05), (fwd, 0.07)):
+                pa = v.clone(); qa = ops.vnet_heads_vupdate_pair_(z, scaled, nw, pa, f, 0.07, fwd, flip, eps2, fwd2)
+                pb = v.clone(); qb = ops.vnet_heads_vupdate_pair_(z, sl, nw, pb, f, 0.07, fwd, flip, eps2, fwd2)
+                assert float((pa - pb).abs().max()) < 2e-14 and err(host(qa), host(qb)) < 1e-12
+                ma = v.clone(); ra = ops.vnet_heads_vupdate_pair_mid_(z, scaled, nw, ma, f, 0.07, fwd, flip, eps2, fwd2)
+                mb = v.clone(); rb = ops.vnet_heads_vupdate_pair_mid_(z, sl, nw, mb, f, 0.07, fwd, flip, eps2, fwd2)
+                assert torch.equal(mb, pb)
+                assert float((ma - mb).abs().max()) < 2e-14
+                for xa, xb in zip(ra, rb):
+                    assert err(host(xa), host(xb)) < 1e-12 * max(1.0, float(xa.abs().max()))
+
+
+def test_heads_sliced_edge_cases(ops):
+    """what the slice image refuses, and how non-finite inputs travel"""
+    rng = np.random.default_rng(6)
+    m, n, k = 70, 40, 256
+    mk = lambda: {nm: (dev(rng.uniform(-1, 1, size=(n, k)) / 16), dev(0.1 * rng.normal(size=n)),
+                       None if nm == 't' else dev(np.ones(n))) for nm in 'stq'}
+    # a weight vector dominated by one entry would keep too few bits of the others: refused
+    hb = mk()
+    hb['q'][0][5, :] *= 1e-9
+    hb['q'][0][5, 7] = 1.0
+    assert ops.heads_sliced_build(hb) is None
+    # other widths and dtypes are not served (the caller keeps the fp64 / fp32 kernels)
+    assert ops.heads_sliced_build({nm: (dev(rng.normal(size=(n, 128))), None, None) for nm in 'stq'}) is None
+    hd = mk()
+    assert ops.heads_sliced_build({nm: (hd[nm][0].float(), None, None) for nm in 'stq'}) is None
+    # zero rows / columns are exact; NaN and Inf poison exactly the outputs that use them
+    hd = mk()
+    hd['t'][0][3, :] = 0.0
+    hd['sliced'] = ops.heads_sliced_build(hd)
+    assert hd['sliced'] is not None
+    z = dev(rng.normal(size=(m, k)))
+    z[4, :] = 0.0
+    z[9, 17] = float('nan')
+    z[11, 200] = float('inf')
+    v = dev(rng.normal(size=(m, n))); f = dev(rng.normal(size=(m, n)))
+    ref = {nm: hd[nm] for nm in 'stq'}
+    va = v.clone(); la = ops.vnet_heads_vupdate_(z, ref, (1.0, 1.0, 1.0), va, f, 0.1, True)
+    vb = v.clone(); lb = ops.vnet_heads_vupdate_(z, hd, (1.0, 1.0, 1.0), vb, f, 0.1, True)
+    bad = torch.zeros(m, dtype=torch.bool, device=v.device); bad[9] = True; bad[11] = True
+    assert bool(torch.isfinite(vb[~bad]).all()) and bool(torch.isfinite(lb[~bad]).all())
+    assert not bool(torch.isfinite(vb[bad]).any()) and not bool(torch.isfinite(lb[bad]).any())
+    assert float((va[~bad] - vb[~bad]).abs().max()) < 2e-14
+    # chain 4 (z = 0): the heads reduce to their biases
+    want = (torch.exp(0.05 * torch.tanh(hd['s'][1])) * v[4]
+            - 0.05 * (f[4] * torch.exp(0.1 * torch.tanh(hd['q'][1])) + hd['t'][1]))
+    assert float((vb[4] - want).abs().max()) < 1e-15
+    # a weight matrix with a non-finite entry poisons that output entry for every chain
+    hn = mk()
+    hn['s'][0][2, 3] = float('nan')
+    hn['sliced'] = ops.heads_sliced_build(hn)
+    assert hn['sliced'] is not None
+    vc = v.clone(); ops.vnet_heads_vupdate_(dev(rng.normal(size=(m, k))), hn, (1.0, 1.0, 1.0), vc, f, 0.1, True)
+    assert not bool(torch.isfinite(vc[:, 2]).any()) and bool(torch.isfinite(vc[:, 3:]).all())
+
+
+@pytest.mark.parametrize('cplx', [True, False])
 @pytest.mark.parametrize('shape', [(3, 4, 3888), (70, 16, 200), (130, 256, 1000),
                                    # >= 512 tiles: the producer / consumer (persistent) kernel; full K,
                                    # short K with ragged M and N, one tile more than a round

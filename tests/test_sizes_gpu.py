@@ -161,6 +161,20 @@ def test_cfg4_trajectory_8x4_units256():
         # amplifies that by ~1e7 per step (see the golden's conditioning note): 1e-7, one order
         # inside the tolerance against the oracle above
         assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max()), (k, np.abs(a - b).max())
+    # the heads ran on the int8-sliced kernel (units [256] qualifies; csrc/heads_sliced.hip); the fp64
+    # MFMA heads give the same trajectory to rounding
+    vn = dyn._get_vnet(0)
+    pm = dyn._perms()
+    assert vn.kernel_weights(pm['in'], pm['out'])['heads_scaled'].get('sliced') is not None
+    try:
+        ops.USE_SLICED_HEADS[0] = False
+        dyn._inject = {'normals': nrm, 'u': u}
+        xo_f, m_f = dyn((dev(x), torch.tensor(beta)))
+    finally:
+        ops.USE_SLICED_HEADS[0] = True
+    assert np.array_equal(host(m_f['acc_mask']), mo['acc_mask'])
+    assert np.abs(host(xo_f) - host(xo)).max() <= 1e-7
+    assert np.abs(host(m_f['acc']) - host(m['acc'])).max() <= 1e-7
     # observables of the output configuration through the slice-resident plaquette kernel
     from oracle import su3 as osu3
     met = lat.calc_metrics(xo.reshape(x.shape))

@@ -1,18 +1,29 @@
-// Does fp64 VALU work of one wavefront overlap with fp64 MFMA work of another wavefront on the
-// same SIMD (gfx950)?  512-thread workgroups, 1 per CU: wavefronts 0-3 (one per SIMD) run a
+// Does VALU work of one wavefront overlap with MFMA work of another wavefront on the same SIMD
+// (gfx950)?  First block: v_mfma_f64_16x16x4_f64 (no: the times add); second block (I8 = true):
+// v_mfma_i32_16x16x64_i8.  512-thread workgroups, 1 per CU: wavefronts 0-3 (one per SIMD) run a
 // v_mfma_f64_16x16x4_f64 loop, wavefronts 4-7 run a VALU loop of the given flavour.
 // build: hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 // mode bits: 1 = MFMA waves active, 2 = VALU waves active; flavour: 0 fp64 fma, 1 fp32 fma, 2 int mad
-template <int FLAV>
+template <int FLAV, bool I8 = false>
 __global__ __launch_bounds__(512) void k(double* out, int it_m, int it_v, int mode) {
   const int wave = threadIdx.x >> 6;
   double res = 0;
   if (wave < 4) {
-    if (mode & 1) {
+    if ((mode & 1) && I8) {
+      v4i32 acc[8], a, b;
+      for (int i = 0; i < 8; ++i) acc[i] = (v4i32){0, 0, 0, 0};
+      a = (v4i32){(int)threadIdx.x, 3, 5, 7}; b = (v4i32){1, (int)threadIdx.x * 3, 2, 9};
+      for (int it = 0; it < it_m * 4; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
+      }
+      for (int i = 0; i < 8; ++i) res += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else if (mode & 1) {
       v4f64 acc[8];
       for (int i = 0; i < 8; ++i) acc[i] = (v4f64){0, 0, 0, 0};
       double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
@@ -70,12 +81,12 @@ double timeit(F f) {
   return ms / 5;
 }
 
-template <int FLAV>
+template <int FLAV, bool I8 = false>
 void run(const char* name, double* out, int it_m, int it_v) {
   const int nb = 256;
   double t[4];
   for (int mode = 1; mode <= 3; ++mode)
-    t[mode] = timeit([&] { hipLaunchKernelGGL(k<FLAV>, dim3(nb), dim3(512), 0, 0, out, it_m, it_v, mode); });
+    t[mode] = timeit([&] { hipLaunchKernelGGL((k<FLAV, I8>), dim3(nb), dim3(512), 0, 0, out, it_m, it_v, mode); });
   printf("%-10s MFMA alone %.3f ms (%.1f TFLOP/s)  VALU alone %.3f ms  both %.3f ms  (sum %.3f, max %.3f)\n", name, t[1],
          256.0 * 4 * it_m * 8 * 2048.0 / t[1] / 1e9, t[2], t[3], t[1] + t[2], t[1] > t[2] ? t[1] : t[2]);
 }
@@ -88,5 +99,9 @@ int main() {
   run<1>("fp32 fma", out, it_m, 16000);
   run<2>("int mad", out, it_m, 16000);
   run<0>("fp64 fma/2", out, it_m, 4000);
+  printf("-- v_mfma_i32_16x16x64_i8 (the TFLOP/s column does not apply)\n");
+  run<0, true>("fp64 fma", out, it_m, 8000);
+  run<1, true>("fp32 fma", out, it_m, 16000);
+  run<2, true>("int mad", out, it_m, 16000);
   return 0;
 }
