@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6       # MI355X fp64 matrix peak (datasheet; v_mfma_f64_16x16x4_f64)
+# dense int8 matrix peak: v_mfma_i32_16x16x64_i8 = 32768 ops per 16 cycles per SIMD, 1024 SIMDs, 2.4 GHz
+# (MI355X_MICROARCH.md: "I8 ~2x the bf16 rate", micro-benchmark floor 3944; tools/microbench/mfma_i8_rate.hip
+# reaches 4.2-4.9 POP/s on this part)
+INT8_MFMA_PEAK_TOPS = 5033.0
 
 # algorithmic bytes per (chain * site) -- SURVEY.md section 8(d): one 3x3 complex128 link is
 # 144 B, a site has 4 links; vec8 = 4 * 8 * 8 B = 256 B per site
@@ -682,14 +686,14 @@ def main():
             from l2hmc import native
             return native.kernel_name(name, [int(i) for i in args.lattice])
 
-        def mfma_roof(names, label, flops):
+        def mfma_roof(names, label, flops, peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s'):
             cnt = sum(ks[n][0] for n in names)
             tt = sum(ks[n][1] for n in names)
             ach = flops / tt / 1e12
             tr_, src = traffic(names[0])
             return {'kernel': label, 'bound': 'mfma', 'achieved': round(ach, 2),
-                    'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                    'frac': round(ach / FP64_MFMA_PEAK_TF, 4), 'traffic': tr_,
+                    'peak': peak, 'unit': unit,
+                    'frac': round(ach / peak, 4), 'traffic': tr_,
                     'traffic_source': src, 'avg_ms': round(tt / cnt * 1e3, 4), 'launches': cnt,
                     'time_s': tt}
 
@@ -706,6 +710,17 @@ def main():
                 per = 3 * 2.0 * args.nchains * args.units[-1] * 36 * V       # s, t, q heads
                 rooflines.append(mfma_roof(heads, 'l2q_vnet_heads_vupdate[_pair]_f64 (3 heads + '
                                            'v-update)', per * sum(ks[n][0] for n in heads)))
+            if 'l2q_vnet_heads_vupdate_sliced_f64' in ks:
+                # the same heads with the fp64 products rebuilt from 28 exact int8 slice products
+                # (csrc/heads_sliced.hip): priced in int8 operations against the int8 MFMA peak; the
+                # fp64-equivalent rate (the flops of the fp64 formulation / time) is given beside it
+                nm = 'l2q_vnet_heads_vupdate_sliced_f64'
+                per = 3 * 2.0 * args.nchains * args.units[-1] * 36 * V
+                r = mfma_roof([nm], 'l2q_vnet_heads_vupdate_sliced_f64 (3 heads as 28 int8 slice GEMMs + '
+                              'v-update)', 28 * per * ks[nm][0], INT8_MFMA_PEAK_TOPS, 'TOP/s')
+                r['fp64_equivalent_TFLOPs'] = round(per * ks[nm][0] / ks[nm][1] / 1e12, 2)
+                r['fp64_mfma_peak_TFLOPs'] = FP64_MFMA_PEAK_TF
+                rooflines.append(r)
             if 'l2q_gemm_f64' in ks:
                 rooflines.append(mfma_roof(['l2q_gemm_f64'], 'l2q_gemm_f64 (input + hidden layers)',
                                            ks['l2q_gemm_f64'][2]))

@@ -35,10 +35,11 @@
 // epilogue as the fp64 kernel (heads_common.hpp).  The RG = M / 64 workgroups that need the same
 // chunks run on ONE XCD (hardware block b -> XCD b % 8) and share its L2: W is read once from HBM.
 #include "heads_common.hpp"
+#include <type_traits>
 #include <vector>
 
 namespace l2q {
-namespace {
+// (kernels outside an anonymous namespace: rocprofv3 tables then carry their names)
 
 constexpr int OZ_NS = 7;                                  // int8 slices per operand
 constexpr int OZ_BITS = 54;                               // fixed-point bits below the vector's exponent
@@ -177,6 +178,23 @@ __device__ __forceinline__ void heads_element(const HeadsArgs& a, double zs, dou
 //     the matrix wavefronts do (VALU per tile ~5000 cycles against 5376 MFMA cycles).  Its operands
 //     (v, F, per-column parameters) are requested one tile ahead.
 // All eight wavefronts pass one s_barrier per chunk.
+#ifndef L2Q_SL_PRIO
+#define L2Q_SL_PRIO 3
+#endif
+#ifndef L2Q_SL_NPD
+#define L2Q_SL_NPD 4          // LDS-DMA pieces (of a wavefront pair's 7 per chunk) issued by the matrix wavefront
+#endif
+#ifndef L2Q_SL_CVT
+#define L2Q_SL_CVT 0
+#endif
+// int32 -> fp64, exact
+__device__ __forceinline__ double i2d(int x) {
+#if L2Q_SL_CVT
+  return __hiloint2double(0x43300000, x ^ 0x80000000) - 4503601774854144.0;   // 2^52 + 2^31 + x, minus the bias
+#else
+  return (double)x;
+#endif
+}
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <bool CPLX, bool FWD, bool PAIR, bool MID>
@@ -202,6 +220,10 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
 
   if (wave < 4) {
     // ================================================================ matrix wavefronts
+    // Nothing but ds_read / MFMA / ds_write: a wavefront issues in order, so every other instruction
+    // that takes longer than an MFMA's 16 cycles (an LDS-DMA piece: ~60, a cluster of ds_reads) drains
+    // the matrix pipe.  The LDS-DMA of the weight images is issued by the update wavefronts.
+    __builtin_amdgcn_s_setprio(L2Q_SL_PRIO);
     v4i32 A[OZ_NS][OZ_KB];
 #pragma unroll
     for (int s = 0; s < OZ_NS; ++s)
@@ -209,101 +231,111 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
       for (int kb = 0; kb < OZ_KB; ++kb)
         A[s][kb] = *reinterpret_cast<const v4i32*>(o.Zs + (rt * OZ_NS + s) * (long)(OZ_KB * OZ_FRAG) +
                                                    kb * OZ_FRAG + lane * 16);
-    const char* wsrc = o.Wsl + t0 * 3 * (long)OZ_CHUNK + lane * 16;
-    auto issue = [&](long qi, int stage) {
-      const char* src = wsrc + qi * (long)OZ_CHUNK;
-#pragma unroll
-      for (int f = 0; f < OZ_NS; ++f) {
-        const int frag = wave + 4 * f;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + frag * OZ_FRAG),
-                                         (lds_ptr_t)(lds + stage * OZ_CHUNK + frag * OZ_FRAG), 16, 0, 0);
-      }
-    };
-    // Three chunk images in LDS: DMA(q + 2) is issued when chunk q starts and confirmed (vmcnt + barrier)
-    // when chunk q + 1 starts, so every image is complete a whole chunk before it is read and the first
-    // fragments of chunk q + 1 can be fetched under the last MFMAs of chunk q: the matrix pipe only
-    // waits at the barrier itself.
-    if (nq > 0) issue(0, 0);
-    if (nq > 1) issue(1, 1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // B(0)
-    if (nq > 2) issue(2, 2);
-    // B fragments of the even / odd k-block.  Loads and their waits are written by hand (the compiler
-    // sinks a ds_read to its first use, or waits lgkmcnt(0) right after issuing the NEXT block's reads):
-    // a block's seven reads are issued before the previous block's MFMAs, `lgkmcnt(7)` then releases the
-    // older seven only.  LDS returns in order; the wait statement carries the fragments as operands so
-    // that no MFMA can be scheduled above it.
+    // B fragments of the even / odd k-block, read and waited for by hand: fragment r of the NEXT block
+    // is requested after MFMA 4 r + 3 of the current one (28 MFMAs per block, slice j = 0 .. 6 in
+    // groups of 7 - j), and group j waits with the lgkmcnt that leaves exactly the younger requests
+    // outstanding (LDS returns in order).  The wait carries its fragment as an operand so that no
+    // MFMA using it can be scheduled above.
     v4i32 bfa[OZ_NS], bfb[OZ_NS];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + lane * 16;
-    auto load_block = [&](v4i32 (&bf)[OZ_NS], int stage, int kb) {
-      const unsigned ad = lds0 + stage * OZ_CHUNK + kb * OZ_FRAG;
-#pragma unroll
-      for (int j = 0; j < OZ_NS; ++j)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[j]) : "v"(ad), "n"(j * OZ_KB * OZ_FRAG));
-    };
-#define L2Q_SL_WAIT(cnt, bf)                                                                          \
-  asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                          \
-               : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]))
-    auto mfma_block = [&](v4i32 (&acc)[OZ_NS], const v4i32 (&bf)[OZ_NS], int kb) {
-#pragma unroll
-      for (int j = 0; j < OZ_NS; ++j)
-#pragma unroll
-        for (int i = 0; i + j < ((L2Q_SL_SKIP & 2) ? j + 1 : OZ_NS); ++i)
-          acc[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i][kb], bf[j], acc[i + j], 0, 0, 0);
-    };
-    int st = 0;                                               // image of chunk qi = qi % 3
+#define L2Q_SL_READ(dst, ad, j) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"((j) * OZ_KB * OZ_FRAG))
 #if L2Q_SL_PROF
-    long long prof_vm = 0, prof_bar = 0;
+    long long prof_lds = 0, prof_bar = 0;
     const long long prof_t0 = clock64();
 #endif
-    if (nq > 0) load_block(bfa, 0, 0);
+    auto wait_for = [&](v4i32& x, auto cnt) {
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(decltype(cnt)::value));
+    };
+    using std::integral_constant;
+    // one k-block: 28 MFMAs on `cur`, the seven fragments of the next block into `nxt` from LDS address nad
+    // (dsrc != nullptr, first block of a chunk: also L2Q_SL_NPD pieces of the LDS-DMA of chunk qi + 2,
+    // one every eight MFMAs; the update wavefront issues the rest -- the split that balances the two)
+    auto block = [&](v4i32 (&acc)[OZ_NS], v4i32 (&cur)[OZ_NS], v4i32 (&nxt)[OZ_NS], int kb, unsigned nad,
+                     const char* dsrc, char* ddst) {
+      int idx = 0;
+#pragma unroll
+      for (int j = 0; j < OZ_NS; ++j) {
+        if (j == 0 || j == 1 || j == OZ_NS - 1) wait_for(cur[j], integral_constant<int, 6>{});
+        else wait_for(cur[j], integral_constant<int, 7>{});
+#pragma unroll
+        for (int i = 0; i + j < OZ_NS; ++i, ++idx) {
+          if (!(L2Q_SL_SKIP & 2) || i == 0)
+            acc[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i][kb], cur[j], acc[i + j], 0, 0, 0);
+          if (dsrc && (idx & 7) == 1 && (idx >> 3) < L2Q_SL_NPD) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int frag = p + 4 * (idx >> 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + frag * OZ_FRAG),
+                                             (lds_ptr_t)(ddst + frag * OZ_FRAG), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if ((idx & 3) == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            switch (idx >> 2) {
+              case 0: L2Q_SL_READ(nxt[0], nad, 0); break;
+              case 1: L2Q_SL_READ(nxt[1], nad, 1); break;
+              case 2: L2Q_SL_READ(nxt[2], nad, 2); break;
+              case 3: L2Q_SL_READ(nxt[3], nad, 3); break;
+              case 4: L2Q_SL_READ(nxt[4], nad, 4); break;
+              case 5: L2Q_SL_READ(nxt[5], nad, 5); break;
+              default: L2Q_SL_READ(nxt[6], nad, 6); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
+    const char* wsrc = o.Wsl + t0 * 3 * (long)OZ_CHUNK + lane * 16;
+    wg_barrier();                                             // B(0): images 0 and 1 are in LDS
+    int st = 0;                                               // image of chunk qi = qi % 3
+    if (nq > 0) {
+#pragma unroll
+      for (int j = 0; j < OZ_NS; ++j) {
+        switch (j) {
+          case 0: L2Q_SL_READ(bfa[0], lds0, 0); break;
+          case 1: L2Q_SL_READ(bfa[1], lds0, 1); break;
+          case 2: L2Q_SL_READ(bfa[2], lds0, 2); break;
+          case 3: L2Q_SL_READ(bfa[3], lds0, 3); break;
+          case 4: L2Q_SL_READ(bfa[4], lds0, 4); break;
+          case 5: L2Q_SL_READ(bfa[5], lds0, 5); break;
+          default: L2Q_SL_READ(bfa[6], lds0, 6); break;
+        }
+      }
+    }
     for (long qi = 0; qi < nq; ++qi) {
       v4i32 acc[OZ_NS];
 #pragma unroll
       for (int g = 0; g < OZ_NS; ++g) acc[g] = (v4i32){0, 0, 0, 0};
-      load_block(bfb, st, 1);
-      L2Q_SL_WAIT(7, bfa);
-      mfma_block(acc, bfa, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_block(bfa, st, 2);
-      L2Q_SL_WAIT(7, bfb);
-      mfma_block(acc, bfb, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      load_block(bfb, st, 3);
-      L2Q_SL_WAIT(7, bfa);
-      mfma_block(acc, bfa, 2);
-      __builtin_amdgcn_sched_barrier(0);
+      const unsigned sb = lds0 + st * OZ_CHUNK;
       const int stn = st == 2 ? 0 : st + 1;
-      // next chunk's first block (its image was confirmed at B(qi)); the last chunk re-reads its own
-      load_block(bfa, qi + 1 < nq ? stn : st, 0);
-      L2Q_SL_WAIT(7, bfb);
-      // last k-block by group s + t ascending: a group's sums leave for the ring two groups after its
-      // last MFMA was issued (no wait on the matrix pipe)
+      // the next chunk's first block (its image was complete at B(qi)); the last chunk re-reads its own
+      const unsigned nb0 = lds0 + (qi + 1 < nq ? stn : st) * OZ_CHUNK;
+      // DMA(qi + 2) into the image chunk qi - 1 occupied (everybody left it before B(qi)); past the last
+      // chunk the last one is fetched again into an image nobody reads
+      const long qd = qi + 2 < nq ? qi + 2 : nq - 1;
+      const int std_ = st == 0 ? 2 : st - 1;
+      block(acc, bfa, bfb, 0, sb + 1 * OZ_FRAG, wsrc + qd * (long)OZ_CHUNK, lds + std_ * OZ_CHUNK);
+      block(acc, bfb, bfa, 1, sb + 2 * OZ_FRAG, nullptr, nullptr);
+      block(acc, bfa, bfb, 2, sb + 3 * OZ_FRAG, nullptr, nullptr);
+      block(acc, bfb, bfa, 3, nb0, nullptr, nullptr);
       char* rb = ring + ((qi & 1) * 4 + p) * RING + lane * 16;
 #pragma unroll
-      for (int g = 0; g < OZ_NS; ++g) {
-#pragma unroll
-        for (int i = 0; i <= ((L2Q_SL_SKIP & 2) ? 0 : g); ++i)
-          acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i][3], bfb[g - i], acc[g], 0, 0, 0);
-        if (g >= 2 && !((L2Q_SL_SKIP & 16) && g < 6)) *reinterpret_cast<v4i32*>(rb + (g - 2) * OZ_FRAG) = acc[g - 2];
-      }
-      *reinterpret_cast<v4i32*>(rb + (OZ_NS - 2) * OZ_FRAG) = acc[OZ_NS - 2];
-      *reinterpret_cast<v4i32*>(rb + (OZ_NS - 1) * OZ_FRAG) = acc[OZ_NS - 1];
+      for (int g = 0; g < OZ_NS; ++g)
+        if (!((L2Q_SL_SKIP & 16) && g < 5)) *reinterpret_cast<v4i32*>(rb + g * OZ_FRAG) = acc[g];
 #if L2Q_SL_PROF
-      { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long c0 = clock64();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long c1 = clock64();
-        asm volatile("s_barrier" ::: "memory"); const long long c2 = clock64();
-        prof_vm += c1 - c0; prof_bar += c2 - c1; }
+      { const long long c0 = clock64(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const long long c1 = clock64(); asm volatile("s_barrier" ::: "memory");
+        prof_lds += c1 - c0; prof_bar += clock64() - c1; }
 #else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // B(qi + 1)
 #endif
-      if (!(L2Q_SL_SKIP & 4) && qi + 3 < nq) issue(qi + 3, st);   // image of chunk qi is free now
       st = stn;
     }
-#undef L2Q_SL_WAIT
+#undef L2Q_SL_READ
 #if L2Q_SL_PROF
     if (o.dbg && lane == 0) {
       long long* d = o.dbg + ((long)blockIdx.x * 8 + wave) * 4;
-      d[0] = clock64() - prof_t0; d[1] = prof_bar; d[2] = prof_vm; d[3] = nq;
+      d[0] = clock64() - prof_t0; d[1] = prof_bar; d[2] = 0; d[3] = prof_lds;
     }
 #endif
     return;
@@ -328,11 +360,11 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
     __builtin_amdgcn_sched_barrier(0);
     double x[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = (double)gg[0][r];
+    for (int r = 0; r < 4; ++r) x[r] = i2d(gg[0][r]);
 #pragma unroll
     for (int g = 1; g < OZ_NS; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[r] = fma(x[r], 256.0, (double)gg[g][r]);
+      for (int r = 0; r < 4; ++r) x[r] = fma(x[r], 256.0, i2d(gg[g][r]));
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[r] = x[r] * rs[r];
   };
@@ -340,18 +372,20 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
     double2 vv[4], ff[4];
     double b0, b1, b2, pcs, pcq, w0, w1, w2;
   };
+  // rows past M re-read the last valid chain, columns past N the last valid entry (never stored)
+  long rowoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rowoff[r] = ((mrow + r) < a.M ? (mrow + r) : (long)a.M - 1) * (long)a.N;
   auto fetch = [&](long t, Operands& q) {
     const long n = t * 16 + (lane & 15);
-    const bool nok = n < a.N;
-    const long nc = nok ? n : 0;
+    const long nc = n < a.N ? n : (long)a.N - 1;
     q.b0 = a.b[0][nc]; q.b1 = a.b[1][nc]; q.b2 = a.b[2][nc];
-    q.pcs = a.cs ? a.cs[nc] : a.ss;
-    q.pcq = a.cq ? a.cq[nc] : a.sq;
+    q.pcs = a.cs[nc];
+    q.pcq = a.cq[nc];
     q.w0 = o.wscale[nc]; q.w1 = o.wscale[(long)a.N + nc]; q.w2 = o.wscale[2 * (long)a.N + nc];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool ok = nok && (mrow + r) < a.M;
-      const long oo = ok ? (mrow + r) * (long)a.N + n : 0;
+      const long oo = rowoff[r] + nc;
       if (CPLX) {
         q.vv[r] = reinterpret_cast<const double2*>(a.vin)[oo];
         q.ff[r] = reinterpret_cast<const double2*>(a.F)[oo];
@@ -380,24 +414,54 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
       q_[r] = q.pcq * tanh_bf(zq);
     }
   };
+  // exp of the step-size-scaled arguments: when every lane's |x| < 0.34 (k = rint(x log2 e) = 0) the
+  // range reduction of exp_bf is the identity -- the polynomial alone gives the same bits
+  auto exp_poly = [](double r) {
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    return fma(p, r, 1.0);
+  };
+  auto exp4x2 = [&](const double (&xa)[4], const double (&xb)[4], double (&ya)[4], double (&yb)[4]) {
+    bool small = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) small = small && fabs(xa[r]) < 0.34 && fabs(xb[r]) < 0.34;
+    if (__all(small)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ya[r] = exp_poly(xa[r]); yb[r] = exp_poly(xb[r]); }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ya[r] = exp_bf(xa[r]); yb[r] = exp_bf(xb[r]); }
+    }
+  };
   auto stage_b = [&] {
     if (L2Q_SL_SKIP & 1) return;
+    double xa[4], xb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double lj = FWD ? heps * s_[r] : -heps * s_[r];
-      es_[r] = exp_bf(lj);
-      eq_[r] = exp_bf(eps * q_[r]);
+      xa[r] = FWD ? heps * s_[r] : -heps * s_[r];
+      xb[r] = eps * q_[r];
     }
+    exp4x2(xa, xb, es_, eq_);
     if (PAIR && !same2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double lj2 = a.fwd2 ? h2 * s_[r] : -h2 * s_[r];
-        es2_[r] = exp_bf(lj2);
-        eq2_[r] = exp_bf(a.eps2 * q_[r]);
+        xa[r] = a.fwd2 ? h2 * s_[r] : -h2 * s_[r];
+        xb[r] = a.eps2 * q_[r];
       }
+      exp4x2(xa, xb, es2_, eq2_);
     }
   };
-  auto stage_c = [&](long t, const Operands& q) {
+  auto stage_c = [&](long t, const Operands& q, double2 (&outv)[4]) {
     const long n = t * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -426,49 +490,97 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
           else { vr = e2 * (vr + h2 * fr); vi = e2 * (vi + h2 * fi); }
         }
       }
-      if (ok) {
-        const long oo = (mrow + r) * (long)a.N + n;
-        if (CPLX) reinterpret_cast<double2*>(a.v)[oo] = make_double2(vr, vi);
-        else a.v[oo] = vr;
+      outv[r] = make_double2(vr, vi);
+    }
+  };
+  auto store = [&](long t, const double2 (&outv)[4]) {
+    const long n = t * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n < a.N && (mrow + r) < a.M) {
+        const long oo = rowoff[r] + n;
+        if (CPLX) reinterpret_cast<double2*>(a.v)[oo] = outv[r];
+        else a.v[oo] = outv[r].x;
       }
     }
   };
   Operands cur, nxt;
+  // LDS-DMA of the weight images (this wavefront's 7 of the 28 pieces of a chunk), one chunk per period:
+  // DMA(k + 2) is issued right after B(k) and waited for before B(k + 1), so every image is complete a
+  // whole chunk before the matrix wavefronts read it.  Past the last chunk the last one is fetched
+  // again (into an image nobody reads): no branch in the instruction stream.
+  const char* wsrc = o.Wsl + t0 * 3 * (long)OZ_CHUNK + lane * 16;
+  auto issue = [&](long qi, int f0) {
+    const long qc = qi < nq ? qi : nq - 1;
+    const int stage = (int)(qi % 3);
+    const char* src = wsrc + qc * (long)OZ_CHUNK;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = f0; f < OZ_NS; ++f) {
+      const int frag = p + 4 * f;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + frag * OZ_FRAG),
+                                       (lds_ptr_t)(lds + stage * OZ_CHUNK + frag * OZ_FRAG), 16, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
 #if L2Q_SL_PROF
   long long prof_bar = 0;
   const long long prof_t0 = clock64();
-  auto cbar = [&] { const long long c0 = clock64(); wg_barrier(); prof_bar += clock64() - c0; };
+#define L2Q_SL_CBAR(vm) do { const long long c0_ = clock64();                                            \
+    asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); prof_bar += clock64() - c0_; } while (0)
 #else
-  auto cbar = [] { wg_barrier(); };
+#define L2Q_SL_CBAR(vm) asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+  // period k = between B(k) and B(k + 1): [stores of the previous tile] DMA(k + 2), the Horner chain of
+  // chunk k - 1, one stage of the epilogue.  The barrier that ends a period waits for its DMA with the
+  // vmcnt that leaves exactly the younger requests outstanding: the 16 operand loads of `fetch` in the
+  // first period of a tile, nothing otherwise (a tile's stores are issued BEFORE the next period's DMA).
   double fs[4], ft[4], fq[4], gs[4], gt[4];
+  double2 outv[4];
   if (ntl > 0) {
+    issue(0, 0);
+    issue(1, 0);
     fetch(t0, cur);
-    cbar();                                          // B(0)
-    cbar();                                          // B(1): chunk 0 is in the ring
+    L2Q_SL_CBAR(16);                                   // B(0)
+    issue(2, L2Q_SL_NPD);
+    L2Q_SL_CBAR(0);                                    // B(1): chunk 0 is in the ring
+    issue(3, L2Q_SL_NPD);
     conv(0, fs);
-    cbar();                                          // B(2)
+    L2Q_SL_CBAR(0);                                    // B(2)
+    issue(4, L2Q_SL_NPD);
     conv(1, ft);
     for (long u = 0; u < ntl; ++u) {
       const long t = t0 + u;
       const bool more = u + 1 < ntl;
-      cbar();                                        // B(3u + 3)
+      L2Q_SL_CBAR(0);                                  // B(3u + 3)
+      if (u > 0) store(t - 1, outv);
+      issue(3 * u + 5, L2Q_SL_NPD);
       conv(3 * u + 2, fq);
-      if (more) fetch(t + 1, nxt);
+      fetch(more ? t + 1 : t, nxt);
       stage_a(cur, fs, ft, fq);
-      if (more) { cbar(); conv(3 * u + 3, gs); }     // B(3u + 4)
+      if (more) {
+        L2Q_SL_CBAR(16);                               // B(3u + 4)
+        issue(3 * u + 6, L2Q_SL_NPD);
+        conv(3 * u + 3, gs);
+      }
       stage_b();
-      if (more) { cbar(); conv(3 * u + 4, gt); }     // B(3u + 5)
-      stage_c(t, cur);
+      if (more) {
+        L2Q_SL_CBAR(0);                                // B(3u + 5)
+        issue(3 * u + 7, L2Q_SL_NPD);
+        conv(3 * u + 4, gt);
+      }
+      stage_c(t, cur, outv);
       if (more) {
         cur = nxt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { fs[r] = gs[r]; ft[r] = gt[r]; }
       }
     }
+    store(t1 - 1, outv);
   } else {
-    cbar();                                          // B(0) = B(nq)
+    L2Q_SL_CBAR(0);                                    // B(0) = B(nq)
   }
+#undef L2Q_SL_CBAR
 #if L2Q_SL_PROF
   if (o.dbg && lane == 0) {
     long long* d = o.dbg + ((long)blockIdx.x * 8 + wave) * 4;
@@ -495,15 +607,14 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
   }
 }
 
-inline long sliced_chunks(long N) { return cdiv(N, 16) * 3; }
-inline size_t sliced_scale_off(long N) { return ((size_t)sliced_chunks(N) * OZ_CHUNK + 255) & ~(size_t)255; }
-inline int sliced_rg(int M) { return (int)cdiv(M, 64); }
-inline int sliced_ncw(int M) {
+static inline long sliced_chunks(long N) { return cdiv(N, 16) * 3; }
+static inline size_t sliced_scale_off(long N) { return ((size_t)sliced_chunks(N) * OZ_CHUNK + 255) & ~(size_t)255; }
+static inline int sliced_rg(int M) { return (int)cdiv(M, 64); }
+static inline int sliced_ncw(int M) {
   const int per_xcd = 32 / sliced_rg(M);        // one workgroup per CU, 32 CUs per XCD
   return 8 * (per_xcd > 0 ? per_xcd : 1);
 }
 
-}  // namespace
 }  // namespace l2q
 
 using namespace l2q;
@@ -557,7 +668,8 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
                                       int forward1, int pair, int flip_between, double eps2, int forward2,
                                       double* logdet, double* logdet1, double* vnorm2_mid, void* ws,
                                       size_t ws_bytes, void* stream) {
-  L2Q_REQUIRE(Z && sliced && bs && bt && bq && v && force && logdet && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(Z && sliced && bs && bt && bq && cs && cq && v && force && logdet && ws, L2Q_EINVAL,
+              "null pointer (the sliced kernel takes per-entry scales cs / cq)");
   L2Q_REQUIRE(K == OZ_K, L2Q_ESHAPE, "the sliced heads kernel serves K = 256");
   L2Q_REQUIRE(M > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
   const bool mid = logdet1 != nullptr;
@@ -611,17 +723,17 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
     const int nblk = rg * ncw;
     std::vector<long long> h((size_t)nblk * 8 * 4);
     (void)hipMemcpy(h.data(), o.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-    double tot[2] = {0, 0}, bar[2] = {0, 0}, vm = 0, mx[2] = {0, 0};
+    double tot[2] = {0, 0}, bar[2] = {0, 0}, vm = 0, ldsw = 0, mx[2] = {0, 0};
     for (int b = 0; b < nblk; ++b)
       for (int w = 0; w < 8; ++w) {
         const long long* d = &h[((size_t)b * 8 + w) * 4];
         const int c = w >= 4;
-        tot[c] += d[0]; bar[c] += d[1]; if (!c) vm += d[2];
+        tot[c] += d[0]; bar[c] += d[1]; if (!c) { vm += d[2]; ldsw += d[3]; }
         if (d[0] > mx[c]) mx[c] = (double)d[0];
       }
     const double n = nblk * 4.0;
-    fprintf(stderr, "[sliced prof] matrix waves: total %.0f (max %.0f) barrier %.0f vmcnt %.0f | update waves: total %.0f barrier %.0f  (clock64 ticks, mean per wave; %lld chunks)\n",
-            tot[0] / n, mx[0], bar[0] / n, vm / n, tot[1] / n, bar[1] / n, h[3]);
+    fprintf(stderr, "[sliced prof] matrix waves: total %.0f (max %.0f) barrier %.0f vmcnt %.0f lgkmcnt %.0f | update waves: total %.0f barrier %.0f  (clock64 ticks, mean per wave)\n",
+            tot[0] / n, mx[0], bar[0] / n, vm / n, ldsw / n, tot[1] / n, bar[1] / n);
   }
 #endif
   launch_finalize(a.logdet_part, logdet, M, ncw, 1, 1.0, 0.0, st);

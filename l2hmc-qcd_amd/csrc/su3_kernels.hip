@@ -1102,6 +1102,8 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
                kick ? 2 : 0, kick ? 1 : kLptPlain);
     else if (t.force_tile) snprintf(buf, buf_bytes, "su3_force_tile_kernel<%s, %d>", kick ? "true" : "false", t.force_occ);
     else snprintf(buf, buf_bytes, "su3_force_kernel<%s, %d>", kick ? "true" : "false", t.force_occ);
+  } else if (!strcmp(entry, "l2q_vnet_heads_vupdate_sliced_f64")) {
+    snprintf(buf, buf_bytes, "heads_sliced_kernel");
   } else if (!strncmp(entry, "l2q_vnet_heads_vupdate", 22)) {
     // (for shapes with whole 16-wide K-slabs, which every SU(3) vnet has)
     snprintf(buf, buf_bytes, "%s", t.heads_dma ? "fused_heads_dma_kernel" : "fused_heads_vupdate_kernel");

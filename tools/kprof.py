@@ -23,6 +23,8 @@ N_ = 36 * V
 heads = {k: (torch.randn(N_, h, dtype=torch.float64, device='cuda') / 16,
              torch.randn(N_, dtype=torch.float64, device='cuda'),
              None if k == 't' else torch.ones(N_, dtype=torch.float64, device='cuda')) for k in 'stq'}
+sl = dict(heads)
+sl['sliced'] = ops.heads_sliced_build(heads)      # int8 slice image (csrc/heads_sliced.hip)
 K = 32 * V
 mask = (torch.rand(36 * V, device='cuda') > 0.5).float()
 xv = torch.randn(nb, K, dtype=torch.float64, device='cuda')
@@ -40,6 +42,8 @@ for _ in range(3):
     ops.gemm(xv, wx, bx, a2=fv, w2=wv, bias2=bx, act='tanh')
     ops.vnet_heads_vupdate_(z, heads, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True)
     ops.vnet_heads_vupdate_pair_(z, heads, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True, False, 0.01, True)
+    ops.vnet_heads_vupdate_(z, sl, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True)
+    ops.vnet_heads_vupdate_pair_(z, sl, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True, False, 0.01, True)
     ops.su3_expm_mul2_n(xn, vn, 0.01, mask, False)
 torch.cuda.synchronize()
 print('kprof done')
