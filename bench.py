@@ -712,14 +712,18 @@ def main():
                                            'v-update)', per * sum(ks[n][0] for n in heads)))
             if 'l2q_vnet_heads_vupdate_sliced_f64' in ks:
                 # the same heads with the fp64 products rebuilt from 28 exact int8 slice products
-                # (csrc/heads_sliced.hip): priced in int8 operations against the int8 MFMA peak; the
-                # fp64-equivalent rate (the flops of the fp64 formulation / time) is given beside it
+                # (csrc/heads_sliced.hip).  `achieved` keeps the contract's meaning -- the ALGORITHMIC
+                # flops of the three fp64 GEMMs / time, against the fp64 MFMA peak (the instruction this
+                # replaces) --; `int8` prices the operations that actually execute (28 x as many) against
+                # the int8 MFMA peak, which is the unit that bounds the kernel
                 nm = 'l2q_vnet_heads_vupdate_sliced_f64'
                 per = 3 * 2.0 * args.nchains * args.units[-1] * 36 * V
-                r = mfma_roof([nm], 'l2q_vnet_heads_vupdate_sliced_f64 (3 heads as 28 int8 slice GEMMs + '
-                              'v-update)', 28 * per * ks[nm][0], INT8_MFMA_PEAK_TOPS, 'TOP/s')
-                r['fp64_equivalent_TFLOPs'] = round(per * ks[nm][0] / ks[nm][1] / 1e12, 2)
-                r['fp64_mfma_peak_TFLOPs'] = FP64_MFMA_PEAK_TF
+                r = mfma_roof([nm], 'l2q_vnet_heads_vupdate_sliced_f64 (3 heads, fp64 products from 28 int8 '
+                              'slice GEMMs, + v-update)', per * ks[nm][0])
+                tops = 28 * per * ks[nm][0] / ks[nm][1] / 1e12
+                r['int8'] = {'ops_per_launch': 28 * per, 'achieved': round(tops, 1),
+                             'peak': INT8_MFMA_PEAK_TOPS, 'unit': 'TOP/s',
+                             'frac': round(tops / INT8_MFMA_PEAK_TOPS, 4)}
                 rooflines.append(r)
             if 'l2q_gemm_f64' in ks:
                 rooflines.append(mfma_roof(['l2q_gemm_f64'], 'l2q_gemm_f64 (input + hidden layers)',
