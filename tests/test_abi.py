@@ -164,3 +164,16 @@ def test_comm_entry_points_validate_without_gpu():
     assert lib.l2q_comm_destroy(None) == -1
     if not torch.cuda.is_available():
         assert lib.l2q_init(0) == -3                       # L2Q_EHIP: no device visible
+
+
+def test_sliced_heads_waits_are_sound():
+    """csrc/heads_sliced.hip counts its vmcnt / lgkmcnt waits by hand; the ISA of every template instance
+    keeps at least N memory instructions between the LDS-DMA of a period and the `vmcnt(N)` in front of the
+    barrier that publishes the image (tools/check_sliced_waits.py; hipcc cross-compiles without a GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_sliced_waits',
+                                                  os.path.join(ROOT, 'tools', 'check_sliced_waits.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad, report = mod.check(mod.isa())
+    assert n == 12 and bad == 0, report
