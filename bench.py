@@ -272,7 +272,57 @@ def spot_check(dyn, lat, x, args):
     out.update({'hmc_acc_last8': round(float(np.mean(accs[-8:])), 4),
                 'hmc_plaq_after_24_traj': round(plq, 5), 'ok': bool(ok)})
     assert ok, f'spot check against the oracle failed: {out}'
+    if args.mode == 'l2hmc':
+        out['heads'] = heads_check(dyn, x4, args)
     return out
+
+
+def heads_check(dyn, x4, args):
+    """One heads + momentum update with the NETWORK AND STATE OF THE TIMED RUN through the int8-sliced
+    kernel and through the fp64 MFMA kernel (untimed): their difference, and for chains 0 / 1 and the
+    first 512 entries the distance of each from a long-double evaluation on the host (numpy float128:
+    x87 80-bit).  The sliced kernel is the one the timed trajectories ran when `sliced` is true."""
+    from l2hmc import _ops as ops
+    nb = args.nchains
+    xn = ops.su3_pack(x4)
+    vnet = dyn._get_vnet(0)
+    fn, z, w = dyn._v_inputs_n(vnet, xn, torch.tensor(args.beta), None)
+    hs = w['heads_scaled']
+    res = {'sliced': hs.get('sliced') is not None and ops.USE_SLICED_HEADS[0]}
+    if not res['sliced']:
+        return res
+    g = torch.Generator(device='cuda').manual_seed(7)
+    v = torch.randn(fn.reshape(nb, -1).shape, dtype=torch.float64, device='cuda', generator=g)
+    v = torch.complex(v, torch.randn(v.shape, dtype=torch.float64, device='cuda', generator=g))
+    f = fn.reshape(nb, -1)
+    nw, eps = (vnet.nw.s, vnet.nw.t, vnet.nw.q), 0.05
+    va = v.clone()
+    la = ops.vnet_heads_vupdate_(z, hs, nw, va, f, eps, True)
+    try:
+        ops.USE_SLICED_HEADS[0] = False
+        vb = v.clone()
+        lb = ops.vnet_heads_vupdate_(z, hs, nw, vb, f, eps, True)
+    finally:
+        ops.USE_SLICED_HEADS[0] = True
+    res['max_abs_diff_v'] = float((va - vb).abs().max())
+    res['max_abs_diff_logdet'] = float((la - lb).abs().max())
+    res['logdet_abs_max'] = float(lb.abs().max())
+    LD, rows, cols = np.longdouble, [0, min(1, nb - 1)], slice(0, 512)
+    zz = z[rows].cpu().numpy().astype(LD)
+    y = {k: zz @ hs[k][0][cols].cpu().numpy().astype(LD).T + hs[k][1][cols].cpu().numpy().astype(LD) for k in 'stq'}
+    sv = hs['s'][2][cols].cpu().numpy().astype(LD) * np.tanh(y['s'])
+    qv = hs['q'][2][cols].cpu().numpy().astype(LD) * np.tanh(y['q'])
+    tv = LD(nw[1]) * y['t']
+    h = LD(0.5) * LD(eps)
+    es, eq = np.exp(h * sv), np.exp(LD(eps) * qv)
+    v0, f0 = v[rows][:, cols].cpu().numpy(), f[rows][:, cols].cpu().numpy()
+    wr = es * v0.real.astype(LD) - h * (f0.real.astype(LD) * eq + tv)
+    wi = es * v0.imag.astype(LD) - h * (f0.imag.astype(LD) * eq)
+    for name, got in (('sliced', va), ('fp64_mfma', vb)):
+        gh = got[rows][:, cols].cpu().numpy()
+        res[f'{name}_vs_long_double'] = float(max(np.abs(gh.real.astype(LD) - wr).max(),
+                                                  np.abs(gh.imag.astype(LD) - wi).max()))
+    return res
 
 
 def secondary(dyn, x, beta, args, nlf_exec):
@@ -563,6 +613,12 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    # stdout carries ONE line, the JSON record: everything else a library may print there (librccl
+    # writes its version banner to stdout when the first communicator is created, through C stdio,
+    # flushed at exit) is sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with '
                  f'--nproc-per-node {args.gpus} (or from a bare shell, which self-spawns)')
@@ -780,7 +836,7 @@ def main():
                 del dyn, lat, x, m
                 torch.cuda.empty_cache()
                 out['secondary_u1'] = secondary_u1()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
