@@ -42,6 +42,11 @@ extern __shared__ __attribute__((aligned(1024))) char hd_lds[];
 #define HD_BN 256          // N-tile width and ring depth (A/B builds: tools/ab_build.sh ... -DHD_BN=128 -DHD_STAGES=3)
 #define HD_STAGES 2
 #endif
+#ifndef HD_SPREAD
+#define HD_SPREAD 0        // LDS-DMA pieces of the next slab: 0 back to back at the top of the slab; 1 one per MFMA group
+                           // over the whole slab (6.28 ms against 5.76-5.83: the late pieces have not landed at the
+                           // next barrier); 2 two per group over the first K-step (5.75: within noise).  Round 3.
+#endif
 #ifndef HD_BK
 #define HD_BK 64           // K-slab in halves: 64 (128-byte rows, 8 chunks) or 32 (64-byte rows, 4 chunks)
 #endif
@@ -127,10 +132,12 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    {
-      const long kn = ks + kHdStages - 1;
-      int sn = st + kHdStages - 1;
-      if (sn >= kHdStages) sn -= kHdStages;
+    const long kn = ks + kHdStages - 1;
+    int sn = st + kHdStages - 1;
+    if (sn >= kHdStages) sn -= kHdStages;
+    // past the last slab the last one is fetched again (into the stage nobody reads any more): no branch
+    const long kq = (kn < nslab ? kn : nslab - 1) * kHdBK;
+    if (!HD_SPREAD) {
       if (kn < nslab) issue(sn, kn * kHdBK);
     }
     const char* sb = hd_lds + st * kHdStage;
@@ -144,6 +151,21 @@ __global__ __launch_bounds__(64 * kHdWaves, kHdWaves / 4) void gemm_h_dma_kernel
         const vec_t fa = *reinterpret_cast<const vec_t*>(sb + offA[s] + i * 16 * kHdRow);
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = MfmaH<HT>::run(fb[j], fa, acc[i][j]);
+        if (HD_SPREAD) {
+          // one piece behind each group of NI MFMAs: a piece holds the wavefront's issue for ~76 cycles;
+          // back to back at the top of the slab (and on both wavefronts of a SIMD at once, right after
+          // the barrier) they leave the matrix pipe idle
+#pragma unroll
+          for (int q = (HD_SPREAD == 2 ? (s == 0 ? i * LQ / MI : LQ) : (s * MI + i) * LQ / (KS * MI));
+               q < (HD_SPREAD == 2 ? (s == 0 ? (i + 1) * LQ / MI : LQ) : (s * MI + i + 1) * LQ / (KS * MI)); ++q) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int g = kHdWaves * q + wave;
+            const char* src = (q < LQA ? a1 : w1) + kq * 2 + (unsigned long)vo[q];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_ptr_t)(hd_lds + sn * kHdStage + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
     }
     if (++st == kHdStages) st = 0;
