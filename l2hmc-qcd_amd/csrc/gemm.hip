@@ -21,6 +21,10 @@ namespace l2q {
 #ifndef L2Q_BK
 #define L2Q_BK 16
 #endif
+#ifndef L2Q_GD_SPREAD
+#define L2Q_GD_SPREAD 0      // 1: LDS-DMA pieces of gemm_dma_f64_kernel spread over the slab's MFMAs (input layer 0.652-0.655
+                           // against 0.644-0.645 ms back to back: not the limiter; tools/time_gemm_in.py)
+#endif
 #ifndef L2Q_HEADS_OCC
 #define L2Q_HEADS_OCC 2
 #endif
@@ -920,11 +924,11 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
   const char* w1 = reinterpret_cast<const char*>(W) + (TW ? n0 * 8 : n0 * K * 8);
   const char* a2 = reinterpret_cast<const char*>(A2) + m0 * K2 * 8;      // K2 != 0 only without TA / TW
   const char* w2 = reinterpret_cast<const char*>(W2) + n0 * K2 * 8;
-  auto issue = [&](int stage, long k0) {
+  auto issue = [&](int stage, long k0, int q0 = 0, int q1 = 8) {
     const bool second = k0 >= K;                       // wave-uniform: a slab never straddles K
     const long kk = second ? k0 - K : k0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = q0; q < q1; ++q) {
       const int g = 4 * q + wave;
       const char* src;
       if (q < 4) src = TA ? a1 + (kk + (g & 15)) * (long)M * 8 : (second ? a2 : a1) + kk * 8;
@@ -954,7 +958,10 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
   for (long k0 = kbeg; k0 < kend; k0 += BK, st ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (k0 + BK < kend) issue(st ^ 1, k0 + BK);
+    if (!L2Q_GD_SPREAD && k0 + BK < kend) issue(st ^ 1, k0 + BK);
+    // (L2Q_GD_SPREAD: the next slab's eight LDS-DMA pieces go out two per k-quad, behind eight MFMAs each,
+    // instead of back to back; past the last slab the last one is fetched again into the idle stage)
+    const long kn = k0 + BK < kend ? k0 + BK : k0;
     const char* sb = lds + st * STAGE;
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
@@ -965,9 +972,15 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
         fb[i] = *reinterpret_cast<const T*>(sb + offB[kq] + i * stepB);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+        if (L2Q_GD_SPREAD && (i & 1)) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue(st ^ 1, kn, 2 * kq + (i >> 1), 2 * kq + (i >> 1) + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   }
 
