@@ -25,15 +25,19 @@
 // every output that uses it, as in fp64.  The kernel is an INFERENCE path: the training tape keeps
 // the fp64 kernels (weights change every step and the reverse sweep reuses their products).
 //
-// Kernel.  256 threads = 4 wavefronts, two workgroups per CU.  A workgroup owns 64 chains (wavefront
-// w: 16 of them, its 7 x 4 int8 A-fragments = 112 VGPRs stay in registers for the whole launch) and
-// walks a contiguous range of 16-entry output tiles; per tile the three heads' weight slices
-// (3 chunks of 28 KB, stored pre-swizzled in MFMA fragment order by the build kernel) stream
-// global -> LDS by LDS-DMA, double-buffered, one barrier per chunk.  Per chunk and wavefront: 28
-// ds_read_b128, 112 MFMAs (1792 issue cycles), 28 int32 -> fp64 conversions in a Horner chain.  After
-// the third chunk the wavefront holds z_s, z_t, z_q of 16 x 16 elements and applies the same
-// epilogue as the fp64 kernel (heads_common.hpp).  The RG = M / 64 workgroups that need the same
-// chunks run on ONE XCD (hardware block b -> XCD b % 8) and share its L2: W is read once from HBM.
+// Kernel (details at heads_sliced_kernel).  One 512-thread workgroup per CU: four "matrix" wavefronts
+// (16 chains each, their 7 x 4 int8 A-fragments = 112 VGPRs stationary in registers) and four "update"
+// wavefronts, one of each per SIMD.  A workgroup owns 64 chains and walks a contiguous range of
+// 16-entry output tiles; per tile the three heads' weight slices (3 chunks of 28 KB, stored
+// pre-swizzled in MFMA fragment order by the build kernel) stream global -> LDS by LDS-DMA through
+// three images, one barrier per chunk.  Per chunk a matrix wavefront issues 28 ds_read_b128 and 112
+// MFMAs and hands its 7 int32 group sums to its update wavefront through an LDS ring; that one runs
+// the Horner chain and, after the third chunk of a tile, the same epilogue as the fp64 kernel
+// (heads_common.hpp).  The RG = M / 64 workgroups that need the same chunks run on ONE XCD (hardware
+// block b -> XCD b % 8) and share its L2: W is read once from HBM (PMC: 1.005 x algorithmic).
+// (First version: 256-thread workgroups of four symmetric wavefronts, two per CU: 40-140 spilled
+// VGPRs -- the A fragments, the fp64 constants of the epilogue and its operands do not fit one
+// wavefront's 256 registers, and scratch traffic shares vmcnt with the LDS-DMA.)
 #include "heads_common.hpp"
 #include <type_traits>
 #include <vector>
