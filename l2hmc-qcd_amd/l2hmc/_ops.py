@@ -470,8 +470,9 @@ def _sliced_call(z, heads, scales, v, force, eps1, forward1, pair, flip, eps2, f
 
 
 def _use_sliced(z, heads) -> bool:
+    # (the sliced kernel takes per-entry scales; a heads dict with scalar scales stays on the fp64 kernel)
     return (USE_SLICED_HEADS[0] and heads.get('sliced') is not None and z.dtype == torch.float64
-            and z.shape[1] == SLICED_K)
+            and z.shape[1] == SLICED_K and heads['s'][2] is not None and heads['q'][2] is not None)
 
 
 def vnet_heads_vupdate_(z: torch.Tensor, heads: dict, scales, v: torch.Tensor,
