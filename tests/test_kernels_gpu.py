@@ -418,6 +418,13 @@ def test_heads_sliced_edge_cases(ops):
     want = (torch.exp(0.05 * torch.tanh(hd['s'][1])) * v[4]
             - 0.05 * (f[4] * torch.exp(0.1 * torch.tanh(hd['q'][1])) + hd['t'][1]))
     assert float((vb[4] - want).abs().max()) < 1e-15
+    # scalar scales (no per-entry cs / cq): the call stays on the fp64 kernel even with a slice image
+    hsc = {nm: (hd[nm][0], hd[nm][1], None) for nm in 'stq'}
+    zc = dev(rng.normal(size=(m, k)))
+    v1 = v.clone(); l1 = ops.vnet_heads_vupdate_(zc, hsc, (0.9, 1.1, 0.8), v1, f, 0.1, True)
+    hsc['sliced'] = hd['sliced']
+    v2 = v.clone(); l2 = ops.vnet_heads_vupdate_(zc, hsc, (0.9, 1.1, 0.8), v2, f, 0.1, True)
+    assert torch.equal(v1, v2) and torch.equal(l1, l2)
     # a weight matrix with a non-finite entry poisons that output entry for every chain
     hn = mk()
     hn['s'][0][2, 3] = float('nan')
