@@ -528,11 +528,13 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
     __builtin_amdgcn_sched_barrier(0);
   };
 #if L2Q_SL_PROF
-  long long prof_bar = 0;
+  long long prof_bar = 0, prof_mem = 0, prof_conv = 0;
   const long long prof_t0 = clock64();
+#define L2Q_SL_T(acc, ...) do { const long long c0_ = clock64(); __VA_ARGS__; acc += clock64() - c0_; } while (0)
 #define L2Q_SL_CBAR(vm) do { const long long c0_ = clock64();                                            \
     asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); prof_bar += clock64() - c0_; } while (0)
 #else
+#define L2Q_SL_T(acc, ...) do { __VA_ARGS__; } while (0)
 #define L2Q_SL_CBAR(vm) asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
   // period k = between B(k) and B(k + 1): [stores of the previous tile] DMA(k + 2), the Horner chain of
@@ -557,21 +559,20 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
       const long t = t0 + u;
       const bool more = u + 1 < ntl;
       L2Q_SL_CBAR(0);                                  // B(3u + 3)
-      if (u > 0) store(t - 1, outv);
-      issue(3 * u + 5, L2Q_SL_NPD);
-      conv(3 * u + 2, fq);
-      fetch(more ? t + 1 : t, nxt);
+      L2Q_SL_T(prof_mem, if (u > 0) store(t - 1, outv); issue(3 * u + 5, L2Q_SL_NPD));
+      L2Q_SL_T(prof_conv, conv(3 * u + 2, fq));
+      L2Q_SL_T(prof_mem, fetch(more ? t + 1 : t, nxt));
       stage_a(cur, fs, ft, fq);
       if (more) {
         L2Q_SL_CBAR(16);                               // B(3u + 4)
-        issue(3 * u + 6, L2Q_SL_NPD);
-        conv(3 * u + 3, gs);
+        L2Q_SL_T(prof_mem, issue(3 * u + 6, L2Q_SL_NPD));
+        L2Q_SL_T(prof_conv, conv(3 * u + 3, gs));
       }
       stage_b();
       if (more) {
         L2Q_SL_CBAR(0);                                // B(3u + 5)
-        issue(3 * u + 7, L2Q_SL_NPD);
-        conv(3 * u + 4, gt);
+        L2Q_SL_T(prof_mem, issue(3 * u + 7, L2Q_SL_NPD));
+        L2Q_SL_T(prof_conv, conv(3 * u + 4, gt));
       }
       stage_c(t, cur, outv);
       if (more) {
@@ -585,10 +586,11 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
     L2Q_SL_CBAR(0);                                    // B(0) = B(nq)
   }
 #undef L2Q_SL_CBAR
+#undef L2Q_SL_T
 #if L2Q_SL_PROF
   if (o.dbg && lane == 0) {
     long long* d = o.dbg + ((long)blockIdx.x * 8 + wave) * 4;
-    d[0] = clock64() - prof_t0; d[1] = prof_bar; d[2] = 0; d[3] = nq;
+    d[0] = clock64() - prof_t0; d[1] = prof_bar; d[2] = prof_mem; d[3] = prof_conv;
   }
 #endif
   // ---- per-chain partials of this column worker (fixed order: deterministic)
@@ -727,17 +729,18 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
     const int nblk = rg * ncw;
     std::vector<long long> h((size_t)nblk * 8 * 4);
     (void)hipMemcpy(h.data(), o.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-    double tot[2] = {0, 0}, bar[2] = {0, 0}, vm = 0, ldsw = 0, mx[2] = {0, 0};
+    double tot[2] = {0, 0}, bar[2] = {0, 0}, vm = 0, ldsw = 0, mx[2] = {0, 0}, umem = 0, uconv = 0;
     for (int b = 0; b < nblk; ++b)
       for (int w = 0; w < 8; ++w) {
         const long long* d = &h[((size_t)b * 8 + w) * 4];
         const int c = w >= 4;
         tot[c] += d[0]; bar[c] += d[1]; if (!c) { vm += d[2]; ldsw += d[3]; }
+        else { umem += d[2]; uconv += d[3]; }
         if (d[0] > mx[c]) mx[c] = (double)d[0];
       }
     const double n = nblk * 4.0;
-    fprintf(stderr, "[sliced prof] matrix waves: total %.0f (max %.0f) barrier %.0f vmcnt %.0f lgkmcnt %.0f | update waves: total %.0f barrier %.0f  (clock64 ticks, mean per wave)\n",
-            tot[0] / n, mx[0], bar[0] / n, vm / n, ldsw / n, tot[1] / n, bar[1] / n);
+    fprintf(stderr, "[sliced prof] matrix waves: total %.0f (max %.0f) barrier %.0f vmcnt %.0f lgkmcnt %.0f | update waves: total %.0f barrier %.0f dma+fetch+store issue %.0f conv %.0f  (clock64 ticks, mean per wave)\n",
+            tot[0] / n, mx[0], bar[0] / n, vm / n, ldsw / n, tot[1] / n, bar[1] / n, umem / n, uconv / n);
   }
 #endif
   launch_finalize(a.logdet_part, logdet, M, ncw, 1, 1.0, 0.0, st);
