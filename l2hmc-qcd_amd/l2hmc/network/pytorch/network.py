@@ -118,6 +118,48 @@ def zero_weights(m):
             nn.init.constant_(m.bias.data, 0)
 
 
+# ---------------------------------------------------------------- seed-level initialisation
+# The reference builds its networks on the host and consumes the GLOBAL torch generator in an
+# order that the results depend on ("same (lattice, beta, seed) -> same chain"):
+#   get_and_call_network (network.py:572-631): group.random(xshape), group.random_momentum(xshape),
+#   then LeapfrogLayer.__init__ (:454-516): hidden Linear layers, scale, transf, transl are
+#   initialised at construction, whereas the conv stack, its Linear, vlayer and xlayer are Lazy
+#   modules that draw their weights at the first forward -- conv layers in order, the stack's
+#   Linear, then vlayer BEFORE xlayer (InputLayer.forward :449-450) -- and that dummy forward runs
+#   in train mode, so Dropout draws one mask and BatchNorm1d takes one running-statistics step.
+# Here every parameter is drawn on the host generator in that order and then moved to DEVICE.
+def _uninit(cls, *args, **kw) -> nn.Module:
+    """`cls(*args)` with uninitialised host parameters and no generator use: the stand-in for
+    the reference's Lazy* layers until `reset_parameters()` runs at their first-forward slot."""
+    return torch.nn.utils.skip_init(cls, *args, device='cpu', **kw)
+
+
+_BURN_CHUNK = 1 << 24        # multiple of 16: torch's CPU normal fill transforms groups of 16
+
+
+def advance_randn(numel: int, dtype: Optional[torch.dtype] = None) -> None:
+    """Advance the global host generator exactly like ``torch.randn(numel, dtype=dtype)`` without
+    holding the values: chunks that are multiples of 16 draw the same uniforms in the same
+    groups as one call (ATen normal_fill: all uniforms first, Box-Muller per 16; a tail that is
+    not a multiple of 16 redraws the last 16 -- kept inside the final chunk)."""
+    dtype = dtype or torch.get_default_dtype()
+    left = int(numel)
+    while left > 0:
+        n = left if left < 2 * _BURN_CHUNK else _BURN_CHUNK
+        torch.randn(n, dtype=dtype)
+        left -= n
+
+
+def advance_rand(numel: int, dtype: Optional[torch.dtype] = None) -> None:
+    """Same for ``torch.rand`` (serial per element on the host: any chunking is equivalent)."""
+    dtype = dtype or torch.get_default_dtype()
+    left = int(numel)
+    while left > 0:
+        n = min(left, _BURN_CHUNK)
+        torch.rand(n, dtype=dtype)
+        left -= n
+
+
 def _linear_bwd(dpre: Tensor, x: Tensor, weight, bias,
                 need_dx: bool = True, xT: Optional[Tensor] = None,
                 wgrad: Optional[Tensor] = None, bgrad: Optional[Tensor] = None) -> Optional[Tensor]:
@@ -156,9 +198,10 @@ class ScaledTanh(nn.Module):
 
     def __init__(self, in_features: int, out_features: int) -> None:
         super().__init__()
-        self.coeff = nn.parameter.Parameter(torch.zeros(1, out_features, device=DEVICE))
+        self.coeff = nn.parameter.Parameter(torch.zeros(1, out_features))
         self.layer = nn.Linear(in_features=in_features, out_features=out_features,
-                               device=DEVICE)
+                               device='cpu')                  # host generator (see above)
+        self.to(DEVICE)
 
     def forward(self, x):
         return ops.gemm(x.to(DEVICE).contiguous(), self.layer.weight.detach(),
@@ -169,7 +212,9 @@ class ScaledTanh(nn.Module):
 class ConvStack(nn.Module):
     def __init__(self, xshape: Sequence[int], conv_config: ConvolutionConfig,
                  activation_fn: Any, use_batch_norm: bool = False,
-                 in_channels: Optional[int] = None) -> None:
+                 in_channels: Optional[int] = None, lazy: bool = False) -> None:
+        """lazy=True leaves the parameters uninitialised for the owner to `materialize()` at
+        the reference's first-forward slot; stand-alone stacks draw them here."""
         super().__init__()
         if len(xshape) == 3:
             d, nt, nx = xshape[0], xshape[1], xshape[2]
@@ -193,12 +238,12 @@ class ConvStack(nn.Module):
         if filters:
             assert len(filters) == len(sizes)
             self.layers.append(PeriodicPadding(sizes[0] - 1))
-            self.layers.append(nn.Conv2d(cin, filters[0], sizes[0], device=DEVICE))
+            self.layers.append(_uninit(nn.Conv2d, cin, filters[0], sizes[0]))
             self.plan.append((1, sizes[0], 1, None))          # no activation after conv #1
             h, w, cin = h + sizes[0] - 1, w + sizes[0] - 1, filters[0]
             for idx, (f, n) in enumerate(zip(filters[1:], sizes[1:])):
                 self.layers.append(PeriodicPadding(n - 1))
-                self.layers.append(nn.Conv2d(cin, f, n, device=DEVICE))
+                self.layers.append(_uninit(nn.Conv2d, cin, f, n))
                 ci = len(self.layers) - 1
                 pool = 1
                 if (idx + 1) % 2 == 0:
@@ -211,9 +256,18 @@ class ConvStack(nn.Module):
         if use_batch_norm:
             raise NotImplementedError('ConvStack(use_batch_norm=True) is never used by the '
                                       'reference (network.py:407-411)')
-        self.layers.append(nn.Linear(cin * h * w, self.xdim, device=DEVICE))
+        self.layers.append(_uninit(nn.Linear, cin * h * w, self.xdim))
         self.linear_index = len(self.layers) - 1
         self.layers.append(self.activation_fn)
+        if not lazy:
+            self.materialize()
+            self.to(DEVICE)
+
+    def materialize(self) -> None:
+        """Draw the Lazy layers' weights in first-forward order (network.py:341-344)."""
+        for layer in self.layers:
+            if isinstance(layer, (nn.Conv2d, nn.Linear)):
+                layer.reset_parameters()
 
     def _clast_weight(self, ci: int) -> Tensor:
         """conv weight as [cout, k, k, cin] (K columns of the implicit GEMM in the order in which
@@ -348,7 +402,7 @@ class InputLayer(nn.Module):
                  conv_config: Optional[ConvolutionConfig] = None,
                  input_shapes: Optional[dict[str, Sequence[int] | int]] = None,
                  x_features: Optional[int] = None, v_features: Optional[int] = None,
-                 conv_channels: Optional[int] = None) -> None:
+                 conv_channels: Optional[int] = None, lazy: bool = False) -> None:
         super().__init__()
         self.xshape = xshape
         self.net_config = network_config
@@ -366,13 +420,24 @@ class InputLayer(nn.Module):
                 and len(conv_config.filters) > 0:
             conv_stack = ConvStack(xshape=xshape, conv_config=conv_config,
                                    activation_fn=self.activation_fn,
-                                   in_channels=conv_channels)
+                                   in_channels=conv_channels, lazy=True)
         self.conv_stack = conv_stack
         has_conv = isinstance(conv_stack, ConvStack)
         xin = self.xdim if has_conv else (x_features or self.input_shapes['x'])
         vin = v_features or self.input_shapes['v']
-        self.xlayer = nn.Linear(xin, self.net_config.units[0], device=DEVICE)
-        self.vlayer = nn.Linear(vin, self.net_config.units[0], device=DEVICE)
+        self.xlayer = _uninit(nn.Linear, xin, self.net_config.units[0])
+        self.vlayer = _uninit(nn.Linear, vin, self.net_config.units[0])
+        if not lazy:
+            self.materialize()
+            self.to(DEVICE)
+
+    def materialize(self) -> None:
+        """First-forward order of the reference's Lazy layers: the conv stack, then vlayer, then
+        xlayer (network.py:446-450)."""
+        if isinstance(self.conv_stack, ConvStack):
+            self.conv_stack.materialize()
+        self.vlayer.reset_parameters()
+        self.xlayer.reset_parameters()
 
     def forward(self, inputs: tuple[Tensor, Tensor]) -> Tensor:
         x, v = inputs
@@ -409,17 +474,21 @@ class LeapfrogLayer(nn.Module):
         self.input_layer = InputLayer(
             xshape=xshape, network_config=network_config, activation_fn=self.activation_fn,
             conv_config=conv_config, input_shapes=input_shapes, x_features=x_features,
-            v_features=v_features, conv_channels=conv_channels)
+            v_features=v_features, conv_channels=conv_channels, lazy=True)
         self.units = self.net_config.units
         self.hidden_layers = nn.ModuleList()
         for idx, units in enumerate(self.units[1:]):
-            self.hidden_layers.append(nn.Linear(self.units[idx], units, device=DEVICE))
+            self.hidden_layers.append(nn.Linear(self.units[idx], units, device='cpu'))
         self.scale = ScaledTanh(self.units[-1], self.xdim)
         self.transf = ScaledTanh(self.units[-1], self.xdim)
-        self.transl = nn.Linear(self.units[-1], self.xdim, device=DEVICE)
+        self.transl = nn.Linear(self.units[-1], self.xdim, device='cpu')
         self.dropout = nn.Dropout(self.net_config.dropout_prob)
         if self.net_config.use_batch_norm:
-            self.batch_norm = nn.BatchNorm1d(self.units[-1], device=DEVICE)
+            self.batch_norm = nn.BatchNorm1d(self.units[-1])
+        # the reference's Lazy input layers draw their weights at the first forward, i.e. after
+        # everything above (nothing else touches the generator in between)
+        self.input_layer.materialize()
+        self.to(DEVICE)
         self._head_cache: dict = {}
 
     def set_net_weight(self, net_weight: NetWeight):
@@ -669,8 +738,10 @@ class LeapfrogLayer(nn.Module):
         return self.training and (float(self.net_config.dropout_prob) > 0
                                   or bool(self.net_config.use_batch_norm))
 
-    def forward_train(self, x: Tensor, v: Tensor) -> tuple[Tensor, Tensor, Tensor, dict]:
-        """(s, t, q, ctx).  x: the network's x input ([nb, C, T, X] when there is a conv stack,
+    def forward_train(self, x: Tensor, v: Tensor, drop_keep: Optional[Tensor] = None
+                      ) -> tuple[Tensor, Tensor, Tensor, dict]:
+        """(s, t, q, ctx).  drop_keep: a given dropout keep-mask [nb, units[-1]] instead of a
+        fresh draw (the construction-time dummy forward replays the host generator's mask).  x: the network's x input ([nb, C, T, X] when there is a conv stack,
         otherwise anything flattenable to [nb, Kx]); v likewise.  reference: network.py:522-551
         under autograd."""
         il = self.input_layer
@@ -707,7 +778,8 @@ class LeapfrogLayer(nn.Module):
                      'xshape': tuple(x.shape), 'vshape': tuple(v.shape)}
         p = float(self.net_config.dropout_prob)
         if p > 0 and self.training:
-            keep = torch.bernoulli(torch.full_like(z, 1.0 - p))
+            keep = torch.bernoulli(torch.full_like(z, 1.0 - p)) if drop_keep is None \
+                else drop_keep.to(device=z.device, dtype=z.dtype)
             z = ops.mul(z, keep, 1.0 / (1.0 - p))
             ctx['drop'] = keep
         if self.net_config.use_batch_norm:
@@ -806,6 +878,28 @@ def get_network(xshape, network_config, input_shapes=None, net_weight=None, conv
                          conv_config=conv_config, name=name, **kw)
 
 
+def _dummy_inputs(group, xshape: Sequence[int], values: bool):
+    """The two draws `get_and_call_network` of the reference makes before building a network
+    (network.py:589-590): `group.random(xshape)` and `group.random_momentum(xshape)`, on the
+    host generator, in the default dtype.  values=False only advances the generator (the draws
+    feed a dummy forward whose outputs are discarded; nothing but BatchNorm's running statistics
+    remembers them)."""
+    n = int(np.prod(xshape))
+    if isinstance(group, SU3) or getattr(group, '_name', None) == 'SU3':
+        if values:
+            return group.random(xshape), group.random_momentum(xshape)
+        advance_randn(n)                      # group.py:115-116: real and imaginary normals
+        advance_randn(n)
+        for _ in range(8):                    # utils.py:171-183 randTAH3: 8 draws of shape[:-2]
+            advance_randn(n // 9)
+        return None, None
+    if values:
+        return group.random(xshape), group.random_momentum(xshape)
+    advance_rand(n)                           # u1/group.py:158-162
+    advance_randn(n)
+    return None, None
+
+
 def get_and_call_network(xshape: Sequence[int], *, network_config: NetworkConfig,
                          is_xnet: bool, group: U1Phase | SU3,
                          input_shapes: Optional[dict[str, int | Sequence[int]]] = None,
@@ -815,18 +909,50 @@ def get_and_call_network(xshape: Sequence[int], *, network_config: NetworkConfig
     """The reference materialises its Lazy layers with one dummy forward
     (network.py:572-631); the widths that call would discover are computed directly here:
     U1 xnet sees [cos, sin] (4 channels, 2*xdim features), SU3 xnet sees real||imag
-    (2*xdim features), SU3 vnet sees the 8-component vectors (input_shapes)."""
+    (2*xdim features), SU3 vnet sees the 8-component vectors (input_shapes).
+
+    What that dummy forward leaves behind is reproduced so that a seed gives the reference's
+    (CPU-path) networks: the generator advances by the two dummy draws, every layer draws its
+    weights at the reference's slot (see `_uninit`), Dropout draws its train-mode mask, and
+    BatchNorm1d's running statistics take the one step of that forward (through the training
+    kernels, on the drawn inputs)."""
     xdim = int(np.cumprod(xshape[1:])[-1])
+    su3 = isinstance(group, SU3) or getattr(group, '_name', None) == 'SU3'
     kw: dict = {}
-    if isinstance(group, SU3) or getattr(group, '_name', None) == 'SU3':
+    if su3:
         if is_xnet:
             kw.update(x_features=2 * xdim, v_features=2 * xdim)
     else:
         kw['conv_channels'] = 4 if is_xnet else 2
         if is_xnet:
             kw['x_features'] = 2 * xdim
-    return get_network(xshape=xshape, network_config=network_config, input_shapes=input_shapes,
-                       net_weight=net_weight, conv_config=conv_config, name=name, **kw)
+    bn = bool(network_config.use_batch_norm)
+    x, v = _dummy_inputs(group, xshape, values=bn)
+    net = get_network(xshape=xshape, network_config=network_config, input_shapes=input_shapes,
+                      net_weight=net_weight, conv_config=conv_config, name=name, **kw)
+    p = float(network_config.dropout_prob)
+    keep = None
+    if p > 0:
+        # network.py:538-539 in train mode: F.dropout's mask does not depend on the values
+        z = torch.ones(int(xshape[0]), int(network_config.units[-1]))
+        keep = (torch.nn.functional.dropout(z, p, training=True) != 0)
+    if bn:
+        with torch.no_grad():
+            nb = int(xshape[0])
+            if su3:
+                if is_xnet:
+                    xi = torch.cat([x.real, x.imag], dim=1).reshape(nb, -1)
+                    vi = torch.cat([v.real, v.imag], dim=1).reshape(nb, -1)
+                else:
+                    xi = group.group_to_vec(x).reshape(nb, -1)
+                    vi = group.group_to_vec(v).reshape(nb, -1)
+            else:
+                xi = group.group_to_vec(x) if is_xnet else x
+                vi = v
+            dt = net.transl.weight.dtype
+            net.forward_train(xi.to(DEVICE).to(dt).contiguous(), vi.to(DEVICE).to(dt).contiguous(),
+                              drop_keep=keep)
+    return net
 
 
 class NetworkFactory(BaseNetworkFactory):

@@ -233,6 +233,31 @@ class DynamicsOracle:
             out['logdet'] = np.stack(logdets)
         return x_, v_, out
 
+    def transition_kernel(self, x, v, beta, forward: bool, history=False):
+        """Single-direction kernel, dynamics.py:1031-1063 -- including its call
+        ``compute_accept_prob(state_init=state, state_prop=sinit, ...)`` (:1053-1057), i.e. the
+        FINAL state in the `init` slot: dh = H(final) - H(start) + sumlogdet, the opposite sign
+        convention of transition_kernel_fb (:1023).  Restated as written."""
+        nb = x.shape[0]
+        lf = self.forward_lf if forward else self.backward_lf
+        sumlogdet = np.zeros(nb, dtype=self.dtype)
+        x_, v_ = x, v
+        energies = [self.hamiltonian(x_, v_, beta)] if history else []
+        logdets = [sumlogdet.copy()] if history else []
+        for step in range(self.nlf):
+            x_, v_, ld = lf(step, x_, v_, beta)
+            sumlogdet = sumlogdet + ld
+            if history:
+                energies.append(self.hamiltonian(x_, v_, beta))
+                logdets.append(sumlogdet.copy())
+        acc = self.accept_prob(self.hamiltonian(x_, v_, beta),
+                               self.hamiltonian(x, v, beta), sumlogdet)
+        out = {'acc': acc, 'sumlogdet': sumlogdet}
+        if history:
+            out['energy'] = np.stack(energies)
+            out['logdet'] = np.stack(logdets)
+        return x_, v_, out
+
     # ------------------------------------------------------------ full transitions
     def random_momentum(self, normals):
         """SU3: normals [8, nb, 4, T, X, Y, Z] -> TAH matrices; U1: [nb, 2, T, X] -> flat.
@@ -254,6 +279,16 @@ class DynamicsOracle:
         """dynamics.py:660-702"""
         v = self.random_momentum(normals)
         xp, vp, m = self.transition_kernel_fb(x, v, beta, history=history)
+        xo, vo, ma = self._select(x, xp, v, vp, m['acc'], u)
+        m.update({'acc_mask': ma, 'sumlogdet': ma * m['sumlogdet'],
+                  'v_init': v, 'x_prop': xp, 'v_prop': vp, 'v_out': vo})
+        return xo, m
+
+    def apply_transition(self, x, beta, forward: bool, normals, u, history=False):
+        """merge_directions=False: dynamics.py:704-742 with the direction already drawn
+        (`torch.rand(1) > 0.5`, :709)."""
+        v = self.random_momentum(normals)
+        xp, vp, m = self.transition_kernel(x, v, beta, forward, history=history)
         xo, vo, ma = self._select(x, xp, v, vp, m['acc'], u)
         m.update({'acc_mask': ma, 'sumlogdet': ma * m['sumlogdet'],
                   'v_init': v, 'x_prop': xp, 'v_prop': vp, 'v_out': vo})

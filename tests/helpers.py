@@ -369,3 +369,129 @@ def check_leapfrog_layer_backward(act: str, device: str, dtype, tol: float):
             assert e < tol * max(1.0, float(p.grad.abs().max())), (n, e)
     finally:
         torch.set_default_dtype(old)
+
+
+# ------------------------------------------------------------------ "modes" fixtures
+# tests/golden/modes_*.npz (make_golden_modes.py): the reference built from (lattice, beta, seed)
+# alone, in the configuration branches the first fixtures leave out.
+MODES_U1 = ['modes_u1_nomerge', 'modes_u1_nomerge_b', 'modes_u1_shared', 'modes_u1_sep_nosplit',
+            'modes_u1_shared_split']
+MODES_SU3 = ['modes_su3_sep', 'modes_su3_nomerge', 'modes_su3_nomerge_b', 'modes_su3_bn']
+
+
+def modes_net_kwargs(g):
+    conv = None
+    if g['conv_filters'].size:
+        conv = {'filters': [int(i) for i in g['conv_filters']],
+                'sizes': [int(i) for i in g['conv_sizes']],
+                'pool': [int(i) for i in g['conv_pool']]}
+    return dict(nunits=len(g['units']), activation=str(g['activation']), conv=conv,
+                use_batch_norm=bool(g['use_batch_norm']))
+
+
+def modes_state_dict(g):
+    """state_dict of the fixture's trajectory: what the seed gave + the recorded perturbation."""
+    sd = sub(g, 'init.')
+    sd.update(sub(g, 'pert.'))
+    return sd
+
+
+def modes_oracle(g):
+    """DynamicsOracle for a modes_* fixture: which LeapfrogLayer a sub-update calls follows
+    use_separate_networks / use_split_xnets like dynamics.py:1112-1135."""
+    sd = modes_state_dict(g)
+    kw = modes_net_kwargs(g)
+    group = str(g['group'])
+    sep, split = bool(g['use_separate_networks']), bool(g['use_split_xnets'])
+    nlf = int(g['nleapfrog'])
+    dtype = np.float64 if group == 'SU3' else np.float32
+    if group == 'SU3':
+        kw.pop('conv')
+
+    def vnet(step, x, f):
+        return onet.leapfrog_layer(x, f, sub(sd, f'vnet.{step}.' if sep else 'vnet.'), **kw)
+
+    def xnet(step, first, x, v):
+        pre = 'xnet.'
+        if sep:
+            pre += f'{step}.'
+            if split:
+                pre += 'first.' if first else 'second.'
+        return onet.leapfrog_layer(x, v, sub(sd, pre), **kw)
+    L = tuple(int(i) for i in g['latvolume'])
+    return DynamicsOracle(group, L, nlf, [sd[f'xeps.{i}'] for i in range(nlf)],
+                          [sd[f'veps.{i}'] for i in range(nlf)], g['masks'], vnet=vnet,
+                          xnet=xnet if group == 'U1' else None, use_ncp=bool(g['use_ncp']),
+                          merge_directions=bool(g['merge_directions']), dtype=dtype)
+
+
+def seed_all(s):
+    import torch
+    torch.manual_seed(int(s))
+    np.random.seed(int(s))
+
+
+def build_from_seed(g, verbose=True):
+    """Product Dynamics from the fixture's configuration and SEED only (no weights loaded)."""
+    import l2hmc.configs as cfgs
+    from l2hmc.dynamics.pytorch.dynamics import Dynamics
+    from l2hmc.network.pytorch.network import NetworkFactory
+    group = str(g['group'])
+    L = [int(i) for i in g['latvolume']]
+    nb = int(g['nchains'])
+    seed_all(g['seed'])
+    dc = cfgs.DynamicsConfig(nchains=nb, group=group, latvolume=L, nleapfrog=int(g['nleapfrog']),
+                             eps=float(g['eps']), eps_hmc=float(g['eps']),
+                             use_ncp=bool(g['use_ncp']), verbose=verbose,
+                             use_split_xnets=bool(g['use_split_xnets']),
+                             use_separate_networks=bool(g['use_separate_networks']),
+                             merge_directions=bool(g['merge_directions']))
+    kw = modes_net_kwargs(g)
+    nc = cfgs.NetworkConfig(units=[int(i) for i in g['units']], activation_fn=kw['activation'],
+                            dropout_prob=float(g['dropout_prob']),
+                            use_batch_norm=kw['use_batch_norm'])
+    cc = cfgs.ConvolutionConfig(**kw['conv']) if kw['conv'] else cfgs.ConvolutionConfig()
+    if group == 'U1':
+        from l2hmc.lattice.u1.pytorch.lattice import LatticeU1 as Lat
+        xdim = dc.xdim
+        dims = {'xnet': {'x': [xdim, 2], 'v': [xdim]}, 'vnet': {'x': [xdim], 'v': [xdim]}}
+    else:
+        from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3 as Lat
+        xdim = int(np.prod(dc.xshape[1:-2])) * 8
+        dims = {'xnet': {'x': [xdim], 'v': [xdim]}, 'vnet': {'x': [xdim], 'v': [xdim]}}
+    spec = cfgs.InputSpec(xshape=tuple(dc.xshape), **dims)
+    lat = Lat(nb, L)
+    nf = NetworkFactory(input_spec=spec, network_config=nc, conv_config=cc,
+                        net_weights=cfgs.NetWeights(x=cfgs.NetWeight(1., 1., 1.),
+                                                    v=cfgs.NetWeight(1., 1., 1.)))
+    dyn = Dynamics(potential_fn=lat.action, config=dc, network_factory=nf)
+    return dyn, lat
+
+
+def check_init_state(dyn, g, prefix='init.', bn_tol=2e-6):
+    """Every parameter the seed determines is BIT-equal to the reference's; BatchNorm running
+    statistics (one momentum step of the construction-time dummy forward, computed by different
+    arithmetic) within bn_tol.  Returns the number of bit-equal tensors."""
+    sd = dyn.state_dict()
+    ref = sub(g, prefix)
+    mine = {k for k in sd if not k.startswith('networks.')}
+    assert mine == set(ref), (sorted(mine - set(ref))[:5], sorted(set(ref) - mine)[:5])
+    n = 0
+    for k, r in ref.items():
+        a = sd[k].detach().cpu().numpy()
+        assert a.shape == r.shape and a.dtype == r.dtype, (k, a.shape, r.shape, a.dtype, r.dtype)
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert np.abs(a - r).max() <= bn_tol * max(1.0, np.abs(r).max()), (k, np.abs(a - r).max())
+        else:
+            assert np.array_equal(a, r), (k, float(np.abs(a - r).max()))
+            n += 1
+    return n
+
+
+def apply_pert(dyn, g):
+    """Load the fixture's recorded perturbation (coeffs, step sizes, BN statistics)."""
+    import torch
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(g, 'pert.').items()}
+    res = dyn.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    dyn._eps_cache = {}

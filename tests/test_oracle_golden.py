@@ -236,3 +236,37 @@ def test_u1_cfg2_shape_oracle_vs_reference(golden, name, monkeypatch):
     assert dx.max() < 1e-3, dx.max()
     dx = np.abs(np.angle(np.exp(1j * (m['x_prop'].reshape(2, -1) - g['x_prop'].reshape(2, -1)))))
     assert dx.max() < 1e-3, dx.max()
+
+
+import helpers as _helpers  # noqa: E402
+
+
+@pytest.mark.parametrize('name', _helpers.MODES_U1 + _helpers.MODES_SU3)
+def test_modes_oracle_vs_reference(golden, name):
+    """The oracle branches the first fixtures never exercised, pinned to the real reference
+    (tests/golden/make_golden_modes.py): merge_directions=False -- single-direction kernel with
+    the swapped accept arguments, both directions -- shared / per-step / split network lookup,
+    SU(3) separate networks, SU(3) BatchNorm."""
+    g = golden(name)
+    d = _helpers.modes_oracle(g)
+    su3_ = str(g['group']) == 'SU3'
+    x, beta = g['x'], float(g['beta'])
+    nb = x.shape[0]
+    if bool(g['merge_directions']):
+        xo, m = d.apply_transition_fb(x, beta, g['normals'], g['u'], history=True)
+    else:
+        xo, m = d.apply_transition(x, beta, bool(g['forward']), g['normals'], g['u'],
+                                   history=True)
+    te, ta, tx = (1e-5, 1e-5, 1e-7) if su3_ else (2e-2, 1e-2, 2e-3)
+    close(m['v_init'].reshape(nb, -1), g['v_init'].reshape(nb, -1), 0.0)
+    close(m['energy'], g['energy'], te)
+    close(m['logdet'], g['logdet'], te)
+    close(m['acc'], g['acc'], ta)
+    assert np.array_equal(m['acc_mask'], g['acc_mask'])
+    close(m['sumlogdet'], g['sumlogdet'], te)
+    if su3_:
+        close(m['x_prop'], g['x_prop'], tx)
+        close(xo, g['x_out'], tx)
+    else:
+        dx = np.abs(np.angle(np.exp(1j * (xo - g['x_out'].reshape(nb, -1)))))
+        assert dx.max() < tx, dx.max()
