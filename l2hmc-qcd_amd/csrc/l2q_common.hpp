@@ -19,7 +19,8 @@ struct Tuning {
                           // 1: L2 t-sweep, 0: flat
   int heads_dma = 1;      // heads + v-update: LDS-DMA staged kernel (0: register-staged kernel of round 1)
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
-  int force_tile = 5;     // 5: slice-resident thread-per-link, streamed factors, 2 workgroups / CU
+  int force_tile = 5;     // 6: as 5 with two adjacent x-planes per workgroup (su3_force_pair.hip: half the x-halo),
+                          // 5: slice-resident thread-per-link, streamed factors, 2 workgroups / CU
                           // (su3_force_link.hip), 4: staples split by plane over wavefronts (su3_force_nu.hip), 3: rows
                           // split over wavefronts (su3_force_rows.hip), 2: slice-resident
                           // thread-per-link, 1: LDS-tiled (64 sites x 4 mu), 0: flat

@@ -66,21 +66,22 @@ __device__ __forceinline__ double2 lds_ld(int addr) {
 // Operand loads.  IN (compile time): the operand's site is inside the tile for every lane ->
 // ds_read_b128 from the LDS copy at byte address `lds` (entry e at + e * kEnt); otherwise a
 // buffer load from the chain: per-lane site offset `voff`, uniform (link, slice) offset `soff`.
-template <bool IN>
+// (ENT: bytes between the entries of a link in LDS = 16 x the sites of the tile)
+template <bool IN, int ENT = kEnt>
 __device__ __forceinline__ void ld_full(M3& m, int lds, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int V16) {
 #pragma unroll
   for (int e = 0; e < 9; ++e) {
-    const double2 d = IN ? lds_ld(lds + e * kEnt) : buf_ld(rs, voff, soff + e * V16);
+    const double2 d = IN ? lds_ld(lds + e * ENT) : buf_ld(rs, voff, soff + e * V16);
     m.re[e] = d.x; m.im[e] = d.y;
   }
 }
 
 // row `row` of the link (row is wave-uniform)
-template <bool IN>
+template <bool IN, int ENT = kEnt>
 __device__ __forceinline__ void ld_row(R3& a, int lds, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int V16, int row) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double2 d = IN ? lds_ld(lds + (3 * row + k) * kEnt) : buf_ld(rs, voff, soff + (3 * row + k) * V16);
+    const double2 d = IN ? lds_ld(lds + (3 * row + k) * ENT) : buf_ld(rs, voff, soff + (3 * row + k) * V16);
     a.re[k] = d.x; a.im[k] = d.y;
   }
 }
@@ -96,19 +97,19 @@ __device__ __forceinline__ void ld_colc(R3& a, int lds, __amdgpu_buffer_rsrc_t r
 }
 
 // Operand: LDS (IN, compile time) at byte address lds, else the chain buffer at (voff, soff).
-template <bool IN>
+template <bool IN, int ENT = kEnt>
 struct Opnd {
   int lds, voff, soff;
 };
 
 // t = A * B^H (ADJ_A = false) or A^H * B^H (ADJ_A = true); B streamed by rows
-template <bool ADJ_A, bool IN>
-__device__ __forceinline__ void mul_xh_stream(M3& t, const M3& a, const Opnd<IN>& b,
+template <bool ADJ_A, bool IN, int ENT>
+__device__ __forceinline__ void mul_xh_stream(M3& t, const M3& a, const Opnd<IN, ENT>& b,
                                               __amdgpu_buffer_rsrc_t rs, int V16) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     R3 br;
-    ld_row<IN>(br, b.lds, rs, b.voff, b.soff, V16, j);
+    ld_row<IN, ENT>(br, b.lds, rs, b.voff, b.soff, V16, j);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       double sr = 0.0, si = 0.0;
@@ -126,13 +127,13 @@ __device__ __forceinline__ void mul_xh_stream(M3& t, const M3& a, const Opnd<IN>
 }
 
 // acc += T * C^H (ADJ_C = true) or T * C (ADJ_C = false); C streamed by rows
-template <bool ADJ_C, bool IN>
-__device__ __forceinline__ void mac_stream(M3& acc, const M3& t, const Opnd<IN>& c,
+template <bool ADJ_C, bool IN, int ENT>
+__device__ __forceinline__ void mac_stream(M3& acc, const M3& t, const Opnd<IN, ENT>& c,
                                            __amdgpu_buffer_rsrc_t rs, int V16) {
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     R3 cr;
-    ld_row<IN>(cr, c.lds, rs, c.voff, c.soff, V16, q);
+    ld_row<IN, ENT>(cr, c.lds, rs, c.voff, c.soff, V16, q);
     if (ADJ_C) {
       // acc_iq += sum_k t_ik conj(C_qk)
 #pragma unroll
@@ -161,9 +162,9 @@ __device__ __forceinline__ void mac_stream(M3& acc, const M3& t, const Opnd<IN>&
   }
 }
 
-template <bool IN>
-__device__ __forceinline__ void ld_m(M3& m, const Opnd<IN>& o, __amdgpu_buffer_rsrc_t rs, int V16) {
-  ld_full<IN>(m, o.lds, rs, o.voff, o.soff, V16);
+template <bool IN, int ENT>
+__device__ __forceinline__ void ld_m(M3& m, const Opnd<IN, ENT>& o, __amdgpu_buffer_rsrc_t rs, int V16) {
+  ld_full<IN, ENT>(m, o.lds, rs, o.voff, o.soff, V16);
 }
 
 }  // namespace l2q

@@ -996,6 +996,11 @@ bool force_link_applicable(const Dims& d);
 int force_link_inmask(const Dims& d);
 void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
                        hipStream_t st, const double2* vin = nullptr);
+// su3_force_pair.hip
+bool force_pair_applicable(const Dims& d);
+int force_pair_inmask(const Dims& d);
+void launch_force_pair(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
+                       hipStream_t st, const double2* vin = nullptr);
 }  // namespace l2q
 
 using namespace l2q;
@@ -1018,7 +1023,11 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
   constexpr int kFS = KICK ? kFSKick : kFSPlain;
   constexpr int kVar = KICK ? 2 : 0;
   constexpr int kLpt = KICK ? 1 : kLptPlain;
-  if (tuning().force_tile == 5 && force_link_applicable(d)) {
+  if (tuning().force_tile == 6 && force_pair_applicable(d)) {
+    launch_force_pair(KICK, xn, d, nb, coef, out, st);
+    return;
+  }
+  if (tuning().force_tile >= 5 && force_link_applicable(d)) {
     launch_force_link(KICK, xn, d, nb, coef, out, st);
     return;
   }
@@ -1091,7 +1100,9 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
     const bool kick = !strcmp(entry, "l2q_su3_force_kick");
     const int fs = kick ? kFSKick : kFSPlain;
     const Dims dd{T, X, Y, Z, T * X * Y * Z};
-    if (t.force_tile == 5 && force_link_applicable(dd))
+    if (t.force_tile == 6 && force_pair_applicable(dd))
+      snprintf(buf, buf_bytes, "su3_force_pair_kernel<%d, %d>", kick ? 1 : 0, force_pair_inmask(dd));
+    else if (t.force_tile >= 5 && force_link_applicable(dd))
       snprintf(buf, buf_bytes, "su3_force_link_kernel<%d, %d>", kick ? 1 : 0, force_link_inmask(dd));
     else if (t.force_tile >= 4 && force_nu_applicable(dd) && (kick ? nu_preferred<true>(dd) : nu_preferred<false>(dd)))
       snprintf(buf, buf_bytes, "su3_force_nu_kernel<%d, %d>", kick ? 1 : 0, force_nu_inmask(dd));
@@ -1242,7 +1253,12 @@ int l2q_su3_force_kick_to(const void* xn, double beta, double coef, const void* 
   L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
   Dims d{T, X, Y, Z, T * X * Y * Z};
   hipStream_t st = (hipStream_t)stream;
-  if (v_in != v_out && tuning().force_tile == 5 && force_link_applicable(d)) {
+  if (v_in != v_out && tuning().force_tile == 6 && force_pair_applicable(d)) {
+    launch_force_pair(true, (const double2*)xn, d, nb, coef * beta / 3.0, (double2*)v_out, st,
+                      (const double2*)v_in);
+    return check_launch("l2q_su3_force_kick_to");
+  }
+  if (v_in != v_out && tuning().force_tile >= 5 && force_link_applicable(d)) {
     launch_force_link(true, (const double2*)xn, d, nb, coef * beta / 3.0, (double2*)v_out, st,
                       (const double2*)v_in);
     return check_launch("l2q_su3_force_kick_to");

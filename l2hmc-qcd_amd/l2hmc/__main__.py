@@ -29,6 +29,26 @@ def _summary(res: dict, nb: int) -> dict:
     return out
 
 
+def get_experiment(cfg: dict, keep=None, skip=None):
+    """Seed, set the default dtype, build the Experiment -- the order of the reference's entry
+    point (__main__.py:55-93): `setup_torch(seed=cfg.seed, ...)`, float64 default for the fp64
+    precisions, then `Experiment(cfg)` continuing that generator stream."""
+    import torch
+    from l2hmc.utils.dist import setup_torch
+    framework = str(cfg.get('framework'))
+    if framework not in cfgs.SYNONYMS['pytorch']:
+        raise ValueError('Framework must be specified, one of: [pytorch] (the TensorFlow back-end '
+                         f'is outside this build); got {framework!r}')
+    cfg['framework'] = 'pytorch'
+    seed = cfg.get('seed')
+    setup_torch(seed=0 if seed is None else int(seed), backend=cfg.get('backend', 'DDP'),
+                port=str(cfg.get('port', '2345')))
+    if str(cfg.get('precision')) in cfgs.FP64_SYNONYMS + ['f64']:
+        torch.set_default_dtype(torch.float64)
+    from l2hmc.experiment.pytorch.experiment import Experiment
+    return Experiment(cfg, keep=keep, skip=skip)
+
+
 def main(argv=None) -> dict:
     overrides = list(sys.argv[1:] if argv is None else argv)
     config_name, outdir = 'config', None
@@ -44,8 +64,7 @@ def main(argv=None) -> dict:
         else:
             rest.append(a)
     cfg = cfgs.get_config(rest, config_name=config_name)
-    from l2hmc.experiment.pytorch.experiment import Experiment
-    ex = Experiment(cfg)
+    ex = get_experiment(cfg)
     out: dict = {}
     nb = ex.config.dynamics.nchains
     x = None

@@ -423,6 +423,23 @@ def get_config(overrides: Optional[list[str]] = None, config_name: str = 'config
     return compose_flat(CONF_DIR, config_name, overrides or [])
 
 
+def get_experiment(overrides: Optional[list[str]] = None, build_networks: bool = True,
+                   keep: Optional[str | list[str]] = None,
+                   skip: Optional[str | list[str]] = None):
+    """Compose the config and build the Experiment (configs.py:1008-1034 of the reference; the
+    entry its own SU(3) smoke script uses, train4dSU3.py:207).  PyTorch only: the TensorFlow
+    back-end is outside this build."""
+    cfg = get_config(overrides)
+    framework = str(cfg.get('framework'))
+    if framework in SYNONYMS['pytorch']:
+        from l2hmc.experiment.pytorch.experiment import Experiment
+        return Experiment(cfg, keep=keep, skip=skip, build_networks=build_networks)
+    if framework in SYNONYMS['tensorflow']:
+        raise ValueError('get_experiment: framework=tensorflow is not part of this build '
+                         '(the hot path is the PyTorch one)')
+    raise ValueError(f'Unexpected value for `cfg.framework: {framework}')
+
+
 def instantiate(cfg: dict) -> ExperimentConfig:
     from l2hmc.utils.compose import instantiate as _inst
     return _inst(cfg)

@@ -9,7 +9,6 @@ import torch
 import l2hmc.configs as cfgs
 from l2hmc.trainers.pytorch.trainer import Trainer
 from l2hmc.utils import dist as D
-from l2hmc.utils.dist import setup_torch
 
 
 class Experiment:
@@ -17,20 +16,26 @@ class Experiment:
                  keep=None, skip=None) -> None:
         self.cfg = cfg
         self.config = cfgs.instantiate(cfg) if isinstance(cfg, dict) else cfg
+        # Seeding is the CALLER's job, like in the reference: its Experiment never seeds
+        # (experiment/pytorch/experiment.py:141-225); `python -m l2hmc` seeds with cfg.seed through
+        # setup_torch right before it builds the Experiment (__main__.py:78-92) and a script such
+        # as train4dSU3.py seeds with its own value (:61) before configs.get_experiment.  The
+        # networks and masks drawn below therefore continue the caller's generator stream exactly
+        # as the reference's do, and so does everything after construction (start configuration,
+        # momenta, accept uniforms): one process, same seed -> the reference's CPU-path chain.
+        #
         # Data parallelism: the MODEL must be identical on every rank, the CHAINS
-        # must differ.  (1) everything is seeded with the base seed, the Trainer builds networks
-        # and numpy masks from it; (2) rank 0's parameters / buffers and masks are broadcast (DDP
-        # constructor semantics, trainers/pytorch/trainer.py:246-257 of the reference) so that a
-        # nondeterministic initialiser cannot split the replicas; (3) only then torch / cuda /
-        # numpy are reseeded per rank (`chain_seed`), so lattice.random(), momenta and accept
-        # uniforms are independent streams.  The reference seeds everything with
-        # seed * (rank + 1) (utils/dist.py:340), which also makes its numpy masks rank-dependent.
-        self._rank = setup_torch(seed=self.config.seed, backend=self.config.backend,
-                                 port=self.config.port)
-        self.trainer = Trainer(self.config, build_networks=build_networks)
+        # must differ.  Rank 0's parameters / buffers and masks are broadcast (DDP constructor
+        # semantics, trainers/pytorch/trainer.py:246-257 of the reference; the masks too, which the
+        # reference leaves rank-dependent) and ranks > 0 then move to their own chain streams
+        # (`chain_seed`); rank 0 keeps its stream, i.e. stays the single-process chain.
+        env = D.setup_torch_distributed(self.config.backend, self.config.port)
+        self._rank = env['rank']
+        self.trainer = Trainer(self.config, build_networks=build_networks, keep=keep, skip=skip)
         self.lattice = self.trainer.lattice
         D.sync_model(self.trainer.dynamics)
-        D.seed_everything(D.chain_seed(self.config.seed, self._rank))
+        if env['world_size'] > 1 and self._rank > 0:
+            D.seed_everything(D.chain_seed(self.config.seed, self._rank))
 
     def build_trainer(self, **kw) -> Trainer:
         return self.trainer

@@ -29,10 +29,14 @@ Tensor = torch.Tensor
 
 
 class Trainer:
-    def __init__(self, cfg: cfgs.ExperimentConfig | dict, build_networks: bool = True):
+    def __init__(self, cfg: cfgs.ExperimentConfig | dict, build_networks: bool = True,
+                 keep=None, skip=None):
         if isinstance(cfg, dict):
             cfg = cfgs.instantiate(cfg)
         self.config = cfg
+        # stored like the reference does (trainers/trainer.py:65-66; it never reads them again)
+        self.keep = [keep] if isinstance(keep, str) else keep
+        self.skip = [skip] if isinstance(skip, str) else skip
         if cfg.precision == 'float64' or cfg.dynamics.group.upper() == 'SU3':
             torch.set_default_dtype(torch.float64)
         self.device = DEVICE

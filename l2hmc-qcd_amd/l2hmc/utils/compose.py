@@ -2,7 +2,8 @@
 the target boxes).  Supports the subset the reference's configs use: a ``defaults`` list with
 ``_self_``, ``group: option`` entries and ``override /group: option`` entries inside option
 files, command-line overrides ``group=option`` (``+experiment=su3`` too) and dotted
-``a.b.c=value`` (YAML-typed), ``${a.b}`` interpolation, and ``_target_`` instantiation of
+``a.b.c=value`` (YAML-typed), ``${a.b}`` / ``${a.b[0]}`` / ``${now:%H-%M}`` interpolation,
+mandatory values (``???``), ``hydra.run.dir`` (kept as ``rundir``) and ``_target_`` instantiation of
 ``l2hmc.configs`` dataclasses (reference: conf/config.yaml:36-62, configs.py:991-1005).
 """
 from __future__ import annotations
@@ -47,11 +48,24 @@ def _set_dotted(cfg: dict, key: str, value: Any) -> None:
     cur[parts[-1]] = value
 
 
+_INDEXED = re.compile(r'([^\[\]]+)((?:\[\d+\])*)')
+
+
 def _get_dotted(cfg: dict, key: str) -> Any:
+    """`a.b.c`, with list indexing `a.b[0]` (conf/logdir/default.yaml uses latvolume[0])."""
+    if key.startswith('now:'):                    # hydra's ${now:%Y-%m-%d} resolver
+        import datetime
+        return _NOW.setdefault('t', datetime.datetime.now()).strftime(key[4:])
     cur: Any = cfg
     for p in key.split('.'):
-        cur = cur[p]
+        m = _INDEXED.fullmatch(p)
+        cur = cur[m.group(1)]
+        for i in re.findall(r'\[(\d+)\]', m.group(2)):
+            cur = cur[int(i)]
     return cur
+
+
+_NOW: dict = {}                                    # one timestamp per process, like hydra's job
 
 
 _INTERP = re.compile(r'\$\{([^}]+)\}')
@@ -71,7 +85,7 @@ def _resolve(node: Any, root: dict) -> Any:
 
 
 def compose(conf_dir: os.PathLike, config_name: str = 'config',
-            overrides: list[str] | None = None) -> dict:
+            overrides: list[str] | None = None, finish: bool = True) -> dict:
     conf_dir = Path(conf_dir)
     overrides = list(overrides or [])
     primary = _load(conf_dir / f'{config_name}.yaml')
@@ -122,7 +136,6 @@ def compose(conf_dir: os.PathLike, config_name: str = 'config',
         path = _option_file(conf_dir, g, selection[g])
         body = _load(path)
         body.pop('defaults', None)
-        body.pop('hydra', None)
         is_global = open(path).readline().strip().startswith('# @package _global_') \
             or g in ('mode', 'experiment')
         if is_global:
@@ -133,7 +146,17 @@ def compose(conf_dir: os.PathLike, config_name: str = 'config',
         _merge(cfg, body)
     for key, val in value_overrides:
         _set_dotted(cfg, key, val)
-    cfg.pop('hydra', None)
+    return _finish(cfg) if finish else cfg
+
+
+def _finish(cfg: dict) -> dict:
+    """Of the `hydra:` node only run.dir means something without hydra: it becomes the top-level
+    `rundir` (conf/logdir/*.yaml, conf/mode/exp.yaml).  A run dir that needs a missing mandatory
+    value (`???`) is left for `instantiate` to report."""
+    hydra = cfg.pop('hydra', None) or {}
+    run_dir = (hydra.get('run') or {}).get('dir')
+    if run_dir is not None:
+        cfg['rundir'] = run_dir
     return _resolve(cfg, cfg)
 
 
@@ -156,12 +179,22 @@ def compose_flat(conf_dir: os.PathLike, config_name: str, overrides: list[str] |
     overrides = list(overrides or [])
     group_ovs = [o for o in overrides if o.partition('=')[0].lstrip('+~') in groups]
     value_ovs = [o for o in overrides if o not in group_ovs]
-    cfg = compose(conf_dir, 'config', sel + group_ovs)
+    cfg = compose(conf_dir, 'config', sel + group_ovs, finish=False)
+    rest.pop('hydra', None)
     _merge(cfg, rest)
     for ov in value_ovs:
         key, _, val = ov.partition('=')
         _set_dotted(cfg, key.lstrip('+~'), yaml.safe_load(val))
-    return _resolve(cfg, cfg)
+    return _finish(cfg)
+
+
+def _missing(node: Any, pre: str = '') -> list[str]:
+    if isinstance(node, dict):
+        return [m for k, v in node.items() if k != 'rundir'
+                for m in _missing(v, f'{pre}.{k}' if pre else str(k))]
+    if isinstance(node, list):
+        return [m for i, v in enumerate(node) for m in _missing(v, f'{pre}[{i}]')]
+    return [pre] if isinstance(node, str) and '???' in node else []
 
 
 def _instantiate_node(node: Any) -> Any:
@@ -182,6 +215,11 @@ def instantiate(cfg: dict):
     import dataclasses
     import l2hmc.configs as cfgs
     cfg = deepcopy(cfg)
+    missing = _missing(cfg)
+    if missing:
+        # hydra / omegaconf: MissingMandatoryValue on access of a `???` node
+        raise ValueError('Missing mandatory value: ' + ', '.join(missing)
+                         + ' (set on the command line, e.g. ' + missing[0] + '=...)')
     target = cfg.get('_target_', 'l2hmc.configs.ExperimentConfig')
     mod, _, cls = target.rpartition('.')
     klass = getattr(importlib.import_module(mod), cls)

@@ -49,12 +49,17 @@ def setup_torch_distributed(backend: Optional[str] = None, port: str = '2345') -
     return env
 
 
-def setup_torch(seed: int, backend: Optional[str] = None, port: str = '2345') -> int:
-    """Initialise the process group and the RNGs.  Weights and masks must be identical on
+def setup_torch(seed: int, backend: Optional[str] = None, port: str = '2345',
+                precision: Optional[str] = None) -> int:
+    """Initialise the process group, the default dtype (`precision`: float16 / float32 / float64,
+    like utils/dist.py:293-341 of the reference) and the RNGs.  Weights and masks must be identical on
     every rank, so the *model* seed is the base seed; per-rank streams (chains, momenta)
     use ``chain_seed`` (the reference seeds everything with seed*(rank+1)*(local_rank+1),
     dist.py:340, which makes the numpy masks differ per rank -- SURVEY.md 8(e))."""
     env = setup_torch_distributed(backend, port)
+    if precision is not None:
+        torch.set_default_dtype({'float16': torch.float16, 'float32': torch.float32,
+                                 'float64': torch.float64}.get(precision, torch.float32))
     seed_everything(seed)
     return env['rank']
 

@@ -36,6 +36,17 @@ def grab(x: Any) -> np.ndarray:
     return np.asarray(x)
 
 
+def format_pair(k: str, v) -> str:
+    """`key=value` the way the reference prints step summaries (utils/history.py:59-64)."""
+    if isinstance(v, (int, bool, np.integer)):
+        return f'{k}={v}'
+    return f'{k}={v:<.3f}'
+
+
+def summarize_dict(d: dict) -> str:
+    return ' '.join([format_pair(k, v) for k, v in d.items()])
+
+
 class BaseHistory:
     def __init__(self, steps: Optional[Steps] = None):
         self.steps = steps

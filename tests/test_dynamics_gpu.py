@@ -1136,7 +1136,7 @@ def test_from_seed_trajectory(golden, name):
     x = lat.random()
     nb = x.shape[0]
     if su3:
-        assert err(host(x), g['x']) < 1e-13
+        assert err(host(x), g['x']) < 1e-10     # projectSU of a Gaussian matrix: conditioning ~1e3
     else:
         assert np.abs(np.angle(np.exp(1j * (host(x) - g['x'])))).max() < 1e-6
     beta = torch.tensor(float(g['beta']))

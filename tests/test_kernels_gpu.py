@@ -111,12 +111,14 @@ def test_su3_stencils_vs_oracle(ops, L):
     from l2hmc import native
     # every kernel variant (register budget, flat vs t-sweep plaquette, flat vs LDS-tiled
     # force, with / without the XCD remap) must give the same numbers
-    # (force_tile 5 = thread per link with streamed factors, su3_force_link.hip; plaq_sweep 3 = planes
+    # (force_tile 6 = two x-planes per workgroup, su3_force_pair.hip -- (3,8,8,8), (2,2,8,8), (1,2,8,8) with
+    # whole (y,z) planes per group, (2,4,8,16) with half planes; it falls back to 5 elsewhere;
+    # force_tile 5 = thread per link with streamed factors, su3_force_link.hip; plaq_sweep 3 = planes
     # over wavefronts, su3_plaq_nu.hip;
     # force_tile 3 = rows split over wavefronts, su3_force_rows.hip: the lattices above cover its
     # four tile-residency specialisations -- Z | 64, Y Z | 64, X Y Z | 64, none -- and T = 1)
     for occ in (2, 3, 4):
-        for variant in (0, 1, 2, 3, 4, 5):
+        for variant in (0, 1, 2, 3, 4, 5, 6):
             for swz in (0, 1):
                 native.set_tuning('force_occ', occ); native.set_tuning('plaq_occ', occ)
                 native.set_tuning('plaq_sweep', min(variant, 3)); native.set_tuning('force_tile', variant)

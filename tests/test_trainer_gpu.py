@@ -236,3 +236,54 @@ def test_cli_precision_and_improved_action():
         assert {'train', 'eval', 'hmc'} <= set(out) and np.isfinite(out['train']['loss_last'])
     finally:
         torch.set_default_dtype(old)
+
+
+def test_train4dsu3_call_sequence():
+    """The call sequence of the reference's own SU(3) integration script (train4dSU3.py:61,
+    108-190, 200-260) through the product, name for name: seed with setup_torch, load
+    conf/su3-min.yaml, `dict_to_list_of_overrides` -> `configs.get_experiment`, `random_state`,
+    HMC steps (`trainer.hmc_step`), eval steps, train steps, `BaseHistory.update` +
+    `summarize_dict`, `g.checkSU` on the unflattened output."""
+    import yaml
+    from l2hmc.configs import CONF_DIR, dict_to_list_of_overrides, get_experiment
+    from l2hmc.experiment.pytorch.experiment import Experiment
+    import l2hmc.group.su3.pytorch.group as g
+    from l2hmc.utils.dist import setup_torch
+    from l2hmc.utils.history import BaseHistory, summarize_dict
+    _ = setup_torch(precision='float64', backend='DDP', seed=4351)
+    with (CONF_DIR / 'su3-min.yaml').open('r') as stream:
+        conf = dict(yaml.safe_load(stream))
+    conf['dynamics']['nchains'] = 8                      # (64 in the file; the sequence is the point)
+    overrides = dict_to_list_of_overrides(conf)
+    ex = get_experiment(overrides=[*overrides], build_networks=True, keep=['loss'], skip='dt')
+    assert isinstance(ex, Experiment) and ex.trainer.keep == ['loss'] and ex.trainer.skip == ['dt']
+    assert ex.config.dynamics.group == 'SU3' and list(ex.config.dynamics.latvolume) == [4, 4, 4, 4]
+    assert ex.config.network.units == [1] and ex.config.conv.filters in (None, [], '')
+    state = ex.trainer.dynamics.random_state(6.0)
+    assert isinstance(state.x, torch.Tensor) and isinstance(state.beta, torch.Tensor)
+    # HMC(...)  train4dSU3.py:108-149
+    hist = BaseHistory()
+    x = state.x
+    for step in range(3):
+        x, metrics_ = ex.trainer.hmc_step((x, state.beta.item()), eps=0.1, nleapfrog=1)
+        avgs = hist.update({'hmc_step': step, 'dt': 0.0, **metrics_})
+        assert 'acc=' in summarize_dict(avgs)
+    xhmc = ex.trainer.dynamics.unflatten(x)
+    avg, mx = g.checkSU(xhmc)
+    assert float(mx.max()) < 1e-10                   # plain HMC stays on the group manifold
+    # eval(...)  :152-193
+    hist = BaseHistory()
+    x = state.x
+    for step in range(3):
+        x, metrics_ = ex.trainer.eval_step((x, 6.0))
+        avgs = hist.update({'eval_step': step, 'dt': 0.0, **metrics_})
+        assert np.isfinite(avgs['loss'])
+    assert ex.trainer.dynamics.unflatten(x).shape == state.x.shape
+    # the training loop :239-255
+    hist = BaseHistory()
+    x = state.x
+    for step in range(3):
+        x, metrics_ = ex.trainer.train_step((x, state.beta))
+        avgs = hist.update({'train_step': step, 'dt': 0.0, **metrics_})
+        assert np.isfinite(avgs['loss']) and 0.0 <= avgs['acc'] <= 1.0
+    assert len(hist.history['loss']) == 3
