@@ -344,6 +344,45 @@ def secondary(dyn, x, beta, args, nlf_exec):
         dyn.config.verbose = True
         res['l2hmc_verbose_true'] = rate(lambda: dyn((x, beta)))
         dyn.config.verbose = False
+        # sampler-loop convenience (opt-in): the transition keeps the native-layout original of the
+        # x it returned and reuses it when that very tensor comes straight back
+        try:
+            dyn.cache_native_output = True
+            state = {'x': x}
+
+            def chained():
+                state['x'], _ = dyn((state['x'], beta))
+            res['l2hmc_native_output_cache'] = rate(chained)
+        finally:
+            dyn.cache_native_output = False
+            dyn._xcache = None
+        # the same trajectory with the three head layers scaled by 0.03 (random-init heads are O(1)
+        # per entry: dH ~ -50 from a hot start and every chain rejects; scaled, the accept
+        # probability is inside (0, 1) -- tests/test_sizes_gpu.py pins exactly this set-up to the
+        # oracle): the accept / select path exercised with both outcomes, same shapes and kernels
+        if dyn._networks_built:
+            heads = [dyn.vnet.scale.layer, dyn.vnet.transl, dyn.vnet.transf.layer]
+            keep = [(l.weight.detach().clone(), l.bias.detach().clone()) for l in heads]
+            try:
+                with torch.no_grad():
+                    for l in heads:
+                        l.weight.mul_(0.03)
+                        l.bias.mul_(0.03)
+                box = {}
+
+                def scaled():
+                    _, box['m'] = dyn((x, beta))
+                r = rate(scaled)
+                a = box['m']['acc']
+                res['l2hmc_scaled_heads'] = {
+                    'value': r, 'head_scale': 0.03, 'accept_prob_mean': round(float(a.mean()), 4),
+                    'accept_prob_min': round(float(a.min()), 4), 'accept_prob_max': round(float(a.max()), 4),
+                    'accepted_fraction': round(float(box['m']['acc_mask'].mean()), 4)}
+            finally:
+                with torch.no_grad():
+                    for l, (w0, b0) in zip(heads, keep):
+                        l.weight.copy_(w0)
+                        l.bias.copy_(b0)
         res['hmc'] = rate(lambda: dyn.apply_transition_hmc((x, beta), eps=0.01,
                                                            nleapfrog=nlf_exec))
         # the headline trajectory replayed from a HIP graph (Dynamics.make_graphed): what the
@@ -586,19 +625,18 @@ def native_comm_probe(dist, world, n_params, reps=3):
     fatal for the headline)."""
     try:
         from l2hmc.utils.dist import NativeComm
-        c = NativeComm(rank=0 if dist is None else dist.get_rank(), world_size=world)
-        buf = torch.ones(n_params, dtype=torch.float64, device='cuda')
-        c.all_reduce_(buf)
-        torch.cuda.synchronize()
-        ok = bool((buf == float(world)).all())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        with NativeComm(rank=0 if dist is None else dist.get_rank(), world_size=world) as c:
+            buf = torch.ones(n_params, dtype=torch.float64, device='cuda')
             c.all_reduce_(buf)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        c.close()
+            torch.cuda.synchronize()
+            ok = bool((buf == float(world)).all())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                c.all_reduce_(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
         return {'route': 'l2q_allreduce_grads (C ABI -> librccl)', 'ranks': world,
                 'bytes': n_params * 8, 'ms': round(ms, 3), 'sum_correct': ok,
                 'algbw_GBps': round(n_params * 8 / ms / 1e6, 2)}
@@ -645,13 +683,13 @@ def main():
         dyn, lat = tr.dynamics, tr.lattice
     else:
         dyn, lat = build(args, seed)
-    cseed = seed + 1_000_003 * (rank + 1)          # chain streams: distinct from the model seed on every rank
+    from l2hmc.utils.dist import chain_seed
+    cseed = chain_seed(seed, rank)                 # chain streams: distinct from the model seed on every rank
     x = hot_start(args, seed=cseed)
-    # sampler-loop conveniences, named in config.workload: the transition keeps the native-layout
-    # original of the x it returned and reuses it when that very tensor comes straight back (the
-    # reference's eval_step does compat_proj first: one 0.2 ms pack more), and mc_states.out.v is
-    # selected on first access (nothing in a sampler loop reads it)
-    dyn.cache_native_output = True
+    # The headline times the DEFAULT `Dynamics` (what a user gets): every trajectory packs the x it
+    # is handed into the native layout, like the reference's eval_step pays compat_proj.  The opt-in
+    # native-output cache (skips that 0.2 ms pack when x_out is fed straight back) is reported as
+    # `secondary.l2hmc_native_output_cache`.
     if train:
         # per-rank stream for momenta / accept uniforms (chains differ, the model does not)
         torch.manual_seed(cseed)
@@ -693,10 +731,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    per_rank = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own time for its K steps (rank 0 reports min / median / max of the per-rank
+        # rates next to the contract's max-over-ranks value)
+        ts = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(world)]
+        dist.all_gather(ts, torch.tensor([dt], dtype=torch.float64, device='cuda'))
+        per_rank = sorted(float(t.item()) for t in ts)
+        dt = per_rank[-1]
     acc = m['acc']
     assert torch.isfinite(acc).all() and torch.isfinite(x).all(), 'non-finite trajectory'
     ar = allreduce_probe(tr, dist, world) if train else None
@@ -803,9 +845,8 @@ def main():
             'config': {'workload': f'4D SU(3) {"x".join(map(str, args.lattice))}, beta={args.beta}, '
                                    f'{args.nchains} chains/GPU, complex128/fp64, {what}, '
                                    f'nleapfrog={args.nleapfrog} ({nlf_exec} LF steps/trajectory), '
-                                   f'vnet units {args.units}, verbose=False; sampler-loop conveniences on: '
-                                   f'native-output cache (x_out fed straight back skips one pack), '
-                                   f'mc_states.out.v selected lazily',
+                                   f'vnet units {args.units}, verbose=False, default Dynamics switches '
+                                   f'(mc_states.out.v is formed on first access)',
                        'global_chains': world * args.nchains, 'parallelism': f'chains sharded x{world}'},
             # ranks of the RCCL communicator that executed in this run (N = 1: the one-rank
             # communicator of the native probe, if it ran)
@@ -818,6 +859,12 @@ def main():
             'kernels': kernels,
             'accept_prob_mean': round(float(acc.mean()), 4),
         }
+        if per_rank is not None:
+            unit_per_rank = args.nchains * nlf_exec * args.steps
+            rates = sorted(unit_per_rank / t for t in per_rank)
+            out['per_rank'] = {'unit': 'chain*leapfrog-steps/s per rank', 'min': round(rates[0], 1),
+                               'median': round(rates[len(rates) // 2], 1), 'max': round(rates[-1], 1),
+                               'seconds_min': round(per_rank[0], 4), 'seconds_max': round(per_rank[-1], 4)}
         if probe is not None:
             out['grad_allreduce_probe'] = probe
         if nprobe is not None:

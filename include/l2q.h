@@ -270,8 +270,14 @@ size_t l2q_vnet_heads_ws_bytes(int M, long N);
  * point (mean |w| below 2^-6 of the largest): keep the fp64 kernel then.  The call synchronises the
  * stream.  l2q_vnet_heads_vupdate_sliced_f64 is the four fp64 entry points in one: v_in NULL = in
  * place; pair = 0 ignores flip_between / eps2 / forward2; logdet1 / vnorm2_mid non-NULL (pair only) =
- * the mid-point outputs.  Results agree with the fp64 kernels to fp64 rounding (not bit for bit). */
+ * the mid-point outputs.  Results agree with the fp64 kernels to fp64 rounding (not bit for bit).
+ * The per-call operand Z gets the same conditioning test as the weights, as a DIAGNOSTIC: rows whose
+ * mean |z| is below 2^-6 of their largest entry (possible with an unbounded activation; never with
+ * tanh) are counted per device -- their products are exact to 2^-54 K max|z| max|w| rather than to
+ * fp64 rounding of sum |z||w|.  l2q_heads_sliced_zflag copies the count to *count (host), optionally
+ * resets it, and synchronises the stream. */
 size_t l2q_heads_sliced_bytes(int K, long N);
+int l2q_heads_sliced_zflag(int reset, int* count, void* stream);
 int l2q_heads_sliced_build(const double* Ws, const double* Wt, const double* Wq, int K, long N, void* sliced,
                            size_t sliced_bytes, int* usable, void* stream);
 size_t l2q_vnet_heads_sliced_ws_bytes(int M, long N);

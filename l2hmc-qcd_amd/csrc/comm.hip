@@ -7,9 +7,20 @@
 // librccl is resolved at run time (dlopen of the soname): libl2q.so itself has no link-time
 // dependency on it, and inside a PyTorch process the copy PyTorch already loaded is the one used.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <cstdlib>
+#include <mutex>
 
 #include "l2q_common.hpp"
+
+// The handful of RCCL declarations this file needs, spelled out (values as in <rccl/rccl.h> of
+// ROCm 7.x = NCCL's ABI): building libl2q.so needs neither the RCCL headers nor the library.
+extern "C" {
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
 
 namespace l2q {
 namespace {
@@ -21,30 +32,39 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                             hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  char why[256] = "librccl not loaded";
 };
 
+// Resolved ONCE (std::call_once: concurrent first calls are safe); a failed resolution is
+// remembered with its reason, and EVERY entry that finds it failed reports that reason again
+// (l2q_last_error must not be left holding an unrelated, older message).
+// L2Q_RCCL_LIB names another library with the same five entry points (tests: a host-memory fake).
 Rccl& rccl() {
   static Rccl r;
-  if (r.ok || r.h) return r;
-  for (const char* name : {"librccl.so.1", "librccl.so"}) {
-    r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (r.h) break;
-  }
-  if (!r.h) {
-    set_error("librccl.so.1 not found (%s)", dlerror());
-    return r;
-  }
-  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
-  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
-  r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
-  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
-  r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
-  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
-  r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy && r.GetErrorString;
-  if (!r.ok) set_error("librccl: missing symbols");
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = getenv("L2Q_RCCL_LIB");
+    const char* names[3] = {env && *env ? env : "librccl.so.1", "librccl.so", nullptr};
+    for (int i = 0; names[i] && !r.h; ++i) {
+      r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+      if (env && *env) break;                       // an explicit choice is not second-guessed
+    }
+    if (!r.h) {
+      const char* e = dlerror();
+      snprintf(r.why, sizeof r.why, "%s not found (%s)", names[0], e ? e : "dlopen failed");
+      return;
+    }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy && r.GetErrorString;
+    if (!r.ok) snprintf(r.why, sizeof r.why, "librccl: missing symbols");
+  });
+  if (!r.ok) set_error("%s", r.why);
   return r;
 }
 

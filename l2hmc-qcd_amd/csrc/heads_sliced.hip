@@ -122,8 +122,24 @@ __global__ __launch_bounds__(256) void oz_split_kernel(const double* __restrict_
     double sc = 0.0;
     if (r < R) sc = bad ? __longlong_as_double(0x7ff8000000000000LL) : ldexp(1.0, e - 30);
     if (r < R || scale_pad) scale[r] = sc;          // (W: [3][N] packed, no room for the padding vectors)
-    if (flag && r < R && !bad && sm < rho_min * OZ_K * mx) atomicOr(flag, 1);
+    if (flag && r < R && !bad && sm < rho_min * OZ_K * mx) atomicAdd(flag, 1);
   }
+}
+
+// rows of Z (activation vectors) whose mean |entry| was below 2^-6 of their largest one since the
+// counter was last reset: the conditioning guard the weights get at build time, as a diagnostic for
+// the per-call operand (one counter per device; l2q_heads_sliced_zflag reads it)
+__device__ int oz_zflag_dev;
+static int* oz_zflag_ptr() {
+  static int* cache[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!cache[dev]) {
+    int* p = nullptr;
+    if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(oz_zflag_dev)) != hipSuccess) return nullptr;
+    cache[dev] = p;
+  }
+  return cache[dev];
 }
 
 struct SlicedArgs {
@@ -661,6 +677,20 @@ int l2q_heads_sliced_build(const double* Ws, const double* Wt, const double* Wq,
   return check_launch("l2q_heads_sliced_build");
 }
 
+int l2q_heads_sliced_zflag(int reset, int* count, void* stream) {
+  L2Q_REQUIRE(count, L2Q_EINVAL, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  int* p = oz_zflag_ptr();
+  L2Q_REQUIRE(p, L2Q_EHIP, "device symbol not found");
+  if (hipMemcpyAsync(count, p, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      (reset && hipMemsetAsync(p, 0, sizeof(int), st) != hipSuccess) ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    set_error("l2q_heads_sliced_zflag: %s", hipGetErrorString(hipGetLastError()));
+    return L2Q_EHIP;
+  }
+  return L2Q_OK;
+}
+
 size_t l2q_vnet_heads_sliced_ws_bytes(int M, long N) {
   if (M <= 0 || N <= 0) return 0;
   const size_t mpad = (size_t)sliced_rg(M) * 64;
@@ -693,7 +723,7 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
   double* zscale = (double*)(zs + (mpad / 16) * OZ_CHUNK);
   double* part = zscale + mpad;
   hipLaunchKernelGGL(oz_split_kernel, dim3((unsigned)cdiv(mpad, 4)), dim3(256), 0, st, Z, (long)M, mpad, 1, 0,
-                     zs, zscale, 1, (int*)nullptr, 0.0);
+                     zs, zscale, 1, oz_zflag_ptr(), 0x1p-6);
   HeadsArgs a;
   a.Z = Z; a.W[0] = a.W[1] = a.W[2] = nullptr;
   a.b[0] = bs; a.b[1] = bt; a.b[2] = bq; a.cs = cs; a.cq = cq;

@@ -38,6 +38,19 @@ namespace l2q {
 #define L2Q_LK_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
+// Timing experiments (tools/ab_build.sh ... -DL2Q_LK_EXP=bits; results are WRONG, only the clock is read):
+//   1  halo operands come from the tile's own LDS copy (no neighbour loads from L2 / HBM)
+//   2  the output is stored only where it equals a magic value (no store traffic, arithmetic kept)
+//   4  no slice refresh: the own-link prefetch and the LDS rewrite are skipped (with 1: no global loads)
+//   8  no slice barriers
+//  16  plain (write-back) stores instead of streaming ones
+//  64  planes in the order z, y, x (the staples whose operands are all in LDS first)
+//  32  the output is stored AFTER the slice refresh (the vmcnt wait for the prefetched own link then does
+//      not include the acknowledgement of this iteration's stores: vmcnt is in order on gfx9)
+#ifndef L2Q_LK_EXP
+#define L2Q_LK_EXP 0
+#endif
+
 constexpr int kLkThreads = kRS * 4;
 constexpr int kLkOffS0 = 0, kLkOffS1 = 3 * kPlaneB, kLkOffT = 6 * kPlaneB;
 constexpr int kLkLds = 7 * kPlaneB;
@@ -114,21 +127,28 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
     auto on = [&](int rho, int qb) {
       return Opnd<true>{offSn + (rho - 1) * kPlaneB + lb + qb, qb, rho * 9 * V16 + gnxt};
     };
+#if L2Q_LK_EXP & 1
+    auto gco = [&](int rho, int qb) { return oc(rho, q_sp); };
+    auto gno = [&](int rho, int qb) { return on(rho == 0 ? 1 : rho, q_sp); };
+#else
     auto gco = [&](int rho, int qb) { return Opnd<false>{0, qb, rho * 9 * V16 + gcur}; };
     auto gno = [&](int rho, int qb) { return Opnd<false>{0, qb, rho * 9 * V16 + gnxt}; };
+#endif
     // prefetch the thread's own link of the slice that enters LDS after this iteration
     double2 pre[9];
-    if (more) {
+    if (more && !(L2Q_LK_EXP & 4)) {
       const int tp = MU == 0 ? tnext : ((tnext + 1 == T) ? 0 : tnext + 1);
 #pragma unroll
       for (int e = 0; e < 9; ++e) pre[e] = buf_ld(rs, q_sp, (MU * 9 + e) * V16 + tp * Vs16);
     }
     M3 acc;
+    double2 outv[9];
     m3_zero(acc);
     if constexpr (MU == 0) {
       if (it >= c.lo) {
 #pragma unroll
-        for (int nu = 1; nu < 4; ++nu) {
+        for (int nu_ = 1; nu_ < 4; ++nu_) {
+          const int nu = (L2Q_LK_EXP & 64) ? 4 - nu_ : nu_;
           M3 a, t;
           if (it >= c.lo) {
           // up:   U_nu(s+t) U_t(s+nu)^H U_nu(s)^H
@@ -176,7 +196,8 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
       }
       if (it >= c.lo) {
 #pragma unroll
-        for (int nu = 1; nu < 4; ++nu) {
+        for (int nu_ = 1; nu_ < 4; ++nu_) {
+          const int nu = (L2Q_LK_EXP & 64) ? 4 - nu_ : nu_;
           if (nu == MU) continue;
           M3 a, t;
           if (it >= c.lo) {
@@ -241,24 +262,47 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
             const double2 o = buf_ld_nt(rv, q_sp, so + e * V16);
             v2.x += o.x; v2.y += o.y;
           }
-          buf_st_nt(ro, q_sp, so + e * V16, v2);
+          outv[e] = v2;
         }
+      if (!(L2Q_LK_EXP & 32)) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+          if (!(L2Q_LK_EXP & 2) || outv[e].x == 1.2345e300) {
+            if (L2Q_LK_EXP & 16) buf_st(ro, q_sp, so + e * V16, outv[e]);
+            else buf_st_nt(ro, q_sp, so + e * V16, outv[e]);
+          }
+      }
     }
-    __syncthreads();                                  // slice tcur consumed
-    if (more) {
+    if (!(L2Q_LK_EXP & 8)) __syncthreads();           // slice tcur consumed
+    if (more && !(L2Q_LK_EXP & 4)) {
       const int dst = (MU == 0 ? kLkOffT : offSc) + own;
 #pragma unroll
       for (int e = 0; e < 9; ++e) *reinterpret_cast<double2*>(fr_lds + dst + e * kEnt) = pre[e];
     }
+    if ((L2Q_LK_EXP & 32) && it >= c.lo) {
+      const int so = MU * 9 * V16 + gcur;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        if (L2Q_LK_EXP & 16) buf_st(ro, q_sp, so + e * V16, outv[e]);
+        else buf_st_nt(ro, q_sp, so + e * V16, outv[e]);
+      }
+    }
     cur ^= 1;
-    __syncthreads();                                  // next slice in place
+    if (!(L2Q_LK_EXP & 8)) __syncthreads();           // next slice in place
   }
 }
 
 template <int MODE, int INM>
 __global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
     const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
-    const double2* vin, double2* out, int lo) {
+    const double2* vin, double2* out, int lo, int stagger) {
+  // The two workgroups co-resident on a CU start together, do identical work and would stay in
+  // lock-step: both at their slice barriers / halo loads at the same time, both wanting the fp64
+  // pipe at the same time.  Delaying the second resident set ONCE (tuning force_stagger, units of
+  // ~2k cycles) keeps them out of phase for the rest of the launch.
+  if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
   const int per_chain = nsb * tsplit;
   const long c = w / per_chain;
@@ -305,7 +349,8 @@ static void launch_link_variant(const double2* xn, Dims d, int nb, int nsb, int 
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds);
   }
   hipLaunchKernelGGL((su3_force_link_kernel<MODE, INM>), dim3((unsigned)((long)nb * nsb * tsplit)),
-                     dim3(kLkThreads), kLkLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, vin, out, 1);
+                     dim3(kLkThreads), kLkLds, st, xn, d, nsb, tsplit, tuning().xcd_swizzle, coef, vin, out, 1,
+                     tuning().force_stagger);
 }
 
 int force_link_inmask(const Dims& d) {

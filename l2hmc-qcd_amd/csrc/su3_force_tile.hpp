@@ -102,14 +102,34 @@ struct Opnd {
   int lds, voff, soff;
 };
 
+// Row pipelining (L2Q_ROW_PIPE, default on): the next row of a streamed operand is requested BEFORE
+// the current row's 36 FMAs, so that the ~100-cycle LDS latency of a row hides behind the arithmetic of
+// the previous one instead of stalling the wavefront seven times per staple (ISA before: ds_read x3,
+// s_waitcnt, fma ... per row; PMC: the SIMDs issued 73 % of the time with two wavefronts each).
+#ifndef L2Q_ROW_PIPE
+#define L2Q_ROW_PIPE 1
+#endif
+
 // t = A * B^H (ADJ_A = false) or A^H * B^H (ADJ_A = true); B streamed by rows
 template <bool ADJ_A, bool IN, int ENT>
 __device__ __forceinline__ void mul_xh_stream(M3& t, const M3& a, const Opnd<IN, ENT>& b,
                                               __amdgpu_buffer_rsrc_t rs, int V16) {
+  R3 rows[2];
+#if L2Q_ROW_PIPE
+  ld_row<IN, ENT>(rows[0], b.lds, rs, b.voff, b.soff, V16, 0);
+#endif
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    R3 br;
+#if L2Q_ROW_PIPE
+    if (j < 2) {
+      ld_row<IN, ENT>(rows[(j + 1) & 1], b.lds, rs, b.voff, b.soff, V16, j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const R3& br = rows[j & 1];
+#else
+    R3& br = rows[0];
     ld_row<IN, ENT>(br, b.lds, rs, b.voff, b.soff, V16, j);
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       double sr = 0.0, si = 0.0;
@@ -130,10 +150,22 @@ __device__ __forceinline__ void mul_xh_stream(M3& t, const M3& a, const Opnd<IN,
 template <bool ADJ_C, bool IN, int ENT>
 __device__ __forceinline__ void mac_stream(M3& acc, const M3& t, const Opnd<IN, ENT>& c,
                                            __amdgpu_buffer_rsrc_t rs, int V16) {
+  R3 rows[2];
+#if L2Q_ROW_PIPE
+  ld_row<IN, ENT>(rows[0], c.lds, rs, c.voff, c.soff, V16, 0);
+#endif
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    R3 cr;
+#if L2Q_ROW_PIPE
+    if (q < 2) {
+      ld_row<IN, ENT>(rows[(q + 1) & 1], c.lds, rs, c.voff, c.soff, V16, q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const R3& cr = rows[q & 1];
+#else
+    R3& cr = rows[0];
     ld_row<IN, ENT>(cr, c.lds, rs, c.voff, c.soff, V16, q);
+#endif
     if (ADJ_C) {
       // acc_iq += sum_k t_ik conj(C_qk)
 #pragma unroll

@@ -452,6 +452,17 @@ def heads_sliced_build(heads: dict):
     return buf if usable.value else None
 
 
+def heads_sliced_zflag(reset: bool = True) -> int:
+    """Number of activation rows handed to the sliced heads kernel since the last reset whose mean
+    |entry| was below 2^-6 of their largest one (include/l2q.h: l2q_heads_sliced_zflag; synchronises).
+    0 with tanh networks; > 0 means the sliced products of those rows carry the absolute bound
+    2^-54 K max|z| max|w| instead of fp64's relative one -- `dyn.sliced_heads = False` selects fp64."""
+    import ctypes
+    count = ctypes.c_int(0)
+    N.call('l2q_heads_sliced_zflag', int(reset), ctypes.byref(count))
+    return int(count.value)
+
+
 def _sliced_call(z, heads, scales, v, force, eps1, forward1, pair, flip, eps2, forward2, v_src=None,
                  mid=False):
     m, k = z.shape
@@ -471,7 +482,8 @@ def _sliced_call(z, heads, scales, v, force, eps1, forward1, pair, flip, eps2, f
 
 def _use_sliced(z, heads) -> bool:
     # (the sliced kernel takes per-entry scales; a heads dict with scalar scales stays on the fp64 kernel)
-    return (USE_SLICED_HEADS[0] and heads.get('sliced') is not None and z.dtype == torch.float64
+    return (USE_SLICED_HEADS[0] and heads.get('use_sliced', True) and heads.get('sliced') is not None
+            and z.dtype == torch.float64
             and z.shape[1] == SLICED_K and heads['s'][2] is not None and heads['q'][2] is not None)
 
 

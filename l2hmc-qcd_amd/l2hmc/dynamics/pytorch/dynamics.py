@@ -572,11 +572,12 @@ class Dynamics(nn.Module):
         p = self._perms()
         w = vnet.kernel_weights(p['in'], p['out'])
         hs = w['heads_scaled']
-        if 'sliced' not in hs:
-            # int8 slice image of the head weights (csrc/heads_sliced.hip); lives in the
-            # version-keyed weight cache, so it is rebuilt whenever a parameter changes
-            hs['sliced'] = (ops.heads_sliced_build(hs)
-                            if self.sliced_heads and ops.USE_SLICED_HEADS[0] else None)
+        # int8 slice image of the head weights (csrc/heads_sliced.hip); lives in the version-keyed
+        # weight cache, so it is rebuilt whenever a parameter changes.  Both knobs are consulted on
+        # EVERY call (`use_sliced`), the image is built the first time they are both on.
+        hs['use_sliced'] = bool(self._sliced_wanted(vnet) and ops.USE_SLICED_HEADS[0])
+        if hs['use_sliced'] and 'sliced' not in hs:
+            hs['sliced'] = ops.heads_sliced_build(hs)
         zkey = ('z', id(vnet))
         if cache is not None and zkey in cache:
             return fn, cache[zkey], w
@@ -592,6 +593,17 @@ class Dynamics(nn.Module):
         if cache is not None:
             cache[zkey] = z
         return fn, z, w
+
+    def _sliced_wanted(self, vnet) -> bool:
+        """`sliced_heads`: True -> networks whose last hidden activation is BOUNDED (tanh: every row
+        of Z has |z| <= 1 and the fixed-point split of a row keeps >= 46 bits of every entry that
+        matters); 'force' -> any activation (an unbounded activation can produce a row with one
+        dominant entry, whose small entries the per-row fixed point resolves less finely than fp64:
+        error relative to K max|z| max|w| instead of sum |z||w| -- `ops.heads_sliced_zflag()` tells
+        whether such a row was seen); False -> the fp64 MFMA kernels."""
+        if self.sliced_heads == 'force':
+            return True
+        return bool(self.sliced_heads) and getattr(vnet, 'act', None) == 'tanh'
 
     def _fused_u1(self, net) -> Optional[dict]:
         """Weights in the layout of the fused U(1) sub-update kernels, or None when the fused
@@ -1420,7 +1432,8 @@ class GraphedTransition:
         params = (eps_ids, tuple(p._version for p in plist))
         masks = tuple(id(m) for m in d.masks)
         flags = (d.fuse_heads, d.fuse_x_updates, d.reuse_v_inputs, d.pair_v_updates,
-                 d.fuse_u1_steps, d.fuse_half_heads, d.merge_hmc_kicks,
+                 d.fuse_u1_steps, d.fuse_half_heads, d.merge_hmc_kicks, d.sliced_heads,
+                 ops.USE_SLICED_HEADS[0], d.pair_v_updates_verbose,
                  getattr(d, 'fuse_x_vec8', None), d.net_precision, d.config.verbose, d.training)
         return (ops.PARAM_GENERATION[0], params, masks, flags)
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     'l2q_vnet_heads_ws_bytes': (Z, [I, L]),
     'l2q_heads_sliced_bytes': (Z, [I, L]),
     'l2q_heads_sliced_build': (I, [P, P, P, I, L, P, Z, P, P]),
+    'l2q_heads_sliced_zflag': (I, [I, P, P]),
     'l2q_vnet_heads_sliced_ws_bytes': (Z, [I, L]),
     'l2q_vnet_heads_vupdate_sliced_f64': (I, [P, I, I, L, P, P, P, D, P, D, P, P, D, P, P, P, I, D, I, I, I, D,
                                               I, P, P, P, P, Z, P]),

@@ -194,10 +194,23 @@ class NativeComm:
         return flat
 
     def close(self) -> None:
-        from l2hmc import native
-        if self._comm is not None and self._comm.value:
-            native.load().l2q_comm_destroy(self._comm)
-        self._comm = None
+        comm, self._comm = getattr(self, '_comm', None), None
+        if comm is not None and comm.value:
+            from l2hmc import native
+            native.load().l2q_comm_destroy(comm)
+
+    # a communicator is a device-side resource: release it with the object / the `with` block
+    def __enter__(self) -> 'NativeComm':
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown: the library may be gone)
+            pass
 
 
 def cleanup() -> None:

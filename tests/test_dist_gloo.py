@@ -189,3 +189,103 @@ def test_experiment_two_ranks_same_model_different_chains(tmp_path):
     assert not torch.equal(r0['x'], r1['x'])                        # independent chains
     assert not torch.equal(r0['v'], r1['v']) and not (r0['np'] == r1['np']).all()
     assert not torch.equal(r0['xo'], r1['xo'])
+
+
+# --------------------------------------------------------------------------- NativeComm bootstrap
+def _fake_rccl(tmp):
+    """tests/native_host/fake_rccl.c -> a shared library with RCCL's five entry points on HOST memory"""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    so = os.path.join(tmp, 'libfake_rccl.so')
+    subprocess.run(['gcc', '-O1', '-shared', '-fPIC', '-o', so,
+                    os.path.join(ROOT, 'tests', 'native_host', 'fake_rccl.c')], check=True)
+    return so
+
+
+def _native_comm_worker(rank, world, port, out, so, mode):
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), L2Q_RCCL_LIB=so,
+                      FAKE_RCCL_DIR=out, FAKE_RCCL_TIMEOUT_S='4')
+    from l2hmc import native
+    from l2hmc.utils import dist as D
+    native.ptr = lambda t: t.data_ptr()             # host buffers: the fake library sums host memory
+    native.stream_ptr = lambda: 0
+    D.setup_torch_distributed('gloo', str(port))
+    res = {}
+    if mode == 'ok':
+        with D.NativeComm() as c:                   # id on rank 0 -> broadcast over gloo -> init on both
+            assert (c.rank, c.world_size) == (rank, world)
+            g64 = torch.arange(5, dtype=torch.float64) * (rank + 1)
+            g32 = torch.full((3,), float(rank + 1), dtype=torch.float32)
+            c.all_reduce_(g64)
+            c.all_reduce_(g32)
+            with pytest.raises(TypeError):
+                c.all_reduce_(torch.zeros(2, dtype=torch.int32))
+            res = {'g64': g64, 'g32': g32}
+        assert c._comm is None                      # released by the context manager
+        # ParamArena-style use: the flat gradient of a model, averaged like DDP
+        c2 = D.NativeComm()
+        flat = torch.full((4,), float(10 * (rank + 1)), dtype=torch.float64)
+        c2.all_reduce_(flat)
+        res['mean'] = flat / world
+        del c2                                      # __del__ destroys the communicator
+    elif mode == 'mismatch':
+        # every rank draws ITS OWN id (a bootstrap that forgot the broadcast): the rendezvous must fail
+        # with an error on both ranks -- not hang
+        import ctypes as C
+        lib = native.load()
+        ident = C.create_string_buffer(128)
+        assert lib.l2q_comm_unique_id(ident) == 0
+        import time
+        time.sleep(0.01 * rank)
+        comm = C.c_void_p()
+        rc = lib.l2q_comm_init(ident, world, rank, C.byref(comm))
+        res = {'rc': rc, 'err': lib.l2q_last_error().decode()}
+    torch.save(res, os.path.join(out, f'n{rank}.pt'))
+    D.cleanup()
+
+
+def test_native_comm_bootstrap_two_ranks(tmp_path):
+    """utils.dist.NativeComm with world_size 2 on the CPU container: the C-ABI route l2q_comm_unique_id
+    -> (broadcast of the 128 bytes over the torch.distributed group) -> l2q_comm_init ->
+    l2q_allreduce_grads -> l2q_comm_destroy, with librccl replaced by a host-memory fake
+    (L2Q_RCCL_LIB).  The first real multi-GPU run then only has RCCL itself left to discover."""
+    so = _fake_rccl(str(tmp_path))
+    port = _free_port()
+    mp.spawn(_native_comm_worker, args=(2, port, str(tmp_path), so, 'ok'), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f'n{i}.pt') for i in range(2)]
+    for k in ('g64', 'g32', 'mean'):
+        assert torch.equal(r[0][k], r[1][k]), k
+    assert torch.equal(r[0]['g64'], torch.arange(5, dtype=torch.float64) * 3)
+    assert torch.equal(r[0]['g32'], torch.full((3,), 3.0))
+    assert torch.equal(r[0]['mean'], torch.full((4,), 15.0, dtype=torch.float64))
+
+
+def test_native_comm_id_mismatch_fails_instead_of_hanging(tmp_path):
+    so = _fake_rccl(str(tmp_path))
+    port = _free_port()
+    mp.spawn(_native_comm_worker, args=(2, port, str(tmp_path), so, 'mismatch'), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f'n{i}.pt') for i in range(2)]
+    assert all(x['rc'] != 0 for x in r)
+    assert all('ncclCommInitRank' in x['err'] for x in r), [x['err'] for x in r]
+
+
+def test_rccl_resolution_failure_reports_its_reason_every_time(tmp_path):
+    """after a failed resolution every entry point re-states why (no stale message)."""
+    import subprocess
+    code = (
+        "import sys, ctypes as C; sys.path.insert(0, %r)\n"
+        "from l2hmc import native\n"
+        "lib = native.load(); buf = C.create_string_buffer(128)\n"
+        "assert lib.l2q_comm_unique_id(buf) != 0\n"
+        "e1 = lib.l2q_last_error().decode()\n"
+        "assert lib.l2q_set_tuning(b'no_such_knob', 1) != 0\n"       # another error in between
+        "assert lib.l2q_last_error().decode() != e1\n"
+        "c = C.c_void_p(); assert lib.l2q_comm_init(buf, 1, 0, C.byref(c)) != 0\n"
+        "e2 = lib.l2q_last_error().decode()\n"
+        "assert e1 == e2 and 'libdoes_not_exist' in e1, (e1, e2)\n" % os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    env = dict(os.environ, L2Q_RCCL_LIB='libdoes_not_exist.so')
+    subprocess.run([sys.executable, '-c', code], check=True, env=env)

@@ -619,10 +619,15 @@ def test_u1_half_precision_networks(hd, lat, nb, units, act, bn):
         ld = dyn._lf_n(1, xn, vn, 2.5, forward)
         dyn.fuse_half_heads = True
         dx = torch.remainder(res[hd][0] - xn + np.pi, 2 * np.pi) - np.pi
-        # (the fused epilogue uses the hardware exp / log / sin / cos: ~1e-6 per operation)
-        assert float(dx.abs().max()) < 1e-3, float(dx.abs().max())
-        assert float((res[hd][1] - vn).abs().max()) < 1e-3 * scale
-        assert float((res[hd][2] - ld).abs().max()) < 1e-3 * max(1.0, float(ld.abs().max()))
+        # (the fused epilogue uses the hardware exp / log / sin / cos: ~1e-6 per operation; and the
+        # two paths accumulate the 16-bit layers in different orders, so a pre-activation that
+        # sits on a 16-bit rounding boundary may round to the other neighbour -- one ulp_16 of one
+        # s / t / q entry, a whole chain's worth when it happens in a hidden activation.  The
+        # pin to the reference's own 16-bit results is test_u1_{fp16,bf16}_reference_golden.)
+        tol = max(1e-3, 0.5 * ulp)
+        assert float(dx.abs().max()) < tol, float(dx.abs().max())
+        assert float((res[hd][1] - vn).abs().max()) < tol * scale
+        assert float((res[hd][2] - ld).abs().max()) < tol * max(1.0, float(ld.abs().max()))
     # (iii) whole merged trajectory
     dyn.fuse_u1_steps = True
     beta = torch.tensor(2.5)
@@ -1094,13 +1099,14 @@ def test_save_load_init_weights_reversibility(group, tmp_path):
     for d_ in (a, b):
         d_._inject = {'normals': nrm, 'u': u}
         xo, m = d_((x, beta))
-        outs.append((xo.clone(), m['acc'].clone()))
+        outs.append((xo.clone(), m['acc'].clone(), m['mc_states'].proposed.x.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert abs(b._eps('x', 1) - a._eps('x', 1)) < 1e-7
     b.init_weights('xavier_uniform')
     b._inject = {'normals': nrm, 'u': u}
     xo, m = b((x, beta))
-    assert not torch.equal(xo, outs[0][0])
+    # (the PROPOSAL: x_out coincides whenever every chain rejects under both sets of weights)
+    assert not torch.equal(m['mc_states'].proposed.x, outs[0][2])
     rev = a.test_reversibility()
     if group == 'U1':
         # the reference's NCP backward x-update (dynamics.py:1430-1477) is not the exact inverse of
