@@ -338,6 +338,40 @@ def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
     return x, v, history, tape
 
 
+def trajectory_train(dyn, xn: Tensor, vn: Tensor, beta: float, forward: bool):
+    """Single-direction trajectory of `merge_directions=False` (dynamics.py:1031-1063) recording the
+    tape: nleapfrog forward (or backward) generalised leapfrog steps, no momentum flip, and the
+    accept probability with the reference's SWAPPED arguments (`compute_accept_prob(state_init=
+    state, state_prop=sinit)`, :1053-1057): dh = H(final) - H(start) + sumlogdet -- `tape.swapped`
+    tells loss_and_seeds.  Returns (x_prop, v_prop, history, tape)."""
+    if not dyn._networks_built:
+        raise RuntimeError('training needs networks (Dynamics(network_factory=...))')
+    tape = Tape()
+    nb = xn.shape[0]
+    x, v = xn, vn
+    sumlogdet = dyn._zeros_nb(nb)
+    h_init = dyn._hamiltonian_n(xn, vn, beta)
+    history: dict = {}
+    verbose = dyn.config.verbose
+    if verbose:
+        dyn.update_history(dyn._metrics_n(x, v, beta, sumlogdet, None, None), history)
+    nlf = dyn.config.nleapfrog
+    share = {} if (dyn.group == 'SU3' and getattr(dyn, 'reuse_v_inputs', True)) else None
+    for step in range(nlf):
+        x, v, ld = _lf_train(dyn, tape, step, x, v, beta, forward, share)
+        sumlogdet = sumlogdet + ld
+        if verbose:
+            dyn.update_history(dyn._metrics_n(x, v, beta, sumlogdet, step, None), history)
+    h_fin = dyn._hamiltonian_n(x, v, beta)
+    acc = dyn._accept_prob_n(h_fin, h_init, sumlogdet)
+    history.update({'acc': acc, 'sumlogdet': sumlogdet})
+    if verbose:
+        history = dyn._stack_history(history)
+    tape.h_init = h_init
+    tape.swapped = True
+    return x, v, history, tape
+
+
 # ------------------------------------------------------------------------------ loss + seeds
 def loss_and_seeds(dyn, loss_fn, xn_init: Tensor, x_prop: Tensor, v_prop: Tensor, tape: Tape,
                    sumlogdet: Tensor, beta: float):
@@ -358,6 +392,8 @@ def loss_and_seeds(dyn, loss_fn, xn_init: Tensor, x_prop: Tensor, v_prop: Tensor
     with torch.enable_grad():
         h_prop = ke_p + beta * (V - cos_p)
         dh = tape.h_init.detach() - h_prop + sld
+        if getattr(tape, 'swapped', False):            # single-direction kernel: see trajectory_train
+            dh = h_prop - tape.h_init.detach() + sld
         acc = torch.exp(torch.minimum(dh, torch.zeros_like(dh)))
         loss = loss_fn.loss_from_sums(si[:, 0], si[:, 1], cos_p, sin_p, acc)
         g_cos, g_sin, g_ke, g_sld = torch.autograd.grad(loss, [cos_p, sin_p, ke_p, sld],
@@ -393,6 +429,8 @@ def _loss_and_seeds_su3(dyn, loss_fn, xn_init, x_prop, v_prop, tape, sumlogdet, 
         if c1 != 0.0:
             h_prop = h_prop + (-beta * c1 / 3.0) * rs_p
         dh = tape.h_init.detach() - h_prop + sld
+        if getattr(tape, 'swapped', False):
+            dh = h_prop - tape.h_init.detach() + sld
         acc = torch.exp(torch.minimum(dh, torch.zeros_like(dh)))
         loss = loss_fn.loss_from_sums_su3(pl_i, pl_p, d2, acc, nelem=x_prop[0].numel())
         grads = torch.autograd.grad(loss, leaves, allow_unused=True)
@@ -602,11 +640,21 @@ def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1
     parameters' .grad (zero them first)."""
     from l2hmc.dynamics.pytorch.dynamics import _beta
     b = _beta(beta)
+    merged = bool(dyn.config.merge_directions)
+    forward = True
+    if not merged:
+        # the reference trains on what `forward` samples with: `apply_transition`, one direction per
+        # step drawn BEFORE the momenta (dynamics.py:709); tests pin it through dyn._inject['forward']
+        inj = dyn._inject.get('forward') if dyn._inject else None
+        forward = bool(torch.rand(1) > 0.5) if inj is None else bool(inj)
     xn = dyn._pack(x)
     vn = dyn._momentum_n(xn.shape[0])
     nets = _native_begin(dyn, xn.shape[0])
     try:
-        x_, v_, hist, tape = trajectory_fb_train(dyn, xn, vn, b)
+        if merged:
+            x_, v_, hist, tape = trajectory_fb_train(dyn, xn, vn, b)
+        else:
+            x_, v_, hist, tape = trajectory_train(dyn, xn, vn, b, forward)
         loss, gx, gv, gl = loss_and_seeds(dyn, loss_fn, xn, x_, v_, tape, hist['sumlogdet'], b)
         if loss_weight != 1.0:
             gx, gv, gl = gx * loss_weight, gv * loss_weight, gl * loss_weight

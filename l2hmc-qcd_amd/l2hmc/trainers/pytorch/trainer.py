@@ -190,15 +190,8 @@ class Trainer:
         dynamics/pytorch/training.py) -> data-parallel all-reduce of the flat gradient ->
         clip_grad_norm -> fused Adam.  U(1) and SU(3)."""
         from l2hmc.dynamics.pytorch import training as T
-        if not self.config.dynamics.merge_directions:
-            # the reference would train on `apply_transition` (one random direction per step with
-            # its swapped accept-probability arguments, dynamics.py:704-742, 1031-1063); the tape /
-            # reverse sweep here covers the merged forward+backward trajectory only.  Training a
-            # different transition than eval_step samples with would be silent and wrong.
-            raise NotImplementedError(
-                'train_step: dynamics.merge_directions=False is not differentiated by this build '
-                '(sampling with it works: eval_step / Dynamics.apply_transition); train with '
-                'merge_directions=True')
+        # (merge_directions=False trains on the single-direction kernel the reference's forward
+        # samples with, swapped accept arguments included: training.trajectory_train)
         gas = int(getattr(self.config, 'gradient_accumulation_steps', 1) or 1)
         if gas != 1:
             raise NotImplementedError(

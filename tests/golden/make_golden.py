@@ -51,12 +51,13 @@ def state_dict_np(mod, prefix=''):
 
 
 def build_dynamics(group, latvolume, nb, nlf, eps, units, act, conv=None, sep=False,
-                   split=False, bn=False, dropout=0.0, nw=None, verbose=True, seed=0, c1=0.0):
+                   split=False, bn=False, dropout=0.0, nw=None, verbose=True, seed=0, c1=0.0,
+                   merge=True):
     seed_all(seed)
     dc = cfgs.DynamicsConfig(nchains=nb, group=group, latvolume=list(latvolume),
                              nleapfrog=nlf, eps=eps, eps_hmc=eps, use_ncp=True,
                              verbose=verbose, use_split_xnets=split,
-                             use_separate_networks=sep, merge_directions=True)
+                             use_separate_networks=sep, merge_directions=merge)
     nc = cfgs.NetworkConfig(units=list(units), activation_fn=act, dropout_prob=dropout,
                             use_batch_norm=bn)
     cc = cfgs.ConvolutionConfig(**conv) if conv else cfgs.ConvolutionConfig()

@@ -6,6 +6,7 @@ parameters after one Adam step) from the REAL reference in train mode.
     PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py f64
     PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py f32
     PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py su3
+    PYTHONPATH=/tmp/oracle_stubs:/tmp/oracle/src python3 tests/golden/make_golden_train.py nomerge
 
 `f64`: U(1) 4x4, dense networks, float64 default dtype (tight tolerance); `f32`: U(1) 4x6 with
 the conv stack (a pooling layer), float32.  Sequence = Trainer.train_step of the reference
@@ -20,9 +21,9 @@ import torch
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 WHICH = sys.argv[1]
-if WHICH in ('f64', 'su3', 'su3c1'):
+if WHICH in ('f64', 'su3', 'su3c1', 'nomerge'):
     torch.set_default_dtype(torch.float64)
-sys.argv = [sys.argv[0], 'su3' if WHICH in ('f64', 'su3', 'su3c1') else 'u1']
+sys.argv = [sys.argv[0], 'su3' if WHICH in ('f64', 'su3', 'su3c1', 'nomerge') else 'u1']
 sys.path.insert(0, OUT)
 import make_golden as mg  # noqa: E402  (imports the reference, sets nothing else)
 import l2hmc.configs as cfgs  # noqa: E402
@@ -31,9 +32,13 @@ from l2hmc.loss.pytorch.loss import LatticeLoss  # noqa: E402
 npy = mg.npy
 
 
-def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps=0.1, lr=1e-3):
+def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps=0.1, lr=1e-3,
+               merge=True, want_forward=None):
+    """merge=False: the reference trains on `apply_transition` -- one direction, drawn with
+    torch.rand(1) before the momenta (dynamics.py:704-742), accept probability with the swapped
+    arguments of transition_kernel (:1053-1057); want_forward picks a draw seed by direction."""
     dyn, lat = mg.build_dynamics('U1', L, nb, nlf=nlf, eps=eps, units=units, act=act, conv=conv,
-                                 sep=True, split=True, bn=bn, dropout=0.0, seed=seed)
+                                 sep=True, split=True, bn=bn, dropout=0.0, seed=seed, merge=merge)
     mg.perturb(dyn, seed + 1)
     bt = torch.tensor(beta)
     mg.seed_all(seed + 2)
@@ -47,10 +52,17 @@ def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps
     dyn.train()
     loss_fn = LatticeLoss(lat, loss_cfg)
     opt = torch.optim.Adam(dyn.parameters(), lr=lr)
-    mg.seed_all(seed + 3)
-    nrm = torch.randn(nb, 2, *L)
-    u = torch.rand(nb)
-    mg.seed_all(seed + 3)
+    dseed, fwd = seed + 3, True
+    while True:
+        mg.seed_all(dseed)
+        if not merge:
+            fwd = bool(torch.rand(1) > 0.5)
+        nrm = torch.randn(nb, 2, *L)
+        u = torch.rand(nb)
+        if merge or want_forward is None or fwd == want_forward:
+            break
+        dseed += 1000
+    mg.seed_all(dseed)
     xinit = dyn.g.compat_proj(x.reshape(dyn.xshape))
     xinit.requires_grad_(True)
     opt.zero_grad()
@@ -71,6 +83,7 @@ def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps
             acc_mask=npy(m['acc_mask']), sumlogdet=npy(m['sumlogdet']), loss=npy(loss),
             lr=lr, charge_weight=loss_cfg.charge_weight, use_mixed_loss=loss_cfg.use_mixed_loss,
             units=np.array(units), activation=act, use_batch_norm=bn,
+            merge_directions=merge, forward=fwd,
             conv_filters=np.array(conv['filters'] if conv else []),
             conv_sizes=np.array(conv['sizes'] if conv else []),
             conv_pool=np.array(conv['pool'] if conv else []),
@@ -81,13 +94,13 @@ def train_case(name, L, nb, nlf, units, act, conv, beta, seed, bn, loss_cfg, eps
 
 
 def su3_train_case(name, L, nb, nlf, units, act, beta, seed, bn, loss_cfg, eps=0.006, lr=1e-3,
-                   c1=0.0):
+                   c1=0.0, merge=True):
     """SU(3): vnet only (the xnet is never called, dynamics.py:1420-1425).  Start near
     equilibrium and pick a draw whose acceptance is not saturated so that the gradient also
     flows through acc.  The reference's train_step begins with compat_proj (projectSU)."""
     from l2hmc.group.su3.pytorch import utils as U
     dyn, lat = mg.build_dynamics('SU3', L, nb, nlf=nlf, eps=eps, units=units, act=act, bn=bn,
-                                 dropout=0.0, seed=seed, c1=c1)
+                                 dropout=0.0, seed=seed, c1=c1, merge=merge)
     mg.perturb(dyn, seed + 1)
     bt = torch.tensor(beta)
     mg.seed_all(seed + 2)
@@ -110,6 +123,9 @@ def su3_train_case(name, L, nb, nlf, units, act, beta, seed, bn, loss_cfg, eps=0
             break
     sd = best[1]
     mg.seed_all(sd)
+    fwd = True
+    if not merge:
+        fwd = bool(torch.rand(1) > 0.5)
     nrm = torch.stack([torch.randn(shape) for _ in range(8)])
     u = torch.rand(nb)
     mg.seed_all(sd)
@@ -134,6 +150,7 @@ def su3_train_case(name, L, nb, nlf, units, act, beta, seed, bn, loss_cfg, eps=0
             charge_weight=loss_cfg.charge_weight, plaq_weight=loss_cfg.plaq_weight,
             rmse_weight=loss_cfg.rmse_weight, use_mixed_loss=loss_cfg.use_mixed_loss,
             units=np.array(units), activation=act, use_batch_norm=bn, c1=c1,
+            merge_directions=merge, forward=fwd,
             # the SU(3) xnet is never called: no gradient, no update -- not stored
             **{'sd.' + k: a for k, a in sd0.items() if 'xnet' not in k},
             **{'sd1.' + k: a for k, a in sd1.items() if 'xnet' not in k},
@@ -155,6 +172,16 @@ if __name__ == '__main__':
                        loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.05,
                                                 rmse_weight=0.1, plaq_weight=0.1),
                        eps=0.004, c1=-0.331)
+    elif WHICH == 'nomerge':
+        lc = cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.01)
+        train_case('u1_train_nomerge_fwd', (4, 4), 5, 2, [8, 6], 'leaky_relu', None, beta=2.0, seed=500,
+                   bn=True, loss_cfg=lc, merge=False, want_forward=True)
+        train_case('u1_train_nomerge_bwd', (4, 6), 5, 3, [8], 'tanh', None, beta=3.0, seed=520,
+                   bn=False, loss_cfg=cfgs.LossConfig(use_mixed_loss=False, charge_weight=0.5),
+                   merge=False, want_forward=False)
+        su3_train_case('su3_train_nomerge', (2, 3, 2, 4), 3, 2, [6], 'tanh', beta=6.0, seed=540, bn=False,
+                       loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.05,
+                                                rmse_weight=0.1, plaq_weight=0.1), merge=False)
     elif WHICH == 'f64':
         train_case('u1_train_f64', (4, 4), 6, 2, [8, 6], 'leaky_relu', None, beta=2.0, seed=300,
                    bn=True, loss_cfg=cfgs.LossConfig(use_mixed_loss=True, charge_weight=0.01))

@@ -193,9 +193,10 @@ def build_u1_train_dynamics(g, dropout=0.0):
     L = [int(i) for i in g['latvolume']]
     nb = int(g['x'].shape[0])
     nlf = int(g['nleapfrog'])
+    merge = bool(g['merge_directions']) if 'merge_directions' in g else True
     dc = cfgs.DynamicsConfig(nchains=nb, group='U1', latvolume=L, nleapfrog=nlf, eps=0.1,
                              eps_hmc=0.1, use_ncp=True, verbose=False, use_split_xnets=True,
-                             use_separate_networks=True, merge_directions=True)
+                             use_separate_networks=True, merge_directions=merge)
     kw = u1_net_kwargs(g)
     nc = cfgs.NetworkConfig(units=[int(i) for i in g['units']], activation_fn=kw['activation'],
                             dropout_prob=dropout, use_batch_norm=kw['use_batch_norm'])
@@ -226,6 +227,8 @@ def check_train_step(g, dyn, loss_fn, rtol, atol_rel, adam_min_grad=0.0):
     arena = T.ParamArena(dyn)
     arena.zero_grad()
     dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    if 'forward' in g and not bool(g['merge_directions']):
+        dyn._inject['forward'] = bool(g['forward'])          # the direction draw of apply_transition
     x = torch.from_numpy(g['x'])
     beta = torch.tensor(float(g['beta']))
     xin = dyn.g.compat_proj(dyn.unflatten(x.to(dyn.device)))
@@ -291,9 +294,10 @@ def build_su3_train_dynamics(g):
     L = [int(i) for i in g['latvolume']]
     nb = int(g['x'].shape[0])
     nlf = int(g['nleapfrog'])
+    merge = bool(g['merge_directions']) if 'merge_directions' in g else True
     dc = cfgs.DynamicsConfig(nchains=nb, group='SU3', latvolume=L, nleapfrog=nlf, eps=0.006,
                              eps_hmc=0.006, verbose=False, use_split_xnets=False,
-                             use_separate_networks=False, merge_directions=True)
+                             use_separate_networks=False, merge_directions=merge)
     nc = cfgs.NetworkConfig(units=[int(i) for i in g['units']], activation_fn=str(g['activation']),
                             dropout_prob=0.0, use_batch_norm=bool(g['use_batch_norm']))
     V = int(np.prod(L))
