@@ -292,8 +292,11 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
   }
 }
 
+#ifndef L2Q_LK_OCC
+#define L2Q_LK_OCC 2
+#endif
 template <int MODE, int INM>
-__global__ __launch_bounds__(kLkThreads, 2) void su3_force_link_kernel(
+__global__ __launch_bounds__(kLkThreads, L2Q_LK_OCC) void su3_force_link_kernel(
     const double2* __restrict__ xn, Dims d, int nsb, int tsplit, int swz, double coef,
     const double2* vin, double2* out, int lo, int stagger) {
   // The two workgroups co-resident on a CU start together, do identical work and would stay in

@@ -45,5 +45,12 @@ for _ in range(3):
     ops.vnet_heads_vupdate_(z, sl, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True)
     ops.vnet_heads_vupdate_pair_(z, sl, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True, False, 0.01, True)
     ops.su3_expm_mul2_n(xn, vn, 0.01, mask, False)
+# the two-x-plane force kernel (su3_force_pair.hip, tuning force_tile = 6), for its own traffic counters
+if os.environ.get('L2Q_KPROF_PAIR', '1') == '1':
+    native.set_tuning('force_tile', 6)
+    for _ in range(3):
+        native.call('l2q_su3_force', xn, 6.0, f, nb, *L)
+        native.call('l2q_su3_force_kick', xn, 6.0, -0.005, vn, nb, *L)
+    native.set_tuning('force_tile', 5)
 torch.cuda.synchronize()
 print('kprof done')
