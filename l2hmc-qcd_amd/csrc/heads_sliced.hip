@@ -35,6 +35,9 @@
 // the Horner chain and, after the third chunk of a tile, the same epilogue as the fp64 kernel
 // (heads_common.hpp).  The RG = M / 64 workgroups that need the same chunks run on ONE XCD (hardware
 // block b -> XCD b % 8) and share its L2: W is read once from HBM (PMC: 1.005 x algorithmic).
+// (Round 4: the eight per-column epilogue parameters through one 1 KB LDS-DMA piece per tile instead of
+// eight 8-byte loads per update wavefront -- 32 fewer registers, 0 spills also in the MID variants, but 3 %
+// SLOWER on one box (profiles/r04h_heads_ab.txt: 0.957 vs 0.930 ms): the loads were L1 hits; reverted.)
 // (First version: 256-thread workgroups of four symmetric wavefronts, two per CU: 40-140 spilled
 // VGPRs -- the A fragments, the fp64 constants of the epilogue and its operands do not fit one
 // wavefront's 256 registers, and scratch traffic shares vmcnt with the LDS-DMA.)
@@ -142,33 +145,11 @@ static int* oz_zflag_ptr() {
   return cache[dev];
 }
 
-// The eight per-column parameters of the epilogue, interleaved (64 B per output entry, the columns past N
-// repeat the last one): one 1 KB LDS-DMA piece per 16-column tile brings them to all four update
-// wavefronts, instead of eight 8-byte loads per wavefront and tile (their issue was 27 % of the update
-// wavefronts' time, and the 32 registers of the two operand sets spilled the MID variants).
-__global__ __launch_bounds__(256) void oz_pack_colp_kernel(long N, long Npad, const double* __restrict__ bs,
-                                                            const double* __restrict__ bt,
-                                                            const double* __restrict__ bq,
-                                                            const double* __restrict__ cs,
-                                                            const double* __restrict__ cq,
-                                                            const double* __restrict__ wscale,
-                                                            double* __restrict__ out) {
-  const long n = blockIdx.x * 256L + threadIdx.x;
-  if (n >= Npad) return;
-  const long c = n < N ? n : N - 1;
-  double2* o = reinterpret_cast<double2*>(out + n * 8);
-  o[0] = make_double2(bs[c], bt[c]);
-  o[1] = make_double2(bq[c], cs[c]);
-  o[2] = make_double2(cq[c], wscale[c]);
-  o[3] = make_double2(wscale[N + c], wscale[2 * N + c]);
-}
-
 struct SlicedArgs {
   const char* Zs;          // [Mpad / 16] chunks
   const double* zscale;    // [Mpad]
   const char* Wsl;         // [ceil(N / 16)][3] chunks
   const double* wscale;    // [3][N]
-  const double* colp;      // [ceil(N / 16) * 16][8]: b_s, b_t, b_q, c_s, c_q, wscale_s, wscale_t, wscale_q per column
   int ncw;                 // column workers = partial columns per chain
   int tiles_per_cw;
   int rg;                  // row groups of 64 chains
@@ -242,9 +223,8 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 template <bool CPLX, bool FWD, bool PAIR, bool MID>
 __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, SlicedArgs o) {
   constexpr int RING = OZ_NS * OZ_FRAG;                       // 7 KB: one wavefront's group sums of a chunk
-  __shared__ __attribute__((aligned(1024))) char lds[3 * OZ_CHUNK + 2 * 4 * RING + 2 * 1024];   // 142 KB
+  __shared__ __attribute__((aligned(1024))) char lds[3 * OZ_CHUNK + 2 * 4 * RING];           // 140 KB
   char* const ring = lds + 3 * OZ_CHUNK;
-  char* const pbuf = ring + 2 * 4 * RING;                     // two tiles' column parameters
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // hardware block b runs on XCD b % 8: the RG row groups of one column worker share an XCD
@@ -413,22 +393,19 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
   };
   struct Operands {
     double2 vv[4], ff[4];
+    double b0, b1, b2, pcs, pcq, w0, w1, w2;
   };
   // rows past M re-read the last valid chain, columns past N the last valid entry (never stored)
   long rowoff[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) rowoff[r] = ((mrow + r) < a.M ? (mrow + r) : (long)a.M - 1) * (long)a.N;
-  // tile t's column parameters -> pbuf[slot]: this wavefront's quarter (16 lanes x 16 B) of the 1 KB piece
-  auto fetch_colp = [&](long t, int slot) {
-    if (lane < 16) {
-      const char* src = reinterpret_cast<const char*>(o.colp) + t * 1024 + p * 256 + lane * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (lds_ptr_t)(pbuf + slot * 1024 + p * 256), 16, 0, 0);
-    }
-  };
   auto fetch = [&](long t, Operands& q) {
     const long n = t * 16 + (lane & 15);
     const long nc = n < a.N ? n : (long)a.N - 1;
+    q.b0 = a.b[0][nc]; q.b1 = a.b[1][nc]; q.b2 = a.b[2][nc];
+    q.pcs = a.cs[nc];
+    q.pcq = a.cq[nc];
+    q.w0 = o.wscale[nc]; q.w1 = o.wscale[(long)a.N + nc]; q.w2 = o.wscale[2 * (long)a.N + nc];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long oo = rowoff[r] + nc;
@@ -448,18 +425,16 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
   double es_[4], eq_[4], es2_[4], eq2_[4], s_[4], q_[4], t_[4];
   const double eps = a.eps, heps = 0.5 * a.eps, h2 = 0.5 * a.eps2;
   const bool same2 = PAIR && a.eps2 == a.eps && a.fwd2 == (int)FWD;
-  auto stage_a = [&](int slot, const double (&fs)[4], const double (&ft)[4], const double (&fq)[4]) {
-    const double2* cp = reinterpret_cast<const double2*>(pbuf + slot * 1024 + (lane & 15) * 64);
-    const double2 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];   // (b_s, b_t) (b_q, c_s) (c_q, w_s) (w_t, w_q)
+  auto stage_a = [&](const Operands& q, const double (&fs)[4], const double (&ft)[4], const double (&fq)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double zs = fma(fs[r], c2.y, c0.x);
-      const double zt = fma(ft[r], c3.x, c0.y);
-      const double zq = fma(fq[r], c3.y, c1.x);
+      const double zs = fma(fs[r], q.w0, q.b0);
+      const double zt = fma(ft[r], q.w1, q.b1);
+      const double zq = fma(fq[r], q.w2, q.b2);
       if (L2Q_SL_SKIP & 1) { s_[r] = zs; q_[r] = zq; t_[r] = zt; continue; }
-      s_[r] = c1.y * tanh_bf(zs);
+      s_[r] = q.pcs * tanh_bf(zs);
       t_[r] = a.st * zt;
-      q_[r] = c2.x * tanh_bf(zq);
+      q_[r] = q.pcq * tanh_bf(zq);
     }
   };
   // exp of the step-size-scaled arguments: when every lane's |x| < 0.34 (k = rint(x log2 e) = 0) the
@@ -583,16 +558,15 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
 #endif
   // period k = between B(k) and B(k + 1): [stores of the previous tile] DMA(k + 2), the Horner chain of
   // chunk k - 1, one stage of the epilogue.  The barrier that ends a period waits for its DMA with the
-  // vmcnt that leaves exactly the younger requests outstanding: the 8 operand loads of `fetch` in the
-  // first period of a tile (the column-parameter piece is issued BEFORE them), nothing otherwise (a tile's stores are issued BEFORE the next period's DMA).
+  // vmcnt that leaves exactly the younger requests outstanding: the 16 operand loads of `fetch` in the
+  // first period of a tile, nothing otherwise (a tile's stores are issued BEFORE the next period's DMA).
   double fs[4], ft[4], fq[4], gs[4], gt[4];
   double2 outv[4];
   if (ntl > 0) {
     issue(0, 0);
     issue(1, 0);
-    fetch_colp(t0, 0);
     fetch(t0, cur);
-    L2Q_SL_CBAR(8);                                    // B(0)
+    L2Q_SL_CBAR(16);                                   // B(0)
     issue(2, L2Q_SL_NPD);
     L2Q_SL_CBAR(0);                                    // B(1): chunk 0 is in the ring
     issue(3, L2Q_SL_NPD);
@@ -606,10 +580,10 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
       L2Q_SL_CBAR(0);                                  // B(3u + 3)
       L2Q_SL_T(prof_mem, if (u > 0) store(t - 1, outv); issue(3 * u + 5, L2Q_SL_NPD));
       L2Q_SL_T(prof_conv, conv(3 * u + 2, fq));
-      L2Q_SL_T(prof_mem, fetch_colp(more ? t + 1 : t, (int)((u + 1) & 1)); fetch(more ? t + 1 : t, nxt));
-      stage_a((int)(u & 1), fs, ft, fq);
+      L2Q_SL_T(prof_mem, fetch(more ? t + 1 : t, nxt));
+      stage_a(cur, fs, ft, fq);
       if (more) {
-        L2Q_SL_CBAR(8);                                // B(3u + 4)
+        L2Q_SL_CBAR(16);                               // B(3u + 4)
         L2Q_SL_T(prof_mem, issue(3 * u + 6, L2Q_SL_NPD));
         L2Q_SL_T(prof_conv, conv(3 * u + 3, gs));
       }
@@ -726,9 +700,7 @@ int l2q_heads_sliced_zflag(int reset, int* count, void* stream) {
 size_t l2q_vnet_heads_sliced_ws_bytes(int M, long N) {
   if (M <= 0 || N <= 0) return 0;
   const size_t mpad = (size_t)sliced_rg(M) * 64;
-  const size_t npad = (size_t)cdiv(N, 16) * 16;
-  return (mpad / 16) * OZ_CHUNK + mpad * sizeof(double) + (size_t)M * sliced_ncw(M) * 3 * sizeof(double) + 512 +
-         npad * 8 * sizeof(double) + 256;
+  return (mpad / 16) * OZ_CHUNK + mpad * sizeof(double) + (size_t)M * sliced_ncw(M) * 3 * sizeof(double) + 512;
 }
 
 int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, const void* sliced,
@@ -756,10 +728,6 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
   char* zs = (char*)ws;
   double* zscale = (double*)(zs + (mpad / 16) * OZ_CHUNK);
   double* part = zscale + mpad;
-  const long npad = cdiv(N, 16) * 16;
-  double* colp = (double*)(((uintptr_t)(part + (size_t)M * ncw * 3) + 255) & ~(uintptr_t)255);
-  hipLaunchKernelGGL(oz_pack_colp_kernel, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, st, N, npad, bs, bt, bq,
-                     cs, cq, (const double*)((const char*)sliced + sliced_scale_off(N)), colp);
   hipLaunchKernelGGL(oz_split_kernel, dim3((unsigned)cdiv(mpad, 4)), dim3(256), 0, st, Z, (long)M, mpad, 1, 0,
                      zs, zscale, 1, oz_zflag_ptr(), 0x1p-6);
   HeadsArgs a;
@@ -773,7 +741,6 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
   SlicedArgs o;
   o.Zs = zs; o.zscale = zscale; o.Wsl = (const char*)sliced;
   o.wscale = (const double*)((const char*)sliced + sliced_scale_off(N));
-  o.colp = colp;
   o.ncw = ncw; o.rg = rg; o.dbg = nullptr;
 #if L2Q_SL_PROF
   static long long* dbg = nullptr;
