@@ -77,6 +77,8 @@ def parse():
     ap.add_argument('--no-comm-probe', action='store_true')
     ap.add_argument('--no-u1', action='store_true', help='skip the untimed U(1) cfg-2 / cfg-3 block')
     ap.add_argument('--cpu-chains', type=int, default=32)
+    ap.add_argument('--fp64-input-layer', action='store_true',
+                    help='A/B: the vnet input layer on the fp64 MFMA kernel instead of the int8-sliced one')
     return ap.parse_args()
 
 
@@ -126,6 +128,8 @@ def build(args, seed):
     nf = NetworkFactory(spec, nc, cfgs.ConvolutionConfig(),
                         cfgs.NetWeights(x=cfgs.NetWeight(0., 1., 1.), v=cfgs.NetWeight(1., 1., 1.)))
     dyn = Dynamics(lat.action, dc, nf if args.mode == 'l2hmc' else None)
+    if args.fp64_input_layer:
+        dyn.sliced_input = False
     dyn.eval()
     return dyn, lat
 
@@ -183,6 +187,8 @@ class KernelTimer:
             orig(name, *a)
             e1.record()
             fl = 2.0 * a[2] * a[3] * (a[4] + a[7]) if name in ('l2q_gemm_f64', 'l2q_gemm_f32') else 0.0
+            if name == 'l2q_gemm_sliced_f64':      # (A, image, K, e, A2, image2, K2, e2, M, N, ...)
+                fl = 2.0 * a[8] * a[9] * (a[2] + a[6])
             timer.records.append((name, fl, e0, e1))
         native.call = timed_call
         import l2hmc._ops as ops
@@ -274,7 +280,43 @@ def spot_check(dyn, lat, x, args):
     assert ok, f'spot check against the oracle failed: {out}'
     if args.mode == 'l2hmc':
         out['heads'] = heads_check(dyn, x4, args)
+        out['input_layer'] = input_check(dyn, x4, args)
     return out
+
+
+def input_check(dyn, x4, args):
+    """The vnet's input layer on the inputs of the timed run (su3_to_vec(projectSU(x)), su3_to_vec(projectSU(
+    force))) through the int8-sliced kernel (csrc/gemm_sliced.hip) and through the fp64 MFMA kernel
+    (untimed): their difference, and for chains 0 / 1 and the first 32 hidden units the distance of each
+    from a long-double evaluation on the host.  `sliced` says which one the timed trajectories ran."""
+    from l2hmc import _ops as ops
+    nb = args.nchains
+    xn = ops.su3_pack(x4)
+    vnet = dyn._get_vnet(0)
+    fn, _, w = dyn._v_inputs_n(vnet, xn, torch.tensor(args.beta), None)
+    res = {'sliced': bool(w is not None and w.get('input_img') is not None and ops.USE_SLICED_INPUT[0]
+                          and dyn.sliced_input)}
+    if not res['sliced']:
+        return res
+    xv = ops.su3_projsu_vec8_n(xn).reshape(nb, -1)
+    fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
+    za = vnet.hidden_flat(xv, fv, dict(w, hidden=[]), sliced_exp=ops.SLICED_INPUT_EXP)
+    try:
+        ops.USE_SLICED_INPUT[0] = False
+        zb = vnet.hidden_flat(xv, fv, dict(w, hidden=[]), sliced_exp=ops.SLICED_INPUT_EXP)
+    finally:
+        ops.USE_SLICED_INPUT[0] = True
+    res['max_abs_diff'] = float((za - zb).abs().max())
+    res['input_abs_max'] = float(max(xv.abs().max(), fv.abs().max()))
+    LD, rows, cols = np.longdouble, [0, min(1, nb - 1)], slice(0, 32)
+    ld = lambda t: t.detach().cpu().numpy().astype(LD)
+    pre = (ld(xv[rows]) @ ld(w['wx'][cols]).T + ld(fv[rows]) @ ld(w['wv'][cols]).T
+           + ld(w['bx'][cols]) + ld(w['bv'][cols]))
+    if vnet.act == 'tanh':
+        want = np.tanh(pre)
+        for name, got in (('sliced', za), ('fp64_mfma', zb)):
+            res[f'{name}_vs_long_double'] = float(np.abs(ld(got[rows][:, cols]) - want).max())
+    return res
 
 
 def heads_check(dyn, x4, args):
@@ -820,6 +862,17 @@ def main():
                               'slice GEMMs, + v-update)', per * ks[nm][0])
                 tops = 28 * per * ks[nm][0] / ks[nm][1] / 1e12
                 r['int8'] = {'ops_per_launch': 28 * per, 'achieved': round(tops, 1),
+                             'peak': INT8_MFMA_PEAK_TOPS, 'unit': 'TOP/s',
+                             'frac': round(tops / INT8_MFMA_PEAK_TOPS, 4)}
+                rooflines.append(r)
+            if 'l2q_gemm_sliced_f64' in ks:
+                # the vnet's input layer the same way (csrc/gemm_sliced.hip: 28 int8 slice products per
+                # fp64 product, the activations sliced on the fly)
+                nm = 'l2q_gemm_sliced_f64'
+                r = mfma_roof([nm], 'l2q_gemm_sliced_f64 (input layer, fp64 products from 28 int8 slice '
+                              'GEMMs)', ks[nm][2])
+                tops = 28 * ks[nm][2] / ks[nm][1] / 1e12
+                r['int8'] = {'ops_per_launch': 28 * ks[nm][2] / ks[nm][0], 'achieved': round(tops, 1),
                              'peak': INT8_MFMA_PEAK_TOPS, 'unit': 'TOP/s',
                              'frac': round(tops / INT8_MFMA_PEAK_TOPS, 4)}
                 rooflines.append(r)

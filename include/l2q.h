@@ -213,6 +213,25 @@ int l2q_gemm_f64(const double* A, const double* W, int M, int N, long K, const d
                  const double* coeff, double scale, int act, double* C, void* ws,
                  size_t ws_bytes, void* stream);
 size_t l2q_gemm_ws_bytes(int M, int N, long K, long K2);
+/* The same layer (fp64 operands and result) with the products rebuilt from exact int8 x int8 -> int32 digit
+ * products on v_mfma_i32_16x16x64_i8 (csrc/gemm_sliced.hip) -- for the input layer of the
+ * SU(3) vnet, whose K = 64 V runs to 2 x 131 072 at 8^4 (network/pytorch/network.py:430-451, xlayer + vlayer).
+ * l2q_gemm_sliced_build turns one weight matrix W [N][K] into its digit image (l2q_gemm_sliced_bytes(N, K)
+ * bytes, 256-byte aligned: 7 int8 planes in MFMA fragment order + one power-of-two scale per output row;
+ * rebuild when W changes; *usable = 0 for a non-finite entry; the call synchronises the stream).
+ * l2q_gemm_sliced_f64 slices the activations ON THE FLY against ONE exponent per operand: every entry of A must
+ * satisfy |a| < 2^a_exp (A2: a2_exp) -- the vnet inputs su3_to_vec(projectSU(.)) do with a_exp = 2 --; a value
+ * outside the range or a NaN turns the whole output into NaN (as a NaN operand would).  Needs M, N multiples of
+ * 64 and K, K2 multiples of 64.  Results agree with l2q_gemm_f64 to the accumulation error of that kernel
+ * (not bit for bit).  A2 / image2 may be NULL (K2 = 0). */
+size_t l2q_gemm_sliced_bytes(int N, long K);
+int l2q_gemm_sliced_build(const double* W, int N, long K, void* image, size_t image_bytes, int* usable,
+                          void* stream);
+size_t l2q_gemm_sliced_ws_bytes(int M, int N, long K, long K2);
+int l2q_gemm_sliced_f64(const double* A, const void* image, long K, int a_exp, const double* A2,
+                        const void* image2, long K2, int a2_exp, int M, int N, const double* bias,
+                        const double* bias2, const double* coeff, double scale, int act, double* C, void* ws,
+                        size_t ws_bytes, void* stream);
 /* The three output heads of a LeapfrogLayer AND the generalised momentum update in one kernel
  * (network.py:547-551 + dynamics.py:1266-1297): for chain m, entry n
  *   s = cs[n] tanh(Z.Ws[n] + bs[n]);  t = scale_t (Z.Wt[n] + bt[n]);  q = cq[n] tanh(Z.Wq[n] + bq[n])

@@ -1118,6 +1118,8 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
   } else if (!strncmp(entry, "l2q_vnet_heads_vupdate", 22)) {
     // (for shapes with whole 16-wide K-slabs, which every SU(3) vnet has)
     snprintf(buf, buf_bytes, "%s", t.heads_dma ? "fused_heads_dma_kernel" : "fused_heads_vupdate_kernel");
+  } else if (!strcmp(entry, "l2q_gemm_sliced_f64")) {
+    snprintf(buf, buf_bytes, "gemm_sliced_kernel");
   } else if (!strcmp(entry, "l2q_gemm_f64")) {
     snprintf(buf, buf_bytes, "%s", t.heads_dma ? "gemm_dma_f64_kernel" : "gemm_nt_kernel");
   }

@@ -314,6 +314,56 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+# int8-sliced fp64 input layer (csrc/gemm_sliced.hip): [True] = use the digit images when the network
+# offers them (LeapfrogLayer.kernel_weights builds them for fp64 SU(3) vnets whose shapes qualify)
+USE_SLICED_INPUT = [True]
+SLICED_INPUT_EXP = 2          # |su3_to_vec(projectSU(.))| < 2.31 < 2^2 for every entry of the vnet inputs
+
+
+def gemm_sliced_ok(m: int, n: int, k: int, k2: int = 0) -> bool:
+    """Shapes csrc/gemm_sliced.hip serves."""
+    return m > 0 and m % 64 == 0 and n % 64 == 0 and k > 0 and k % 64 == 0 and k2 % 64 == 0
+
+
+def gemm_sliced_pays(m: int, n: int, k: int, k2: int = 0) -> bool:
+    """Shapes at which the int8-sliced layer is faster than the fp64 MFMA layer (measured at n = 256,
+    tools/sweep_gemm_sliced.py, profiles/r04_gemm_sliced_sweep.txt): m (k + k2) >= 2^24, e.g. 256 chains
+    with k + k2 >= 65 536 (the 8^4 lattice has 262 144); below it the fixed 64 x 64 tiles leave CUs idle."""
+    return gemm_sliced_ok(m, n, k, k2) and m * n * (k + k2) >= 1 << 32
+
+
+def gemm_sliced_build(w: torch.Tensor):
+    """Digit image of one fp64 weight matrix [n, k] (include/l2q.h: l2q_gemm_sliced_build); None when
+    the matrix does not qualify (dtype, shape, non-finite entry)."""
+    import ctypes
+    n, k = w.shape
+    if w.dtype != torch.float64 or not w.is_cuda or n % 64 or k % 64:
+        return None
+    nbytes = int(N.load().l2q_gemm_sliced_bytes(n, k))
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    usable = ctypes.c_int(0)
+    N.call('l2q_gemm_sliced_build', w.contiguous(), n, k, buf, nbytes, ctypes.byref(usable))
+    return buf if usable.value else None
+
+
+def gemm_sliced(a: torch.Tensor, image: torch.Tensor, n: int, bias: Optional[torch.Tensor] = None, *,
+                a_exp: int = SLICED_INPUT_EXP, a2: Optional[torch.Tensor] = None,
+                image2: Optional[torch.Tensor] = None, a2_exp: int = SLICED_INPUT_EXP,
+                bias2: Optional[torch.Tensor] = None, coeff: Optional[torch.Tensor] = None,
+                scale: float = 1.0, act: Optional[str] = None) -> torch.Tensor:
+    """epi(a @ W.T (+ a2 @ W2.T) + bias (+ bias2)) with W / W2 given as digit images and the fp64
+    activations sliced on the fly: every |a| must be < 2^a_exp (else the output is NaN)."""
+    m, k = a.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    if a.dtype != torch.float64 or not gemm_sliced_ok(m, n, k, k2) or (a2 is not None and image2 is None):
+        raise N.L2QError(f'gemm_sliced: a{tuple(a.shape)} n {n} k2 {k2} {a.dtype}')
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    ws = N.workspace(int(N.load().l2q_gemm_sliced_ws_bytes(m, n, k, k2)), a.device)
+    N.call('l2q_gemm_sliced_f64', a, image, k, int(a_exp), a2, image2, k2, int(a2_exp), m, n, bias, bias2,
+           coeff, float(scale), N.ACT[act], out, ws, ws.numel())
+    return out
+
+
 def gemm_ex(a: torch.Tensor, w: torch.Tensor, a_trans: bool = False, w_trans: bool = False,
             out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """C (+)= Aop @ Wop^T without transposed copies (include/l2q.h: l2q_gemm_ex).  a: [m, k], or

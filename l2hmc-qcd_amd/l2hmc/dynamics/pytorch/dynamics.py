@@ -236,6 +236,9 @@ class Dynamics(nn.Module):
         # fp64 heads with K = 256 outside the training tape: products rebuilt from exact int8 slice
         # products on the int8 matrix cores (csrc/heads_sliced.hip; same values to fp64 rounding)
         self.sliced_heads = True
+        # fp64 input layer of the SU(3) vnet on the int8 matrix cores (csrc/gemm_sliced.hip): its inputs
+        # su3_to_vec(projectSU(.)) are bounded by 2.31 entry-wise, which the kernel checks (NaN otherwise)
+        self.sliced_input = True
 
     # ------------------------------------------------------------------ construction
     def set_net_precision(self, precision) -> None:
@@ -589,7 +592,7 @@ class Dynamics(nn.Module):
             fv = ops.su3_projsu_vec8_n(fn).reshape(nb, -1)
             if cache is not None:
                 cache['xv'], cache['fv'] = xv, fv
-        z = vnet.hidden_flat(xv, fv, w)
+        z = vnet.hidden_flat(xv, fv, w, sliced_exp=ops.SLICED_INPUT_EXP if self.sliced_input else None)
         if cache is not None:
             cache[zkey] = z
         return fn, z, w
@@ -1433,7 +1436,7 @@ class GraphedTransition:
         masks = tuple(id(m) for m in d.masks)
         flags = (d.fuse_heads, d.fuse_x_updates, d.reuse_v_inputs, d.pair_v_updates,
                  d.fuse_u1_steps, d.fuse_half_heads, d.merge_hmc_kicks, d.sliced_heads,
-                 ops.USE_SLICED_HEADS[0], d.pair_v_updates_verbose,
+                 ops.USE_SLICED_HEADS[0], d.sliced_input, ops.USE_SLICED_INPUT[0], d.pair_v_updates_verbose,
                  getattr(d, 'fuse_x_vec8', None), d.net_precision, d.config.verbose, d.training)
         return (ops.PARAM_GENERATION[0], params, masks, flags)
 

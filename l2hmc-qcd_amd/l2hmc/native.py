@@ -58,6 +58,10 @@ SIGNATURES = {
     'l2q_scale_f64': (I, [P, D, P, L, P]),
     'l2q_gemm_f64': (I, [P, P, I, I, L, P, P, L, P, P, P, D, I, P, P, Z, P]),
     'l2q_gemm_ws_bytes': (Z, [I, I, L, L]),
+    'l2q_gemm_sliced_bytes': (Z, [I, L]),
+    'l2q_gemm_sliced_build': (I, [P, I, L, P, Z, P, P]),
+    'l2q_gemm_sliced_ws_bytes': (Z, [I, I, L, L]),
+    'l2q_gemm_sliced_f64': (I, [P, P, L, I, P, P, L, I, I, I, P, P, P, D, I, P, P, Z, P]),
     'l2q_vnet_heads_vupdate_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, I, D, I, P, P, Z, P]),
     'l2q_vnet_heads_vupdate_to_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, P, I, D, I, P, P, Z, P]),
     'l2q_vnet_heads_vupdate_pair_f64': (I, [P, I, I, L, P, P, P, D, P, P, D, P, P, P, D, P, P, I, D, I, I, D, I, P, P, Z, P]),

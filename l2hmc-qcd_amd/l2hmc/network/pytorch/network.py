@@ -651,12 +651,33 @@ class LeapfrogLayer(nn.Module):
             z = ops.gemm_h(z, hw, hb, act=self.act)
         return z
 
-    def hidden_flat(self, x: Tensor, v: Tensor, w: dict) -> Tensor:
-        """z = last hidden activation [nb, units[-1]] (input layer + hidden layers)."""
+    def hidden_flat(self, x: Tensor, v: Tensor, w: dict, sliced_exp: Optional[int] = None) -> Tensor:
+        """z = last hidden activation [nb, units[-1]] (input layer + hidden layers).
+
+        sliced_exp = e: the caller guarantees |x|, |v| < 2^e entry-wise (the SU(3) vnet inputs
+        su3_to_vec(projectSU(.)) with e = 2), which lets the fp64 input layer run on the int8 matrix
+        cores (csrc/gemm_sliced.hip) when its shapes qualify; the digit images of xlayer / vlayer live in
+        the version-keyed weight cache `w` and are rebuilt whenever a parameter changes."""
         self._check_mode()
         if getattr(self, 'half_dtype', None) is not None:
             raise NotImplementedError('hidden_flat feeds the fp64 fused heads kernel (SU(3))')
-        z = ops.gemm(x, w['wx'], w['bx'], a2=v, w2=w['wv'], bias2=w['bv'], act=self.act)
+        z = None
+        if sliced_exp is not None and ops.USE_SLICED_INPUT[0] and x.dtype == torch.float64 and \
+                ops.gemm_sliced_pays(x.shape[0], w['wx'].shape[0], x.shape[1], v.shape[1]):
+            if 'input_img' not in w:
+                # the images take 7/8 of the weights' bytes again (2 x 235 MB per vnet at cfg-4, 2 x 3.8 GB
+                # at 16^4): built only while that leaves most of the free memory alone
+                need = 2 * (w['wx'].numel() + w['wv'].numel()) * 8
+                ix = iv = None
+                if not x.is_cuda or torch.cuda.mem_get_info(x.device)[0] > 4 * need:
+                    ix, iv = ops.gemm_sliced_build(w['wx']), ops.gemm_sliced_build(w['wv'])
+                w['input_img'] = (ix, iv) if ix is not None and iv is not None else None
+            if w['input_img'] is not None:
+                z = ops.gemm_sliced(x, w['input_img'][0], w['wx'].shape[0], w['bx'], a_exp=sliced_exp,
+                                    a2=v, image2=w['input_img'][1], a2_exp=sliced_exp, bias2=w['bv'],
+                                    act=self.act)
+        if z is None:
+            z = ops.gemm(x, w['wx'], w['bx'], a2=v, w2=w['wv'], bias2=w['bv'], act=self.act)
         for hw, hb in w['hidden']:
             z = ops.gemm(z, hw, hb, act=self.act)
         return z

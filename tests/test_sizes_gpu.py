@@ -226,18 +226,25 @@ def test_cfg4_trajectory_8x4_256chains():
     from l2hmc import _ops as ops
     vn = dyn._get_vnet(0)
     pm = dyn._perms()
+    # (heads on the int8 cores, input layer on the int8 cores): both are the default at this shape; the
+    # fp64 MFMA kernels behind the switches give the same trajectory to rounding
     for verbose in (False, True):
-        for sliced in (True, False):
+        for sliced, sliced_in in ((True, True), (False, True), (True, False)):
             dyn.config.verbose = verbose
             try:
                 ops.USE_SLICED_HEADS[0] = sliced
+                ops.USE_SLICED_INPUT[0] = sliced_in
                 dyn._inject = {'normals': nrm, 'u': u}
                 xo, m = dyn((x, torch.tensor(beta)))
             finally:
                 ops.USE_SLICED_HEADS[0] = True
+                ops.USE_SLICED_INPUT[0] = True
+            kw = vn.kernel_weights(pm['in'], pm['out'])
             if sliced:
-                assert vn.kernel_weights(pm['in'], pm['out'])['heads_scaled'].get('sliced') is not None
-            tag = (verbose, sliced)
+                assert kw['heads_scaled'].get('sliced') is not None
+            if sliced_in:
+                assert kw.get('input_img') is not None            # csrc/gemm_sliced.hip ran
+            tag = (verbose, sliced, sliced_in)
             assert torch.equal(m['acc_mask'].cpu(), want_mask), tag                  # bit-exact
             assert _maxdiff_tiled(m['acc'], dev(mo['acc'])) < 1e-5, tag
             assert _maxdiff_tiled(xo, dev(xo_ref.reshape(2, -1))) < 1e-7, tag

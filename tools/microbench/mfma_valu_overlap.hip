@@ -52,6 +52,48 @@ __global__ __launch_bounds__(512) void k(double* out, int it_m, int it_v, int mo
         for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc[i], a, b);
       }
       for (int i = 0; i < 16; ++i) res += acc[i];
+    } else if (FLAV == 3) {
+      // the fp64 -> balanced base-256 digit conversion of csrc/gemm_sliced.hip (10 instructions per value)
+      double x[16];
+      unsigned accu = 0;
+      unsigned long long bad = 0;
+      for (int i = 0; i < 16; ++i) x[i] = i * 0.01 + threadIdx.x * 1e-4;
+      const double sc = 4503599627370496.0, M24 = 113336795588871485128704.0, M52 = 6755399441055744.0;
+      for (int it = 0; it < it_v; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          bad |= __builtin_amdgcn_fcmp(fabs(x[i]), 4.0, 11);
+          const double t1 = fma(x[i], sc, M24);
+          const double r = fma(x[i], sc, M24 - t1);
+          const double t2 = r + M52;
+          const int H = (int)(unsigned)__double_as_longlong(t1);
+          const int L = (int)(unsigned)__double_as_longlong(t2);
+          const int Lb = L + 0x00808080;
+          const unsigned lo = (unsigned)Lb ^ 0x00808080u;
+          const unsigned hi = ((unsigned)H + (unsigned)(Lb >> 24) + 0x80808080u) ^ 0x80808080u;
+          accu += lo ^ hi;
+          asm volatile("" : "+v"(x[i]));
+        }
+      }
+      res = accu + (double)bad;
+    } else if (FLAV == 4) {
+      unsigned acc[16];
+      for (int i = 0; i < 16; ++i) acc[i] = i;
+      unsigned a = 3 + threadIdx.x;
+      for (int it = 0; it < it_v; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_perm(acc[i], a, 0x05010400u);
+      }
+      for (int i = 0; i < 16; ++i) res += acc[i];
+    } else if (FLAV == 5) {
+      double acc[16];
+      for (int i = 0; i < 16; ++i) acc[i] = i;
+      double a = 1.0 + threadIdx.x * 1e-9;
+      for (int it = 0; it < it_v; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = acc[i] + a;
+      }
+      for (int i = 0; i < 16; ++i) res += acc[i];
     } else {
       unsigned acc[16];
       for (int i = 0; i < 16; ++i) acc[i] = i;
@@ -103,5 +145,8 @@ int main() {
   run<0, true>("fp64 fma", out, it_m, 8000);
   run<1, true>("fp32 fma", out, it_m, 16000);
   run<2, true>("int mad", out, it_m, 16000);
+  run<3, true>("convert", out, it_m, 1600);
+  run<4, true>("v_perm", out, it_m, 16000);
+  run<5, true>("fp64 add", out, it_m, 8000);
   return 0;
 }
