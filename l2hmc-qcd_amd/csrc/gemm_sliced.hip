@@ -50,6 +50,9 @@ typedef int gs_v4i __attribute__((ext_vector_type(4)));
 typedef unsigned gs_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* gs_lds_ptr_t;
 
+#ifndef L2Q_GS_EXP
+#define L2Q_GS_EXP 0
+#endif
 constexpr int GS_NS = 7;                       // int8 digits per value
 constexpr int GS_BITS = 54;                    // fixed-point bits below the operand's exponent
 constexpr int GS_FRAG = 1024;                  // one MFMA operand fragment: 64 lanes x 16 bytes
@@ -81,6 +84,19 @@ __device__ __forceinline__ int gs_slice16_impl(Get get, double sc, double lim, g
     int Lb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) xj[i] = get(j0 + i);
+#if defined(L2Q_GS_EXP) && (L2Q_GS_EXP & 1)
+    // timing experiment: no conversion arithmetic (the raw bits go through the transposes)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[j0 + i] = (unsigned)__double_as_longlong(xj[i]) ^ 0x00808080u;       // (an instruction reads the loaded register)
+      hi[j0 + i] = (unsigned)(__double_as_longlong(xj[i]) >> 32) ^ 0x80808080u;
+    }
+    if (PIN)
+      asm volatile("" : "+v"(lo[j0]), "+v"(hi[j0]), "+v"(lo[j0 + 1]), "+v"(hi[j0 + 1]), "+v"(lo[j0 + 2]), "+v"(hi[j0 + 2]),
+                   "+v"(lo[j0 + 3]), "+v"(hi[j0 + 3]));
+    hook(j0 + 3);
+    continue;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) t1[i] = fma(xj[i], sc, M24);
 #pragma unroll
@@ -198,9 +214,6 @@ __global__ __launch_bounds__(256) void gs_build_kernel(const double* __restrict_
 // loaded bits instead of digits (no slicing arithmetic), 2 one MFMA per digit pair instead of four,
 // 4 no weight LDS-DMA after the prologue, 8 no activation loads after the prologue, 64 print the shader
 // clock measured over the kernel
-#ifndef L2Q_GS_EXP
-#define L2Q_GS_EXP 0
-#endif
 
 struct GsArgs {
   const double* A[2];       // activations [M][K]
@@ -460,15 +473,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sliced_kernel(GsArgs a, int swz) 
       load1(ld[f], asrc + 8 * f);
       __builtin_amdgcn_sched_barrier(0);
     };
-    if (L2Q_GS_EXP & 1) {
-#pragma unroll
-      for (int s = 0; s < GS_NS; ++s) out[s] = (gs_v4u){(unsigned)__double_as_longlong(get(2 * s)), (unsigned)__double_as_longlong(get(2 * s + 1)), 0u, 1u};
-      (void)get(14);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) hook(j);
-    } else {
-      bad |= gs_slice16_impl<true>(get, sc, lim, out, hook);
-    }
+    bad |= gs_slice16_impl<true>(get, sc, lim, out, hook);
     char* dst = lds + (q & 1) * GS_OPER + h * (GS_NS * GS_FRAG) + (hr + 16 * hg) * 16;
 #pragma unroll
     for (int s = 0; s < GS_NS; ++s) *reinterpret_cast<gs_v4u*>(dst + s * GS_FRAG) = out[s];
