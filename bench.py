@@ -537,6 +537,25 @@ def secondary_u1(steps=3):
             dt = (time.perf_counter() - t0) / steps
             native.call, ops.N.call = orig_native, orig_ops
             assert bool(torch.isfinite(x).all())
+            # the same trajectory replayed from a HIP graph (Dynamics.make_graphed; VERDICT r03 item 7: the
+            # dense cfg-2 block is launch-bound in eager mode)
+            try:
+                gr = dyn.make_graphed(x, beta=float(beta))
+                xo, _ = gr(x)
+                x = dyn.g.compat_proj(xo.reshape(x.shape))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    xo, mg = gr(x)
+                    x = dyn.g.compat_proj(xo.reshape(x.shape))
+                torch.cuda.synchronize()
+                dtg = (time.perf_counter() - t0) / steps
+                assert bool(torch.isfinite(x).all())
+                graphed = {'ms_per_trajectory': round(dtg * 1e3, 3), 'value': round(nb * 2 * nlf / dtg, 1),
+                           'accept_prob_mean': round(float(mg['acc'].mean()), 4)}
+                gr = None
+            except Exception as e:  # noqa: BLE001
+                graphed = f'failed: {type(e).__name__}: {e}'[:200]
             agg = {}
             for name, fl, e0, e1, by in recs:
                 d = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -570,7 +589,7 @@ def secondary_u1(steps=3):
                         'value': round(nb * 2 * nlf / dt, 1), 'unit': 'chain*leapfrog-steps/s',
                         'steps': steps, 'accept_prob_mean': round(float(m['acc'].mean()), 4),
                         'kernel_time_fraction_of_wall': round(tot / (dt * steps), 4),
-                        'dominant_kernel': dom, 'kernels': top}
+                        'dominant_kernel': dom, 'kernels': top, 'hip_graph': graphed}
         except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
             import traceback
             out[tag] = f'failed: {type(e).__name__}: {e} | ' + traceback.format_exc()[-400:]

@@ -177,3 +177,17 @@ def test_sliced_heads_waits_are_sound():
     spec.loader.exec_module(mod)
     n, bad, report = mod.check(mod.isa())
     assert n == 12 and bad == 0, report
+
+
+def test_gemm_sliced_isa_discipline():
+    """csrc/gemm_sliced.hip issues its activation loads and LDS reads as asm with hand-placed waits; the ISA
+    must keep the loads in place (8 register tuples, refilled where they were read, never copied), read a
+    loaded register only behind its vmcnt wait, and issue every MFMA behind the lgkmcnt wait of its
+    fragments (tools/check_gemm_sliced_isa.py; hipcc cross-compiles without a GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_gemm_sliced_isa',
+                                                  os.path.join(ROOT, 'tools', 'check_gemm_sliced_isa.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, report = mod.check(mod.isa())
+    assert bad == 0, report

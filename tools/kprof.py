@@ -32,6 +32,11 @@ fv = torch.randn(nb, K, dtype=torch.float64, device='cuda')
 wx = torch.randn(h, K, dtype=torch.float64, device='cuda') / K ** 0.5
 wv = torch.randn(h, K, dtype=torch.float64, device='cuda') / K ** 0.5
 bx = torch.randn(h, dtype=torch.float64, device='cuda')
+# the int8-sliced input layer (csrc/gemm_sliced.hip): inputs bounded like su3_to_vec(projectSU(.)) (< 4)
+img = None
+if ops.gemm_sliced_pays(nb, h, K, K):
+    img = (ops.gemm_sliced_build(wx), ops.gemm_sliced_build(wv))
+    xvb, fvb = xv.clamp(-3.9, 3.9), fv.clamp(-3.9, 3.9)
 for _ in range(3):
     ops.su3_plaq_sums_n(xn, L)
     native.call('l2q_su3_force_kick', xn, 6.0, -0.005, vn, nb, *L)
@@ -40,6 +45,8 @@ for _ in range(3):
     ops.su3_expm_mul_n(xn, vn, 0.01)
     ops.su3_projsu_vec8_n(xn)
     ops.gemm(xv, wx, bx, a2=fv, w2=wv, bias2=bx, act='tanh')
+    if img is not None:
+        ops.gemm_sliced(xvb, img[0], h, bx, a2=fvb, image2=img[1], bias2=bx, act='tanh')
     ops.vnet_heads_vupdate_(z, heads, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True)
     ops.vnet_heads_vupdate_pair_(z, heads, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True, False, 0.01, True)
     ops.vnet_heads_vupdate_(z, sl, (1., 1., 1.), vn.reshape(nb, -1), f.reshape(nb, -1), 0.01, True)

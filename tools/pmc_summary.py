@@ -26,6 +26,7 @@ ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'fused_heads_dma_kernel<true, true, false, false>': 'l2q_vnet_heads_vupdate_f64',
     'gemm_dma_f64_kernel<false, false, false>': 'l2q_gemm_f64',
     'heads_sliced_kernel<true, true, true, false>': 'l2q_vnet_heads_vupdate_sliced_f64',
+    'gemm_sliced_kernel': 'l2q_gemm_sliced_f64',
     'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_expm_mul_kernel<true, false>': 'l2q_su3_expm_mul2',
     'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
 }
