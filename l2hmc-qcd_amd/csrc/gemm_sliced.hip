@@ -292,7 +292,12 @@ __global__ __launch_bounds__(512, 1) void gemm_sliced_kernel(GsArgs a, int swz) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) racc[t][r] = 0.0;
     }
-    const char* abase = lds + (2 * wm) * (GS_NS * GS_FRAG) + lane * 16;
+    // The activation fragments are XOR-swizzled in LDS: piece (row r, k-chunk g) of a fragment sits in slot
+    // 16 g + (r ^ 2 g) instead of 16 g + r.  A helper's ds_write_b128 (8 consecutive lanes = 2 rows x 4 chunks)
+    // then covers all 32 banks once instead of hitting four of them 4 times (PMC before: half of the LDS-active
+    // cycles of the kernel were bank conflicts), and the matrix wavefronts' ds_read_b128 lane groups stay
+    // conflict-free (both checked by enumeration over the bank model of MI355X_MICROARCH.md).
+    const char* abase = lds + (2 * wm) * (GS_NS * GS_FRAG) + ((lane & 48) | ((lane & 15) ^ ((lane >> 4) * 2))) * 16;
     const char* bbase = lds + 2 * GS_OPER + (2 * wn) * (GS_NS * GS_FRAG) + lane * 16;
     int p3 = 0;                                                // p % 3
     // The weight digits come in by LDS-DMA, issued by the MATRIX wavefronts (the helpers are the longer path:
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sliced_kernel(GsArgs a, int swz) 
       __builtin_amdgcn_sched_barrier(0);
     };
     bad |= gs_slice16_impl<true>(get, sc, lim, out, hook);
-    char* dst = lds + (q & 1) * GS_OPER + h * (GS_NS * GS_FRAG) + (hr + 16 * hg) * 16;
+    char* dst = lds + (q & 1) * GS_OPER + h * (GS_NS * GS_FRAG) + ((hr ^ (2 * hg)) + 16 * hg) * 16;   // (swizzled, see abase)
 #pragma unroll
     for (int s = 0; s < GS_NS; ++s) *reinterpret_cast<gs_v4u*>(dst + s * GS_FRAG) = out[s];
   };
