@@ -648,6 +648,19 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef L2Q_SWZ
 #define L2Q_SWZ(r) (((r) >> 1) & 7)
 #endif
+// Qualifier of the fragment reads of the LDS-DMA kernels.  Plain loads are merged by the compiler into
+// ds_read2st64_b64, whose lane groups and 32-bank model differ from ds_read_b64's (MI355X_MICROARCH.md, LDS
+// table): rows r and r ^ 1 of the swizzle above then share a bank -- PMC: 47-50 % of the LDS-active cycles of
+// these kernels are bank conflicts.  `volatile` keeps them single ds_read_b64 (conflict-free, 2 cycles each).
+// Measured (tools/gpu_job_lds.sh, same box, two rounds): input layer 0.649 -> 0.643 ms, heads pair 1.335 -> 1.318 ms:
+// the LDS was not what these kernels wait for, the conflict-free form is simply never slower.
+#ifndef L2Q_LDS_Q
+#define L2Q_LDS_Q volatile
+#endif
+template <typename T>
+__device__ __forceinline__ T lds_frag(const char* p) {
+  return *(const L2Q_LDS_Q __attribute__((address_space(3))) T*)(const __attribute__((address_space(3))) char*)p;
+}
 
 // MID (pair kernels): per-step metrics need the state BETWEEN the two updates -- the kernel also
 // returns the first update's log-Jacobian and sum |v|^2 of the intermediate momentum (per-row
@@ -722,13 +735,13 @@ __global__ __launch_bounds__(kBlock, 2) void fused_heads_dma_kernel(HeadsArgs a,
     for (int kq = 0; kq < 4; ++kq) {
       double fa[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const double*>(sb + offA[kq] + i * 16 * ROWB);
+      for (int i = 0; i < 2; ++i) fa[i] = lds_frag<double>(sb + offA[kq] + i * 16 * ROWB);
 #pragma unroll
       for (int h = 0; h < 3; ++h) {
         double fb[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          fb[j] = *reinterpret_cast<const double*>(sb + offB[kq] + (h * BN + j * 16) * ROWB);
+          fb[j] = lds_frag<double>(sb + offB[kq] + (h * BN + j * 16) * ROWB);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -968,8 +981,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_dma_f64_kernel(
       T fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const T*>(sb + offA[kq] + i * stepA);
-        fb[i] = *reinterpret_cast<const T*>(sb + offB[kq] + i * stepB);
+        fa[i] = lds_frag<T>(sb + offA[kq] + i * stepA);
+        fb[i] = lds_frag<T>(sb + offB[kq] + i * stepB);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
