@@ -547,11 +547,14 @@ static inline size_t gs_image_bytes(int N, long K) {
 }
 static inline size_t gs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// k per group: about 512 workgroups in all (two rounds of one per CU), at least 4096 k (64 slabs: the
+// k per group: about 256 workgroups in all (one round of one per CU), at least 4096 k (64 slabs: the
 // prologue and the partial-sum traffic stay small), at most 64 int32 ranges
 static long gs_pick_klen(int M, int N, long K, long K2) {
   const long tiles = (long)(M / GS_T) * (N / GS_T);
-  long klen = cdiv(cdiv((K + K2) * tiles, 512), 1024) * 1024;
+#ifndef L2Q_GS_TARGET
+#define L2Q_GS_TARGET 256      // (A/B at cfg-4, same box: 256 -> 0.450 ms, 512 -> 0.454-0.464, 1024 -> 0.471-0.476)
+#endif
+  long klen = cdiv(cdiv((K + K2) * tiles, L2Q_GS_TARGET), 1024) * 1024;
   if (klen < 4096) klen = 4096;
   if (klen > 64L * GS_RANGE) klen = 64L * GS_RANGE;
   return klen;
