@@ -245,9 +245,18 @@ __device__ __forceinline__ void m3_expm(M3& out, const M3& ain) {
   // coefficients of A^n / n!  on {I, A, A^2}
   double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0, cr = 0.5, ci = 0.0;   // n = 2: A^2/2
   double f0r = 1.0, f0i = 0.0, f1r = 1.0, f1i = 0.0, f2r = 0.5, f2i = 0.0;
+  // 1 / (n + 1) from a table of correctly rounded constants (scalar loads): written as a division the rolled
+  // loop carries an IEEE fp64 division sequence per step (13 of its ~45 instructions), and fully unrolled the
+  // kernels that inline this go from 158 to 168 VGPRs and spill
+#ifndef L2Q_EXPM_DIV
+#define L2Q_EXPM_DIV 0
+#endif
+  static constexpr double kInv[22] = {
+      1.0 / 1, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11,
+      1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22};
 #pragma unroll 1
   for (int n = 2; n < 22; ++n) {
-    const double inv = 1.0 / (double)(n + 1);
+    const double inv = L2Q_EXPM_DIV ? 1.0 / (double)(n + 1) : kInv[n];
     double xr, xi, yr, yi, zr, zi;
     cmul(xr, xi, cr, ci, p0r, p0i);                  // c p0
     cmul(yr, yi, cr, ci, p1r, p1i);                  // c p1

@@ -47,14 +47,24 @@ __device__ __forceinline__ void m3_expm_frechet(M3& E, M3& L, const M3& B, const
   m3_zero(L);
   m3_identity(P);
   m3_zero(M);
-  double f = 1.0;
+  // 1 / n! by the same successive divisions as before, evaluated at compile time (a rolled loop cannot fold
+  // `f /= n` and pays an IEEE fp64 division sequence per step)
+  struct InvFact {
+    double v[14];
+    constexpr InvFact() : v{} {
+      double f = 1.0;
+      v[0] = 1.0;
+      for (int n = 1; n <= 13; ++n) { f /= (double)n; v[n] = f; }
+    }
+  };
+  static constexpr InvFact kF{};
 #pragma unroll 1
   for (int n = 1; n <= 13; ++n) {
     // M <- M X + P Gs and P <- P X, row by row IN PLACE: row i of either result depends on row i
     // of M and P only, so a three-entry temporary replaces a full scratch matrix (six live
     // matrices instead of seven: what takes the reverse x-update kernel from one to two
     // wavefronts per SIMD)
-    f /= (double)n;
+    const double f = kF.v[n];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       double tr[3], ti[3];

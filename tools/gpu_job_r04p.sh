@@ -1,0 +1,19 @@
+#!/usr/bin/env bash
+set -u
+cd "$(dirname "$0")/.."
+o=gpurun_out/r04p; mkdir -p $o
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -q -m gpu -x > $o/t_all.log 2>&1; echo "all rc=$?" | tee -a $o/summary.txt
+python bench.py --no-cpu-baseline --no-u1 --no-comm-probe > $o/bench_l2hmc.json 2> $o/bench.err; echo "bench rc=$?" | tee -a $o/summary.txt
+python bench.py --mode train --no-u1 --no-cpu-baseline --no-spot-check --no-comm-probe > $o/bench_train.json 2> $o/bench_train.err; echo "train rc=$?" | tee -a $o/summary.txt
+python bench.py --mode hmc --no-u1 --no-cpu-baseline --no-comm-probe > $o/bench_hmc.json 2> $o/bench_hmc.err
+tail -4 $o/t_all.log
+python - $o <<'PY'
+import json, sys
+o = sys.argv[1]
+for f in ('bench_l2hmc', 'bench_train', 'bench_hmc'):
+    d = json.loads(open(f'{o}/{f}.json').readline())
+    print(f, d['value'], d['ms_per_step'])
+    for k, v in list(d['kernels'].items())[:8]:
+        print('   ', k, v)
+PY
