@@ -13,6 +13,10 @@
 
 namespace l2q {
 
+#ifndef L2Q_EXPB_STASH
+#define L2Q_EXPB_STASH 1
+#endif
+
 // ------------------------------------------------------------------ x half-update (expm) VJP
 // forward (l2q_su3_expm_mul): x' = keep (.) x + expm(eps v) @ ((1 - keep) (.) x)
 //   g_x = keep (.) g + (1 - keep) (.) (E^H g);   g_E = g y^H,  y = (1 - keep) (.) x
@@ -22,6 +26,15 @@ __global__ __launch_bounds__(kBlock, 2) void su3_expm_mul_bwd_kernel(
     const float* __restrict__ mask, int complement, const double2* __restrict__ gxn, double2* gx,
     double2* gv, int V, long nblk, double* __restrict__ partial) {
   __shared__ double lds[4];
+#if L2Q_EXPB_STASH
+  // g and v are needed before AND after the Frechet derivative and cannot stay in registers across it: each
+  // thread parks its copies in its own LDS slots (entry-major: conflict-free 16-byte accesses, no barrier --
+  // nobody else touches them) instead of fetching them a second time (the in-flight working set of an XCD,
+  // ~7 MB, does not fit its 4 MB L2: the second fetch went to the fabric).  72 KiB: two workgroups per CU.
+  extern __shared__ __attribute__((aligned(16))) double2 stash[];
+  double2* sg = stash + threadIdx.x;
+  double2* sv = stash + 9 * kBlock + threadIdx.x;
+#endif
   const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;     // f = chain*4 + mu
   const int s = (int)blk * kBlock + threadIdx.x;
   const int mu = (int)(f & 3);
@@ -43,6 +56,10 @@ __global__ __launch_bounds__(kBlock, 2) void su3_expm_mul_bwd_kernel(
       M3 x, g;
       load_link(x, xn + f * 9L * V, V, s);
       load_link(g, gxn + f * 9L * V, V, s);
+#if L2Q_EXPB_STASH
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sg[i * kBlock] = make_double2(g.re[i], g.im[i]);
+#endif
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const double k1 = 1.0 - keep_of(i);
@@ -53,6 +70,10 @@ __global__ __launch_bounds__(kBlock, 2) void su3_expm_mul_bwd_kernel(
     {
       M3 v;
       load_link(v, vn + f * 9L * V, V, s);
+#if L2Q_EXPB_STASH
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sv[i * kBlock] = make_double2(v.re[i], v.im[i]);
+#endif
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -61,10 +82,19 @@ __global__ __launch_bounds__(kBlock, 2) void su3_expm_mul_bwd_kernel(
         }
     }
     M3 EB, gA;
+#ifdef L2Q_FRECHET_SERIES
+    m3_expm_frechet_series(EB, gA, B, gE);             // (A/B build: the matrix-valued Taylor recursion)
+#else
     m3_expm_frechet(EB, gA, B, gE);                    // EB = expm(eps v)^H
+#endif
     {
       M3 g, gy;
+#if L2Q_EXPB_STASH
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { const double2 d = sg[i * kBlock]; g.re[i] = d.x; g.im[i] = d.y; }
+#else
       load_link(g, gxn + f * 9L * V, V, s);
+#endif
       m3_mul_nn(gy, EB, g);                              // E^H g
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
@@ -76,7 +106,12 @@ __global__ __launch_bounds__(kBlock, 2) void su3_expm_mul_bwd_kernel(
     }
     {
       M3 v;
+#if L2Q_EXPB_STASH
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { const double2 d = sv[i * kBlock]; v.re[i] = d.x; v.im[i] = d.y; }
+#else
       load_link(v, vn + f * 9L * V, V, s);
+#endif
       de = m3_inner(gA, v);
     }
     double2* gvf = gv + f * 9L * V;
@@ -270,7 +305,12 @@ int l2q_su3_expm_mul_bwd(const void* xn, const void* vn, double eps, const float
   const long nblk = cdiv(V, kBlock);
   L2Q_REQUIRE(ws_bytes >= (size_t)nb * 4 * nblk * sizeof(double), L2Q_EINVAL, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(su3_expm_mul_bwd_kernel, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock), 0, st,
+  const size_t stash_bytes = L2Q_EXPB_STASH ? 2 * 9 * kBlock * sizeof(double2) : 0;
+  static PerDeviceOnce attr_once;
+  if (L2Q_EXPB_STASH && attr_once.first())
+    (void)hipFuncSetAttribute((const void*)su3_expm_mul_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)stash_bytes);
+  hipLaunchKernelGGL(su3_expm_mul_bwd_kernel, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock), stash_bytes, st,
                      (const double2*)xn, (const double2*)vn, eps, mask_n, complement,
                      (const double2*)gxnew, (double2*)gx, (double2*)gv, (int)V, nblk, (double*)ws);
   launch_finalize((const double*)ws, deps, nb, 4 * nblk, 1, 1.0, 0.0, st);

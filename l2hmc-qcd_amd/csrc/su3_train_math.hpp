@@ -5,6 +5,12 @@
 
 namespace l2q {
 
+#ifdef __HIP_DEVICE_COMPILE__
+__device__ __forceinline__ bool l2q_wave_any(bool p) { return __any(p) != 0; }
+#else
+__device__ __forceinline__ bool l2q_wave_any(bool p) { return p; }      // host pass / host test build
+#endif
+
 __device__ __forceinline__ void m3_adjoint(M3& r, const M3& a) {
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -20,10 +26,128 @@ __device__ __forceinline__ double m3_inner(const M3& a, const M3& b) {
   return s;
 }
 
-// E = exp(B) and L = L_exp(B)[G] (Frechet derivative of the exponential at B in direction G):
+// E = exp(B) and L = L_exp(B)[G] (Frechet derivative of the exponential at B in direction G) through the
+// Cayley-Hamilton form the forward kernel uses (m3_expm): with X = B / 2^s, |X|_F < 0.25,
+//   exp(X) = f0 I + f1 X + f2 X^2,   f_i analytic in the invariants p2 = tr X, p1 = (p2^2 - tr X^2) / 2, p0 = det X,
+//   L_exp(X)[G] = df0 I + df1 X + df2 X^2 + f1 G + f2 (X G + G X),
+//   dp2 = tr G,  dp1 = p2 tr G - tr(X G),  dp0 = tr(adj(X) G) = tr(X^2 G) - p2 tr(X G) + p1 tr G,
+// where (df0, df1, df2) is the tangent of the scalar recursion A^(n+1)/(n+1)! = [c p0, a - c p1, b + c p2] / (n+1)
+// carried next to its state: three 3x3 products and 12 scalar steps instead of the 13 x 3 products of the
+// matrix-valued Taylor recursion below (4.2k -> 1.5k fp64 FMAs per link before the squarings), and four
+// live matrices instead of six.  Squarings: L <- E L + L E, E <- E E.  Valid for any complex 3x3 B.
+__device__ __forceinline__ void m3_expm_frechet(M3& E, M3& L, const M3& B, const M3& G) {
+  double n2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) n2 += B.re[i] * B.re[i] + B.im[i] * B.im[i];
+  const double nrm = sqrt(n2);
+  int s = 0;
+  double scale = 1.0;
+  if (nrm > 0.25) {
+    int ex;
+    (void)frexp(nrm, &ex);
+    s = ex + 2;                                      // nrm / 2^s in [0.125, 0.25)
+    if (s > 60) s = 60;
+    scale = ldexp(1.0, -s);
+  }
+  M3 X, Gs, X2;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    X.re[i] = B.re[i] * scale; X.im[i] = B.im[i] * scale;
+    Gs.re[i] = G.re[i] * scale; Gs.im[i] = G.im[i] * scale;
+  }
+  m3_mul_nn(X2, X, X);
+  const double p2r = X.re[0] + X.re[4] + X.re[8], p2i = X.im[0] + X.im[4] + X.im[8];
+  const double t2r = X2.re[0] + X2.re[4] + X2.re[8], t2i = X2.im[0] + X2.im[4] + X2.im[8];
+  double sqr, sqi;
+  cmul(sqr, sqi, p2r, p2i, p2r, p2i);
+  const double p1r = 0.5 * (sqr - t2r), p1i = 0.5 * (sqi - t2i);
+  double p0r, p0i;
+  m3_det(p0r, p0i, X);
+  // tr G, tr(X G), tr(X^2 G)
+  const double g0r = Gs.re[0] + Gs.re[4] + Gs.re[8], g0i = Gs.im[0] + Gs.im[4] + Gs.im[8];
+  double g1r = 0.0, g1i = 0.0, g2r = 0.0, g2i = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e = 3 * i + j, et = 3 * j + i;
+      g1r = fma(X.re[e], Gs.re[et], g1r); g1r = fma(-X.im[e], Gs.im[et], g1r);
+      g1i = fma(X.re[e], Gs.im[et], g1i); g1i = fma(X.im[e], Gs.re[et], g1i);
+      g2r = fma(X2.re[e], Gs.re[et], g2r); g2r = fma(-X2.im[e], Gs.im[et], g2r);
+      g2i = fma(X2.re[e], Gs.im[et], g2i); g2i = fma(X2.im[e], Gs.re[et], g2i);
+    }
+  double xr, xi, yr, yi, zr, zi;
+  const double q2r = g0r, q2i = g0i;                                   // dp2
+  cmul(xr, xi, p2r, p2i, g0r, g0i);
+  const double q1r = xr - g1r, q1i = xi - g1i;                         // dp1
+  cmul(yr, yi, p2r, p2i, g1r, g1i);
+  cmul(zr, zi, p1r, p1i, g0r, g0i);
+  const double q0r = g2r - yr + zr, q0i = g2i - yi + zi;               // dp0
+  // state (a, b, c) = coefficients of X^n / n! on {I, X, X^2}, tangent (da, db, dc); n = 2: X^2 / 2
+  double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0, cr = 0.5, ci = 0.0;
+  double dar = 0.0, dai = 0.0, dbr = 0.0, dbi = 0.0, dcr = 0.0, dci = 0.0;
+  double f0r = 1.0, f0i = 0.0, f1r = 1.0, f1i = 0.0, f2r = 0.5, f2i = 0.0;
+  double d0r = 0.0, d0i = 0.0, d1r = 0.0, d1i = 0.0, d2r = 0.0, d2i = 0.0;
+  // 0.25^n / n! < 3e-18 from n = 13 on; the tangent term of order n is ~ 0.25^(n-1) / (n-1)!: terms up to n = 14
+  static constexpr double kInvN[16] = {1.0 / 1, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8,
+                                       1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16};
+#pragma unroll 1
+  for (int n = 2; n < 14; ++n) {
+    const double inv = kInvN[n];                                       // 1 / (n + 1)
+    double ur, ui, vr, vi, wr, wi;
+    // tangent first (it reads the old state)
+    cmul(xr, xi, dcr, dci, p0r, p0i); cmul(ur, ui, cr, ci, q0r, q0i);
+    cmul(yr, yi, dcr, dci, p1r, p1i); cmul(vr, vi, cr, ci, q1r, q1i);
+    cmul(zr, zi, dcr, dci, p2r, p2i); cmul(wr, wi, cr, ci, q2r, q2i);
+    const double ndar = (xr + ur) * inv, ndai = (xi + ui) * inv;
+    const double ndbr = (dar - yr - vr) * inv, ndbi = (dai - yi - vi) * inv;
+    const double ndcr = (dbr + zr + wr) * inv, ndci = (dbi + zi + wi) * inv;
+    cmul(xr, xi, cr, ci, p0r, p0i);
+    cmul(yr, yi, cr, ci, p1r, p1i);
+    cmul(zr, zi, cr, ci, p2r, p2i);
+    const double nar = xr * inv, nai = xi * inv;
+    const double nbr = (ar - yr) * inv, nbi = (ai - yi) * inv;
+    const double ncr = (br + zr) * inv, nci = (bi + zi) * inv;
+    ar = nar; ai = nai; br = nbr; bi = nbi; cr = ncr; ci = nci;
+    dar = ndar; dai = ndai; dbr = ndbr; dbi = ndbi; dcr = ndcr; dci = ndci;
+    f0r += ar; f0i += ai; f1r += br; f1i += bi; f2r += cr; f2i += ci;
+    d0r += dar; d0i += dai; d1r += dbr; d1i += dbi; d2r += dcr; d2i += dci;
+  }
+  M3 T;
+  m3_mul_nn(T, X, Gs);
+  m3_mac_nn(T, Gs, X);                                                 // X G + G X
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    cmul(xr, xi, f1r, f1i, X.re[i], X.im[i]);
+    cmul(yr, yi, f2r, f2i, X2.re[i], X2.im[i]);
+    E.re[i] = xr + yr; E.im[i] = xi + yi;
+    cmul(xr, xi, d1r, d1i, X.re[i], X.im[i]);
+    cmul(yr, yi, d2r, d2i, X2.re[i], X2.im[i]);
+    cmul(zr, zi, f1r, f1i, Gs.re[i], Gs.im[i]);
+    double wr, wi;
+    cmul(wr, wi, f2r, f2i, T.re[i], T.im[i]);
+    L.re[i] = (xr + yr) + (zr + wr); L.im[i] = (xi + yi) + (zi + wi);
+  }
+  E.re[0] += f0r; E.re[4] += f0r; E.re[8] += f0r;
+  E.im[0] += f0i; E.im[4] += f0i; E.im[8] += f0i;
+  L.re[0] += d0r; L.re[4] += d0r; L.re[8] += d0r;
+  L.im[0] += d0i; L.im[4] += d0i; L.im[8] += d0i;
+#pragma unroll 1
+  for (int k = 0; k < s; ++k) {
+    M3 t;
+    m3_mul_nn(t, E, L);
+    m3_mac_nn(t, L, E);
+    L = t;
+    m3_mul_nn(t, E, E);
+    E = t;
+  }
+}
+
+// The round-2 form of the same pair (kept for A/B, -DL2Q_FRECHET_SERIES, and as the cross-check of the
+// host test): E = exp(B) and L = L_exp(B)[G]
 // scaling & squaring on the Taylor series, M_n = M_{n-1} X + X^{n-1} G,
 // L_0 = sum M_n / n!, then L <- E L + L E, E <- E E per squaring.
-__device__ __forceinline__ void m3_expm_frechet(M3& E, M3& L, const M3& B, const M3& G) {
+__device__ __forceinline__ void m3_expm_frechet_series(M3& E, M3& L, const M3& B, const M3& G) {
   double n2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) n2 += B.re[i] * B.re[i] + B.im[i] * B.im[i];
@@ -116,8 +240,9 @@ __device__ __forceinline__ void m3_expm_frechet(M3& E, M3& L, const M3& B, const
 // ------------------------------------------------------------------ projectSU -> vec8 VJP
 // J^H A J and V J for the complex Jacobi rotation in the (P, Q) plane:
 //   J_PP = cs, J_PQ = sn, J_QP = -sn ph, J_QQ = cs ph   (ph = e^{-i arg h_PQ})
+// (returns whether this lane rotated at all)
 template <int P, int Q>
-__device__ __forceinline__ void jacobi_rotate(M3& H, M3& Vm) {
+__device__ __forceinline__ bool jacobi_rotate(M3& H, M3& Vm) {
   const double cr = H.re[3 * P + Q], ci = H.im[3 * P + Q];
   const double ac = sqrt(cr * cr + ci * ci);
   const double a = H.re[3 * P + P], b = H.re[3 * Q + Q];
@@ -126,11 +251,14 @@ __device__ __forceinline__ void jacobi_rotate(M3& H, M3& Vm) {
   // lanes of a wavefront converge at different sweeps)
   const bool live = (ac > 1e-19 * (fabs(a) + fabs(b))) && (ac > 1e-140);
   const double acs = live ? ac : 1.0;
-  const double tau = (b - a) / (2.0 * acs);
-  const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)) with tau = (b - a) / (2 |c|), written without forming tau,
+  // and one reciprocal of |c| for the phase: three IEEE divisions per rotation instead of five
+  const double d = b - a, c2 = 2.0 * acs;
+  const double t = (d >= 0.0 ? c2 : -c2) / (fabs(d) + sqrt(d * d + c2 * c2));
   const double cs = live ? 1.0 / sqrt(1.0 + t * t) : 1.0;
   const double sn = live ? t * cs : 0.0;
-  const double pr = live ? cr / acs : 1.0, pi = live ? -ci / acs : 0.0;   // ph = conj(c) / |c|
+  const double iac = 1.0 / acs;
+  const double pr = live ? cr * iac : 1.0, pi = live ? -ci * iac : 0.0;   // ph = conj(c) / |c|
   // right-multiply by J: columns P, Q of H and of V
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -159,6 +287,7 @@ __device__ __forceinline__ void jacobi_rotate(M3& H, M3& Vm) {
   H.re[3 * P + Q] = 0.0; H.im[3 * P + Q] = 0.0;
   H.re[3 * Q + P] = 0.0; H.im[3 * Q + P] = 0.0;
   H.im[3 * P + P] = 0.0; H.im[3 * Q + Q] = 0.0;
+  return live;
 }
 
 // y = su3_to_vec(projectSU(M)):  g_M += VJP(g_y).  projectSU(M) = U e^{i theta},
@@ -187,17 +316,21 @@ __device__ __forceinline__ void m3_projsu_vec8_vjp(M3& g, const M3& m, const dou
   m3_identity(vm);
 #pragma unroll 1
   for (int sweep = 0; sweep < 6; ++sweep) {
-    jacobi_rotate<0, 1>(a2, vm);
-    jacobi_rotate<0, 2>(a2, vm);
-    jacobi_rotate<1, 2>(a2, vm);
+    bool live = jacobi_rotate<0, 1>(a2, vm);
+    live |= jacobi_rotate<0, 2>(a2, vm);
+    live |= jacobi_rotate<1, 2>(a2, vm);
+    // a sweep in which no lane of the wavefront rotated leaves every later sweep an identity as well
+    // (same bits): links that are already unitary -- the x of every v-net call -- stop after one or two
+    if (!l2q_wave_any(live)) break;
   }
   const double ev[3] = {sqrt(fabs(a2.re[0])), sqrt(fabs(a2.re[4])), sqrt(fabs(a2.re[8]))};   // eig(H)
+  const double iev[3] = {1.0 / ev[0], 1.0 / ev[1], 1.0 / ev[2]};
   M3 t, u;
   m3_mul_nn(t, m, vm);                                 // M V
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { t.re[3 * i + j] /= ev[j]; t.im[3 * i + j] /= ev[j]; }
+    for (int j = 0; j < 3; ++j) { t.re[3 * i + j] *= iev[j]; t.im[3 * i + j] *= iev[j]; }
   m3_mul_na(u, t, vm);                                 // U = M V diag(1/h) V^H
   double dr, di;
   m3_det(dr, di, u);

@@ -1,7 +1,8 @@
 // Host driver around the per-link device math of the SU(3) training kernels.
 // stdin: op name, then the operands as doubles; stdout: the result matrices.
 //   projsu_vjp : M (9 complex), gy (8)          -> g_M (9 complex)
-//   frechet    : B (9 complex), G (9 complex)   -> exp(B), L_exp(B)[G]
+//   frechet    : B (9 complex), G (9 complex)   -> exp(B), L_exp(B)[G]   (Cayley-Hamilton form, ships)
+//   frechet_series : the same pair from the matrix-valued Taylor recursion (kept for A/B)
 //   expm       : A (9 complex)                  -> m3_expm(A)
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,12 @@ int main() {
       M3 b, g, e, l;
       if (!read_m3(b) || !read_m3(g)) return 1;
       m3_expm_frechet(e, l, b, g);
+      print_m3(e);
+      print_m3(l);
+    } else if (!strcmp(op, "frechet_series")) {
+      M3 b, g, e, l;
+      if (!read_m3(b) || !read_m3(g)) return 1;
+      m3_expm_frechet_series(e, l, b, g);
       print_m3(e);
       print_m3(l);
     } else if (!strcmp(op, "expm")) {

@@ -51,9 +51,28 @@ def test_expm_and_frechet(host):
         assert float((e - ref).abs().max()) < 1e-13 * max(1.0, float(ref.abs().max()))
         Ar = A.clone().requires_grad_(True)
         (gA,) = torch.autograd.grad(torch.matrix_exp(Ar), Ar, G)
-        e2, l = host('frechet', A.conj().T.contiguous(), G)       # g_A = L_exp(A^H)[G]
-        assert float((l - gA).abs().max()) < 1e-12 * max(1.0, float(gA.abs().max()))
-        assert float((e2 - ref.conj().T).abs().max()) < 1e-13 * max(1.0, float(ref.abs().max()))
+        # g_A = L_exp(A^H)[G]: the Cayley-Hamilton form that ships and the Taylor recursion kept for A/B
+        for op in ('frechet', 'frechet_series'):
+            e2, l = host(op, A.conj().T.contiguous(), G)
+            assert float((l - gA).abs().max()) < 1e-12 * max(1.0, float(gA.abs().max())), op
+            assert float((e2 - ref.conj().T).abs().max()) < 1e-13 * max(1.0, float(ref.abs().max())), op
+
+
+def test_frechet_in_the_algebra(host):
+    """eps * v of the x-update is (nearly) anti-Hermitian and traceless: tr X ~ 0, det X imaginary -- the
+    invariants the Cayley-Hamilton tangent recursion is driven by degenerate there; norms on both sides
+    of the scaling threshold (0.25) and the squaring chain (up to 2^6)."""
+    g = torch.Generator().manual_seed(11)
+    worst = 0.0
+    for scale in (1e-6, 1e-3, 0.05, 0.1, 0.2, 0.5, 2.0, 10.0):
+        for _ in range(6):
+            A = scale * E._tah(crnd(g, 3, 3))
+            G = crnd(g, 3, 3)
+            Ar = A.clone().requires_grad_(True)
+            (gA,) = torch.autograd.grad(torch.matrix_exp(Ar), Ar, G)
+            _, l = host('frechet', A.conj().T.contiguous(), G)
+            worst = max(worst, float((l - gA).abs().max()) / max(1.0, float(gA.abs().max())))
+    assert worst < 1e-12, worst
 
 
 @pytest.mark.parametrize('kind', ['generic', 'near_su3', 'tah'])
