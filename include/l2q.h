@@ -307,6 +307,17 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
                                       int forward1, int pair, int flip_between, double eps2, int forward2,
                                       double* logdet, double* logdet1, double* vnorm2_mid, void* ws,
                                       size_t ws_bytes, void* stream);
+/* The forward pass of the TRAINING tape on the same kernel (network.py:547-551 + dynamics.py:1266-1297 under
+ * autograd: trainers/pytorch/trainer.py:1316-1367): one (not paired) out-of-place v-update v_in -> v AND the
+ * three heads as the update uses them -- s = cs tanh(.), t = scale_t (.), q = cq tanh(.), [M][N] fp64 each --
+ * for the reverse sweep (l2q_v_update_bwd_c128, the heads' VJPs).  The slice image is rebuilt once per
+ * optimiser step from that step's weights (l2q_heads_sliced_build).  Same workspace as the call above. */
+int l2q_vnet_heads_vupdate_sliced_tape_f64(const double* Z, int M, int K, long N, const void* sliced,
+                                           const double* bs, const double* cs, const double* bt, double scale_t,
+                                           const double* bq, const double* cq, const void* v_in, void* v,
+                                           const void* force, int is_complex, double eps, int forward,
+                                           double* s_out, double* t_out, double* q_out, double* logdet, void* ws,
+                                           size_t ws_bytes, void* stream);
 /* fp32 variant on v_mfma_f32_16x16x4_f32 (U(1) networks). */
 int l2q_gemm_f32(const float* A, const float* W, int M, int N, long K, const float* A2,
                  const float* W2, long K2, const float* bias, const float* bias2,
@@ -509,6 +520,13 @@ size_t l2q_colsum_ws_bytes(long M, int N);
  * t = scale * pre, dpre = scale * ds. */
 int l2q_scaled_tanh_bwd(const void* ds, const void* s, const void* coeff, double scale, int M,
                         int N, int elem_bytes, void* dpre, void* stream);
+/* l2q_scaled_tanh_bwd with the column sums of the head's parameter gradients formed in the same pass:
+ * bgrad[n] += sum_m dpre[m][n] (nn.Linear bias) and, with coeff, cgrad[n] += sum_m ds[m][n] s[m][n]
+ * (ScaledTanh.coeff) -- the bits of l2q_scaled_tanh_bwd + two l2q_colsum passes (same row partition and
+ * summation order).  ws_bytes >= 2 * l2q_colsum_ws_bytes(M, N). */
+int l2q_scaled_tanh_bwd_sums(const void* ds, const void* s, const void* coeff, double scale, int M, int N,
+                             int elem_bytes, void* dpre, void* bgrad, void* cgrad, void* ws, size_t ws_bytes,
+                             void* stream);
 /* nn.BatchNorm1d in train mode over x[M][N] (network.py:543-544): batch mean / biased
  * variance, y = (x - mean) invstd gamma + beta; running stats (may be NULL) updated with
  * `momentum` and the unbiased variance like torch. */
@@ -606,6 +624,16 @@ int l2q_v_update_bwd_c128(const void* v, const void* force, const double* s, con
                           const double* gl, int nb, long n, void* dv, void* dF, double* ds,
                           double* dt, double* dq, double* deps, void* ws, size_t ws_bytes,
                           void* stream);
+/* The same VJP with (dF, ds, dt, dq) = this update's cotangents + (acc_dF, acc_ds, acc_dt, acc_dq): the
+ * two v-updates either side of a momentum flip or a step boundary act on the same x, hence on ONE force and
+ * ONE network evaluation (dynamics.py:1187-1228 with a shared vnet), and the reverse sweep hands the
+ * later one's cotangents to the earlier one before the single backward pass through network and force.
+ * acc_* may alias nothing that is written. */
+int l2q_v_update_bwd_acc_c128(const void* v, const void* force, const double* s, const double* t,
+                              const double* q, double eps, int forward, const void* gv, const double* gl,
+                              int nb, long n, const void* acc_dF, const double* acc_ds, const double* acc_dt,
+                              const double* acc_dq, void* dv, void* dF, double* ds, double* dt, double* dq,
+                              double* deps, void* ws, size_t ws_bytes, void* stream);
 /* gx[c][:] += 2 a[c] (x[c][:] - y[c][:]) over n doubles per chain (cotangent of
  * l2q_diff_norm2_reduce, the rmse term of LatticeLoss, loss.py:119-148) */
 int l2q_diff_bwd_f64(const double* x, const double* y, const double* a, int nb, long n, double* gx,

@@ -93,6 +93,10 @@ struct HeadsArgs {
   double* ld1_part;       // MID kernels: log-Jacobian of the first update alone, [M][ncols_part]
   double* ke_part;        // MID kernels: sum |v|^2 after the first update,        [M][ncols_part]
   int M, N, K, ncols_part;
+  // TAPE kernels (heads_sliced.hip): the heads themselves, [M][N] each, for the reverse sweep of training
+  double* tape_s = nullptr;
+  double* tape_t = nullptr;
+  double* tape_q = nullptr;
 };
 
 }  // namespace l2q

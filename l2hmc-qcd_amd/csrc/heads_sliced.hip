@@ -220,7 +220,10 @@ __device__ __forceinline__ double i2d(int x) {
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool CPLX, bool FWD, bool PAIR, bool MID>
+// TAPE: the three heads (s, t, q as the update uses them) are stored as well -- the forward pass of the
+// training tape; 12 more stores per lane and tile, issued with the tile's other stores (they are older
+// than the next `fetch`, so the hand-counted vmcnt waits do not change).
+template <bool CPLX, bool FWD, bool PAIR, bool MID, bool TAPE = false>
 __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, SlicedArgs o) {
   constexpr int RING = OZ_NS * OZ_FRAG;                       // 7 KB: one wavefront's group sums of a chunk
   __shared__ __attribute__((aligned(1024))) char lds[3 * OZ_CHUNK + 2 * 4 * RING];           // 140 KB
@@ -524,6 +527,7 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
         const long oo = rowoff[r] + n;
         if (CPLX) reinterpret_cast<double2*>(a.v)[oo] = outv[r];
         else a.v[oo] = outv[r].x;
+        if (TAPE) { a.tape_s[oo] = s_[r]; a.tape_t[oo] = t_[r]; a.tape_q[oo] = q_[r]; }
       }
     }
   };
@@ -647,6 +651,100 @@ static inline int sliced_ncw(int M) {
 
 using namespace l2q;
 
+static int sliced_launch(const char* who, double* tape_s, double* tape_t, double* tape_q, const double* Z, int M,
+                         int K, long N, const void* sliced,
+                                      const double* bs, const double* cs, double scale_s, const double* bt,
+                                      double scale_t, const double* bq, const double* cq, double scale_q,
+                                      const void* v_in, void* v, const void* force, int is_complex, double eps1,
+                                      int forward1, int pair, int flip_between, double eps2, int forward2,
+                                      double* logdet, double* logdet1, double* vnorm2_mid, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(Z && sliced && bs && bt && bq && cs && cq && v && force && logdet && ws, L2Q_EINVAL,
+              "null pointer (the sliced kernel takes per-entry scales cs / cq)");
+  L2Q_REQUIRE(K == OZ_K, L2Q_ESHAPE, "the sliced heads kernel serves K = 256");
+  L2Q_REQUIRE(M > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
+  const bool mid = logdet1 != nullptr;
+  L2Q_REQUIRE(!mid || (pair && vnorm2_mid), L2Q_EINVAL, "mid-point outputs belong to the pair kernel");
+  L2Q_REQUIRE(ws_bytes >= l2q_vnet_heads_sliced_ws_bytes(M, N), L2Q_ESHAPE, "workspace too small");
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const void* vin = v_in ? v_in : v;
+  L2Q_REQUIRE(al(Z) && al(v) && al(vin) && al(force) && (reinterpret_cast<uintptr_t>(sliced) & 255) == 0 &&
+                  (reinterpret_cast<uintptr_t>(ws) & 255) == 0,
+              L2Q_ESHAPE, "operands must be 16-byte aligned (slice buffer and workspace 256-byte)");
+  hipStream_t st = (hipStream_t)stream;
+  const int rg = sliced_rg(M), ncw = sliced_ncw(M);
+  const long mpad = (long)rg * 64;
+  char* zs = (char*)ws;
+  double* zscale = (double*)(zs + (mpad / 16) * OZ_CHUNK);
+  double* part = zscale + mpad;
+  hipLaunchKernelGGL(oz_split_kernel, dim3((unsigned)cdiv(mpad, 4)), dim3(256), 0, st, Z, (long)M, mpad, 1, 0,
+                     zs, zscale, 1, oz_zflag_ptr(), 0x1p-6);
+  HeadsArgs a;
+  a.tape_s = tape_s; a.tape_t = tape_t; a.tape_q = tape_q;
+  a.Z = Z; a.W[0] = a.W[1] = a.W[2] = nullptr;
+  a.b[0] = bs; a.b[1] = bt; a.b[2] = bq; a.cs = cs; a.cq = cq;
+  a.ss = scale_s; a.st = scale_t; a.sq = scale_q; a.eps = eps1; a.eps2 = eps2; a.fwd2 = forward2;
+  a.flip = flip_between;
+  a.v = (double*)v; a.vin = (const double*)vin; a.F = (const double*)force;
+  a.logdet_part = part; a.ld1_part = part + (size_t)M * ncw; a.ke_part = part + 2 * (size_t)M * ncw;
+  a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncw;
+  SlicedArgs o;
+  o.Zs = zs; o.zscale = zscale; o.Wsl = (const char*)sliced;
+  o.wscale = (const double*)((const char*)sliced + sliced_scale_off(N));
+  o.ncw = ncw; o.rg = rg; o.dbg = nullptr;
+#if L2Q_SL_PROF
+  static long long* dbg = nullptr;
+  if (!dbg) (void)hipMalloc(&dbg, 4096 * 8 * 4 * sizeof(long long));
+  (void)hipMemsetAsync(dbg, 0, 4096 * 8 * 4 * sizeof(long long), st);
+  o.dbg = dbg;
+#endif
+  o.tiles_per_cw = (int)cdiv(cdiv(N, 16), ncw);
+  const dim3 grid((unsigned)(rg * ncw)), block(512);
+#define L2Q_SL(C, F, P, MD) hipLaunchKernelGGL((heads_sliced_kernel<C, F, P, MD>), grid, block, 0, st, a, o)
+#define L2Q_SL_F(C, P, MD) do { if (forward1) L2Q_SL(C, true, P, MD); else L2Q_SL(C, false, P, MD); } while (0)
+#define L2Q_SL_C(P, MD) do { if (is_complex) L2Q_SL_F(true, P, MD); else L2Q_SL_F(false, P, MD); } while (0)
+  if (tape_s) {
+    if (is_complex) {
+      if (forward1) hipLaunchKernelGGL((heads_sliced_kernel<true, true, false, false, true>), grid, block, 0, st, a, o);
+      else hipLaunchKernelGGL((heads_sliced_kernel<true, false, false, false, true>), grid, block, 0, st, a, o);
+    } else {
+      if (forward1) hipLaunchKernelGGL((heads_sliced_kernel<false, true, false, false, true>), grid, block, 0, st, a, o);
+      else hipLaunchKernelGGL((heads_sliced_kernel<false, false, false, false, true>), grid, block, 0, st, a, o);
+    }
+  } else if (mid) L2Q_SL_C(true, true);
+  else if (pair) L2Q_SL_C(true, false);
+  else L2Q_SL_C(false, false);
+#undef L2Q_SL_C
+#undef L2Q_SL_F
+#undef L2Q_SL
+#if L2Q_SL_PROF
+  {
+    (void)hipStreamSynchronize(st);
+    const int nblk = rg * ncw;
+    std::vector<long long> h((size_t)nblk * 8 * 4);
+    (void)hipMemcpy(h.data(), o.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double tot[2] = {0, 0}, bar[2] = {0, 0}, vm = 0, ldsw = 0, mx[2] = {0, 0}, umem = 0, uconv = 0;
+    for (int b = 0; b < nblk; ++b)
+      for (int w = 0; w < 8; ++w) {
+        const long long* d = &h[((size_t)b * 8 + w) * 4];
+        const int c = w >= 4;
+        tot[c] += d[0]; bar[c] += d[1]; if (!c) { vm += d[2]; ldsw += d[3]; }
+        else { umem += d[2]; uconv += d[3]; }
+        if (d[0] > mx[c]) mx[c] = (double)d[0];
+      }
+    const double n = nblk * 4.0;
+    fprintf(stderr, "[sliced prof] matrix waves: total %.0f (max %.0f) barrier %.0f vmcnt %.0f lgkmcnt %.0f | update waves: total %.0f barrier %.0f dma+fetch+store issue %.0f conv %.0f  (clock64 ticks, mean per wave)\n",
+            tot[0] / n, mx[0], bar[0] / n, vm / n, ldsw / n, tot[1] / n, bar[1] / n, umem / n, uconv / n);
+  }
+#endif
+  launch_finalize(a.logdet_part, logdet, M, ncw, 1, 1.0, 0.0, st);
+  if (mid) {
+    launch_finalize(a.ld1_part, logdet1, M, ncw, 1, 1.0, 0.0, st);
+    launch_finalize(a.ke_part, vnorm2_mid, M, ncw, 1, 1.0, 0.0, st);
+  }
+  return check_launch(who);
+}
+
 extern "C" {
 
 size_t l2q_heads_sliced_bytes(int K, long N) {
@@ -710,81 +808,21 @@ int l2q_vnet_heads_vupdate_sliced_f64(const double* Z, int M, int K, long N, con
                                       int forward1, int pair, int flip_between, double eps2, int forward2,
                                       double* logdet, double* logdet1, double* vnorm2_mid, void* ws,
                                       size_t ws_bytes, void* stream) {
-  L2Q_REQUIRE(Z && sliced && bs && bt && bq && cs && cq && v && force && logdet && ws, L2Q_EINVAL,
-              "null pointer (the sliced kernel takes per-entry scales cs / cq)");
-  L2Q_REQUIRE(K == OZ_K, L2Q_ESHAPE, "the sliced heads kernel serves K = 256");
-  L2Q_REQUIRE(M > 0 && N > 0 && N < 2000000000L, L2Q_EINVAL, "bad size");
-  const bool mid = logdet1 != nullptr;
-  L2Q_REQUIRE(!mid || (pair && vnorm2_mid), L2Q_EINVAL, "mid-point outputs belong to the pair kernel");
-  L2Q_REQUIRE(ws_bytes >= l2q_vnet_heads_sliced_ws_bytes(M, N), L2Q_ESHAPE, "workspace too small");
-  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  const void* vin = v_in ? v_in : v;
-  L2Q_REQUIRE(al(Z) && al(v) && al(vin) && al(force) && (reinterpret_cast<uintptr_t>(sliced) & 255) == 0 &&
-                  (reinterpret_cast<uintptr_t>(ws) & 255) == 0,
-              L2Q_ESHAPE, "operands must be 16-byte aligned (slice buffer and workspace 256-byte)");
-  hipStream_t st = (hipStream_t)stream;
-  const int rg = sliced_rg(M), ncw = sliced_ncw(M);
-  const long mpad = (long)rg * 64;
-  char* zs = (char*)ws;
-  double* zscale = (double*)(zs + (mpad / 16) * OZ_CHUNK);
-  double* part = zscale + mpad;
-  hipLaunchKernelGGL(oz_split_kernel, dim3((unsigned)cdiv(mpad, 4)), dim3(256), 0, st, Z, (long)M, mpad, 1, 0,
-                     zs, zscale, 1, oz_zflag_ptr(), 0x1p-6);
-  HeadsArgs a;
-  a.Z = Z; a.W[0] = a.W[1] = a.W[2] = nullptr;
-  a.b[0] = bs; a.b[1] = bt; a.b[2] = bq; a.cs = cs; a.cq = cq;
-  a.ss = scale_s; a.st = scale_t; a.sq = scale_q; a.eps = eps1; a.eps2 = eps2; a.fwd2 = forward2;
-  a.flip = flip_between;
-  a.v = (double*)v; a.vin = (const double*)vin; a.F = (const double*)force;
-  a.logdet_part = part; a.ld1_part = part + (size_t)M * ncw; a.ke_part = part + 2 * (size_t)M * ncw;
-  a.M = M; a.N = (int)N; a.K = K; a.ncols_part = ncw;
-  SlicedArgs o;
-  o.Zs = zs; o.zscale = zscale; o.Wsl = (const char*)sliced;
-  o.wscale = (const double*)((const char*)sliced + sliced_scale_off(N));
-  o.ncw = ncw; o.rg = rg; o.dbg = nullptr;
-#if L2Q_SL_PROF
-  static long long* dbg = nullptr;
-  if (!dbg) (void)hipMalloc(&dbg, 4096 * 8 * 4 * sizeof(long long));
-  (void)hipMemsetAsync(dbg, 0, 4096 * 8 * 4 * sizeof(long long), st);
-  o.dbg = dbg;
-#endif
-  o.tiles_per_cw = (int)cdiv(cdiv(N, 16), ncw);
-  const dim3 grid((unsigned)(rg * ncw)), block(512);
-#define L2Q_SL(C, F, P, MD) hipLaunchKernelGGL((heads_sliced_kernel<C, F, P, MD>), grid, block, 0, st, a, o)
-#define L2Q_SL_F(C, P, MD) do { if (forward1) L2Q_SL(C, true, P, MD); else L2Q_SL(C, false, P, MD); } while (0)
-#define L2Q_SL_C(P, MD) do { if (is_complex) L2Q_SL_F(true, P, MD); else L2Q_SL_F(false, P, MD); } while (0)
-  if (mid) L2Q_SL_C(true, true);
-  else if (pair) L2Q_SL_C(true, false);
-  else L2Q_SL_C(false, false);
-#undef L2Q_SL_C
-#undef L2Q_SL_F
-#undef L2Q_SL
-#if L2Q_SL_PROF
-  {
-    (void)hipStreamSynchronize(st);
-    const int nblk = rg * ncw;
-    std::vector<long long> h((size_t)nblk * 8 * 4);
-    (void)hipMemcpy(h.data(), o.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-    double tot[2] = {0, 0}, bar[2] = {0, 0}, vm = 0, ldsw = 0, mx[2] = {0, 0}, umem = 0, uconv = 0;
-    for (int b = 0; b < nblk; ++b)
-      for (int w = 0; w < 8; ++w) {
-        const long long* d = &h[((size_t)b * 8 + w) * 4];
-        const int c = w >= 4;
-        tot[c] += d[0]; bar[c] += d[1]; if (!c) { vm += d[2]; ldsw += d[3]; }
-        else { umem += d[2]; uconv += d[3]; }
-        if (d[0] > mx[c]) mx[c] = (double)d[0];
-      }
-    const double n = nblk * 4.0;
-    fprintf(stderr, "[sliced prof] matrix waves: total %.0f (max %.0f) barrier %.0f vmcnt %.0f lgkmcnt %.0f | update waves: total %.0f barrier %.0f dma+fetch+store issue %.0f conv %.0f  (clock64 ticks, mean per wave)\n",
-            tot[0] / n, mx[0], bar[0] / n, vm / n, ldsw / n, tot[1] / n, bar[1] / n, umem / n, uconv / n);
-  }
-#endif
-  launch_finalize(a.logdet_part, logdet, M, ncw, 1, 1.0, 0.0, st);
-  if (mid) {
-    launch_finalize(a.ld1_part, logdet1, M, ncw, 1, 1.0, 0.0, st);
-    launch_finalize(a.ke_part, vnorm2_mid, M, ncw, 1, 1.0, 0.0, st);
-  }
-  return check_launch("l2q_vnet_heads_vupdate_sliced_f64");
+  return sliced_launch("l2q_vnet_heads_vupdate_sliced_f64", nullptr, nullptr, nullptr, Z, M, K, N, sliced, bs, cs,
+                       scale_s, bt, scale_t, bq, cq, scale_q, v_in, v, force, is_complex, eps1, forward1, pair,
+                       flip_between, eps2, forward2, logdet, logdet1, vnorm2_mid, ws, ws_bytes, stream);
+}
+
+int l2q_vnet_heads_vupdate_sliced_tape_f64(const double* Z, int M, int K, long N, const void* sliced,
+                                           const double* bs, const double* cs, const double* bt, double scale_t,
+                                           const double* bq, const double* cq, const void* v_in, void* v,
+                                           const void* force, int is_complex, double eps, int forward,
+                                           double* s_out, double* t_out, double* q_out, double* logdet, void* ws,
+                                           size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(s_out && t_out && q_out, L2Q_EINVAL, "null pointer");
+  return sliced_launch("l2q_vnet_heads_vupdate_sliced_tape_f64", s_out, t_out, q_out, Z, M, K, N, sliced, bs, cs, 1.0,
+                       bt, scale_t, bq, cq, 1.0, v_in, v, force, is_complex, eps, forward, 0, 0, 0.0, 0, logdet,
+                       nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -239,13 +239,17 @@ __global__ __launch_bounds__(kBlock, 2) void su3_staple_bwd_kernel(
 
 // ------------------------------------------------------------------ complex v-update VJP
 // v, F, g_v complex [nb][n]; s, t, q real [nb][n] (dynamics.py:1266-1297 on complex momenta)
-template <bool FWD>
+// ACC: (dF, ds, dt, dq) = this update's cotangents + those of the v-update that SHARED its force and heads
+// (aF, as, at, aq; the tape's primary / secondary pairs, training.py): one pass instead of four axpy launches
+template <bool FWD, bool ACC = false>
 __global__ __launch_bounds__(kBlock) void v_update_bwd_cplx_kernel(
     const double2* __restrict__ v, const double2* __restrict__ force, const double* __restrict__ s,
     const double* __restrict__ t, const double* __restrict__ q, double eps,
     const double2* __restrict__ gv, const double* __restrict__ gl, long n, long nblk,
     double2* __restrict__ dv, double2* __restrict__ dF, double* __restrict__ ds,
-    double* __restrict__ dt, double* __restrict__ dq, double* __restrict__ partial) {
+    double* __restrict__ dt, double* __restrict__ dq, double* __restrict__ partial,
+    const double2* __restrict__ aF = nullptr, const double* __restrict__ as = nullptr,
+    const double* __restrict__ at = nullptr, const double* __restrict__ aq = nullptr) {
   __shared__ double lds[4];
   const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const long j = blk * kBlock + threadIdx.x;
@@ -268,11 +272,19 @@ __global__ __launch_bounds__(kBlock) void v_update_bwd_cplx_kernel(
       dBr = g.x * es; dBi = g.y * es;
     }
     dv[o] = make_double2(g.x * es, g.y * es);
-    dF[o] = make_double2(dBr * 0.5 * eps * eq, dBi * 0.5 * eps * eq);
-    dt[o] = 0.5 * eps * dBr;
     const double dQ = 0.5 * eps * eq * (dBr * fj.x + dBi * fj.y);
-    ds[o] = FWD ? 0.5 * eps * dS : -0.5 * eps * dS;
-    dq[o] = eps * dQ;
+    double2 oF = make_double2(dBr * 0.5 * eps * eq, dBi * 0.5 * eps * eq);
+    double ot = 0.5 * eps * dBr, os = FWD ? 0.5 * eps * dS : -0.5 * eps * dS, oq = eps * dQ;
+    if (ACC) {
+      // (same order as the axpy it replaces: x += p)
+      const double2 pF = aF[o];
+      oF.x += pF.x; oF.y += pF.y;
+      os += as[o]; ot += at[o]; oq += aq[o];
+    }
+    dF[o] = oF;
+    dt[o] = ot;
+    ds[o] = os;
+    dq[o] = oq;
     de = 0.5 * (dBr * fqr + dBi * fqi) + (FWD ? 0.5 * sj * dS : -0.5 * sj * dS) + qj * dQ;
   }
   const double r = block_sum(de, lds);
@@ -364,15 +376,42 @@ int l2q_v_update_bwd_c128(const void* v, const void* force, const double* s, con
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(nb * nblk)), block(kBlock);
   if (forward)
-    hipLaunchKernelGGL(v_update_bwd_cplx_kernel<true>, grid, block, 0, st, (const double2*)v,
+    hipLaunchKernelGGL((v_update_bwd_cplx_kernel<true, false>), grid, block, 0, st, (const double2*)v,
                        (const double2*)force, s, t, q, eps, (const double2*)gv, gl, n, nblk,
-                       (double2*)dv, (double2*)dF, ds, dt, dq, (double*)ws);
+                       (double2*)dv, (double2*)dF, ds, dt, dq, (double*)ws, (const double2*)nullptr,
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr);
   else
-    hipLaunchKernelGGL(v_update_bwd_cplx_kernel<false>, grid, block, 0, st, (const double2*)v,
+    hipLaunchKernelGGL((v_update_bwd_cplx_kernel<false, false>), grid, block, 0, st, (const double2*)v,
                        (const double2*)force, s, t, q, eps, (const double2*)gv, gl, n, nblk,
-                       (double2*)dv, (double2*)dF, ds, dt, dq, (double*)ws);
+                       (double2*)dv, (double2*)dF, ds, dt, dq, (double*)ws, (const double2*)nullptr,
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr);
   launch_finalize((const double*)ws, deps, nb, nblk, 1, 1.0, 0.0, st);
   return check_launch("l2q_v_update_bwd_c128");
+}
+
+int l2q_v_update_bwd_acc_c128(const void* v, const void* force, const double* s, const double* t,
+                              const double* q, double eps, int forward, const void* gv, const double* gl,
+                              int nb, long n, const void* acc_dF, const double* acc_ds, const double* acc_dt,
+                              const double* acc_dq, void* dv, void* dF, double* ds, double* dt, double* dq,
+                              double* deps, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(v && force && s && t && q && gv && dv && dF && ds && dt && dq && deps && ws, L2Q_EINVAL,
+              "null pointer");
+  L2Q_REQUIRE(acc_dF && acc_ds && acc_dt && acc_dq, L2Q_EINVAL, "null pointer (cotangents to add)");
+  L2Q_REQUIRE(nb > 0 && n > 0, L2Q_EINVAL, "non-positive size");
+  const long nblk = cdiv(n, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * nblk * sizeof(double), L2Q_EINVAL, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(nb * nblk)), block(kBlock);
+  if (forward)
+    hipLaunchKernelGGL((v_update_bwd_cplx_kernel<true, true>), grid, block, 0, st, (const double2*)v,
+                       (const double2*)force, s, t, q, eps, (const double2*)gv, gl, n, nblk, (double2*)dv,
+                       (double2*)dF, ds, dt, dq, (double*)ws, (const double2*)acc_dF, acc_ds, acc_dt, acc_dq);
+  else
+    hipLaunchKernelGGL((v_update_bwd_cplx_kernel<false, true>), grid, block, 0, st, (const double2*)v,
+                       (const double2*)force, s, t, q, eps, (const double2*)gv, gl, n, nblk, (double2*)dv,
+                       (double2*)dF, ds, dt, dq, (double*)ws, (const double2*)acc_dF, acc_ds, acc_dt, acc_dq);
+  launch_finalize((const double*)ws, deps, nb, nblk, 1, 1.0, 0.0, st);
+  return check_launch("l2q_v_update_bwd_acc_c128");
 }
 
 int l2q_diff_bwd_f64(const double* x, const double* y, const double* a, int nb, long n, double* gx,

@@ -130,6 +130,46 @@ __global__ void scaled_tanh_bwd_kernel(const T* __restrict__ ds, const T* __rest
   dpre[i] = ds[i] * g * ((T)1 - th * th);
 }
 
+// The same VJP with the two column sums the head's parameter gradients need formed in the same pass:
+// partial_b[r][n] = sum over the block's rows of dpre (bias gradient), partial_c[r][n] = sum of ds * s
+// (d s / d coeff = s: the ScaledTanh coefficient gradient).  Row partition, summation order and the
+// second stage are those of l2q_colsum: the results are the bits of the three separate passes.
+template <typename T>
+__global__ __launch_bounds__(1024) void scaled_tanh_bwd_sums_kernel(
+    const T* __restrict__ ds, const T* __restrict__ s, const T* __restrict__ coeff, T scale, long M, int N,
+    long rpb, T* __restrict__ dpre, double* __restrict__ partial_b, double* __restrict__ partial_c) {
+  __shared__ double part[2][1024];
+  const int CX = blockDim.x, RY = blockDim.y;
+  const int cx = threadIdx.x, ry = threadIdx.y;
+  const long col = (long)blockIdx.x * CX + cx;
+  const long r0 = (long)blockIdx.y * rpb;
+  long r1 = r0 + rpb; if (r1 > M) r1 = M;
+  double sb = 0.0, sc = 0.0;
+  if (col < N) {
+    const T g = coeff ? scale * Math<T>::exp(coeff[col]) : scale;
+    for (long m = r0 + ry; m < r1; m += RY) {
+      const long i = m * N + col;
+      const T d = ds[i];
+      T o;
+      if (!coeff) o = scale * d;
+      else if (g == (T)0) o = (T)0;
+      else { const T th = s[i] / g; o = d * g * ((T)1 - th * th); }
+      dpre[i] = o;
+      sb += (double)o;
+      if (coeff) sc += (double)d * (double)s[i];
+    }
+  }
+  part[0][ry * CX + cx] = sb;
+  part[1][ry * CX + cx] = sc;
+  __syncthreads();
+  if (ry == 0 && col < N) {
+    double rb = 0.0, rc = 0.0;
+    for (int k = 0; k < RY; ++k) { rb += part[0][k * CX + cx]; rc += part[1][k * CX + cx]; }
+    partial_b[(long)blockIdx.y * N + col] = rb;
+    if (coeff) partial_c[(long)blockIdx.y * N + col] = rc;
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm1d (train mode)
 // One workgroup per feature column (N is 16..256 here, M = chains).
 template <typename T>
@@ -547,6 +587,32 @@ int l2q_scaled_tanh_bwd(const void* ds, const void* s, const void* coeff, double
                                     st, (const T*)ds, (const T*)s, (const T*)coeff, (T)scale, N,
                                     total, (T*)dpre));
   return check_launch("l2q_scaled_tanh_bwd");
+}
+
+int l2q_scaled_tanh_bwd_sums(const void* ds, const void* s, const void* coeff, double scale, int M, int N,
+                             int elem_bytes, void* dpre, void* bgrad, void* cgrad, void* ws, size_t ws_bytes,
+                             void* stream) {
+  L2Q_REQUIRE(ds && dpre && bgrad && ws && (s || !coeff) && (cgrad || !coeff), L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(M > 0 && N > 0, L2Q_EINVAL, "non-positive size");
+  L2Q_REQUIRE(ws_bytes >= 2 * l2q_colsum_ws_bytes(M, N), L2Q_EINVAL, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long rpb = colsum_rows_per_block(M);
+  const long R = cdiv(M, rpb);
+  int cx = 64;
+  while (cx > 8 && cx / 2 >= N) cx /= 2;
+  const dim3 blk(cx, 1024 / cx), grid((unsigned)cdiv(N, cx), (unsigned)R);
+  double* pb = (double*)ws;
+  double* pc = pb + (size_t)R * N;
+  L2Q_DISPATCH_T(elem_bytes, {
+    hipLaunchKernelGGL(scaled_tanh_bwd_sums_kernel<T>, grid, blk, 0, st, (const T*)ds, (const T*)s,
+                       (const T*)coeff, (T)scale, (long)M, N, rpb, (T*)dpre, pb, pc);
+    hipLaunchKernelGGL(colsum_final_kernel<T>, dim3(grid1(N, 64)), dim3(kBlock), 0, st, (const double*)pb, R, N,
+                       1.0, 1, (T*)bgrad);
+    if (coeff)
+      hipLaunchKernelGGL(colsum_final_kernel<T>, dim3(grid1(N, 64)), dim3(kBlock), 0, st, (const double*)pc, R,
+                         N, 1.0, 1, (T*)cgrad);
+  });
+  return check_launch("l2q_scaled_tanh_bwd_sums");
 }
 
 int l2q_bn_train_fwd(const void* x, const void* gamma, const void* beta, double eps,

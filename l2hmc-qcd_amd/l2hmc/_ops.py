@@ -487,6 +487,9 @@ USE_SLICED_HEADS = [True]
 SLICED_K = 256
 
 
+SLICED_IMAGE_MAX_FREE_FRACTION = [0.25]     # heads_sliced_build: largest share of the free device memory
+
+
 def heads_sliced_build(heads: dict):
     """int8 slice image of the three head weight matrices (include/l2q.h: l2q_heads_sliced_build).
     Returns the uint8 device buffer, or None when the weights do not qualify (dtype, K, dynamic range)."""
@@ -496,10 +499,51 @@ def heads_sliced_build(heads: dict):
     if ws_.dtype != torch.float64 or k != SLICED_K or not ws_.is_cuda:
         return None
     nbytes = int(N.load().l2q_heads_sliced_bytes(k, n))
+    # the image lives NEXT TO the fp64 weights (+87 % of their size: 0.7 GB per vnet at 8^4, 11 GB at 16^4):
+    # built only while it is a small part of what the device still has (free + the allocator's idle blocks)
+    free, _total = torch.cuda.mem_get_info(ws_.device)
+    idle = torch.cuda.memory_reserved(ws_.device) - torch.cuda.memory_allocated(ws_.device)
+    if nbytes > SLICED_IMAGE_MAX_FREE_FRACTION[0] * (free + idle):
+        return None
     buf = torch.empty(nbytes, dtype=torch.uint8, device=ws_.device)
     usable = ctypes.c_int(0)
     N.call('l2q_heads_sliced_build', ws_, wt, wq, k, n, buf, nbytes, ctypes.byref(usable))
     return buf if usable.value else None
+
+
+def heads_sliced_build_into(ws_: torch.Tensor, wt: torch.Tensor, wq: torch.Tensor,
+                            buf: Optional[torch.Tensor] = None):
+    """The slice image of three [n, 256] fp64 weight matrices, written into `buf` when it has the right size
+    (the training loop rebuilds the image every optimiser step: no allocation after the first).
+    Returns (buffer, usable)."""
+    import ctypes
+    n, k = ws_.shape
+    nbytes = int(N.load().l2q_heads_sliced_bytes(k, n))
+    if buf is None or buf.numel() != nbytes or buf.device != ws_.device:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=ws_.device)
+    usable = ctypes.c_int(0)
+    N.call('l2q_heads_sliced_build', ws_, wt, wq, k, n, buf, nbytes, ctypes.byref(usable))
+    return buf, bool(usable.value)
+
+
+def vnet_heads_vupdate_sliced_tape(z: torch.Tensor, image: torch.Tensor, bs: torch.Tensor, cs: torch.Tensor,
+                                   bt: torch.Tensor, scale_t: float, bq: torch.Tensor, cq: torch.Tensor,
+                                   v: torch.Tensor, force: torch.Tensor, eps: float, forward: bool):
+    """Forward pass of the training tape on the int8-sliced heads kernel (include/l2q.h:
+    l2q_vnet_heads_vupdate_sliced_tape_f64): (v', logdet [nb], s, t, q); v is not written.
+    cs / cq: per-entry scales nw.s exp(coeff_s) / nw.q exp(coeff_q)."""
+    m, k = z.shape
+    n = bs.numel()
+    out = torch.empty_like(v)
+    s = torch.empty((m, n), dtype=torch.float64, device=z.device)
+    t = torch.empty_like(s)
+    q = torch.empty_like(s)
+    logdet = torch.empty(m, dtype=torch.float64, device=z.device)
+    nbytes = int(N.load().l2q_vnet_heads_sliced_ws_bytes(m, n))
+    ws = N.workspace(nbytes, z.device)
+    N.call('l2q_vnet_heads_vupdate_sliced_tape_f64', z, m, k, n, image, bs, cs, bt, float(scale_t), bq, cq, v,
+           out, force, int(v.is_complex()), float(eps), int(forward), s, t, q, logdet, ws, ws.numel())
+    return out, logdet, s, t, q
 
 
 def heads_sliced_zflag(reset: bool = True) -> int:
@@ -885,6 +929,17 @@ def scaled_tanh_bwd(ds: torch.Tensor, s: Optional[torch.Tensor], coeff: Optional
     return dpre
 
 
+def scaled_tanh_bwd_sums(ds: torch.Tensor, s: Optional[torch.Tensor], coeff: Optional[torch.Tensor],
+                         scale: float, bgrad: torch.Tensor, cgrad: Optional[torch.Tensor]) -> torch.Tensor:
+    """scaled_tanh_bwd + `bgrad += colsum(dpre)` + (with coeff) `cgrad += colsum(ds * s)` in one pass."""
+    m, n = ds.shape
+    dpre = torch.empty_like(ds)
+    ws = N.workspace(2 * int(N.load().l2q_colsum_ws_bytes(m, n)), ds.device)
+    N.call('l2q_scaled_tanh_bwd_sums', ds, s, coeff, float(scale), m, n, ds.element_size(), dpre, bgrad,
+           cgrad, ws, ws.numel())
+    return dpre
+
+
 def bn_train_fwd(x: torch.Tensor, gamma, beta, eps: float, momentum: float, running_mean,
                  running_var):
     m, n = x.shape
@@ -1088,16 +1143,22 @@ def su3_rect_bwd_(gx: torch.Tensor, xn: torch.Tensor, w: torch.Tensor,
     return gx
 
 
-def v_update_bwd_c128(v, force, s, t, q, eps: float, forward: bool, gv, gl):
-    """complex momenta: -> (dv, dF, ds, dt, dq, deps[nb])"""
+def v_update_bwd_c128(v, force, s, t, q, eps: float, forward: bool, gv, gl, acc=None):
+    """complex momenta: -> (dv, dF, ds, dt, dq, deps[nb]).  acc = (aF, as, at, aq): cotangents added to
+    (dF, ds, dt, dq) in the same pass (the v-update that shared this one's force and heads)."""
     nb = v.shape[0]
     n = v.numel() // nb
     dv, dF = torch.empty_like(v), torch.empty_like(v)
     ds, dt, dq = (torch.empty_like(s) for _ in range(3))
     deps = torch.empty(nb, dtype=torch.float64, device=v.device)
     ws = N.workspace(nb * ((n + 255) // 256) * 8, v.device)
-    N.call('l2q_v_update_bwd_c128', v, force, s, t, q, float(eps), int(forward), gv, gl, nb, n, dv,
-           dF, ds, dt, dq, deps, ws, ws.numel())
+    if acc is not None:
+        aF, as_, at, aq = acc
+        N.call('l2q_v_update_bwd_acc_c128', v, force, s, t, q, float(eps), int(forward), gv, gl, nb, n,
+               aF, as_, at, aq, dv, dF, ds, dt, dq, deps, ws, ws.numel())
+    else:
+        N.call('l2q_v_update_bwd_c128', v, force, s, t, q, float(eps), int(forward), gv, gl, nb, n, dv,
+               dF, ds, dt, dq, deps, ws, ws.numel())
     return dv, dF, ds, dt, dq, deps
 
 

@@ -236,6 +236,7 @@ class Dynamics(nn.Module):
         # fp64 heads with K = 256 outside the training tape: products rebuilt from exact int8 slice
         # products on the int8 matrix cores (csrc/heads_sliced.hip; same values to fp64 rounding)
         self.sliced_heads = True
+        self.sliced_train_heads = True      # training tape: heads + first v-update on the TAPE instances of that kernel
         # fp64 input layer of the SU(3) vnet on the int8 matrix cores (csrc/gemm_sliced.hip): its inputs
         # su3_to_vec(projectSU(.)) are bounded by 2.31 entry-wise, which the kernel checks (NaN otherwise)
         self.sliced_input = True

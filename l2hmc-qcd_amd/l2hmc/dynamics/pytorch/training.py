@@ -240,6 +240,21 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
     F = ops.su3_force_n(x, beta, dyn.latvolume)
     xv = ops.su3_projsu_vec8_n(x).reshape(nb, -1)
     fv = ops.su3_projsu_vec8_n(F).reshape(nb, -1)
+    if (vnet.native_active() and getattr(dyn, 'sliced_train_heads', True) and ops.USE_SLICED_HEADS[0]
+            and vnet.sliced_train_image() is not None):
+        # the heads and this v-update in one launch on the int8 matrix cores (TAPE kernel: s, t, q are
+        # stored for the reverse sweep); the image is rebuilt once per optimiser step
+        z, ctx = vnet.forward_train(xv, fv, hidden_only=True)
+        v_new, ld, sn, tn, qn = vnet.heads_vupdate_train_sliced(z, ctx, v.reshape(nb, -1), F.reshape(nb, -1),
+                                                                 eps, forward)
+        v_new = v_new.reshape(v.shape)
+        tape.entries.append({'kind': 'v', 'step': st, 'forward': forward, 'x': x, 'v': v, 'F': F,
+                             's': sn, 't': tn, 'q': qn, 'ctx': ctx, 'net': vnet, 'eps': eps})
+        if share is not None:
+            share.clear()
+            share.update({'x': x, 'net': vnet, 'F': F, 's': sn, 't': tn, 'q': qn,
+                          'idx': len(tape.entries) - 1})
+        return v_new, ld
     if vnet.native_active():
         # native-order weight shadows (LeapfrogLayer.native_train_begin): no activation transposes
         sn, tn, qn, ctx = vnet.forward_train(xv, fv)
@@ -504,9 +519,10 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
             continue
         if kind == 'v':
             x, v, F = e['x'], e['v'], e['F']
+            # (a primary entry adds the cotangents its secondary deferred to it in the same pass)
             dv, dF, dsn, dtn, dqn, deps = ops.v_update_bwd_c128(
                 v.reshape(nb, -1), F.reshape(nb, -1), e['s'], e['t'], e['q'], e['eps'],
-                e['forward'], gv.reshape(nb, -1), gl)
+                e['forward'], gv.reshape(nb, -1), gl, acc=pend.pop(idx, None))
             if e.get('primary') is not None:
                 # same x, force and (s, t, q) as the primary entry: hand the cotangents over
                 assert e['primary'] not in pend
@@ -514,9 +530,6 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
                 gv = dv.reshape(v.shape)
                 eps_acc.setdefault(('v', e['step']), []).append(deps)
                 continue
-            if idx in pend:
-                pF, ps, pt, pq = pend.pop(idx)
-                ops.add_(dF, pF); ops.add_(dsn, ps); ops.add_(dtn, pt); ops.add_(dqn, pq)
             dF = dF.reshape(F.shape)
             if e['ctx'].get('native'):
                 dxr, dfr = e['net'].backward(e['ctx'], dsn, dtn, dqn)

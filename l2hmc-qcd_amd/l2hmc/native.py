@@ -73,6 +73,8 @@ SIGNATURES = {
     'l2q_vnet_heads_sliced_ws_bytes': (Z, [I, L]),
     'l2q_vnet_heads_vupdate_sliced_f64': (I, [P, I, I, L, P, P, P, D, P, D, P, P, D, P, P, P, I, D, I, I, I, D,
                                               I, P, P, P, P, Z, P]),
+    'l2q_vnet_heads_vupdate_sliced_tape_f64': (I, [P, I, I, L, P, P, P, P, D, P, P, P, P, P, I, D, I, P, P, P, P,
+                                                   P, Z, P]),
     'l2q_gemm_f32': (I, [P, P, I, I, L, P, P, L, P, P, P, F, I, P, P, Z, P]),
     'l2q_gemm_ex': (I, [P, I, P, I, I, I, L, I, I, P, P, Z, P]),
     'l2q_gemm_h': (I, [I, P, I, P, I, I, L, P, P, L, P, P, P, F, I, P, I, P, Z, P]),
@@ -107,6 +109,7 @@ SIGNATURES = {
     'l2q_colsum': (I, [P, P, L, I, D, I, I, P, P, Z, P]),
     'l2q_colsum_ws_bytes': (Z, [L, I]),
     'l2q_scaled_tanh_bwd': (I, [P, P, P, D, I, I, I, P, P]),
+    'l2q_scaled_tanh_bwd_sums': (I, [P, P, P, D, I, I, I, P, P, P, P, Z, P]),
     'l2q_bn_train_fwd': (I, [P, P, P, D, D, P, P, I, I, I, P, P, P, P]),
     'l2q_bn_bwd': (I, [P, P, P, P, P, I, I, I, P, P, P, P]),
     'l2q_col2im_periodic_f32': (I, [P, L, L, L, L, I, I, I, I, I, I, P, P]),
@@ -127,6 +130,7 @@ SIGNATURES = {
     'l2q_su3_rect_force_add': (I, [P, D, P, I, I, I, I, I, P]),
     'l2q_su3_rect_bwd': (I, [P, P, P, I, I, I, I, I, P]),
     'l2q_v_update_bwd_c128': (I, [P, P, P, P, P, D, I, P, P, I, L, P, P, P, P, P, P, P, Z, P]),
+    'l2q_v_update_bwd_acc_c128': (I, [P, P, P, P, P, D, I, P, P, I, L, P, P, P, P, P, P, P, P, P, P, P, Z, P]),
     'l2q_diff_bwd_f64': (I, [P, P, P, I, L, P, P]),
 }
 

@@ -162,7 +162,8 @@ def advance_rand(numel: int, dtype: Optional[torch.dtype] = None) -> None:
 
 def _linear_bwd(dpre: Tensor, x: Tensor, weight, bias,
                 need_dx: bool = True, xT: Optional[Tensor] = None,
-                wgrad: Optional[Tensor] = None, bgrad: Optional[Tensor] = None) -> Optional[Tensor]:
+                wgrad: Optional[Tensor] = None, bgrad: Optional[Tensor] = None,
+                bias_done: bool = False) -> Optional[Tensor]:
     """Backward of y = x W^T + b given dpre = dL/dy: W.grad += dpre^T x, b.grad += colsum(dpre),
     returns dL/dx = dpre W (MFMA GEMMs on transposed operands; accumulation into the flat
     gradient arena the parameters' .grad are views of)."""
@@ -173,7 +174,7 @@ def _linear_bwd(dpre: Tensor, x: Tensor, weight, bias,
     # the SU(3) vnet, LeapfrogLayer.native_train_begin)
     ops.gemm_ex(dpre, x, a_trans=True, w_trans=True,
                 out=weight.grad if wgrad is None else wgrad, accumulate=True)
-    if bias is not None:
+    if bias is not None and not bias_done:
         ops.colsum_(bias.grad if bgrad is None else bgrad, dpre)
     if not need_dx:
         return None
@@ -721,6 +722,7 @@ class LeapfrogLayer(nn.Module):
                 torch.index_select(t, dim, perm, out=buf)
                 nat['g'][k].zero_()
         nat['src'] = src
+        nat.pop('sliced', None)            # this step's slice image of the heads: built on first use
         nat['active'] = True
 
     def native_train_end(self) -> None:
@@ -759,12 +761,13 @@ class LeapfrogLayer(nn.Module):
         return self.training and (float(self.net_config.dropout_prob) > 0
                                   or bool(self.net_config.use_batch_norm))
 
-    def forward_train(self, x: Tensor, v: Tensor, drop_keep: Optional[Tensor] = None
-                      ) -> tuple[Tensor, Tensor, Tensor, dict]:
+    def forward_train(self, x: Tensor, v: Tensor, drop_keep: Optional[Tensor] = None,
+                      hidden_only: bool = False) -> tuple[Tensor, Tensor, Tensor, dict]:
         """(s, t, q, ctx).  drop_keep: a given dropout keep-mask [nb, units[-1]] instead of a
         fresh draw (the construction-time dummy forward replays the host generator's mask).  x: the network's x input ([nb, C, T, X] when there is a conv stack,
         otherwise anything flattenable to [nb, Kx]); v likewise.  reference: network.py:522-551
-        under autograd."""
+        under autograd.  hidden_only: stop in front of the heads and return (z, ctx) -- the caller runs
+        heads_vupdate_train_sliced, which completes ctx."""
         il = self.input_layer
         nb = x.shape[0]
         conv_ctx = None
@@ -813,6 +816,8 @@ class LeapfrogLayer(nn.Module):
             bn.num_batches_tracked += 1
         ctx['z'] = z
         ctx['native'] = nw_ is not None
+        if hidden_only:
+            return z, ctx
         if nw_ is not None:
             s = ops.gemm(z, nw_['ws'], nw_['bs'], coeff=nw_['cs'], scale=self.nw.s, act='tanh')
             t = ops.gemm(z, nw_['wt'], nw_['bt'], scale=self.nw.t)
@@ -825,6 +830,45 @@ class LeapfrogLayer(nn.Module):
                          coeff=self.transf.coeff.detach().reshape(-1), scale=self.nw.q, act='tanh')
         ctx['s'], ctx['q'] = s, q
         return s, t, q, ctx
+
+    # ---- the heads of the training tape on the int8-sliced kernel (csrc/heads_sliced.hip, TAPE instances)
+    def sliced_train_image(self):
+        """Slice image of this step's native-order head weights, or None when the layer does not qualify
+        (not in native-order training, fp32, units[-1] != 256, an unbounded activation in front of the heads,
+        dropout / BatchNorm between them, or weights the 54-bit fixed point refuses).  Built on first use
+        after native_train_begin (one pass over the 3 x N x 256 weights + a stream synchronisation per
+        optimiser step), into the previous step's buffer."""
+        nat = getattr(self, '_nat', None)
+        if nat is None or not nat.get('active'):
+            return None
+        if 'sliced' in nat:
+            return nat['sliced']
+        w = nat['w']
+        ok = (w['ws'].dtype == torch.float64 and w['ws'].is_cuda and w['ws'].shape[1] == ops.SLICED_K
+              and self.act == 'tanh' and not self.net_config.use_batch_norm
+              and not (float(self.net_config.dropout_prob) > 0 and self.training)
+              and isinstance(self.scale, ScaledTanh) and isinstance(self.transf, ScaledTanh))
+        image = None
+        if ok:
+            buf, usable = ops.heads_sliced_build_into(w['ws'], w['wt'], w['wq'], nat.get('sliced_buf'))
+            nat['sliced_buf'] = buf
+            if usable:
+                image = {'image': buf, 'cs': float(self.nw.s) * torch.exp(w['cs']),
+                         'cq': float(self.nw.q) * torch.exp(w['cq'])}
+        nat['sliced'] = image
+        return image
+
+    def heads_vupdate_train_sliced(self, z: Tensor, ctx: dict, v: Tensor, force: Tensor, eps: float,
+                                   forward: bool):
+        """(v', logdet, s, t, q) from the hidden activations of forward_train(..., hidden_only=True): the three
+        heads and the first momentum update that consumes them in one kernel; completes ctx for backward."""
+        im = self.sliced_train_image()
+        w = self._nat['w']
+        v_new, ld, s, t, q = ops.vnet_heads_vupdate_sliced_tape(
+            z, im['image'], w['bs'], im['cs'], w['bt'], float(self.nw.t), w['bq'], im['cq'], v, force, eps,
+            forward)
+        ctx['s'], ctx['q'] = s, q
+        return v_new, ld, s, t, q
 
     def backward(self, ctx: dict, ds: Tensor, dt: Tensor, dq: Tensor) -> tuple[Tensor, Tensor]:
         """Accumulates every parameter's .grad; returns (dL/dx_in, dL/dv_in) shaped like the
@@ -840,21 +884,22 @@ class LeapfrogLayer(nn.Module):
         ng_ = self._nat['g'] if native else None
         for head, cot, out, tag in ((self.scale, ds, ctx['s'], 's'), (self.transl, dt, None, 't'),
                                     (self.transf, dq, ctx['q'], 'q')):
+            # the head's VJP with its bias and coefficient gradients (column sums over the chains; d s / d coeff
+            # = s) formed in the same pass over (cot, out)
+            lin = head.layer if isinstance(head, ScaledTanh) else head
+            bg = ng_['b' + tag] if native else lin.bias.grad
             if isinstance(head, ScaledTanh):
                 nw = self.nw.s if head is self.scale else self.nw.q
                 co = head.coeff.detach().reshape(-1) if not native else nw_['c' + tag]
                 cg = head.coeff.grad.reshape(-1) if not native else ng_['c' + tag]
-                ops.colsum_(cg, cot, out)                               # d s / d coeff = s
-                dpre = ops.scaled_tanh_bwd(cot, out, co, nw)
-                lin = head.layer
+                dpre = ops.scaled_tanh_bwd_sums(cot, out, co, nw, bg, cg)
             else:
-                dpre = ops.scaled_tanh_bwd(cot, None, None, self.nw.t)
-                lin = head
+                dpre = ops.scaled_tanh_bwd_sums(cot, None, None, self.nw.t, bg, None)
             if native:
                 d = _linear_bwd(dpre, z, nw_['w' + tag], nw_['b' + tag], xT=zT,
-                                wgrad=ng_['w' + tag], bgrad=ng_['b' + tag])
+                                wgrad=ng_['w' + tag], bgrad=ng_['b' + tag], bias_done=True)
             else:
-                d = _linear_bwd(dpre, z, lin.weight, lin.bias, xT=zT)
+                d = _linear_bwd(dpre, z, lin.weight, lin.bias, xT=zT, bias_done=True)
             dz = d if dz is None else ops.add_(dz, d)
         if self.net_config.use_batch_norm:
             bn = self.batch_norm

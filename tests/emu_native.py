@@ -329,6 +329,13 @@ def l2q_scaled_tanh_bwd(ds, s, coeff, scale, M, N, esz, dpre):
     dpre.copy_(ds * g * (1 - th * th))
 
 
+def l2q_scaled_tanh_bwd_sums(ds, s, coeff, scale, M, N, esz, dpre, bgrad, cgrad, ws=None, wsn=0):
+    l2q_scaled_tanh_bwd(ds, s, coeff, scale, M, N, esz, dpre)
+    l2q_colsum(dpre, None, M, N, 1.0, 1, esz, bgrad)
+    if coeff is not None:
+        l2q_colsum(ds, s, M, N, 1.0, 1, esz, cgrad)
+
+
 def l2q_bn_train_fwd(x, gamma, beta, eps, momentum, rm, rv, M, N, esz, y, mean, invstd):
     mu = x.mean(0)
     var = x.var(0, unbiased=False)
@@ -691,6 +698,12 @@ def l2q_v_update_bwd_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, dv, dF
     g = _vjp(f, [v.reshape(nb, n), force.reshape(nb, n), s, t, q, e], [gv.reshape(nb, n), gl])
     dv.copy_(g[0].reshape(dv.shape)); dF.copy_(g[1].reshape(dF.shape))
     ds.copy_(g[2]); dt.copy_(g[3]); dq.copy_(g[4]); deps.copy_(g[5])
+
+
+def l2q_v_update_bwd_acc_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, aF, as_, at, aq, dv, dF, ds,
+                              dt, dq, deps, ws, wsn):
+    l2q_v_update_bwd_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, dv, dF, ds, dt, dq, deps, ws, wsn)
+    dF.add_(aF.reshape(dF.shape)); ds.add_(as_); dt.add_(at); dq.add_(aq)
 
 
 def l2q_diff_bwd_f64(x, y, a, nb, n, gx):

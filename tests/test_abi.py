@@ -176,7 +176,7 @@ def test_sliced_heads_waits_are_sound():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     n, bad, report = mod.check(mod.isa())
-    assert n == 12 and bad == 0, report
+    assert n == 16 and bad == 0, report            # 12 inference instances + the 4 TAPE ones
 
 
 def test_gemm_sliced_isa_discipline():

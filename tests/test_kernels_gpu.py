@@ -399,6 +399,13 @@ def test_heads_sliced_edge_cases(ops):
     assert ops.heads_sliced_build({nm: (dev(rng.normal(size=(n, 128))), None, None) for nm in 'stq'}) is None
     hd = mk()
     assert ops.heads_sliced_build({nm: (hd[nm][0].float(), None, None) for nm in 'stq'}) is None
+    # an image that would take more than its share of the free device memory is not built
+    frac = ops.SLICED_IMAGE_MAX_FREE_FRACTION[0]
+    try:
+        ops.SLICED_IMAGE_MAX_FREE_FRACTION[0] = 0.0
+        assert ops.heads_sliced_build(mk()) is None
+    finally:
+        ops.SLICED_IMAGE_MAX_FREE_FRACTION[0] = frac
     # zero rows / columns are exact; NaN and Inf poison exactly the outputs that use them
     hd = mk()
     hd['t'][0][3, :] = 0.0
@@ -1000,3 +1007,46 @@ def test_u1_heads_update_h_stream_equals_tile(hd, dims):
                 assert dl < (1e-5 * max(1.0, float(res[0][1].abs().max())) + 2 * ulp * 0.17) * n ** 0.5, dl
     finally:
         native.set_tuning('heads_h_stream', 0)
+
+
+@pytest.mark.parametrize('cplx', [True, False])
+@pytest.mark.parametrize('shape', [(33, 40), (256, 1152), (100, 8200)])
+def test_heads_sliced_tape(ops, cplx, shape):
+    """TAPE instances of the sliced kernel (the forward pass of the training tape): the momentum and logdet are
+    the bits of the inference instance, and the stored heads s, t, q equal the three fp64 GEMM heads of
+    LeapfrogLayer.forward_train to fp64 rounding of the dot products."""
+    m, n = shape
+    k = 256
+    rng = np.random.default_rng(8)
+    z = dev(np.tanh(rng.normal(size=(m, k))))
+    heads = {}
+    for nm in 'stq':
+        w = dev(rng.uniform(-1, 1, size=(n, k)) / 16); b = dev(0.1 * rng.normal(size=n))
+        c = None if nm == 't' else dev(np.exp(0.3 * rng.normal(size=n)))
+        heads[nm] = (w, b, c)
+    nw = (1.0, 1.1, 1.0)
+    if cplx:
+        v = dev(rng.normal(size=(m, n)) + 1j * rng.normal(size=(m, n)))
+        f = dev(rng.normal(size=(m, n)) + 1j * rng.normal(size=(m, n)))
+    else:
+        v = dev(rng.normal(size=(m, n))); f = dev(rng.normal(size=(m, n)))
+    image, usable = ops.heads_sliced_build_into(heads['s'][0], heads['t'][0], heads['q'][0])
+    assert usable
+    sl = dict(heads)
+    sl['sliced'] = image
+    for fwd in (True, False):
+        v0 = v.clone()
+        vt, ld, s, t, q = ops.vnet_heads_vupdate_sliced_tape(z, image, heads['s'][1], heads['s'][2], heads['t'][1],
+                                                             nw[1], heads['q'][1], heads['q'][2], v0, f, 0.07, fwd)
+        assert torch.equal(v0, v)                                                   # out of place
+        vb = v.clone(); lb = ops.vnet_heads_vupdate_(z, sl, nw, vb, f, 0.07, fwd)   # inference instance
+        assert torch.equal(vt, vb) and torch.equal(ld, lb)
+        # the heads as forward_train forms them: scale * exp(coeff) * tanh(z W^T + b), coeff = log(c)
+        s_ref = ops.gemm(z, heads['s'][0], heads['s'][1], coeff=torch.log(heads['s'][2]), scale=1.0, act='tanh')
+        t_ref = ops.gemm(z, heads['t'][0], heads['t'][1], scale=nw[1])
+        q_ref = ops.gemm(z, heads['q'][0], heads['q'][1], coeff=torch.log(heads['q'][2]), scale=1.0, act='tanh')
+        for got, want in ((s, s_ref), (t, t_ref), (q, q_ref)):
+            assert float((got - want).abs().max()) < 5e-15 * max(1.0, float(want.abs().max()))
+        # and the update from them is the v_update kernel's
+        v2, l2 = ops.v_update(v, f, s, t, q, 0.07, fwd)
+        assert float((v2 - vt).abs().max()) < 2e-14 and err(host(l2), host(ld)) < 1e-12
