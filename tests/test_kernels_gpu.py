@@ -1013,7 +1013,7 @@ def test_u1_heads_update_h_stream_equals_tile(hd, dims):
 @pytest.mark.parametrize('shape', [(33, 40), (256, 1152), (100, 8200)])
 def test_heads_sliced_tape(ops, cplx, shape):
     """TAPE instances of the sliced kernel (the forward pass of the training tape): the momentum and logdet are
-    the bits of the inference instance, and the stored heads s, t, q equal the three fp64 GEMM heads of
+    those of the inference instance, and the stored heads s, t, q equal the three fp64 GEMM heads of
     LeapfrogLayer.forward_train to fp64 rounding of the dot products."""
     m, n = shape
     k = 256
@@ -1040,7 +1040,9 @@ def test_heads_sliced_tape(ops, cplx, shape):
                                                              nw[1], heads['q'][1], heads['q'][2], v0, f, 0.07, fwd)
         assert torch.equal(v0, v)                                                   # out of place
         vb = v.clone(); lb = ops.vnet_heads_vupdate_(z, sl, nw, vb, f, 0.07, fwd)   # inference instance
-        assert torch.equal(vt, vb) and torch.equal(ld, lb)
+        # (not bit for bit: hipcc contracts the update's multiply-adds differently in the two instances)
+        assert float((vt - vb).abs().max()) < 4e-15 * max(1.0, float(vb.abs().max()))
+        assert err(host(ld), host(lb)) < 1e-13
         # the heads as forward_train forms them: scale * exp(coeff) * tanh(z W^T + b), coeff = log(c)
         s_ref = ops.gemm(z, heads['s'][0], heads['s'][1], coeff=torch.log(heads['s'][2]), scale=1.0, act='tanh')
         t_ref = ops.gemm(z, heads['t'][0], heads['t'][1], scale=nw[1])
