@@ -73,7 +73,10 @@ struct LkCtx {
 
 __host__ __device__ constexpr int lk_other(int mu, int j) { return j + (j >= mu ? 1 : 0); }
 
-// MODE 0: out = coef * F;  MODE 1: out = vin + coef * F  (vin == out: the in-place kick)
+// MODE 0: out = coef * F;  MODE 1: out = vin + coef * F  (vin == out: the in-place kick);
+// MODE 2 (training, the VJP of the force with the staple sum held constant like the reference's
+//   autograd.grad(action) without create_graph, lattice/su3/pytorch/lattice.py:299-308):
+//   out += coef * TAH(vin) A^H  with vin = g_F, out = g_x  (the same staple sweep, another epilogue)
 template <int MODE, int MU, int INM>
 __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
   constexpr bool IN_MU = lk_in<INM>(MU);
@@ -229,7 +232,34 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
         }
       }
     }
-    if (it >= c.lo) {
+    if (MODE == 2 && it >= c.lo) {
+      // G = TAH(g_F(s, mu)) from memory, then entry (i, j) of G A^H = sum_k G_ik conj(A_jk), added to g_x
+      const int so = MU * 9 * V16 + gcur;
+      M3 gl, g;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const double2 o = buf_ld_nt(rv, q_sp, so + e * V16);
+        gl.re[e] = o.x; gl.im[e] = o.y;
+      }
+      m3_tah(g, gl);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          double sr = 0.0, si = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double ar = acc.re[3 * j + k], ai = -acc.im[3 * j + k];
+            sr = fma(g.re[3 * i + k], ar, sr); sr = fma(-g.im[3 * i + k], ai, sr);
+            si = fma(g.re[3 * i + k], ai, si); si = fma(g.im[3 * i + k], ar, si);
+          }
+          const double2 o = buf_ld_nt(ro, q_sp, so + (3 * i + j) * V16);
+          outv[3 * i + j] = make_double2(fma(c.coef, sr, o.x), fma(c.coef, si, o.y));
+        }
+#pragma unroll
+      for (int e = 0; e < 9; ++e) buf_st_nt(ro, q_sp, so + e * V16, outv[e]);
+    }
+    if (MODE != 2 && it >= c.lo) {
       // W = U A with U streamed by rows from the tile; F = (W - W^H)/2 - tr(W - W^H)/6
       // (group/su3/pytorch/group.py:92-103), formed entry by entry at the store.  The output (and
       // the momentum read by the kick) is touched once: streaming (nt) accesses keep it from
@@ -284,7 +314,7 @@ __device__ __forceinline__ void force_link_sweep(const LkCtx& c) {
 #pragma unroll
       for (int e = 0; e < 9; ++e) *reinterpret_cast<double2*>(fr_lds + dst + e * kEnt) = pre[e];
     }
-    if ((L2Q_LK_EXP & 32) && it >= c.lo) {
+    if ((L2Q_LK_EXP & 32) && MODE != 2 && it >= c.lo) {
       const int so = MU * 9 * V16 + gcur;
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(kLkThreads, L2Q_LK_OCC) void su3_force_link_kernel(
   const int chain_bytes = 36 * k.V16;
   k.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + c * 36L * V), 0, chain_bytes, 0x00020000);
   k.ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + c * 36L * V), 0, chain_bytes, 0x00020000);
-  k.rv = __builtin_amdgcn_make_buffer_rsrc((void*)((MODE == 1 ? vin : out) + c * 36L * V), 0, chain_bytes, 0x00020000);
+  k.rv = __builtin_amdgcn_make_buffer_rsrc((void*)((MODE != 0 ? vin : out) + c * 36L * V), 0, chain_bytes, 0x00020000);
   k.sp = sb * kRS + k.lt;
   {
     int q = k.sp;
@@ -371,6 +401,24 @@ int force_link_inmask(const Dims& d) {
 
 bool force_link_applicable(const Dims& d) {
   return (d.X * d.Y * d.Z) % kRS == 0 && 36.0 * d.V * 16.0 < 2.0e9;
+}
+
+// g_x += coef * TAH(g_F) A^H  (l2q_su3_force_bwd; the staple sum A recomputed by the force sweep)
+void launch_force_link_bwd(const double2* xn, Dims d, int nb, double coef, const double2* gf, double2* gx,
+                           hipStream_t st) {
+  const int Vs = d.X * d.Y * d.Z;
+  const int nsb = Vs / kRS;
+  int tsplit = (int)cdiv(1024, (long)nb * nsb);
+  if (tsplit > d.T) tsplit = d.T;
+  if (tsplit < 1) tsplit = 1;
+  const int tlen = (int)cdiv(d.T, tsplit);
+  tsplit = (int)cdiv(d.T, tlen);
+  switch (force_link_inmask(d)) {
+    case 7: launch_link_variant<2, 7>(xn, d, nb, nsb, tsplit, coef, gf, gx, st); break;
+    case 6: launch_link_variant<2, 6>(xn, d, nb, nsb, tsplit, coef, gf, gx, st); break;
+    case 4: launch_link_variant<2, 4>(xn, d, nb, nsb, tsplit, coef, gf, gx, st); break;
+    default: launch_link_variant<2, 0>(xn, d, nb, nsb, tsplit, coef, gf, gx, st);
+  }
 }
 
 // kick: out = vin + coef * F (vin == nullptr or out: in place)

@@ -148,6 +148,11 @@ __global__ __launch_bounds__(kBlock, 3) void su3_projsu_vec8_bwd_kernel(
   }
 }
 
+// su3_force_link.hip
+bool force_link_applicable(const Dims& d);
+void launch_force_link_bwd(const double2* xn, Dims d, int nb, double coef, const double2* gf, double2* gx,
+                           hipStream_t st);
+
 // ------------------------------------------------------------------ staple-type VJPs
 // Both use the up / down staples of link (s, mu) in direction nu
 //   S_up = U_nu(s+mu) U_mu(s+nu)^H U_nu(s)^H,  S_dn = U_nu(s+mu-nu)^H U_mu(s-nu)^H U_nu(s-nu).
@@ -344,6 +349,13 @@ int l2q_su3_force_bwd(const void* xn, const void* gf, double beta, void* gx, int
   L2Q_REQUIRE(xn && gf && gx, L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(dims_ok4(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
   Dims d{T, X, Y, Z, T * X * Y * Z};
+  // the slice-resident force sweep with the VJP epilogue (su3_force_link.hip, MODE 2) where the force itself
+  // runs on it: the staple sum of the link from LDS-resident slices instead of 18 flat matrix loads per link
+  if (tuning().force_tile >= 5 && force_link_applicable(d)) {
+    launch_force_link_bwd((const double2*)xn, d, nb, beta / 3.0, (const double2*)gf, (double2*)gx,
+                          (hipStream_t)stream);
+    return check_launch("l2q_su3_force_bwd");
+  }
   const long nblk = cdiv(d.V, kBlock);
   hipLaunchKernelGGL(su3_staple_bwd_kernel<0>, dim3((unsigned)(nb * nblk * 4)), dim3(kBlock), 0,
                      (hipStream_t)stream, (const double2*)xn, d, nblk, tuning().xcd_swizzle,

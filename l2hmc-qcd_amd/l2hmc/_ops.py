@@ -520,6 +520,10 @@ def heads_sliced_build_into(ws_: torch.Tensor, wt: torch.Tensor, wq: torch.Tenso
     n, k = ws_.shape
     nbytes = int(N.load().l2q_heads_sliced_bytes(k, n))
     if buf is None or buf.numel() != nbytes or buf.device != ws_.device:
+        free, _total = torch.cuda.mem_get_info(ws_.device)
+        idle = torch.cuda.memory_reserved(ws_.device) - torch.cuda.memory_allocated(ws_.device)
+        if nbytes > SLICED_IMAGE_MAX_FREE_FRACTION[0] * (free + idle):
+            return None, False                       # (same memory gate as heads_sliced_build)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=ws_.device)
     usable = ctypes.c_int(0)
     N.call('l2q_heads_sliced_build', ws_, wt, wq, k, n, buf, nbytes, ctypes.byref(usable))
