@@ -84,6 +84,8 @@ def parse():
     ap.add_argument('--fp64-train-heads', action='store_true',
                     help='A/B (--mode train): the heads of the training tape as three fp64 GEMMs + v_update '
                          'instead of the TAPE instances of the int8-sliced heads kernel')
+    ap.add_argument('--no-defer-weight-grads', action='store_true',
+                    help='A/B (--mode train): weight-gradient GEMMs per network call instead of one per matrix and step')
     return ap.parse_args()
 
 
@@ -158,6 +160,8 @@ def build_trainer(args, seed):
     tr.micro_batch = args.micro_batch
     if args.fp64_train_heads:
         tr.dynamics.sliced_train_heads = False
+    if args.no_defer_weight_grads:
+        tr.dynamics.defer_weight_grads = False
     return tr
 
 

@@ -191,13 +191,18 @@ def su3_mul_n(an: torch.Tensor, bn: torch.Tensor, adjoint_a: bool = False,
     return out
 
 
-def su3_projsu_vec8_n(xn: torch.Tensor) -> torch.Tensor:
-    """[..., 9, V] c128 -> [..., 8, V] float64 (native vec8 order)."""
+def su3_projsu_vec8_n(xn: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[..., 9, V] c128 -> [..., 8, V] float64 (native vec8 order).  out: a contiguous float64 buffer of that
+    many elements to write instead of a new tensor (the training tape's activation arena)."""
     V = xn.shape[-1]
     nf = xn.numel() // (9 * V)
-    out = torch.empty((*xn.shape[:-2], 8, V), dtype=torch.float64, device=xn.device)
+    shape = (*xn.shape[:-2], 8, V)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float64, device=xn.device)
+    elif out.numel() != nf * 8 * V or out.dtype != torch.float64 or not out.is_contiguous():
+        raise N.L2QError('su3_projsu_vec8_n: bad output buffer')
     N.call('l2q_su3_projsu_vec8', xn, out, nf, V)
-    return out
+    return out.view(shape)
 
 
 def su3_kinetic_n(vn: torch.Tensor) -> torch.Tensor:
@@ -934,10 +939,14 @@ def scaled_tanh_bwd(ds: torch.Tensor, s: Optional[torch.Tensor], coeff: Optional
 
 
 def scaled_tanh_bwd_sums(ds: torch.Tensor, s: Optional[torch.Tensor], coeff: Optional[torch.Tensor],
-                         scale: float, bgrad: torch.Tensor, cgrad: Optional[torch.Tensor]) -> torch.Tensor:
-    """scaled_tanh_bwd + `bgrad += colsum(dpre)` + (with coeff) `cgrad += colsum(ds * s)` in one pass."""
+                         scale: float, bgrad: torch.Tensor, cgrad: Optional[torch.Tensor],
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """scaled_tanh_bwd + `bgrad += colsum(dpre)` + (with coeff) `cgrad += colsum(ds * s)` in one pass.
+    out: where dpre goes (a contiguous [m, n] slice of the tape's cotangent arena)."""
     m, n = ds.shape
-    dpre = torch.empty_like(ds)
+    dpre = torch.empty_like(ds) if out is None else out
+    if dpre.shape != ds.shape or dpre.dtype != ds.dtype or not dpre.is_contiguous():
+        raise N.L2QError('scaled_tanh_bwd_sums: bad output buffer')
     ws = N.workspace(2 * int(N.load().l2q_colsum_ws_bytes(m, n)), ds.device)
     N.call('l2q_scaled_tanh_bwd_sums', ds, s, coeff, float(scale), m, n, ds.element_size(), dpre, bgrad,
            cgrad, ws, ws.numel())

@@ -238,13 +238,24 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
                              'primary': share['idx']})
         return v_new, ld
     F = ops.su3_force_n(x, beta, dyn.latvolume)
-    xv = ops.su3_projsu_vec8_n(x).reshape(nb, -1)
-    fv = ops.su3_projsu_vec8_n(F).reshape(nb, -1)
+    # native-order training: the network inputs of all calls of the step side by side in one arena, so that the
+    # weight gradients are ONE GEMM per matrix at the end of the reverse sweep (LeapfrogLayer.defer_slot)
+    slot = None
+    if vnet.native_active() and getattr(dyn, 'defer_weight_grads', True):
+        slot = vnet.defer_slot(nb, 32 * V, 32 * V, getattr(tape, 'defer_cap', 0))
+    if slot is not None:
+        xv = ops.su3_projsu_vec8_n(x, out=slot[1]).reshape(nb, -1)
+        fv = ops.su3_projsu_vec8_n(F, out=slot[2]).reshape(nb, -1)
+    else:
+        xv = ops.su3_projsu_vec8_n(x).reshape(nb, -1)
+        fv = ops.su3_projsu_vec8_n(F).reshape(nb, -1)
     if (vnet.native_active() and getattr(dyn, 'sliced_train_heads', True) and ops.USE_SLICED_HEADS[0]
             and vnet.sliced_train_image() is not None):
         # the heads and this v-update in one launch on the int8 matrix cores (TAPE kernel: s, t, q are
         # stored for the reverse sweep); the image is rebuilt once per optimiser step
         z, ctx = vnet.forward_train(xv, fv, hidden_only=True)
+        if slot is not None:
+            ctx['defer_idx'] = slot[0]
         v_new, ld, sn, tn, qn = vnet.heads_vupdate_train_sliced(z, ctx, v.reshape(nb, -1), F.reshape(nb, -1),
                                                                  eps, forward)
         v_new = v_new.reshape(v.shape)
@@ -258,6 +269,8 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
     if vnet.native_active():
         # native-order weight shadows (LeapfrogLayer.native_train_begin): no activation transposes
         sn, tn, qn, ctx = vnet.forward_train(xv, fv)
+        if slot is not None:
+            ctx['defer_idx'] = slot[0]
     else:
         # the network sees the reference's entry order (mu, site, component)
         s, t, q, ctx = vnet.forward_train(ops.unpack_entries(xv, V, 8), ops.unpack_entries(fv, V, 8))
@@ -326,6 +339,7 @@ def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
                             'xeps': dyn.xeps[0], 'veps': dyn.veps[0]}, history)
     nlf = dyn.config.nleapfrog
     share = {} if (dyn.group == 'SU3' and getattr(dyn, 'reuse_v_inputs', True)) else None
+    tape.defer_cap = (2 * nlf + 1) if share is not None else 4 * nlf     # network calls of this trajectory
     for step in range(nlf):
         x, v, ld = _lf_train(dyn, tape, step, x, v, beta, True, share)
         sumlogdet = sumlogdet + ld
@@ -372,6 +386,7 @@ def trajectory_train(dyn, xn: Tensor, vn: Tensor, beta: float, forward: bool):
         dyn.update_history(dyn._metrics_n(x, v, beta, sumlogdet, None, None), history)
     nlf = dyn.config.nleapfrog
     share = {} if (dyn.group == 'SU3' and getattr(dyn, 'reuse_v_inputs', True)) else None
+    tape.defer_cap = (nlf + 1) if share is not None else 2 * nlf
     for step in range(nlf):
         x, v, ld = _lf_train(dyn, tape, step, x, v, beta, forward, share)
         sumlogdet = sumlogdet + ld
@@ -549,6 +564,8 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
             # the kernel differentiates w.r.t. the signed step it was called with
             eps_acc.setdefault(('x', e['step']), []).append(deps if e['forward'] else -deps)
     assert not pend
+    for net in {id(e['net']): e['net'] for e in tape.entries if e.get('kind') == 'v'}.values():
+        net.flush_deferred()
     _accumulate_eps_grads(dyn, eps_acc)
 
 

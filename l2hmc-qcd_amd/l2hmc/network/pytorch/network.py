@@ -163,7 +163,7 @@ def advance_rand(numel: int, dtype: Optional[torch.dtype] = None) -> None:
 def _linear_bwd(dpre: Tensor, x: Tensor, weight, bias,
                 need_dx: bool = True, xT: Optional[Tensor] = None,
                 wgrad: Optional[Tensor] = None, bgrad: Optional[Tensor] = None,
-                bias_done: bool = False) -> Optional[Tensor]:
+                bias_done: bool = False, skip_dw: bool = False) -> Optional[Tensor]:
     """Backward of y = x W^T + b given dpre = dL/dy: W.grad += dpre^T x, b.grad += colsum(dpre),
     returns dL/dx = dpre W (MFMA GEMMs on transposed operands; accumulation into the flat
     gradient arena the parameters' .grad are views of)."""
@@ -172,8 +172,11 @@ def _linear_bwd(dpre: Tensor, x: Tensor, weight, bias,
     # (rows that are not 16-byte multiples fall back to explicit transposes inside gemm_ex)
     # wgrad / bgrad: accumulate there instead of weight.grad / bias.grad (native-order shadows of
     # the SU(3) vnet, LeapfrogLayer.native_train_begin)
-    ops.gemm_ex(dpre, x, a_trans=True, w_trans=True,
-                out=weight.grad if wgrad is None else wgrad, accumulate=True)
+    # skip_dw: the caller has parked (dpre, x) in the tape's arenas and forms W.grad for all network calls of
+    # the step in ONE GEMM afterwards (LeapfrogLayer.flush_deferred)
+    if not skip_dw:
+        ops.gemm_ex(dpre, x, a_trans=True, w_trans=True,
+                    out=weight.grad if wgrad is None else wgrad, accumulate=True)
     if bias is not None and not bias_done:
         ops.colsum_(bias.grad if bgrad is None else bgrad, dpre)
     if not need_dx:
@@ -723,6 +726,9 @@ class LeapfrogLayer(nn.Module):
                 nat['g'][k].zero_()
         nat['src'] = src
         nat.pop('sliced', None)            # this step's slice image of the heads: built on first use
+        if nat.get('defer') is not None and not nat['defer'].get('off'):
+            nat['defer']['i'] = 0
+            nat['defer']['seen'] = set()
         nat['active'] = True
 
     def native_train_end(self) -> None:
@@ -730,6 +736,7 @@ class LeapfrogLayer(nn.Module):
         nat = getattr(self, '_nat', None)
         if nat is None or not nat.get('active'):
             return
+        self.flush_deferred()                  # (a no-op when the reverse sweep has flushed already)
         with torch.no_grad():
             inv = nat.setdefault('inv', {})
             for k, (par, dim, perm) in nat['src'].items():
@@ -831,6 +838,76 @@ class LeapfrogLayer(nn.Module):
         ctx['s'], ctx['q'] = s, q
         return s, t, q, ctx
 
+    # ---- weight gradients of all network calls of a step in one GEMM per matrix
+    DEFER_MAX_FREE_FRACTION = 0.25
+
+    def defer_slot(self, nb: int, kx: int, kv: int, capacity: int):
+        """Native-order training: activation slots of the next network call of this step inside contiguous
+        arenas ([capacity, nb, k]), or None.  The weight-gradient GEMMs dW += dpre^T x have the chains as their
+        contraction dimension -- 256 deep per call, where the fp64 MFMA kernel spends as long on its prologue,
+        its accumulate epilogue (W.grad read and written per call) and tile quantisation as on the products:
+        0.53 / 0.42 ms per call for the heads / input matrices at cfg-4.  With the inputs (vec8 of x and of
+        the force), the last hidden activations and the heads' pre-activation cotangents of ALL calls of the
+        step kept side by side, flush_deferred forms every W.grad in ONE GEMM with K = calls x chains:
+        0.30 / 0.26 ms per call (tools/gemm_ex_probe.py), W.grad touched once.  Costs the cotangent arenas
+        (3 x calls x chains x N x 8 bytes: 8 GB at cfg-4), taken only while that is a small part of the free
+        device memory; the input arenas replace per-call tensors of the same size."""
+        nat = getattr(self, '_nat', None)
+        if nat is None or not nat.get('active') or capacity <= 0:
+            return None
+        if not getattr(self, 'defer_weight_grads', True):
+            return None
+        d = nat.get('defer')
+        n_out = nat['w']['bs'].numel()
+        units = nat['w']['ws'].shape[1]                # last hidden width (the heads' input)
+        units_in = nat['w']['wx'].shape[0]             # first hidden width (the input layer's output)
+        key = (nb, kx, kv, capacity)
+        if d is None or d['key'] != key:
+            nat.pop('defer', None)
+            dt = nat['w']['ws'].dtype
+            es = 8 if dt == torch.float64 else 4
+            extra = 3 * capacity * nb * n_out * es
+            total = extra + capacity * nb * (kx + kv + units + units_in) * es
+            free, _t = torch.cuda.mem_get_info(nat['w']['ws'].device) if nat['w']['ws'].is_cuda else (1 << 62, 0)
+            idle = (torch.cuda.memory_reserved(nat['w']['ws'].device)
+                    - torch.cuda.memory_allocated(nat['w']['ws'].device)) if nat['w']['ws'].is_cuda else 0
+            if total > self.DEFER_MAX_FREE_FRACTION * (free + idle):
+                nat['defer'] = {'key': key, 'off': True}
+                return None
+            dev = nat['w']['ws'].device
+            d = {'key': key, 'off': False, 'i': 0, 'seen': set(),
+                 'xv': torch.empty((capacity, nb, kx), dtype=dt, device=dev),
+                 'fv': torch.empty((capacity, nb, kv), dtype=dt, device=dev),
+                 'z': torch.empty((capacity, nb, units), dtype=dt, device=dev),
+                 'dpre_in': torch.empty((capacity, nb, units_in), dtype=dt, device=dev),
+                 'dpre': {t: torch.empty((capacity, nb, n_out), dtype=dt, device=dev) for t in 'stq'}}
+            nat['defer'] = d
+        if d.get('off') or d['i'] >= capacity:
+            return None
+        i = d['i']
+        d['i'] += 1
+        return i, d['xv'][i], d['fv'][i]
+
+    def flush_deferred(self) -> None:
+        """W.grad of the five big matrices from the arenas filled by this step's backward calls."""
+        nat = getattr(self, '_nat', None)
+        d = None if nat is None else nat.get('defer')
+        if d is None or d.get('off') or not d['seen']:
+            return
+        n = d['i']
+        if d['seen'] != set(range(n)):
+            raise RuntimeError(f'flush_deferred: backward ran for calls {sorted(d["seen"])} of {n}')
+        nb = d['key'][0]
+        ng_ = nat['g']
+        rows = lambda a: a[:n].reshape(n * nb, -1)
+        for tag in 'stq':
+            ops.gemm_ex(rows(d['dpre'][tag]), rows(d['z']), a_trans=True, w_trans=True, out=ng_['w' + tag],
+                        accumulate=True)
+        ops.gemm_ex(rows(d['dpre_in']), rows(d['xv']), a_trans=True, w_trans=True, out=ng_['wx'], accumulate=True)
+        ops.gemm_ex(rows(d['dpre_in']), rows(d['fv']), a_trans=True, w_trans=True, out=ng_['wv'], accumulate=True)
+        d['i'] = 0
+        d['seen'] = set()
+
     # ---- the heads of the training tape on the int8-sliced kernel (csrc/heads_sliced.hip, TAPE instances)
     def sliced_train_image(self):
         """Slice image of this step's native-order head weights, or None when the layer does not qualify
@@ -882,22 +959,30 @@ class LeapfrogLayer(nn.Module):
                                'native_train_end() has already run')
         nw_ = self._nat['w'] if native else None
         ng_ = self._nat['g'] if native else None
+        # weight gradients deferred to flush_deferred (defer_slot): this call parks its operands in slot di
+        di = ctx.get('defer_idx') if native else None
+        dfr = self._nat.get('defer') if di is not None else None
+        if dfr is not None:
+            dfr['z'][di].copy_(z)
+            dfr['seen'].add(di)
         for head, cot, out, tag in ((self.scale, ds, ctx['s'], 's'), (self.transl, dt, None, 't'),
                                     (self.transf, dq, ctx['q'], 'q')):
             # the head's VJP with its bias and coefficient gradients (column sums over the chains; d s / d coeff
             # = s) formed in the same pass over (cot, out)
             lin = head.layer if isinstance(head, ScaledTanh) else head
             bg = ng_['b' + tag] if native else lin.bias.grad
+            slot = None if dfr is None else dfr['dpre'][tag][di]
             if isinstance(head, ScaledTanh):
                 nw = self.nw.s if head is self.scale else self.nw.q
                 co = head.coeff.detach().reshape(-1) if not native else nw_['c' + tag]
                 cg = head.coeff.grad.reshape(-1) if not native else ng_['c' + tag]
-                dpre = ops.scaled_tanh_bwd_sums(cot, out, co, nw, bg, cg)
+                dpre = ops.scaled_tanh_bwd_sums(cot, out, co, nw, bg, cg, out=slot)
             else:
-                dpre = ops.scaled_tanh_bwd_sums(cot, None, None, self.nw.t, bg, None)
+                dpre = ops.scaled_tanh_bwd_sums(cot, None, None, self.nw.t, bg, None, out=slot)
             if native:
                 d = _linear_bwd(dpre, z, nw_['w' + tag], nw_['b' + tag], xT=zT,
-                                wgrad=ng_['w' + tag], bgrad=ng_['b' + tag], bias_done=True)
+                                wgrad=ng_['w' + tag], bgrad=ng_['b' + tag], bias_done=True,
+                                skip_dw=dfr is not None)
             else:
                 d = _linear_bwd(dpre, z, lin.weight, lin.bias, xT=zT, bias_done=True)
             dz = d if dz is None else ops.add_(dz, d)
@@ -917,8 +1002,10 @@ class LeapfrogLayer(nn.Module):
         il = self.input_layer
         dpre = ops.act_bwd(dz, dact[0], self.act, from_preact=pre)
         if native:
-            dxf = _linear_bwd(dpre, ctx['xf'], nw_['wx'], il.xlayer.bias, wgrad=ng_['wx'])
-            dvf = _linear_bwd(dpre, ctx['vf'], nw_['wv'], il.vlayer.bias, wgrad=ng_['wv'])
+            if dfr is not None:
+                dfr['dpre_in'][di].copy_(dpre)
+            dxf = _linear_bwd(dpre, ctx['xf'], nw_['wx'], il.xlayer.bias, wgrad=ng_['wx'], skip_dw=dfr is not None)
+            dvf = _linear_bwd(dpre, ctx['vf'], nw_['wv'], il.vlayer.bias, wgrad=ng_['wv'], skip_dw=dfr is not None)
         else:
             dxf = _linear_bwd(dpre, ctx['xf'], il.xlayer.weight, il.xlayer.bias)
             dvf = _linear_bwd(dpre, ctx['vf'], il.vlayer.weight, il.vlayer.bias)

@@ -30,3 +30,16 @@ cases = [
 for name, fl, fn in cases:
     t = timeit(fn, iters=10, warm=3)
     print(f'{name}: {t * 1e3:7.3f} ms  {fl / t / 1e12:6.2f} TFLOP/s  ({fl / t / 78.6e12:.2f} of the fp64 MFMA peak)', flush=True)
+
+# the nine calls of a step as ONE GEMM over K = 9 x 256 chains (cotangents and activations kept until the end of
+# the reverse sweep): what deferring the weight-gradient GEMMs would buy
+K9 = 9 * nb
+dpre9, z9 = R(K9, NH), R(K9, h)
+t = timeit(lambda: ops.gemm_ex(dpre9, z9, a_trans=True, w_trans=True, out=gWh, accumulate=True), iters=5, warm=2)
+fl = 2.0 * NH * h * K9
+print(f'heads dW, K = {K9}: {t * 1e3:7.3f} ms = {t * 1e3 / 9:.3f} per call  {fl / t / 1e12:6.2f} TFLOP/s', flush=True)
+del dpre9
+dpi9, xf9 = R(K9, h), R(K9, NI)
+t = timeit(lambda: ops.gemm_ex(dpi9, xf9, a_trans=True, w_trans=True, out=gWx, accumulate=True), iters=5, warm=2)
+fl = 2.0 * h * NI * K9
+print(f'input dW, K = {K9}: {t * 1e3:7.3f} ms = {t * 1e3 / 9:.3f} per call  {fl / t / 1e12:6.2f} TFLOP/s', flush=True)
