@@ -84,6 +84,8 @@ def parse():
     ap.add_argument('--fp64-train-heads', action='store_true',
                     help='A/B (--mode train): the heads of the training tape as three fp64 GEMMs + v_update '
                          'instead of the TAPE instances of the int8-sliced heads kernel')
+    ap.add_argument('--separate-x-halves', action='store_true',
+                    help='A/B (--mode train): the two masked x half-updates of a leapfrog step as two tape entries')
     ap.add_argument('--no-defer-weight-grads', action='store_true',
                     help='A/B (--mode train): weight-gradient GEMMs per network call instead of one per matrix and step')
     return ap.parse_args()
@@ -162,6 +164,8 @@ def build_trainer(args, seed):
         tr.dynamics.sliced_train_heads = False
     if args.no_defer_weight_grads:
         tr.dynamics.defer_weight_grads = False
+    if args.separate_x_halves:
+        tr.dynamics.fuse_x_halves_train = False
     return tr
 
 

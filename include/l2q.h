@@ -589,6 +589,14 @@ size_t l2q_sumsq_ws_bytes(long n);
 int l2q_su3_expm_mul_bwd(const void* xn, const void* vn, double eps, const float* mask_n,
                          int complement, const void* gxnew, void* gx, void* gv, double* deps,
                          int nb, long V, void* ws, size_t ws_bytes, void* stream);
+/* VJP of l2q_su3_expm_mul2 (BOTH masked half-updates of a leapfrog step, the mask first or -- complement_first --
+ * its complement first; dynamics.py:1420-1425 / 1468-1474 under autograd): the derivative of the matrix
+ * exponential is linear in its direction, so the two halves share one exponential and ONE Frechet
+ * derivative.  xn: the links BEFORE both halves; gxnew: cotangent of the links after both; same outputs as
+ * l2q_su3_expm_mul_bwd (deps = the sum over both halves). */
+int l2q_su3_expm_mul2_bwd(const void* xn, const void* vn, double eps, const float* mask_n,
+                          int complement_first, const void* gxnew, void* gx, void* gv, double* deps,
+                          int nb, long V, void* ws, size_t ws_bytes, void* stream);
 /* VJP of l2q_su3_projsu_vec8 (su3_to_vec(projectSU(.)), group.py:138-147): gm += .  `in` are
  * the matrices the forward projected; gvec [nfields][8][V]. */
 int l2q_su3_projsu_vec8_bwd(const void* in, const double* gvec, void* gm, long nfields, long V,

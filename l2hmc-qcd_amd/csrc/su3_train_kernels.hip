@@ -126,6 +126,119 @@ __global__ __launch_bounds__(kBlock, 2) void su3_expm_mul_bwd_kernel(
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// ------------------------------------------------------------------ both x half-updates of a leapfrog step, VJP
+// forward (l2q_su3_expm_mul2): x' = k1 (.) x + E y1,  x'' = k2 (.) x' + E y2   with E = expm(eps v) ONCE,
+//   k1 = the mask (or its complement), k2 = 1 - k1, y1 = (1 - k1) (.) x, y2 = (1 - k2) (.) x'.
+// The Frechet derivative is linear in its direction: both halves share ONE evaluation,
+//   g'  = k2 (.) g  + (1 - k2) (.) (E^H g),   g'' = k1 (.) g' + (1 - k1) (.) (E^H g')   (= g_x),
+//   g_A = L_exp((eps v)^H)[ g y2^H + g' y1^H ],   g_v += eps g_A,   d eps = sum Re tr(g_A^H v).
+// One exponential (Cayley-Hamilton) + one derivative instead of two of each; x and v are parked in LDS
+// (each thread its own slots) between their two uses.
+__global__ __launch_bounds__(kBlock, 2) void su3_expm_mul2_bwd_kernel(
+    const double2* __restrict__ xn, const double2* __restrict__ vn, double eps,
+    const float* __restrict__ mask, int complement_first, const double2* __restrict__ gxn, double2* gx,
+    double2* gv, int V, long nblk, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  extern __shared__ __attribute__((aligned(16))) double2 stash[];
+  double2* sx = stash + threadIdx.x;
+  double2* sv = stash + 9 * kBlock + threadIdx.x;
+  const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;     // f = chain*4 + mu
+  const int s = (int)blk * kBlock + threadIdx.x;
+  const int mu = (int)(f & 3);
+  double de = 0.0;
+  if (s < V) {
+    float k1[9];                                       // 0 / 1: exact in fp32
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float k = mask[(mu * 9 + i) * (long)V + s];
+      k1[i] = complement_first ? 1.0f - k : k;
+    }
+    M3 E;
+    {
+      M3 v, a;
+      load_link(v, vn + f * 9L * V, V, s);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        sv[i * kBlock] = make_double2(v.re[i], v.im[i]);
+        a.re[i] = eps * v.re[i]; a.im[i] = eps * v.im[i];
+      }
+      m3_expm(E, a);
+    }
+    M3 gE, gp;                                         // g y2^H (+ g' y1^H), g'
+    {
+      M3 x, y, xp;
+      load_link(x, xn + f * 9L * V, V, s);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        sx[i * kBlock] = make_double2(x.re[i], x.im[i]);
+        const double m1 = 1.0 - (double)k1[i];
+        y.re[i] = m1 * x.re[i]; y.im[i] = m1 * x.im[i];
+      }
+      m3_mul_nn(xp, E, y);                               // x' = k1 x + E y1
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double k = (double)k1[i];
+        xp.re[i] = fma(k, x.re[i], xp.re[i]); xp.im[i] = fma(k, x.im[i], xp.im[i]);
+        // y2 = (1 - k2) x' = k1 x'
+        y.re[i] = k * xp.re[i]; y.im[i] = k * xp.im[i];
+      }
+      M3 g, t;
+      load_link(g, gxn + f * 9L * V, V, s);
+      m3_mul_na(gE, g, y);                               // g y2^H
+      m3_mul_an(t, E, g);                                // E^H g
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double k2 = 1.0 - (double)k1[i];
+        gp.re[i] = k2 * g.re[i] + (1.0 - k2) * t.re[i];
+        gp.im[i] = k2 * g.im[i] + (1.0 - k2) * t.im[i];
+      }
+    }
+    {
+      M3 y, t;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double2 d = sx[i * kBlock];
+        const double m1 = 1.0 - (double)k1[i];
+        y.re[i] = m1 * d.x; y.im[i] = m1 * d.y;          // y1
+      }
+      m3_mac_na(gE, gp, y);                              // + g' y1^H
+      m3_mul_an(t, E, gp);                               // E^H g'
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double k = (double)k1[i];
+        t.re[i] = k * gp.re[i] + (1.0 - k) * t.re[i];
+        t.im[i] = k * gp.im[i] + (1.0 - k) * t.im[i];
+      }
+      store_link(gx + f * 9L * V, V, s, t);
+    }
+    M3 B;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {                      // B = (eps v)^H
+        const double2 d = sv[(3 * j + i) * kBlock];
+        B.re[3 * i + j] = eps * d.x; B.im[3 * i + j] = -eps * d.y;
+      }
+    M3 EB, gA;
+    m3_expm_frechet(EB, gA, B, gE);
+    {
+      M3 v;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { const double2 d = sv[i * kBlock]; v.re[i] = d.x; v.im[i] = d.y; }
+      de = m3_inner(gA, v);
+    }
+    double2* gvf = gv + f * 9L * V;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      double2 o = gvf[e * (long)V + s];
+      o.x = fma(eps, gA.re[e], o.x); o.y = fma(eps, gA.im[e], o.y);
+      gvf[e * (long)V + s] = o;
+    }
+  }
+  const double r = block_sum(de, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
 // ------------------------------------------------------------------ projectSU -> vec8 VJP
 __global__ __launch_bounds__(kBlock, 3) void su3_projsu_vec8_bwd_kernel(
     const double2* __restrict__ in, const double* __restrict__ gvec, double2* gm, int V,
@@ -332,6 +445,26 @@ int l2q_su3_expm_mul_bwd(const void* xn, const void* vn, double eps, const float
                      (const double2*)gxnew, (double2*)gx, (double2*)gv, (int)V, nblk, (double*)ws);
   launch_finalize((const double*)ws, deps, nb, 4 * nblk, 1, 1.0, 0.0, st);
   return check_launch("l2q_su3_expm_mul_bwd");
+}
+
+int l2q_su3_expm_mul2_bwd(const void* xn, const void* vn, double eps, const float* mask_n,
+                          int complement_first, const void* gxnew, void* gx, void* gv, double* deps,
+                          int nb, long V, void* ws, size_t ws_bytes, void* stream) {
+  L2Q_REQUIRE(xn && vn && mask_n && gxnew && gx && gv && deps && ws, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 200000000L, L2Q_EINVAL, "bad size");
+  const long nblk = cdiv(V, kBlock);
+  L2Q_REQUIRE(ws_bytes >= (size_t)nb * 4 * nblk * sizeof(double), L2Q_EINVAL, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t stash_bytes = 2 * 9 * kBlock * sizeof(double2);
+  static PerDeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute((const void*)su3_expm_mul2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)stash_bytes);
+  hipLaunchKernelGGL(su3_expm_mul2_bwd_kernel, dim3((unsigned)(nb * 4L * nblk)), dim3(kBlock), stash_bytes, st,
+                     (const double2*)xn, (const double2*)vn, eps, mask_n, complement_first,
+                     (const double2*)gxnew, (double2*)gx, (double2*)gv, (int)V, nblk, (double*)ws);
+  launch_finalize((const double*)ws, deps, nb, 4 * nblk, 1, 1.0, 0.0, st);
+  return check_launch("l2q_su3_expm_mul2_bwd");
 }
 
 int l2q_su3_projsu_vec8_bwd(const void* in, const double* gvec, void* gm, long nfields, long V,

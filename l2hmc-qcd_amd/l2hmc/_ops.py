@@ -1107,6 +1107,17 @@ def su3_expm_mul_bwd_n(xn, vn, eps: float, mask_n, complement: bool, gxnew, gv):
     return gx, deps
 
 
+def su3_expm_mul2_bwd_n(xn, vn, eps: float, mask_n, complement_first: bool, gxnew, gv):
+    """VJP of su3_expm_mul2_n (both half-updates, one Frechet derivative): -> (gx, deps[nb]); gv += in place."""
+    nb, _, _, V = xn.shape
+    gx = torch.empty_like(xn)
+    deps = torch.empty(nb, dtype=torch.float64, device=xn.device)
+    ws = N.workspace(nb * 4 * ((V + 255) // 256) * 8, xn.device)
+    N.call('l2q_su3_expm_mul2_bwd', xn, vn, float(eps), mask_n, int(complement_first), gxnew, gx, gv, deps,
+           nb, V, ws, ws.numel())
+    return gx, deps
+
+
 def su3_projsu_vec8_bwd_(gm: torch.Tensor, mn: torch.Tensor, gvec: torch.Tensor) -> torch.Tensor:
     """gm += VJP of su3_projsu_vec8_n at mn for the cotangent gvec [..., 8, V]."""
     V = mn.shape[-1]

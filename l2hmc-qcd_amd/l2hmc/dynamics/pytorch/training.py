@@ -307,8 +307,18 @@ def _lf_train(dyn, tape: Tape, step: int, x, v, beta, forward: bool, share: Opti
     m = dyn._native_masks()[st]
     if dyn.group == 'SU3':
         v, ld = _v_step_su3(dyn, tape, st, x, v, beta, forward, share)
-        for comp, _first in order:
-            x = _x_step_su3(dyn, tape, st, x, v, m, comp, forward)
+        if getattr(dyn, 'fuse_x_halves_train', True):
+            # both masked half-updates in one kernel forward (ONE expm(eps v)) and one kernel in the reverse
+            # sweep (one Frechet derivative for both: it is linear in its direction)
+            eps = dyn._eps('x', st)
+            seps = eps if forward else -eps
+            x_new = ops.su3_expm_mul2_n(x, v, seps, m, order[0][0])
+            tape.entries.append({'kind': 'x2', 'step': st, 'forward': forward, 'x': x, 'v': v, 'mask': m,
+                                 'complement_first': order[0][0], 'eps': seps})
+            x = x_new
+        else:
+            for comp, _first in order:
+                x = _x_step_su3(dyn, tape, st, x, v, m, comp, forward)
         v, l = _v_step_su3(dyn, tape, st, x, v, beta, forward, share)
         return x, v, ld + l
     v, ld = _v_step(dyn, tape, st, x, v, beta, forward)
@@ -558,6 +568,10 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
             ops.su3_force_bwd_(gx, x, dF, beta, lat)
             gv = dv.reshape(v.shape)
             eps_acc.setdefault(('v', e['step']), []).append(deps)
+        elif kind == 'x2':
+            gx, deps = ops.su3_expm_mul2_bwd_n(e['x'], e['v'], e['eps'], e['mask'], e['complement_first'],
+                                               gx, gv)
+            eps_acc.setdefault(('x', e['step']), []).append(deps if e['forward'] else -deps)
         else:
             gx, deps = ops.su3_expm_mul_bwd_n(e['x'], e['v'], e['eps'], e['mask'], e['complement'],
                                               gx, gv)

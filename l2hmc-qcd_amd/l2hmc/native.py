@@ -123,6 +123,7 @@ SIGNATURES = {
     'l2q_sumsq': (I, [P, L, I, P, P, Z, P]),
     'l2q_sumsq_ws_bytes': (Z, [L]),
     'l2q_su3_expm_mul_bwd': (I, [P, P, D, P, I, P, P, P, P, I, L, P, Z, P]),
+    'l2q_su3_expm_mul2_bwd': (I, [P, P, D, P, I, P, P, P, P, I, L, P, Z, P]),
     'l2q_su3_projsu_vec8_bwd': (I, [P, P, P, L, L, P]),
     'l2q_su3_force_bwd': (I, [P, P, D, P, I, I, I, I, I, P]),
     'l2q_su3_plaq_bwd': (I, [P, P, P, I, I, I, I, I, P]),

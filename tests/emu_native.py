@@ -627,6 +627,19 @@ def l2q_su3_expm_mul_bwd(xn, vn, eps, mask_n, complement, gxnew, gx, gv, deps, n
     deps.copy_(g[2])
 
 
+def l2q_su3_expm_mul2_bwd(xn, vn, eps, mask_n, complement_first, gxnew, gx, gv, deps, nb, V, ws, wsn):
+    k1 = _keep_n(mask_n, complement_first, nb, V)
+    e = torch.full((nb,), float(eps), dtype=torch.float64)
+
+    def f(x_, v_, e_):
+        a = e_.reshape(nb, 1, 1, 1) * v_
+        return _expm_mul(_expm_mul(x_, a, 1.0, k1), a, 1.0, 1 - k1)
+    g = _vjp(f, [xn.reshape(nb, 4, 9, V), vn.reshape(nb, 4, 9, V), e], [gxnew.reshape(nb, 4, 9, V)])
+    gx.copy_(g[0].reshape(gx.shape))
+    gv.add_(g[1].reshape(gv.shape))
+    deps.copy_(g[2])
+
+
 def l2q_su3_projsu_vec8_bwd(xn, gvec, gm, nf, V):
     (g,) = _vjp(lambda a: _to_vec8(_proj_su(_mats(a))).transpose(-1, -2),
                 [xn.reshape(nf, 9, V)], [gvec.reshape(nf, 8, V)])
