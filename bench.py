@@ -84,6 +84,8 @@ def parse():
     ap.add_argument('--fp64-train-heads', action='store_true',
                     help='A/B (--mode train): the heads of the training tape as three fp64 GEMMs + v_update '
                          'instead of the TAPE instances of the int8-sliced heads kernel')
+    ap.add_argument('--separate-v-pairs', action='store_true',
+                    help='A/B (--mode train): the two v-updates that share a network call reversed by two kernels')
     ap.add_argument('--separate-x-halves', action='store_true',
                     help='A/B (--mode train): the two masked x half-updates of a leapfrog step as two tape entries')
     ap.add_argument('--no-defer-weight-grads', action='store_true',
@@ -166,6 +168,8 @@ def build_trainer(args, seed):
         tr.dynamics.defer_weight_grads = False
     if args.separate_x_halves:
         tr.dynamics.fuse_x_halves_train = False
+    if args.separate_v_pairs:
+        tr.dynamics.fuse_v_pairs_bwd = False
     return tr
 
 

@@ -642,6 +642,15 @@ int l2q_v_update_bwd_acc_c128(const void* v, const void* force, const double* s,
                               int nb, long n, const void* acc_dF, const double* acc_ds, const double* acc_dt,
                               const double* acc_dq, void* dv, void* dF, double* ds, double* dt, double* dq,
                               double* deps, void* ws, size_t ws_bytes, void* stream);
+/* Both v-updates of such a pair reversed in one pass: v_mid = U1(v1) [, v_mid <- -v_mid], v_out = U2(v_mid) with
+ * ONE force and ONE (s, t, q); gv = cotangent of v_out.  dv = cotangent of v1; (dF, ds, dt, dq) = the sum of both
+ * updates' cotangents; deps1 / deps2 = the per-chain d/d eps of the first / second update.  F, s, t, q are read
+ * once (144 instead of 296 bytes per entry for the two calls above).  ws_bytes >= 2 x the single call's. */
+int l2q_v_update_bwd_pair_c128(const void* v1, const void* v_mid, const void* force, const double* s,
+                               const double* t, const double* q, double eps1, int forward1, double eps2,
+                               int forward2, int flip_between, const void* gv, const double* gl, int nb, long n,
+                               void* dv, void* dF, double* ds, double* dt, double* dq, double* deps1,
+                               double* deps2, void* ws, size_t ws_bytes, void* stream);
 /* gx[c][:] += 2 a[c] (x[c][:] - y[c][:]) over n doubles per chain (cotangent of
  * l2q_diff_norm2_reduce, the rmse term of LatticeLoss, loss.py:119-148) */
 int l2q_diff_bwd_f64(const double* x, const double* y, const double* a, int nb, long n, double* gx,

@@ -1186,6 +1186,22 @@ def v_update_bwd_c128(v, force, s, t, q, eps: float, forward: bool, gv, gl, acc=
     return dv, dF, ds, dt, dq, deps
 
 
+def v_update_bwd_pair_c128(v1, v_mid, force, s, t, q, eps1: float, forward1: bool, eps2: float, forward2: bool,
+                           flip: bool, gv, gl):
+    """Two v-updates that share (force, s, t, q), reversed in one pass (include/l2q.h:
+    l2q_v_update_bwd_pair_c128): -> (dv, dF, ds, dt, dq, deps1[nb], deps2[nb])."""
+    nb = v1.shape[0]
+    n = v1.numel() // nb
+    dv, dF = torch.empty_like(v1), torch.empty_like(v1)
+    ds, dt, dq = (torch.empty_like(s) for _ in range(3))
+    deps1 = torch.empty(nb, dtype=torch.float64, device=v1.device)
+    deps2 = torch.empty_like(deps1)
+    ws = N.workspace(2 * nb * ((n + 255) // 256) * 8, v1.device)
+    N.call('l2q_v_update_bwd_pair_c128', v1, v_mid, force, s, t, q, float(eps1), int(forward1), float(eps2),
+           int(forward2), int(flip), gv, gl, nb, n, dv, dF, ds, dt, dq, deps1, deps2, ws, ws.numel())
+    return dv, dF, ds, dt, dq, deps1, deps2
+
+
 def diff_bwd_(gx: torch.Tensor, x: torch.Tensor, y: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
     """gx += 2 a[c] (x - y) over float64 / complex128 tensors of equal shape."""
     nb = x.shape[0]

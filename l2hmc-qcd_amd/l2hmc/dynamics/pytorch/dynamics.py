@@ -239,6 +239,7 @@ class Dynamics(nn.Module):
         self.sliced_train_heads = True      # training tape: heads + first v-update on the TAPE instances of that kernel
         self.defer_weight_grads = True      # training tape: W.grad of all network calls of a step in one GEMM per matrix
         self.fuse_x_halves_train = True     # training tape (SU3): both x half-updates of a step in one kernel each way
+        self.fuse_v_pairs_bwd = True        # reverse sweep (SU3): the two v-updates that share a network call in one pass
         # fp64 input layer of the SU(3) vnet on the int8 matrix cores (csrc/gemm_sliced.hip): its inputs
         # su3_to_vec(projectSU(.)) are bounded by 2.31 entry-wise, which the kernel checks (NaN otherwise)
         self.sliced_input = True

@@ -536,11 +536,47 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
     gx, gv = gx.contiguous(), gv.contiguous()
     eps_acc: dict = {}
     pend: dict = {}            # primary tape index -> cotangents deferred by the sharing v-update
+    paired: dict = {}          # primary tape index -> its cotangents from the pair kernel
+    flips_done: set = set()
+    fuse_pairs = getattr(dyn, 'fuse_v_pairs_bwd', True)
     for idx in range(len(tape.entries) - 1, -1, -1):
         e = tape.entries[idx]
         kind = e['kind']
         if kind == 'flip':
-            gv = ops.scale(gv, -1.0)
+            if idx not in flips_done:
+                gv = ops.scale(gv, -1.0)
+            continue
+        if kind == 'v' and fuse_pairs and e.get('primary') is not None:
+            # the sharing update and its primary are neighbours on the tape (at most the momentum flip between
+            # them): both reversed in one pass, F / s / t / q read once, their cotangents written once
+            pidx = e['primary']
+            between = tape.entries[pidx + 1:idx]
+            if all(b['kind'] == 'flip' for b in between):
+                pe = tape.entries[pidx]
+                flip = len(between) % 2 == 1
+                dv, dF, dsn, dtn, dqn, deps1, deps2 = ops.v_update_bwd_pair_c128(
+                    pe['v'].reshape(nb, -1), e['v'].reshape(nb, -1), e['F'].reshape(nb, -1), e['s'], e['t'],
+                    e['q'], pe['eps'], pe['forward'], e['eps'], e['forward'], flip, gv.reshape(nb, -1), gl)
+                eps_acc.setdefault(('v', e['step']), []).append(deps2)
+                eps_acc.setdefault(('v', pe['step']), []).append(deps1)
+                paired[pidx] = (dv, dF, dsn, dtn, dqn)
+                flips_done.update(range(pidx + 1, idx))
+                continue
+        if kind == 'v' and idx in paired:
+            x, v, F = e['x'], e['v'], e['F']
+            dv, dF, dsn, dtn, dqn = paired.pop(idx)
+            dF = dF.reshape(F.shape)
+            if e['ctx'].get('native'):
+                dxr, dfr = e['net'].backward(e['ctx'], dsn, dtn, dqn)
+                ops.su3_projsu_vec8_bwd_(dF, F, dfr.reshape(nb, -1))
+                ops.su3_projsu_vec8_bwd_(gx, x, dxr.reshape(nb, -1))
+            else:
+                ds, dt, dq = (ops.unpack_entries(a, V, 9) for a in (dsn, dtn, dqn))
+                dxr, dfr = e['net'].backward(e['ctx'], ds, dt, dq)
+                ops.su3_projsu_vec8_bwd_(dF, F, ops.pack_entries(dfr.reshape(nb, -1), V, 8))
+                ops.su3_projsu_vec8_bwd_(gx, x, ops.pack_entries(dxr.reshape(nb, -1), V, 8))
+            ops.su3_force_bwd_(gx, x, dF, beta, lat)
+            gv = dv.reshape(v.shape)
             continue
         if kind == 'v':
             x, v, F = e['x'], e['v'], e['F']
@@ -577,7 +613,7 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
                                               gx, gv)
             # the kernel differentiates w.r.t. the signed step it was called with
             eps_acc.setdefault(('x', e['step']), []).append(deps if e['forward'] else -deps)
-    assert not pend
+    assert not pend and not paired
     for net in {id(e['net']): e['net'] for e in tape.entries if e.get('kind') == 'v'}.values():
         net.flush_deferred()
     _accumulate_eps_grads(dyn, eps_acc)

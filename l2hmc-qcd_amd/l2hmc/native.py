@@ -131,6 +131,7 @@ SIGNATURES = {
     'l2q_su3_rect_force_add': (I, [P, D, P, I, I, I, I, I, P]),
     'l2q_su3_rect_bwd': (I, [P, P, P, I, I, I, I, I, P]),
     'l2q_v_update_bwd_c128': (I, [P, P, P, P, P, D, I, P, P, I, L, P, P, P, P, P, P, P, Z, P]),
+    'l2q_v_update_bwd_pair_c128': (I, [P, P, P, P, P, P, D, I, D, I, I, P, P, I, L, P, P, P, P, P, P, P, P, Z, P]),
     'l2q_v_update_bwd_acc_c128': (I, [P, P, P, P, P, D, I, P, P, I, L, P, P, P, P, P, P, P, P, P, P, P, Z, P]),
     'l2q_diff_bwd_f64': (I, [P, P, P, I, L, P, P]),
 }

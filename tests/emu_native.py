@@ -713,6 +713,17 @@ def l2q_v_update_bwd_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, dv, dF
     ds.copy_(g[2]); dt.copy_(g[3]); dq.copy_(g[4]); deps.copy_(g[5])
 
 
+def l2q_v_update_bwd_pair_c128(v1, vmid, force, s, t, q, eps1, fwd1, eps2, fwd2, flip, gv, gl, nb, n, dv, dF, ds,
+                               dt, dq, deps1, deps2, ws, wsn):
+    z = lambda a: torch.empty_like(a)
+    dvm, dF2, ds2, dt2, dq2 = z(dv), z(dF), z(ds), z(dt), z(dq)
+    l2q_v_update_bwd_c128(vmid, force, s, t, q, eps2, fwd2, gv, gl, nb, n, dvm, dF2, ds2, dt2, dq2, deps2, ws, wsn)
+    if flip:
+        dvm = -dvm
+    l2q_v_update_bwd_c128(v1, force, s, t, q, eps1, fwd1, dvm, gl, nb, n, dv, dF, ds, dt, dq, deps1, ws, wsn)
+    dF.add_(dF2); ds.add_(ds2); dt.add_(dt2); dq.add_(dq2)
+
+
 def l2q_v_update_bwd_acc_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, aF, as_, at, aq, dv, dF, ds,
                               dt, dq, deps, ws, wsn):
     l2q_v_update_bwd_c128(v, force, s, t, q, eps, forward, gv, gl, nb, n, dv, dF, ds, dt, dq, deps, ws, wsn)
