@@ -240,7 +240,10 @@ __global__ __launch_bounds__(kBlock, 2) void su3_expm_mul2_bwd_kernel(
 }
 
 // ------------------------------------------------------------------ projectSU -> vec8 VJP
-__global__ __launch_bounds__(kBlock, 3) void su3_projsu_vec8_bwd_kernel(
+#ifndef L2Q_PVB_OCC
+#define L2Q_PVB_OCC 2      // two wavefronts per SIMD, no spills: 0.762-0.772 ms against 0.775-0.813 at three (16 spilled registers), 0.85-0.88 at four
+#endif
+__global__ __launch_bounds__(kBlock, L2Q_PVB_OCC) void su3_projsu_vec8_bwd_kernel(
     const double2* __restrict__ in, const double* __restrict__ gvec, double2* gm, int V,
     long nblk) {
   const long f = blockIdx.x / nblk, blk = blockIdx.x % nblk;
