@@ -15,8 +15,9 @@ for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CY
   d="$out/$(echo "$ctr" | tr ' ' '_')"
   mkdir -p "$d"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d "$d" -o p --output-format csv \
-      -- python "$root/tools/kprof.py" > "$d/stdout.log" 2>&1)
+      -- python "$root/${L2Q_KPROF_SCRIPT:-tools/kprof.py}" > "$d/stdout.log" 2>&1)
   echo "pass [$ctr]: rc=$? $(ls "$d" | tr '\n' ' ')"
 done
+# (L2Q_KPROF_SCRIPT=tools/kprof_train.py L2Q_PMC_JSON=profiles/pmc_traffic_train.json: the reverse-sweep kernels)
 python tools/pmc_summary.py "$out/*/p_counter_collection.csv" "profiles/${tag}_pmc_counters.txt" \
-    profiles/pmc_traffic.json
+    "${L2Q_PMC_JSON:-profiles/pmc_traffic.json}"

@@ -26,6 +26,15 @@ ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'fused_heads_dma_kernel<true, true, false, false>': 'l2q_vnet_heads_vupdate_f64',
     'gemm_dma_f64_kernel<false, false, false>': 'l2q_gemm_f64',
     'heads_sliced_kernel<true, true, true, false>': 'l2q_vnet_heads_vupdate_sliced_f64',
+    'heads_sliced_kernel<true, true, true, false, false>': 'l2q_vnet_heads_vupdate_sliced_f64',
+    # the reverse sweep (tools/kprof_train.py)
+    'heads_sliced_kernel<true, true, false, false, true>': 'l2q_vnet_heads_vupdate_sliced_tape_f64',
+    'su3_expm_mul2_bwd_kernel': 'l2q_su3_expm_mul2_bwd', 'su3_expm_mul_bwd_kernel': 'l2q_su3_expm_mul_bwd',
+    'v_update_bwd_pair_cplx_kernel<true, true>': 'l2q_v_update_bwd_pair_c128',
+    'v_update_bwd_cplx_kernel<true, false>': 'l2q_v_update_bwd_c128',
+    'su3_projsu_vec8_bwd_kernel': 'l2q_su3_projsu_vec8_bwd',
+    'su3_force_link_kernel<2': 'l2q_su3_force_bwd',
+    'scaled_tanh_bwd_sums_kernel': 'l2q_scaled_tanh_bwd_sums',
     'gemm_sliced_kernel': 'l2q_gemm_sliced_f64',
     'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_expm_mul_kernel<true, false>': 'l2q_su3_expm_mul2',
     'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
