@@ -349,7 +349,10 @@ def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
                             'xeps': dyn.xeps[0], 'veps': dyn.veps[0]}, history)
     nlf = dyn.config.nleapfrog
     share = {} if (dyn.group == 'SU3' and getattr(dyn, 'reuse_v_inputs', True)) else None
-    tape.defer_cap = (2 * nlf + 1) if share is not None else 4 * nlf     # network calls of this trajectory
+    # network calls of this trajectory -- arenas for the deferred weight gradients only with ONE shared vnet (the
+    # SU(3) default): separate networks see four calls each, not worth an arena per network
+    one_net = len({id(dyn._get_vnet(s)) for s in range(nlf)}) == 1
+    tape.defer_cap = ((2 * nlf + 1) if share is not None else 4 * nlf) if one_net else 0
     for step in range(nlf):
         x, v, ld = _lf_train(dyn, tape, step, x, v, beta, True, share)
         sumlogdet = sumlogdet + ld
@@ -396,7 +399,8 @@ def trajectory_train(dyn, xn: Tensor, vn: Tensor, beta: float, forward: bool):
         dyn.update_history(dyn._metrics_n(x, v, beta, sumlogdet, None, None), history)
     nlf = dyn.config.nleapfrog
     share = {} if (dyn.group == 'SU3' and getattr(dyn, 'reuse_v_inputs', True)) else None
-    tape.defer_cap = (nlf + 1) if share is not None else 2 * nlf
+    one_net = len({id(dyn._get_vnet(s)) for s in range(nlf)}) == 1
+    tape.defer_cap = ((nlf + 1) if share is not None else 2 * nlf) if one_net else 0
     for step in range(nlf):
         x, v, ld = _lf_train(dyn, tape, step, x, v, beta, forward, share)
         sumlogdet = sumlogdet + ld
