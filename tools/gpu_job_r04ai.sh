@@ -3,7 +3,7 @@
 # tables of the l2hmc and train benches (rocprofv3), cfg-5 shard
 set -u
 cd "$(dirname "$0")/.."
-o=gpurun_out/r04ac; mkdir -p $o
+o=gpurun_out/r04ai; mkdir -p $o
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -q -m gpu > $o/t_all.log 2>&1; echo "all rc=$?" | tee -a $o/summary.txt
 tail -4 $o/t_all.log
