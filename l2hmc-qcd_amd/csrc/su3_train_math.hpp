@@ -325,15 +325,18 @@ __device__ __forceinline__ void m3_projsu_vec8_vjp(M3& g, const M3& m, const dou
   }
   const double ev[3] = {sqrt(fabs(a2.re[0])), sqrt(fabs(a2.re[4])), sqrt(fabs(a2.re[8]))};   // eig(H)
   const double iev[3] = {1.0 / ev[0], 1.0 / ev[1], 1.0 / ev[2]};
-  M3 t, u;
-  m3_mul_nn(t, m, vm);                                 // M V
+  // Everything after the decomposition stays in the eigenbasis (round 4: six 3x3 products instead of nine):
+  //   P = U V = M V diag(1/h);   theta from det M (det H > 0, so arg det U = arg det M);
+  //   G' = g_W V;   c = Re tr(g_W^H i W) = -Im(phi tr(G'^H P));   Q = g_U V = conj(phi) G' - (c/3) i P;
+  //   V^H (U^H g_U) V = P^H Q;   Kt_ij = (P^H Q)_ij / (h_i + h_j);   g_M = U (K - K^H) = P (Kt - Kt^H) V^H.
+  M3 pm;
+  m3_mul_nn(pm, m, vm);                                // M V
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { t.re[3 * i + j] *= iev[j]; t.im[3 * i + j] *= iev[j]; }
-  m3_mul_na(u, t, vm);                                 // U = M V diag(1/h) V^H
+    for (int j = 0; j < 3; ++j) { pm.re[3 * i + j] *= iev[j]; pm.im[3 * i + j] *= iev[j]; }
   double dr, di;
-  m3_det(dr, di, u);
+  m3_det(dr, di, m);
   const double theta = -atan2(di, dr) / 3.0;
   const double pr = cos(theta), pi = sin(theta);
   // g_W: adjoint of m3_to_vec8
@@ -346,43 +349,39 @@ __device__ __forceinline__ void m3_projsu_vec8_vjp(M3& g, const M3& m, const dou
   gw.im[0] = -gy[2] - s3 * gy[7];
   gw.im[4] = gy[2] - s3 * gy[7];
   gw.im[8] = 2.0 * s3 * gy[7];
-  // c = Re tr(g_W^H i W), W = u * phi
-  double c = 0.0;
+  M3 gv_;
+  m3_mul_nn(gv_, gw, vm);                              // G' = g_W V
+  double sr = 0.0, si = 0.0;                           // tr(G'^H P)
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    const double wr = u.re[i] * pr - u.im[i] * pi, wi = u.re[i] * pi + u.im[i] * pr;
-    c += gw.re[i] * (-wi) + gw.im[i] * wr;            // i W = (-wi, wr)
+    sr += gv_.re[i] * pm.re[i] + gv_.im[i] * pm.im[i];
+    si += gv_.re[i] * pm.im[i] - gv_.im[i] * pm.re[i];
   }
-  M3 gu;
+  const double c3 = -(pr * si + pi * sr) / 3.0;        // c / 3
+  M3 q;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    // conj(phi) g_W - (c/3) i U
-    gu.re[i] = gw.re[i] * pr + gw.im[i] * pi + (c / 3.0) * u.im[i];
-    gu.im[i] = -gw.re[i] * pi + gw.im[i] * pr - (c / 3.0) * u.re[i];
+    // conj(phi) G' - (c/3) i P
+    q.re[i] = gv_.re[i] * pr + gv_.im[i] * pi + c3 * pm.im[i];
+    q.im[i] = -gv_.re[i] * pi + gv_.im[i] * pr - c3 * pm.re[i];
   }
-  M3 z, zt;
-  m3_mul_an(z, u, gu);                                 // Z = U^H g_U
-  m3_mul_an(t, vm, z);                                 // V^H Z
-  m3_mul_nn(zt, t, vm);                                // V^H Z V
+  M3 zt;
+  m3_mul_an(zt, pm, q);                                // P^H Q
+  const double i01 = 1.0 / (ev[0] + ev[1]), i02 = 1.0 / (ev[0] + ev[2]), i12 = 1.0 / (ev[1] + ev[2]);
+  const double inv[9] = {0.5 * iev[0], i01, i02, i01, 0.5 * iev[1], i12, i02, i12, 0.5 * iev[2]};
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const double inv = 1.0 / (ev[i] + ev[j]);
-      zt.re[3 * i + j] *= inv; zt.im[3 * i + j] *= inv;
-    }
-  M3 k;
-  m3_mul_nn(t, vm, zt);
-  m3_mul_na(k, t, vm);                                 // K = V Kt V^H
+  for (int i = 0; i < 9; ++i) { zt.re[i] *= inv[i]; zt.im[i] *= inv[i]; }
   M3 ka;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {                      // K - K^H
-      ka.re[3 * i + j] = k.re[3 * i + j] - k.re[3 * j + i];
-      ka.im[3 * i + j] = k.im[3 * i + j] + k.im[3 * j + i];
+    for (int j = 0; j < 3; ++j) {                      // Kt - Kt^H
+      ka.re[3 * i + j] = zt.re[3 * i + j] - zt.re[3 * j + i];
+      ka.im[3 * i + j] = zt.im[3 * i + j] + zt.im[3 * j + i];
     }
-  m3_mul_nn(g, u, ka);
+  M3 t;
+  m3_mul_nn(t, pm, ka);
+  m3_mul_na(g, t, vm);                                 // P (Kt - Kt^H) V^H
 }
 
 }  // namespace l2q
