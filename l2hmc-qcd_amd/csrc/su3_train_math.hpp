@@ -240,6 +240,17 @@ __device__ __forceinline__ void m3_expm_frechet_series(M3& E, M3& L, const M3& B
 // ------------------------------------------------------------------ projectSU -> vec8 VJP
 // J^H A J and V J for the complex Jacobi rotation in the (P, Q) plane:
 //   J_PP = cs, J_PQ = sn, J_QP = -sn ph, J_QQ = cs ph   (ph = e^{-i arg h_PQ})
+// Convergence threshold of a rotation, relative to the two diagonal entries.  2^-54 (a quarter ulp of the
+// diagonal): what is left off the diagonal then perturbs M^H M below its own rounding, and the functions of H
+// taken afterwards (1/h, 1/(h_i + h_j)) are smooth, so the result moves by ~1e-16 whatever the gaps are.  The
+// round-2 value 1e-19 kept links that are already unitary rotating for all six sweeps: their M^H M is 1 + 1e-16
+// noise with O(1) rotation angles inside the degenerate cluster, and the off-diagonal only falls linearly there.
+// Measured (tools/projsu_bwd_time.py, 8^4 x 256 chains): 0.707 -> 0.685 ms for unitary links, unchanged for
+// generic matrices (the slowest of a wavefront's 64 lanes sets the sweep count: five or six either way);
+// without any rotation the kernel takes 0.465 ms, i.e. the sweeps are ~0.26 of its 0.73 ms.
+#ifndef L2Q_JACOBI_TOL
+#define L2Q_JACOBI_TOL 0x1p-54
+#endif
 // (returns whether this lane rotated at all)
 template <int P, int Q>
 __device__ __forceinline__ bool jacobi_rotate(M3& H, M3& Vm) {
@@ -249,7 +260,7 @@ __device__ __forceinline__ bool jacobi_rotate(M3& H, M3& Vm) {
   // converged (relative to the diagonal) or so small that cr^2 + ci^2 is denormal and the
   // phase conj(c)/|c| would no longer have unit modulus: identity rotation (branch-free, the
   // lanes of a wavefront converge at different sweeps)
-  const bool live = (ac > 1e-19 * (fabs(a) + fabs(b))) && (ac > 1e-140);
+  const bool live = (ac > L2Q_JACOBI_TOL * (fabs(a) + fabs(b))) && (ac > 1e-140);
   const double acs = live ? ac : 1.0;
   // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)) with tau = (b - a) / (2 |c|), written without forming tau,
   // and one reciprocal of |c| for the phase: three IEEE divisions per rotation instead of five
