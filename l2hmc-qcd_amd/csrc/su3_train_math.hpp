@@ -7,8 +7,23 @@ namespace l2q {
 
 #ifdef __HIP_DEVICE_COMPILE__
 __device__ __forceinline__ bool l2q_wave_any(bool p) { return __any(p) != 0; }
+// 1 / d and 1 / sqrt(x) for finite positive arguments from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26)
+// and two Newton steps each: ~1 ulp in 5 / 8 instructions where the IEEE division and square root sequences take
+// ~13 and ~20 (the Jacobi rotations of the projectSU VJP spend a third of their instructions there)
+__device__ __forceinline__ double l2q_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return fma(r, fma(-d, r, 1.0), r);
+}
+__device__ __forceinline__ double l2q_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  return r * fma(-0.5 * x, r * r, 1.5);
+}
 #else
 __device__ __forceinline__ bool l2q_wave_any(bool p) { return p; }      // host pass / host test build
+__device__ __forceinline__ double l2q_rcp(double d) { return 1.0 / d; }
+__device__ __forceinline__ double l2q_rsqrt(double x) { return 1.0 / sqrt(x); }
 #endif
 
 __device__ __forceinline__ void m3_adjoint(M3& r, const M3& a) {
@@ -255,7 +270,9 @@ __device__ __forceinline__ void m3_expm_frechet_series(M3& E, M3& L, const M3& B
 template <int P, int Q>
 __device__ __forceinline__ bool jacobi_rotate(M3& H, M3& Vm) {
   const double cr = H.re[3 * P + Q], ci = H.im[3 * P + Q];
-  const double ac = sqrt(cr * cr + ci * ci);
+  const double c_2 = cr * cr + ci * ci;
+  const double irc = l2q_rsqrt(c_2 > 1e-290 ? c_2 : 1.0);            // 1 / |c|
+  const double ac = c_2 > 1e-290 ? c_2 * irc : 0.0;
   const double a = H.re[3 * P + P], b = H.re[3 * Q + Q];
   // converged (relative to the diagonal) or so small that cr^2 + ci^2 is denormal and the
   // phase conj(c)/|c| would no longer have unit modulus: identity rotation (branch-free, the
@@ -263,12 +280,13 @@ __device__ __forceinline__ bool jacobi_rotate(M3& H, M3& Vm) {
   const bool live = (ac > L2Q_JACOBI_TOL * (fabs(a) + fabs(b))) && (ac > 1e-140);
   const double acs = live ? ac : 1.0;
   // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)) with tau = (b - a) / (2 |c|), written without forming tau,
-  // and one reciprocal of |c| for the phase: three IEEE divisions per rotation instead of five
+  // and the reciprocal of |c| (from its reciprocal square root) for the phase
   const double d = b - a, c2 = 2.0 * acs;
-  const double t = (d >= 0.0 ? c2 : -c2) / (fabs(d) + sqrt(d * d + c2 * c2));
-  const double cs = live ? 1.0 / sqrt(1.0 + t * t) : 1.0;
+  const double r2 = d * d + c2 * c2;                                  // > 0: c2 >= 2e-140 (or 2 when not live)
+  const double t = (d >= 0.0 ? c2 : -c2) * l2q_rcp(fabs(d) + r2 * l2q_rsqrt(r2));
+  const double cs = live ? l2q_rsqrt(1.0 + t * t) : 1.0;
   const double sn = live ? t * cs : 0.0;
-  const double iac = 1.0 / acs;
+  const double iac = live ? irc : 1.0;
   const double pr = live ? cr * iac : 1.0, pi = live ? -ci * iac : 0.0;   // ph = conj(c) / |c|
   // right-multiply by J: columns P, Q of H and of V
 #pragma unroll
