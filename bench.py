@@ -84,6 +84,9 @@ def parse():
     ap.add_argument('--fp64-train-heads', action='store_true',
                     help='A/B (--mode train): the heads of the training tape as three fp64 GEMMs + v_update '
                          'instead of the TAPE instances of the int8-sliced heads kernel')
+    ap.add_argument('--force-native-training', action='store_true',
+                    help='--mode train: native-order weight shadows even where the traffic estimate prefers the '
+                         'reference-order path (small micro-batches on large lattices)')
     ap.add_argument('--separate-v-pairs', action='store_true',
                     help='A/B (--mode train): the two v-updates that share a network call reversed by two kernels')
     ap.add_argument('--separate-x-halves', action='store_true',
@@ -170,6 +173,9 @@ def build_trainer(args, seed):
         tr.dynamics.fuse_x_halves_train = False
     if args.separate_v_pairs:
         tr.dynamics.fuse_v_pairs_bwd = False
+    if args.force_native_training:
+        tr.dynamics.native_training = 'force'
+
     return tr
 
 

@@ -692,9 +692,8 @@ def _native_begin(dyn, nb: Optional[int] = None) -> list:
     Returns the networks this call switched (the caller ends them); networks that are already in
     native mode (a chunked step begins once for all its micro-batches) are left alone.
     The shadows cost one gather + one scatter of the big matrices (and twice their bytes of HBM) per
-    step, the transposes they replace 18 x 2 passes over the activations of `nb` chains: with few
-    chains per pass on a large lattice (the 16^4 shard in micro-batches of 16: 23 GB of weights)
-    the transposes are the cheaper side and stay."""
+    step; they are skipped only when the device is short of memory (`dyn.native_training = 'force'`
+    takes them regardless)."""
     if dyn.group != 'SU3' or not getattr(dyn, 'native_training', True):
         return []
     from l2hmc.network.pytorch.network import ConvStack
@@ -705,14 +704,24 @@ def _native_begin(dyn, nb: Optional[int] = None) -> list:
         if id(n) in seen or isinstance(n.input_layer.conv_stack, ConvStack) or n.native_active():
             continue
         seen.add(id(n))
-        if nb is not None:
+        have = bool(getattr(n, '_nat', None) and n._nat.get('w'))      # shadows of an earlier step: already paid for
+        if nb is not None and not have and getattr(dyn, 'native_training', True) != 'force':
+            # The shadows (weights + gradients: 2 x the five matrices) and what runs on them -- the sliced tape
+            # heads (+ 7/8 of the head weights), the deferred weight gradients -- are taken whenever three times
+            # the matrices' bytes fit in half of what the device has free.  (Rounds 2-3 compared the shadows'
+            # gather + scatter with the 18 activation transposes they replace and kept the 16^4 shard in
+            # 16-chain micro-batches on the reference-order path: 7.08 s per step at 156.7 GiB; with the shadows
+            # 4.22 s at 213.5 GiB, `profiles/r04am_*`.)
             il = n.input_layer
             wbytes = sum(t.numel() * t.element_size() for t in (
                 il.xlayer.weight, il.vlayer.weight, n.scale.layer.weight, n.transl.weight,
                 n.transf.layer.weight))
-            abytes = nb * (2 * 32 + 3 * 36) * dyn.volume * il.xlayer.weight.element_size()
-            if 2 * wbytes > 18 * abytes:
-                continue
+            dev = il.vlayer.weight.device
+            if dev.type == 'cuda':
+                free, _t = torch.cuda.mem_get_info(dev)
+                idle = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                if 3 * wbytes > 0.5 * (free + idle):
+                    continue
         n.native_train_begin(p['in'], p['out'])
         nets.append(n)
     return nets
