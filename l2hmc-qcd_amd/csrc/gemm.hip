@@ -1041,7 +1041,9 @@ static int pick_splits(int M, int N, long Kt) {
   long s = cdiv(512, tiles);
   const long maxs = Kt / (4 * BK) > 0 ? Kt / (4 * BK) : 1;
   if (s > maxs) s = maxs;
-  if (s > 128) s = 128;
+  // (one or two output tiles -- a 16-chain micro-batch against a 256-wide layer: two workgroups per CU, each
+  // issuing the MFMAs of a full 128-row tile whatever M is, are what sets the streaming rate of the weights)
+  if (s > (tiles <= 2 ? 256 : 128)) s = tiles <= 2 ? 256 : 128;
   return (int)(s < 1 ? 1 : s);
 }
 
