@@ -84,6 +84,9 @@ def parse():
     ap.add_argument('--fp64-train-heads', action='store_true',
                     help='A/B (--mode train): the heads of the training tape as three fp64 GEMMs + v_update '
                          'instead of the TAPE instances of the int8-sliced heads kernel')
+    ap.add_argument('--sliced-train-input', action='store_true',
+                    help='A/B (--mode train): the input layer of the tape on digit images of the step\'s weights '
+                         '(off by default: the per-step image builds cost what the nine calls save)')
     ap.add_argument('--force-native-training', action='store_true',
                     help='--mode train: native-order weight shadows even where the traffic estimate prefers the '
                          'reference-order path (small micro-batches on large lattices)')
@@ -167,6 +170,8 @@ def build_trainer(args, seed):
     tr.micro_batch = args.micro_batch
     if args.fp64_train_heads:
         tr.dynamics.sliced_train_heads = False
+    if args.sliced_train_input:
+        tr.dynamics.sliced_train_input = True
     if args.no_defer_weight_grads:
         tr.dynamics.defer_weight_grads = False
     if args.separate_x_halves:

@@ -237,6 +237,10 @@ class Dynamics(nn.Module):
         # products on the int8 matrix cores (csrc/heads_sliced.hip; same values to fp64 rounding)
         self.sliced_heads = True
         self.sliced_train_heads = True      # training tape: heads + first v-update on the TAPE instances of that kernel
+        # training tape: the vnet input layer on digit images of the step's weights.  Off: at cfg-4 the nine
+        # calls save 9 x (0.62 - 0.45) ms and the two image builds + their stream synchronisations cost as much
+        # (102.9-104.2 vs 102.5 ms per step, alternating on one box); pays only with more calls per step
+        self.sliced_train_input = False
         self.defer_weight_grads = True      # training tape: W.grad of all network calls of a step in one GEMM per matrix
         self.fuse_x_halves_train = True     # training tape (SU3): both x half-updates of a step in one kernel each way
         self.fuse_v_pairs_bwd = True        # reverse sweep (SU3): the two v-updates that share a network call in one pass

@@ -249,11 +249,12 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
     else:
         xv = ops.su3_projsu_vec8_n(x).reshape(nb, -1)
         fv = ops.su3_projsu_vec8_n(F).reshape(nb, -1)
+    sie = ops.SLICED_INPUT_EXP if getattr(dyn, 'sliced_train_input', False) else None  # |vec8(projectSU(.))| < 4
     if (vnet.native_active() and getattr(dyn, 'sliced_train_heads', True) and ops.USE_SLICED_HEADS[0]
             and vnet.sliced_train_image() is not None):
         # the heads and this v-update in one launch on the int8 matrix cores (TAPE kernel: s, t, q are
         # stored for the reverse sweep); the image is rebuilt once per optimiser step
-        z, ctx = vnet.forward_train(xv, fv, hidden_only=True)
+        z, ctx = vnet.forward_train(xv, fv, hidden_only=True, sliced_input_exp=sie)
         if slot is not None:
             ctx['defer_idx'] = slot[0]
         v_new, ld, sn, tn, qn = vnet.heads_vupdate_train_sliced(z, ctx, v.reshape(nb, -1), F.reshape(nb, -1),
@@ -268,7 +269,7 @@ def _v_step_su3(dyn, tape: Tape, st: int, x: Tensor, v: Tensor, beta: float, for
         return v_new, ld
     if vnet.native_active():
         # native-order weight shadows (LeapfrogLayer.native_train_begin): no activation transposes
-        sn, tn, qn, ctx = vnet.forward_train(xv, fv)
+        sn, tn, qn, ctx = vnet.forward_train(xv, fv, sliced_input_exp=sie)
         if slot is not None:
             ctx['defer_idx'] = slot[0]
     else:

@@ -726,6 +726,7 @@ class LeapfrogLayer(nn.Module):
                 nat['g'][k].zero_()
         nat['src'] = src
         nat.pop('sliced', None)            # this step's slice image of the heads: built on first use
+        nat.pop('input_img', None)         # ... and the digit images of the input layer
         if nat.get('defer') is not None and not nat['defer'].get('off'):
             nat['defer']['i'] = 0
             nat['defer']['seen'] = set()
@@ -769,12 +770,15 @@ class LeapfrogLayer(nn.Module):
                                   or bool(self.net_config.use_batch_norm))
 
     def forward_train(self, x: Tensor, v: Tensor, drop_keep: Optional[Tensor] = None,
-                      hidden_only: bool = False) -> tuple[Tensor, Tensor, Tensor, dict]:
+                      hidden_only: bool = False, sliced_input_exp: Optional[int] = None
+                      ) -> tuple[Tensor, Tensor, Tensor, dict]:
         """(s, t, q, ctx).  drop_keep: a given dropout keep-mask [nb, units[-1]] instead of a
         fresh draw (the construction-time dummy forward replays the host generator's mask).  x: the network's x input ([nb, C, T, X] when there is a conv stack,
         otherwise anything flattenable to [nb, Kx]); v likewise.  reference: network.py:522-551
         under autograd.  hidden_only: stop in front of the heads and return (z, ctx) -- the caller runs
-        heads_vupdate_train_sliced, which completes ctx."""
+        heads_vupdate_train_sliced, which completes ctx.  sliced_input_exp = e: the caller guarantees
+        |x|, |v| < 2^e (the SU(3) vnet inputs, e = 2) and native-order training is on: the input layer may run
+        on the digit images of this step's weights (sliced_train_input_images)."""
         il = self.input_layer
         nb = x.shape[0]
         conv_ctx = None
@@ -791,10 +795,18 @@ class LeapfrogLayer(nn.Module):
                                       'activation with the max-pool) -- use another activation_fn')
         fused = None if swish else self.act
         nw_ = self._nat['w'] if self.native_active() else None     # inputs / outputs in native order
-        z = ops.gemm(xf, il.xlayer.weight.detach() if nw_ is None else nw_['wx'],
-                     il.xlayer.bias.detach(), a2=vf,
-                     w2=il.vlayer.weight.detach() if nw_ is None else nw_['wv'],
-                     bias2=il.vlayer.bias.detach(), act=fused)
+        imgs = self.sliced_train_input_images(nb) if (sliced_input_exp is not None and nw_ is not None
+                                                      and fused is not None and conv_ctx is None) else None
+        if imgs is not None:
+            # the input layer of the tape on the int8 matrix cores (csrc/gemm_sliced.hip), like the sampler's
+            z = ops.gemm_sliced(xf, imgs[0], nw_['wx'].shape[0], il.xlayer.bias.detach(), a_exp=sliced_input_exp,
+                                a2=vf, image2=imgs[1], a2_exp=sliced_input_exp, bias2=il.vlayer.bias.detach(),
+                                act=fused)
+        else:
+            z = ops.gemm(xf, il.xlayer.weight.detach() if nw_ is None else nw_['wx'],
+                         il.xlayer.bias.detach(), a2=vf,
+                         w2=il.vlayer.weight.detach() if nw_ is None else nw_['wv'],
+                         bias2=il.vlayer.bias.detach(), act=fused)
         pre = [z] if swish else None
         if swish:
             z = ops.act_fwd(z, 'swish')
@@ -934,6 +946,28 @@ class LeapfrogLayer(nn.Module):
                          'cq': float(self.nw.q) * torch.exp(w['cq'])}
         nat['sliced'] = image
         return image
+
+    def sliced_train_input_images(self, nb: int):
+        """Digit images of this step's native-order xlayer / vlayer weights (csrc/gemm_sliced.hip), or None
+        when the shapes do not qualify (`_ops.gemm_sliced_pays`), the images do not fit comfortably or a
+        matrix is refused.  Built on first use after native_train_begin (two passes over the weights + two
+        stream synchronisations per optimiser step)."""
+        nat = getattr(self, '_nat', None)
+        if nat is None or not nat.get('active'):
+            return None
+        if 'input_img' in nat:
+            return nat['input_img']
+        wx, wv = nat['w']['wx'], nat['w']['wv']
+        imgs = None
+        if (ops.USE_SLICED_INPUT[0] and wx.dtype == torch.float64 and wx.is_cuda
+                and ops.gemm_sliced_pays(nb, wx.shape[0], wx.shape[1], wv.shape[1])):
+            need = 2 * (wx.numel() + wv.numel()) * 8
+            if torch.cuda.mem_get_info(wx.device)[0] + torch.cuda.memory_reserved(wx.device) \
+                    - torch.cuda.memory_allocated(wx.device) > 4 * need:
+                ix, iv = ops.gemm_sliced_build(wx), ops.gemm_sliced_build(wv)
+                imgs = (ix, iv) if ix is not None and iv is not None else None
+        nat['input_img'] = imgs
+        return imgs
 
     def heads_vupdate_train_sliced(self, z: Tensor, ctx: dict, v: Tensor, force: Tensor, eps: float,
                                    forward: bool):
