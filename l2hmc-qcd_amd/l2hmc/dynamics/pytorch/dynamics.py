@@ -247,6 +247,9 @@ class Dynamics(nn.Module):
         # fp64 input layer of the SU(3) vnet on the int8 matrix cores (csrc/gemm_sliced.hip): its inputs
         # su3_to_vec(projectSU(.)) are bounded by 2.31 entry-wise, which the kernel checks (NaN otherwise)
         self.sliced_input = True
+        # train mode + grad mode: forward() records the trajectory and returns tensors with a grad_fn
+        # (the reference's forward_step / loss.backward() contract); False keeps the graph-free sampler
+        self.autograd_forward = True
 
     # ------------------------------------------------------------------ construction
     def set_net_precision(self, precision) -> None:
@@ -1238,8 +1241,53 @@ class Dynamics(nn.Module):
         return xout, hist
 
     def forward(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
+        if self._records_graph():
+            return self._forward_train(inputs)
         return (self.apply_transition_fb(inputs) if self.config.merge_directions
                 else self.apply_transition(inputs))
+
+    # ---- train mode: the trajectory as a node of the caller's autograd graph
+    def _records_graph(self) -> bool:
+        """Train mode with grad mode on and trainable parameters: what the reference's
+        `forward_step` + `loss.backward()` (trainers/pytorch/trainer.py:1266-1314) runs under."""
+        return (self.training and self._networks_built and self.autograd_forward
+                and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+
+    def _forward_train(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
+        """`forward` whose outputs carry a grad_fn (dynamics/pytorch/autograd.py): x_out,
+        metrics['acc'], metrics['sumlogdet'] and the proposed / output states of
+        metrics['mc_states'] back-propagate into `self.parameters()` through the hand-written reverse
+        sweep.  Same draw order as the sampling path: (direction,) momenta, dropout masks, accept
+        uniforms."""
+        from l2hmc import _autograd as AG
+        from l2hmc.dynamics.pytorch import autograd as G
+        x, beta = inputs
+        direction = None
+        if not self.config.merge_directions:
+            inj = self._inject.get('forward') if self._inject else None
+            direction = bool(torch.rand(1) > 0.5) if inj is None else bool(inj)
+        xd = x.to(DEVICE)
+        side: dict = {}
+        xp, vp, sld, acc = G.transition(self, xd, beta, direction, side)
+        nb = xp.shape[0]
+        hist = side['hist']
+        xn, vn = side['xn'], side['vn']
+        u = self._uniform(acc.detach())
+        ma = (acc.detach() > u).to(torch.float32)
+        x_init = xd.detach().reshape(xp.shape)
+        xout = AG.SelectRows.apply(xp, x_init, ma).reshape(nb, -1)
+        su3 = self.group == 'SU3'
+        v_init = (lambda: self._unpack(vn)) if su3 else vn
+        init = State(x=x.reshape(xp.shape), v=v_init, beta=beta, xshape=tuple(xp.shape))
+        prop = State(x=xp, v=vp, beta=beta, xshape=tuple(xp.shape))
+
+        def v_out():
+            vi = self._unpack(vn) if su3 else vn
+            return AG.SelectRows.apply(vp, vi.reshape(vp.shape), ma).reshape(nb, -1)
+        out = State(x=xout, v=v_out, beta=beta, xshape=tuple(xout.shape))
+        hist.update({'acc': acc, 'beta': beta, 'sumlogdet': ma * sld, 'acc_mask': ma,
+                     'mc_states': MonteCarloStates(init=init, proposed=prop, out=out)})
+        return xout, hist
 
     def apply_transition_hmc(self, inputs: tuple[Tensor, Tensor], eps: Optional[float] = None,
                              nleapfrog: Optional[int] = None) -> tuple[Tensor, dict]:

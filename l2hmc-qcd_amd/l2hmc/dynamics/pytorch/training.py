@@ -377,7 +377,7 @@ def trajectory_fb_train(dyn, xn: Tensor, vn: Tensor, beta: float):
     history.update({'acc': acc, 'sumlogdet': sumlogdet})
     if verbose:
         history = dyn._stack_history(history)
-    tape.h_init = h_init
+    tape.h_init, tape.h_prop = h_init, h_prop
     return x, v, history, tape
 
 
@@ -412,7 +412,7 @@ def trajectory_train(dyn, xn: Tensor, vn: Tensor, beta: float, forward: bool):
     history.update({'acc': acc, 'sumlogdet': sumlogdet})
     if verbose:
         history = dyn._stack_history(history)
-    tape.h_init = h_init
+    tape.h_init, tape.h_prop = h_init, h_fin
     tape.swapped = True
     return x, v, history, tape
 
@@ -661,17 +661,26 @@ def train_forward_backward_chunked(dyn, loss_fn, x: Tensor, beta, micro_batch: i
     nb = x.shape[0]
     outs, mets, sizes, loss = [], [], [], 0.0
     inj = dyn._inject
+    direction = None
+    if not dyn.config.merge_directions:
+        # ONE direction per optimiser step, drawn (or injected) here like the unchunked path and the
+        # reference do (dynamics.py:709) and handed to every micro-batch: the step must not mix forward and
+        # backward trajectories, nor consume the host generator once per micro-batch
+        d = inj.get('forward') if inj else None
+        direction = bool(torch.rand(1) > 0.5) if d is None else bool(d)
     nets = _native_begin(dyn, min(nb, micro_batch))     # one gather / scatter for all micro-batches
     try:
         for lo in range(0, nb, micro_batch):
             hi = min(nb, lo + micro_batch)
-            if inj is not None:
+            if inj is not None or direction is not None:
                 sl = {}
-                if inj.get('normals') is not None:
+                if inj is not None and inj.get('normals') is not None:
                     nrm = inj['normals']
                     sl['normals'] = nrm[:, lo:hi] if dyn.group == 'SU3' else nrm[lo:hi]
-                if inj.get('u') is not None:
+                if inj is not None and inj.get('u') is not None:
                     sl['u'] = inj['u'][lo:hi]
+                if direction is not None:
+                    sl['forward'] = direction
                 dyn._inject = sl
             xo, m, l = train_forward_backward(dyn, loss_fn, x[lo:hi], beta,
                                               loss_weight=loss_weight * (hi - lo) / nb)

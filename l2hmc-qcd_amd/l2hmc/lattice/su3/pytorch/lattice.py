@@ -16,6 +16,7 @@ import torch
 
 import l2hmc.group.su3.pytorch.group as g
 from l2hmc import DEVICE
+from l2hmc import _autograd as AG
 from l2hmc import _ops as ops
 from l2hmc.configs import Charges
 from l2hmc.lattice.lattice import Lattice
@@ -61,7 +62,8 @@ class LatticeSU3(Lattice):
 
     # ------------------------------------------------------------ native-layout core
     def pack(self, x: Tensor) -> Tensor:
-        return ops.su3_pack(x.to(DEVICE).reshape(x.shape[0], -1))
+        # (a tensor a transition returned still carries its native-layout original)
+        return AG.su3_pack_cached(x.to(DEVICE))
 
     def unpack(self, xn: Tensor) -> Tensor:
         return ops.su3_unpack(xn, self._lattice_shape)
@@ -95,6 +97,9 @@ class LatticeSU3(Lattice):
         return {'plaq': beta * (1.0 - 8.0 * self.c1), 'rect': beta * self.c1}
 
     def wilson_loops(self, x: Tensor) -> PlaqSums:
+        if AG.wants_grad(x):
+            # differentiable route (loss.backward() of an autograd caller): l2q_su3_plaq_bwd behind it
+            return PlaqSums(AG.SU3PlaqPlanes.apply(x.to(DEVICE), self._lattice_shape).sum(1))
         return PlaqSums(self.plaq_sums_n(self.pack(x)))
 
     def _wilson_loops(self, x: Tensor, needs_rect: bool = False):
@@ -183,6 +188,13 @@ class LatticeSU3(Lattice):
 
     def action(self, x: Tensor, beta: Tensor) -> Tensor:
         """-(1/3) (c_plaq sum Re tr P + c_rect sum Re tr R) (lattice.py:252-269)"""
+        if AG.wants_grad(x):
+            b = _beta(beta)
+            s = (-b * (1.0 - 8.0 * self.c1) / 3.0) * AG.SU3PlaqPlanes.apply(
+                x.to(DEVICE), self._lattice_shape)[:, :, 0].sum(1)
+            if self.c1 != 0.0:
+                s = s + (-b * self.c1 / 3.0) * AG.SU3RectSums.apply(x.to(DEVICE), self._lattice_shape)
+            return s
         return self.action_n(self.pack(x), beta)
 
     def action_with_grad(self, x: Tensor, beta: Tensor) -> tuple[Tensor, Tensor]:

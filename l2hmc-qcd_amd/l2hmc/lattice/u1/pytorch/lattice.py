@@ -9,6 +9,7 @@ from torch.special import i0, i1
 
 import l2hmc.group.u1.pytorch.group as g
 from l2hmc import DEVICE
+from l2hmc import _autograd as AG
 from l2hmc import _ops as ops
 from l2hmc.configs import Charges, LatticeMetrics
 from l2hmc.lattice.lattice import Lattice
@@ -58,6 +59,10 @@ class LatticeU1(Lattice):
 
     def wilson_loops(self, x: Tensor) -> PlaqSumsU1:
         """theta = U0(t,x) + U1(t+1,x) - U0(t,x+1) - U1(t,x), reduced per chain."""
+        if AG.wants_grad(x):
+            # differentiable route (loss.backward() of an autograd caller): l2q_u1_plaq_bwd behind it
+            return PlaqSumsU1(AG.U1PlaqSums.apply(x.to(DEVICE).reshape(-1, *self.xshape),
+                                                  self._lattice_shape))
         return PlaqSumsU1(ops.u1_plaq_sums(self._x(x), self._lattice_shape))
 
     def _get_wloops(self, x: Optional[Tensor] = None) -> PlaqSumsU1:

@@ -1,9 +1,11 @@
-"""``LatticeLoss`` (forward value) -- API of src/l2hmc/loss/pytorch/loss.py:21-210.
+"""``LatticeLoss`` -- API of src/l2hmc/loss/pytorch/loss.py:21-210.
 
 The value is computed from per-chain reductions done by the HIP kernels
-(``l2q_su3_plaq_planes``, ``l2q_u1_plaq_reduce``, ``l2q_diff_norm2_reduce``); no autograd graph
-is attached (the training-gradient path is SURVEY.md 8(f) item 1).  Used by the trainer's
-``eval_step`` / ``hmc_step`` to report ``loss`` exactly like the reference.
+(``l2q_su3_plaq_planes``, ``l2q_u1_plaq_reduce``, ``l2q_diff_norm2_reduce``).  When an input
+requires a gradient (the proposal of a train-mode ``Dynamics.forward``), the reductions run as
+``torch.autograd.Function`` nodes (``l2hmc/_autograd.py``) and ``loss.backward()`` works like in the
+reference (trainers/pytorch/trainer.py:1284-1314); otherwise no graph is attached (``eval_step`` /
+``hmc_step`` report ``loss`` exactly like the reference).
 """
 from __future__ import annotations
 
@@ -12,6 +14,7 @@ from typing import Optional
 import torch
 
 from l2hmc import DEVICE
+from l2hmc import _autograd as AG
 from l2hmc import _ops as ops
 from l2hmc.configs import LossConfig
 from l2hmc.group.su3.pytorch.group import SU3
@@ -47,7 +50,10 @@ class LatticeLoss:
     # per-plane real sums [6, nb] (SU3) -- what `w.real.sum(range(2, ndim))` gives (loss.py:64-65)
     def _plane_sums(self, x: Tensor) -> Tensor:
         assert isinstance(self.lattice, LatticeSU3)
-        s = ops.su3_plaq_planes_n(self.lattice.pack(x), self.lattice._lattice_shape)
+        if AG.wants_grad(x):
+            s = AG.SU3PlaqPlanes.apply(x.to(DEVICE), self.lattice._lattice_shape)
+        else:
+            s = ops.su3_plaq_planes_n(self.lattice.pack(x), self.lattice._lattice_shape)
         return s[:, :, 0].transpose(0, 1)
 
     def _mixed(self, loss: Tensor, weight: Tensor, use_mixed_loss: Optional[bool]) -> Tensor:
@@ -83,7 +89,10 @@ class LatticeLoss:
         if not a.is_complex():
             # same failure as the reference, whose rmse_loss takes `dx.imag` (loss.py:139)
             raise RuntimeError('imag is not implemented for tensors with non-complex dtypes.')
-        d2 = ops.diff_norm2(a.to(torch.complex128), b.to(torch.complex128))
+        if AG.wants_grad(a, b):
+            d2 = AG.DiffNorm2.apply(a.to(torch.complex128), b.to(torch.complex128))
+        else:
+            d2 = ops.diff_norm2(a.to(torch.complex128), b.to(torch.complex128))
         nelem = a.shape[1]
         return self._mixed(acc.to(DEVICE) * (d2 / nelem).to(acc.dtype), self.rmse_weight,
                            use_mixed_loss)

@@ -732,18 +732,30 @@ class LeapfrogLayer(nn.Module):
             nat['defer']['seen'] = set()
         nat['active'] = True
 
-    def native_train_end(self) -> None:
-        """Scatter-add the native-order gradients into the parameters' .grad, leave native mode."""
+    def native_train_end(self, keep_active: bool = False, scatter: bool = True) -> None:
+        """Scatter-add the native-order gradients into the parameters' .grad, leave native mode.
+        keep_active: flush only (the gradient buffers are zeroed, the weight shadows stay: another
+        recorded trajectory of the same optimiser step still needs them -- dynamics/pytorch/autograd.py);
+        scatter=False: leave without touching .grad (a recorded trajectory that was never reversed)."""
         nat = getattr(self, '_nat', None)
         if nat is None or not nat.get('active'):
+            return
+        if not scatter:
+            d = nat.get('defer')
+            if d is not None and not d.get('off'):
+                d['i'] = 0
+                d['seen'] = set()
+            nat['active'] = False
             return
         self.flush_deferred()                  # (a no-op when the reverse sweep has flushed already)
         with torch.no_grad():
             inv = nat.setdefault('inv', {})
             for k, (par, dim, perm) in nat['src'].items():
-                if par.grad is None:
-                    continue
                 g = nat['g'][k]
+                if par.grad is None:
+                    if keep_active:
+                        g.zero_()
+                    continue
                 # perm is a bijection: grad[perm] += g  ==  grad += g[perm^-1]  (a gather and an
                 # add instead of index_add_'s atomics: 0.25 instead of 0.8 ms per 302 MB matrix)
                 ip = inv.get(id(perm))
@@ -755,7 +767,9 @@ class LeapfrogLayer(nn.Module):
                     par.grad.reshape(-1).add_(torch.index_select(g, 0, ip))
                 else:
                     par.grad.add_(torch.index_select(g, dim, ip))
-        nat['active'] = False
+                if keep_active:
+                    g.zero_()
+        nat['active'] = bool(keep_active)
 
     def native_active(self) -> bool:
         nat = getattr(self, '_nat', None)
@@ -781,6 +795,8 @@ class LeapfrogLayer(nn.Module):
         on the digit images of this step's weights (sliced_train_input_images)."""
         il = self.input_layer
         nb = x.shape[0]
+        if getattr(self, 'half_dtype', None) is not None and getattr(self, 'half_train', True):
+            return self._forward_train_half(x, v, drop_keep)
         conv_ctx = None
         if isinstance(il.conv_stack, ConvStack):
             xf, conv_ctx = il.conv_stack.forward_train(x)
@@ -847,6 +863,81 @@ class LeapfrogLayer(nn.Module):
             t = ops.gemm(z, self.transl.weight.detach(), self.transl.bias.detach(), scale=self.nw.t)
             q = ops.gemm(z, self.transf.layer.weight.detach(), self.transf.layer.bias.detach(),
                          coeff=self.transf.coeff.detach().reshape(-1), scale=self.nw.q, act='tanh')
+        ctx['s'], ctx['q'] = s, q
+        return s, t, q, ctx
+
+    def _half_train_weights(self) -> dict:
+        """16-bit copies of the RAW weights for the train-mode forward (kernel_weights() folds the
+        eval-mode BatchNorm into the heads; train mode normalises with batch statistics).  What
+        torch.autocast's weight cache holds during the reference's forward_step."""
+        ver = self._versions()
+        hit = getattr(self, '_half_train_cache', None)
+        if hit is not None and hit['ver'] == ver:
+            return hit
+        hd = self.half_dtype
+        with torch.no_grad():
+            il = self.input_layer
+            r16 = lambda t: t.detach().to(hd).float().contiguous()
+            w16 = lambda t: t.detach().to(hd).contiguous()
+            out = {'ver': ver, 'wx': w16(il.xlayer.weight), 'bx': r16(il.xlayer.bias),
+                   'wv': w16(il.vlayer.weight), 'bv': r16(il.vlayer.bias),
+                   'hidden': [(w16(h.weight), r16(h.bias)) for h in self.hidden_layers],
+                   'ws': w16(self.scale.layer.weight), 'bs': r16(self.scale.layer.bias),
+                   'cs': self.scale.coeff.detach().reshape(-1).contiguous(),
+                   'wt': w16(self.transl.weight), 'bt': r16(self.transl.bias),
+                   'wq': w16(self.transf.layer.weight), 'bq': r16(self.transf.layer.bias),
+                   'cq': self.transf.coeff.detach().reshape(-1).contiguous()}
+        self._half_train_cache = out
+        return out
+
+    def _forward_train_half(self, x: Tensor, v: Tensor, drop_keep: Optional[Tensor] = None):
+        """forward_train under the reference's `autocast_context_train` (trainers/pytorch/trainer.py:211-219,
+        1276-1280): every nn.Linear runs on the 16-bit MFMA kernels with autocast's rounding points (operands
+        and outputs rounded to fp16 / bf16, fp32 accumulation -- the layers the eval path is pinned to the
+        reference's autocast fixtures with), Dropout / BatchNorm act on the 16-bit activations, the ScaledTanh
+        multipliers and everything downstream are fp32.  The tape keeps fp32 copies of the activations: the
+        reverse sweep differentiates THIS forward with the casts as identities (what autocast's backward does)
+        on the fp32 master weights, in fp32 -- the reference runs those products in 16 bit; the difference is
+        below its own fp16-vs-fp32 distance, which is what the tests pin."""
+        il = self.input_layer
+        if isinstance(il.conv_stack, ConvStack):
+            raise NotImplementedError('half-precision training: dense networks (conv=none) only -- train the '
+                                      'conv stack with precision=float32')
+        if self.act == 'swish':
+            raise NotImplementedError('half-precision training: swish keeps pre-activations; use another activation_fn')
+        hd = self.half_dtype
+        nb = x.shape[0]
+        h = self._half_train_weights()
+        xf = x.reshape(nb, -1).float().contiguous()
+        vf = v.reshape(nb, -1).float().contiguous()
+        z = ops.gemm_h(xf, h['wx'], h['bx'], a2=vf, w2=h['wv'], bias2=h['bv'], act=self.act)
+        acts = [z.float()]
+        for hw, hb in h['hidden']:
+            z = ops.gemm_h(z, hw, hb, act=self.act)
+            acts.append(z.float())
+        ctx: dict = {'xf': xf, 'vf': vf, 'acts': acts, 'pre': None, 'conv': None,
+                     'xshape': tuple(x.shape), 'vshape': tuple(v.shape), 'native': False}
+        zf = acts[-1]
+        p = float(self.net_config.dropout_prob)
+        if p > 0 and self.training:
+            keep = torch.bernoulli(torch.full_like(zf, 1.0 - p)) if drop_keep is None \
+                else drop_keep.to(device=zf.device, dtype=zf.dtype)
+            zf = ops.mul(zf, keep, 1.0 / (1.0 - p)).to(hd).float()
+            ctx['drop'] = keep
+        if self.net_config.use_batch_norm:
+            bn = self.batch_norm
+            ctx['bn_in'] = zf
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            zf, ctx['bn_mean'], ctx['bn_invstd'] = ops.bn_train_fwd(
+                zf, bn.weight.detach(), bn.bias.detach(), bn.eps, mom, bn.running_mean, bn.running_var)
+            bn.num_batches_tracked += 1
+            zf = zf.to(hd).float()
+        ctx['z'] = zf
+        z16 = zf.to(hd)
+        f32 = torch.float32
+        s = ops.gemm_h(z16, h['ws'], h['bs'], coeff=h['cs'], scale=self.nw.s, act='tanh', out_dtype=f32)
+        t = ops.gemm_h(z16, h['wt'], h['bt'], scale=self.nw.t, out_dtype=f32)
+        q = ops.gemm_h(z16, h['wq'], h['bq'], coeff=h['cq'], scale=self.nw.q, act='tanh', out_dtype=f32)
         ctx['s'], ctx['q'] = s, q
         return s, t, q, ctx
 

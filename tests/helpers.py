@@ -219,20 +219,42 @@ def build_u1_train_dynamics(g, dropout=0.0):
     return dyn, lat, loss_fn
 
 
-def check_train_step(g, dyn, loss_fn, rtol, atol_rel, adam_min_grad=0.0):
+def check_train_step(g, dyn, loss_fn, rtol, atol_rel, adam_min_grad=0.0, autograd=False):
     """Run the product's forward + reverse sweep + Adam on the fixture's inputs and compare with
-    the reference's loss / gradients / updated parameters.  Returns the worst relative errors."""
+    the reference's loss / gradients / updated parameters.  Returns the worst relative errors.
+
+    autograd=True: the reference caller's LITERAL sequence instead of the product's own trainer
+    entry (trainers/pytorch/trainer.py:1266-1314): `x.requires_grad_(True); optimizer.zero_grad();
+    xout, metrics = dynamics((x, beta)); loss = loss_fn(x, mc_states.proposed.x, acc); loss.backward();
+    torch.optim.Adam(dynamics.parameters()).step()` -- nothing of this repo's training API is called."""
     import torch
     from l2hmc.dynamics.pytorch import training as T
-    arena = T.ParamArena(dyn)
-    arena.zero_grad()
     dyn._inject = {'normals': g['normals'], 'u': g['u']}
     if 'forward' in g and not bool(g['merge_directions']):
         dyn._inject['forward'] = bool(g['forward'])          # the direction draw of apply_transition
     x = torch.from_numpy(g['x'])
     beta = torch.tensor(float(g['beta']))
     xin = dyn.g.compat_proj(dyn.unflatten(x.to(dyn.device)))
-    xout, metrics, loss = T.train_forward_backward(dyn, loss_fn, xin, beta)
+    if autograd:
+        optimizer = torch.optim.Adam(dyn.parameters(), lr=float(g['lr']))
+        xin.requires_grad_(True)
+        optimizer.zero_grad()
+        xout, metrics = dyn((xin, beta))
+        assert xout.grad_fn is not None and metrics['acc'].grad_fn is not None
+        xprop = metrics['mc_states'].proposed.x
+        assert xprop.grad_fn is not None
+        loss = loss_fn(x_init=xin, x_prop=xprop, acc=metrics['acc'])
+        loss.backward()
+        loss = loss.detach()
+
+        class _Opt:                        # the rest of the check steps through `arena.adam_step`
+            def adam_step(self, lr):
+                optimizer.step()
+        arena = _Opt()
+    else:
+        arena = T.ParamArena(dyn)
+        arena.zero_grad()
+        xout, metrics, loss = T.train_forward_backward(dyn, loss_fn, xin, beta)
     dyn._inject = None
     out = {}
     acc = metrics['acc'].detach().cpu().numpy()
@@ -249,6 +271,7 @@ def check_train_step(g, dyn, loss_fn, rtol, atol_rel, adam_min_grad=0.0):
         if not k.startswith('grad.'):
             continue
         ref = g[k]
+        assert names[k[5:]].grad is not None, f'{k}: no gradient reached this parameter'
         got = names[k[5:]].grad.detach().cpu().numpy()
         err = np.abs(got - ref).max()
         scale = max(np.abs(ref).max(), atol_rel * gn)
@@ -499,3 +522,97 @@ def apply_pert(dyn, g):
     res = dyn.load_state_dict(sd, strict=False)
     assert not res.unexpected_keys, res.unexpected_keys
     dyn._eps_cache = {}
+
+
+def check_autograd_bridge_semantics(g, build, tol, sampler=True):
+    """What an autograd caller may do around `loss.backward()` (dynamics/pytorch/autograd.py), on a
+    train-step fixture `g` with `build(g) -> (dyn, lat, loss_fn)`:
+      * a scaled loss gives scaled gradients (GradScaler.scale, trainer.py:1303-1304) and a second
+        backward without zero_grad ACCUMULATES into p.grad;
+      * torch.autograd.grad returns the same gradients without touching p.grad;
+      * two recorded trajectories before one backward (the aux_weight > 0 sequence, :1338-1353) share
+        one set of native-order weight shadows and both contribute;
+      * a recorded trajectory that is dropped without a backward leaves nothing behind;
+      * under torch.no_grad() train mode samples without a graph."""
+    import torch
+    inject = {'normals': g['normals'], 'u': g['u']}
+    if 'forward' in g and not bool(g['merge_directions']):
+        inject['forward'] = bool(g['forward'])
+    beta = torch.tensor(float(g['beta']))
+
+    def step(dyn, loss_fn, scale=1.0, twice=False):
+        xin = dyn.g.compat_proj(dyn.unflatten(torch.from_numpy(g['x']).to(dyn.device)))
+        dyn._inject = dict(inject)
+        xout, m = dyn((xin, beta))
+        loss = loss_fn(x_init=xin, x_prop=m['mc_states'].proposed.x, acc=m['acc'])
+        if twice:
+            dyn._inject = dict(inject)
+            _, m2 = dyn((xin, beta))
+            loss = loss + loss_fn(x_init=xin, x_prop=m2['mc_states'].proposed.x, acc=m2['acc'])
+        dyn._inject = None
+        return xout, m, loss * scale
+
+    def grads(dyn):
+        return {k: p.grad.detach().clone() for k, p in dyn.named_parameters() if p.grad is not None}
+
+    def close(a, b, factor=1.0):
+        assert a.keys() == b.keys() and len(a) > 4
+        for k in a:
+            sc = max(float(b[k].abs().max()), 1e-30)
+            err = float((a[k] - factor * b[k]).abs().max())
+            assert err <= tol * max(sc * abs(factor), 1e-6), (k, err, sc)
+
+    dyn, lat, loss_fn = build(g)
+    _, _, loss = step(dyn, loss_fn)
+    loss.backward()
+    base = grads(dyn)
+    # scaled loss, accumulated on top of the first backward: 1 + 1024
+    _, _, loss = step(dyn, loss_fn, scale=1024.0)
+    loss.backward()
+    close(grads(dyn), base, 1025.0)
+    # torch.autograd.grad: same numbers, p.grad untouched
+    before = grads(dyn)
+    _, _, loss = step(dyn, loss_fn)
+    names = [k for k, p in dyn.named_parameters() if k in base]
+    got = torch.autograd.grad(loss, [dict(dyn.named_parameters())[k] for k in names])
+    close({k: t for k, t in zip(names, got)}, base)
+    close(grads(dyn), before)
+    # two recorded trajectories, one backward
+    for p in dyn.parameters():
+        p.grad = None
+    _, _, loss = step(dyn, loss_fn, twice=True)
+    sess = dyn._ag_session
+    assert sess.live == 2
+    loss.backward()
+    close(grads(dyn), base, 2.0)
+    del loss
+    assert sess.live == 0 and not any(n.native_active() for n in dyn.modules()
+                                      if hasattr(n, 'native_active'))
+    # a dropped trajectory, then a clean step
+    for p in dyn.parameters():
+        p.grad = None
+    xo, m, loss = step(dyn, loss_fn)
+    sess = dyn._ag_session
+    assert sess.live == 1
+    del xo, m, loss
+    import gc
+    gc.collect()
+    assert sess.live == 0
+    _, _, loss = step(dyn, loss_fn)
+    loss.backward()
+    close(grads(dyn), base)
+    # retain_graph is refused loudly (the tape is released by the first backward)
+    _, _, loss = step(dyn, loss_fn)
+    loss.backward(retain_graph=True)
+    try:
+        loss.backward()
+    except RuntimeError as e:
+        assert 'reversed already' in str(e)
+    else:
+        raise AssertionError('second backward through one tape must raise')
+    # no_grad: plain sampler, no graph
+    if sampler and not any(getattr(n, 'training_needs_fresh_forward', lambda: False)()
+                           for n in dyn.modules()):
+        with torch.no_grad():
+            xo, m, _ = step(dyn, loss_fn)
+        assert xo.grad_fn is None and m['acc'].grad_fn is None

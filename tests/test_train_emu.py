@@ -28,24 +28,26 @@ def f64():
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('autograd', [False, True], ids=['trainer', 'autograd'])
 @pytest.mark.parametrize('name', ['u1_train_f64', 'u1_train_f64_plain', 'u1_train_nomerge_fwd',
                                   'u1_train_nomerge_bwd'])
-def test_train_step_host_logic_f64(name, golden, monkeypatch, f64):
+def test_train_step_host_logic_f64(name, autograd, golden, monkeypatch, f64):
     g = golden(name)
     emu_native.install(monkeypatch)
     dyn, lat, loss_fn = helpers.build_u1_train_dynamics(g)
-    out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-9, atol_rel=1e-6)
+    out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-9, atol_rel=1e-6, autograd=autograd)
     assert out['grad_rel'] < 1e-7, out
     assert out['param_abs'] < 1e-7, out      # Adam's g / (|g| + 1e-8) amplifies rounding of tiny g
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
-def test_train_step_host_logic_conv_f32(golden, monkeypatch):
+@pytest.mark.parametrize('autograd', [False, True], ids=['trainer', 'autograd'])
+def test_train_step_host_logic_conv_f32(autograd, golden, monkeypatch):
     g = golden('u1_train_conv')
     emu_native.install(monkeypatch)
     dyn, lat, loss_fn = helpers.build_u1_train_dynamics(g)
     out = helpers.check_train_step(g, dyn, loss_fn, rtol=2e-4, atol_rel=1e-3,
-                                   adam_min_grad=1e-3)
+                                   adam_min_grad=1e-3, autograd=autograd)
     assert out['grad_rel'] < 2e-2, out
     assert out['param_abs'] < 2e-5, out
 
@@ -91,14 +93,16 @@ def test_trainer_train_loop_host_logic(conv, monkeypatch):
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('autograd', [False, True], ids=['trainer', 'autograd'])
 @pytest.mark.parametrize('name', ['su3_train', 'su3_train_c1', 'su3_train_nomerge'])
-def test_su3_train_step_host_logic(name, golden, monkeypatch, f64):
+def test_su3_train_step_host_logic(name, autograd, golden, monkeypatch, f64):
     """SU(3) tape / reverse sweep / loss seeds against the reference's autograd gradients
     (su3_train_c1: improved action, the rectangle term enters the accept probability)."""
     g = golden(name)
     emu_native.install(monkeypatch)
     dyn, lat, loss_fn = helpers.build_su3_train_dynamics(g)
-    out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-7, atol_rel=1e-6, adam_min_grad=1e-6)
+    out = helpers.check_train_step(g, dyn, loss_fn, rtol=1e-7, atol_rel=1e-6, adam_min_grad=1e-6,
+                                   autograd=autograd)
     assert out['grad_rel'] < 1e-5, out
     assert out['param_abs'] < 1e-6, out
 
@@ -397,3 +401,53 @@ def test_trainer_train_step_single_direction(monkeypatch):
         assert not torch.equal(tr.dynamics.vnet['0'].transl.weight.detach(), w0)
     finally:
         torch.set_default_dtype(old)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('name', ['u1_train_f64', 'su3_train', 'su3_train_nomerge'])
+def test_autograd_bridge_semantics_host_logic(name, golden, monkeypatch, f64):
+    g = golden(name)
+    emu_native.install(monkeypatch)
+    build = helpers.build_su3_train_dynamics if name.startswith('su3') else helpers.build_u1_train_dynamics
+    # (the emulator restates the training kernels; the fused SU(3) sampler kernels run on the GPU tier)
+    helpers.check_autograd_bridge_semantics(g, build, tol=1e-7 if name.startswith('su3') else 1e-9,
+                                            sampler=not name.startswith('su3'))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('inject_dir', [True, False, None])
+def test_micro_batched_single_direction_training_host_logic(inject_dir, monkeypatch, f64):
+    """merge_directions=False in chain micro-batches: ONE direction per optimiser step (injected, or one
+    host-generator draw), so the gradient equals the unchunked step's and the generator advances exactly
+    as much (every micro-batch used to draw its own direction)."""
+    import l2hmc.configs as cfgs
+    from l2hmc.trainers.pytorch.trainer import Trainer
+    emu_native.install(monkeypatch)
+    ov = ['dynamics.group=SU3', 'dynamics.latvolume=[2,2,2,2]', 'dynamics.nchains=4',
+          'dynamics.nleapfrog=2', 'dynamics.eps=0.02', 'dynamics.verbose=false',
+          'dynamics.merge_directions=false',
+          'dynamics.use_split_xnets=false', 'dynamics.use_separate_networks=false',
+          'network.units=[4]', 'network.dropout_prob=0.0', 'network.use_batch_norm=false',
+          'network.activation_fn=tanh', 'loss.aux_weight=0.0', 'learning_rate.clip_norm=0.0',
+          'conv=none']
+    grads, after = {}, {}
+    for mb in (None, 2, 3):
+        torch.manual_seed(1)
+        np.random.seed(1)
+        tr = Trainer(cfgs.get_config(ov))
+        tr.micro_batch = mb
+        x = tr.lattice.random()
+        nrm = torch.randn(8, 4, 4, 2, 2, 2, 2, generator=torch.Generator().manual_seed(7))
+        tr.dynamics._inject = {'normals': nrm.numpy(), 'u': np.full(4, 0.5)}
+        if inject_dir is not None:
+            tr.dynamics._inject['forward'] = inject_dir
+        torch.manual_seed(11)                         # the direction draw (when not injected) comes from here
+        xo, m = tr.train_step((x, 6.0))
+        after[mb] = float(torch.rand(1))              # where the host generator stands after the step
+        grads[mb] = {k: p.grad.detach().clone() for k, p in tr.dynamics.named_parameters()
+                     if p.grad is not None}
+    for mb in (2, 3):
+        assert after[mb] == after[None], (mb, after)
+        for k, g in grads[None].items():
+            d = float((grads[mb][k] - g).abs().max())
+            assert d <= 1e-7 * max(1.0, float(g.abs().max())), (mb, k, d)
