@@ -1240,7 +1240,30 @@ class Dynamics(nn.Module):
         hist.update({'acc_mask': ma, 'mc_states': mc_states})
         return xout, hist
 
+    def _follow_autocast(self) -> None:
+        """The reference selects 16-bit networks by wrapping this call in `torch.autocast(dtype=...)`
+        (trainers/pytorch/trainer.py:211-219, 1276-1280).  An autocast region around `forward` switches the
+        U(1) networks to that type (as `set_net_precision` does) and leaving it switches them back; an explicit
+        `set_net_precision` is never overridden.  SU(3) is complex128 by definition: ignored."""
+        if self.group != 'U1' or not self._networks_built:
+            return
+        dt = DEVICE.type if isinstance(DEVICE, torch.device) else str(DEVICE).split(':')[0]
+        half = None
+        if torch.is_autocast_enabled(dt):
+            half = torch.get_autocast_dtype(dt)
+            half = half if half in (torch.float16, torch.bfloat16) else None
+        if half is not None and self.net_precision is None:
+            self.set_net_precision(half)
+            self._precision_from_autocast = True
+        elif half is None and getattr(self, '_precision_from_autocast', False):
+            self.set_net_precision(None)
+            self._precision_from_autocast = False
+        elif half is not None and getattr(self, '_precision_from_autocast', False) \
+                and self.net_precision != half:
+            self.set_net_precision(half)
+
     def forward(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
+        self._follow_autocast()
         if self._records_graph():
             return self._forward_train(inputs)
         return (self.apply_transition_fb(inputs) if self.config.merge_directions

@@ -171,6 +171,51 @@ class ParamArena:
         ops.PARAM_GENERATION[0] += 1
 
 
+class LossScaler:
+    """torch.amp.GradScaler's bookkeeping (defaults included: init 2^16, growth x2 every 2000 clean steps,
+    backoff x0.5) for the flat-arena trainer: the reference scales the loss of its mixed-precision steps,
+    un-scales the gradients, SKIPS the optimiser step when any of them is inf / nan and adapts the scale
+    (trainers/pytorch/trainer.py:256-257, 1303-1313).  The scale is a power of two, so scaling the seeds of
+    the fp32 reverse sweep and folding 1 / scale into the fused Adam changes no bit unless something
+    overflows.  (The reference's 16-bit backward overflows earlier than this fp32 sweep: its first steps at
+    2^16 are typically skipped, tests/golden/u1_train_fp16_overflow.npz; here they are taken.)"""
+
+    def __init__(self, init_scale: float = 2.0 ** 16, growth_factor: float = 2.0,
+                 backoff_factor: float = 0.5, growth_interval: int = 2000, enabled: bool = True):
+        self.scale = float(init_scale)
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.enabled = int(growth_interval), bool(enabled)
+        self.growth_tracker = 0
+        self.skipped = 0
+
+    def get_scale(self) -> float:
+        return self.scale if self.enabled else 1.0
+
+    def update(self, found_inf: bool) -> None:
+        if not self.enabled:
+            return
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self.growth_tracker = 0
+            self.skipped += 1
+        else:
+            self.growth_tracker += 1
+            if self.growth_tracker == self.growth_interval:
+                self.scale *= self.growth_factor
+                self.growth_tracker = 0
+
+    def state_dict(self) -> dict:
+        return {'scale': self.scale, 'growth_factor': self.growth_factor,
+                'backoff_factor': self.backoff_factor, 'growth_interval': self.growth_interval,
+                '_growth_tracker': self.growth_tracker}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.scale = float(sd['scale'])
+        self.growth_factor, self.backoff_factor = float(sd['growth_factor']), float(sd['backoff_factor'])
+        self.growth_interval = int(sd['growth_interval'])
+        self.growth_tracker = int(sd['_growth_tracker'])
+
+
 # ------------------------------------------------------------------------------ forward (tape)
 def _eps_and_slope(p: Tensor) -> tuple[float, float]:
     """eps = sigmoid(log p) = p / (1 + p) and d eps / d p = 1 / (1 + p)^2 (dynamics.py:82-83)"""

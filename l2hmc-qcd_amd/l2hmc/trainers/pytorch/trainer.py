@@ -44,14 +44,18 @@ class Trainer:
         self.g = self.lattice.g
         self.loss_fn = LatticeLoss(lattice=self.lattice, loss_config=cfg.loss)
         self.dynamics = self.build_dynamics(build_networks)
+        self.grad_scaler = None
         if cfg.precision in ('fp16', 'bf16') and build_networks:
             # the reference wraps Dynamics.forward in torch.autocast(dtype=precision)
-            # (trainer.py:211-219): Linear layers in 16 bit, lattice arithmetic in fp32.  Here
-            # that applies to the sampling steps (eval_step / eval); train_step differentiates
-            # the fp32 master weights, so no GradScaler is needed.
+            # (trainer.py:211-219, 1276-1280): Linear layers in 16 bit, lattice arithmetic in fp32 -- in
+            # eval_step AND in train_step, whose loss goes through a GradScaler (:256-257, 1303-1313):
+            # the tape's forward runs the 16-bit layers, the reverse sweep updates fp32 master weights,
+            # `grad_scaler` keeps GradScaler's scale / skip-on-inf bookkeeping.
             if cfg.dynamics.group.upper() != 'U1':
                 raise ValueError(f'precision={cfg.precision}: SU(3) is complex128 by definition')
             self.dynamics.set_net_precision(cfg.precision)
+            from l2hmc.dynamics.pytorch.training import LossScaler
+            self.grad_scaler = LossScaler()
         evals = 2 * cfg.dynamics.nleapfrog if cfg.dynamics.merge_directions \
             else cfg.dynamics.nleapfrog
         self.timers = {k: StepTimer(evals_per_step=evals) for k in ('train', 'eval', 'hmc')}
@@ -211,20 +215,31 @@ class Trainer:
                 return T.train_forward_backward_chunked(self.dynamics, self.loss_fn, xin, beta, mb,
                                                         loss_weight=w)
             return T.train_forward_backward(self.dynamics, self.loss_fn, xin, beta, loss_weight=w)
-        xout, metrics, loss = fwd_bwd(xinit)
+        # mixed precision: `grad_scaler.scale(loss).backward()` = the seeds of the sweep times the scale
+        ls = 1.0 if self.grad_scaler is None else self.grad_scaler.get_scale()
+        xout, metrics, loss = fwd_bwd(xinit, ls)
         loss_tot = loss
         if (aw := self.config.loss.aux_weight) > 0:
             # the reference's `aux_loss += aw * aux_loss` (trainer.py:1343-1353)
             yinit = self.g.random(list(xinit.shape)).to(self.device)
-            _, _m, aux = fwd_bwd(yinit, 1.0 + aw)
+            _, _m, aux = fwd_bwd(yinit, (1.0 + aw) * ls)
             loss_tot = loss + (1.0 + aw) * aux
-        scale = self.arena.all_reduce()
+        scale = self.arena.all_reduce() / ls               # `unscale_`: folded into the fused Adam
         clip = float(self.config.learning_rate.clip_norm)
-        if clip > 0.0:
-            coef = clip / (self.arena.grad_norm(scale) + 1e-6)
-            if coef < 1.0:
-                scale *= coef
-        self.arena.adam_step(lr=float(self.config.learning_rate.lr_init), grad_scale=scale)
+        found_inf = False
+        if clip > 0.0 or self.grad_scaler is not None:
+            gn = self.arena.grad_norm(scale)
+            found_inf = not np.isfinite(gn)
+            if clip > 0.0 and not found_inf:
+                coef = clip / (gn + 1e-6)
+                if coef < 1.0:
+                    scale *= coef
+        if self.grad_scaler is not None:
+            # `grad_scaler.step(optimizer)` skips the update when a gradient is inf / nan; `update()`
+            self.grad_scaler.update(found_inf)
+            metrics['loss_scale'] = ls
+        if not (found_inf and self.grad_scaler is not None):
+            self.arena.adam_step(lr=float(self.config.learning_rate.lr_init), grad_scale=scale)
         metrics.pop('mc_states', None)
         metrics['loss'] = float(loss_tot)
         if self.config.dynamics.verbose:

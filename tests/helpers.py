@@ -616,3 +616,102 @@ def check_autograd_bridge_semantics(g, build, tol, sampler=True):
         with torch.no_grad():
             xo, m, _ = step(dyn, loss_fn)
         assert xo.grad_fn is None and m['acc'].grad_fn is None
+
+
+def check_half_train_step(g, route):
+    """Mixed-precision train step on a u1_train_{fp16,bf16}* fixture (the REAL reference under
+    `torch.autocast(dtype)` + `GradScaler`, tests/golden/make_golden_train.py half).
+
+    route 'trainer': this build's tape with `set_net_precision(half)`, seeds scaled by the fixture's
+    loss scale (what Trainer.train_step does with its LossScaler);
+    route 'autograd': the reference caller's literal sequence -- `with torch.autocast(dtype): dynamics((x,
+    beta))`, `scaler.scale(loss).backward(); scaler.unscale_(opt); scaler.step(opt); scaler.update()` with
+    torch's own GradScaler and Adam.
+
+    Returns distances in units the caller asserts on: `grad_vs_ref16` = |g - g_ref16| / |g_ref16| (global L2),
+    `ref16_vs_ref32` = the reference's own 16-bit-vs-fp32 distance, per-parameter worst ratio, acc / loss
+    differences, parameter update difference."""
+    import torch
+    from l2hmc.dynamics.pytorch import training as T
+    half = {'fp16': torch.float16, 'bf16': torch.bfloat16}[str(g['half'])]
+    dyn, lat, loss_fn = build_u1_train_dynamics(g)
+    dev = dyn.device.type if isinstance(dyn.device, torch.device) else str(dyn.device).split(':')[0]
+    scale = float(g['init_scale'])
+    dyn._inject = {'normals': g['normals'], 'u': g['u']}
+    x = torch.from_numpy(g['x'])
+    beta = torch.tensor(float(g['beta']))
+    xin = dyn.g.compat_proj(dyn.unflatten(x.to(dyn.device)))
+    out = {}
+    if route == 'trainer':
+        dyn.set_net_precision(half)
+        arena = T.ParamArena(dyn)
+        arena.zero_grad()
+        xout, metrics, loss = T.train_forward_backward(dyn, loss_fn, xin, beta, loss_weight=scale)
+        grads = {k: p.grad.detach().cpu().numpy() / scale for k, p in dyn.named_parameters()
+                 if p.grad is not None}
+        arena.adam_step(lr=float(g['lr']), grad_scale=1.0 / scale)
+    else:
+        opt = torch.optim.Adam(dyn.parameters(), lr=float(g['lr']))
+        scaler = torch.amp.GradScaler(dev, init_scale=scale)
+        xin.requires_grad_(True)
+        opt.zero_grad()
+        with torch.autocast(dev, dtype=half):
+            xout, metrics = dyn((xin, beta))
+        assert dyn.net_precision == half
+        loss = loss_fn(xin, metrics['mc_states'].proposed.x, metrics['acc'])
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in dyn.named_parameters()
+                 if p.grad is not None}
+        scaler.step(opt)
+        scaler.update()
+        out['scale_after'] = float(scaler.get_scale())
+        loss = loss.detach()
+    dyn._inject = None
+    assert np.array_equal(metrics['acc_mask'].cpu().numpy(), g['acc_mask'])
+    out['acc'] = float(np.abs(metrics['acc'].detach().cpu().numpy() - g['acc']).max())
+    out['acc_ref16_vs_ref32'] = float(np.abs(g['acc32'] - g['acc']).max())
+    out['loss'] = abs(float(loss) - float(g['loss'])) / max(1.0, abs(float(g['loss'])))
+    xp = metrics['mc_states'].proposed.x.detach().cpu().numpy().reshape(g['x_prop'].shape)
+    out['x_prop'] = float(np.abs(np.angle(np.exp(1j * (xp - g['x_prop'])))).max())
+    out['x_prop_ref16_vs_ref32'] = float(np.abs(np.angle(np.exp(1j * (g['x_prop32'] - g['x_prop'])))).max())
+    keys = [k for k in g if k.startswith('grad.')]
+    n16 = np.sqrt(sum(float((g[k].astype(np.float64) ** 2).sum()) for k in keys))
+    d = np.sqrt(sum(float(((grads[k[5:]].astype(np.float64) - g[k]) ** 2).sum()) for k in keys))
+    dref = np.sqrt(sum(float(((g['grad32.' + k[5:]].astype(np.float64) - g[k]) ** 2).sum()) for k in keys))
+    out['grad_vs_ref16'] = d / n16
+    out['ref16_vs_ref32'] = dref / n16
+    worst = 0.0
+    for k in keys:
+        nk = np.sqrt(float((g[k].astype(np.float64) ** 2).sum()))
+        dk = np.sqrt(float(((grads[k[5:]].astype(np.float64) - g[k]) ** 2).sum()))
+        worst = max(worst, dk / max(nk, 1e-3 * n16))
+    out['grad_worst_param'] = worst
+    sd = dyn.state_dict()
+    wp = 0.0
+    for k in g:
+        if k.startswith('sd1.') and not k.endswith('num_batches_tracked'):
+            name = k[4:]
+            gk = 'grad.' + name if ('grad.' + name) in g else 'grad.networks.' + name
+            diff = np.abs(sd[name].detach().cpu().numpy() - g[k])
+            if gk in g:                       # Adam's first step is lr * sign(g) where g is resolved
+                diff = np.where(np.abs(g[gk]) > 1e-2 * np.abs(g[gk]).max(), diff, 0.0)
+            wp = max(wp, float(diff.max()) if diff.size else 0.0)
+    out['param_abs'] = wp
+    return out
+
+
+def assert_half_train_step(g, name, route, out):
+    """Tolerances of check_half_train_step: the product must be as close to the reference's 16-bit step as
+    the reference's 16-bit step is to its own fp32 step (x 2 for the gradients, x 3 for acc = exp(-dH));
+    without BatchNorm the rounding points are reproduced and the product is much closer than that."""
+    assert out['grad_vs_ref16'] <= max(2.0 * out['ref16_vs_ref32'], 2e-3), out
+    assert out['acc'] <= max(3.0 * out['acc_ref16_vs_ref32'], 2e-3), out
+    assert out['x_prop'] <= max(3.0 * out['x_prop_ref16_vs_ref32'], 1e-3), out
+    assert out['loss'] <= 1e-2, out
+    if name == 'u1_train_fp16':
+        assert out['grad_vs_ref16'] <= 5e-4 and out['param_abs'] <= 1e-6, out
+    else:
+        assert out['param_abs'] <= 2.1 * float(g['lr']), out        # Adam's first step: lr * sign(g)
+    if route == 'autograd':
+        assert out['scale_after'] == float(g['scale_after']), out

@@ -451,3 +451,17 @@ def test_micro_batched_single_direction_training_host_logic(inject_dir, monkeypa
         for k, g in grads[None].items():
             d = float((grads[mb][k] - g).abs().max())
             assert d <= 1e-7 * max(1.0, float(g.abs().max())), (mb, k, d)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+@pytest.mark.parametrize('route', ['trainer', 'autograd'])
+@pytest.mark.parametrize('name', ['u1_train_fp16', 'u1_train_fp16_bn', 'u1_train_bf16'])
+def test_half_precision_train_step_host_logic(name, route, golden, monkeypatch):
+    """autocast + GradScaler training (trainers/pytorch/trainer.py:211-219, 1276-1280, 1303-1313) against the
+    real reference run that way: accept masks bit-equal, gradients within a multiple of the reference's OWN
+    16-bit-vs-fp32 distance (the emulator restates the 16-bit layers' rounding points)."""
+    g = golden(name)
+    emu_native.install(monkeypatch)
+    out = helpers.check_half_train_step(g, route)
+    print(name, route, out)
+    helpers.assert_half_train_step(g, name, route, out)
