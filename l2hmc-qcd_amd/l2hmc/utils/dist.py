@@ -134,6 +134,29 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
             dist.broadcast(t.data, src=src)
 
 
+def model_checksum(module: torch.nn.Module) -> str:
+    """Order-dependent digest of every parameter, buffer and (Dynamics) mask of a model: equal on two ranks
+    exactly when they hold the same bits (bench.py --gpus N asserts it; the data-parallel step relies on it)."""
+    import hashlib
+    h = hashlib.sha256()
+    with torch.no_grad():
+        ts = [p for _n, p in sorted(module.named_parameters())] + [b for _n, b in sorted(module.named_buffers())]
+        ts += list(getattr(module, 'masks', []) or [])
+        for t in ts:
+            t = t.detach()
+            # two order-sensitive moments in fp64 instead of shipping the bytes of 1.4 GB matrices to the host
+            f = (torch.view_as_real(t) if t.is_complex() else t).double().reshape(-1)
+            if f.numel() == 0:
+                continue
+            if f.numel() > (1 << 24) and not f.is_cuda:
+                # (host-resident giants: the never-called SU(3) xnet) the plain sum only
+                h.update(repr((tuple(t.shape), float(f.sum()))).encode())
+                continue
+            w = torch.arange(1, f.numel() + 1, dtype=torch.float64, device=f.device)
+            h.update(repr((tuple(t.shape), float(f.sum()), float((f * w).sum() / f.numel()))).encode())
+    return h.hexdigest()[:16]
+
+
 def sync_model(dynamics, src: int = 0) -> None:
     """Make `dynamics` identical on every rank: broadcast rank `src`'s parameters, buffers and
     the numpy-drawn leapfrog masks.  No-op without a process group."""
