@@ -1018,9 +1018,17 @@ def u1_masked_cos_sin_bwd_(dx, x, mask, complement: bool, dout) -> torch.Tensor:
 
 
 def conv2d_periodic_gemm_train(x: torch.Tensor, layout: str, w: torch.Tensor, b: torch.Tensor,
-                               pool: int = 1, act: Optional[str] = None):
-    """conv2d_periodic_gemm that also returns what the backward pass needs."""
+                               pool: int = 1, act: Optional[str] = None,
+                               half: Optional[torch.dtype] = None):
+    """conv2d_periodic_gemm that also returns what the backward pass needs.
+    half = float16 | bfloat16: the layer as torch.autocast runs it in the reference's train step -- input,
+    weight and bias rounded to that type, fp32 accumulation (products of 16-bit values are exact in fp32:
+    the fp32 MFMA GEMM gives what the 16-bit one gives, to summation order), the convolution's output rounded,
+    the activation's output rounded; everything stays in fp32 containers for the backward pass."""
     x = x.contiguous()
+    if half is not None:
+        r16 = lambda t: t.to(half).float()
+        x, w, b = r16(x), r16(w), r16(b)
     if layout == 'nchw':
         nb, C, H, W = x.shape
         strides = (C * H * W, H * W, W, 1)
@@ -1036,7 +1044,13 @@ def conv2d_periodic_gemm_train(x: torch.Tensor, layout: str, w: torch.Tensor, b:
     N.call('l2q_im2col_periodic_f32', x, *strides, nb, C, H, W, k, int(clast), col)
     pool = max(int(pool), 1)
     wk = (w.permute(0, 2, 3, 1) if clast else w).reshape(cout, Kc).contiguous()
-    y = gemm(col, wk, b.contiguous(), act=None if pool > 1 else act)
+    if half is not None and pool == 1 and act is not None:
+        # rounding point between the convolution and its activation
+        y = act_fwd(gemm(col, wk, b.contiguous(), act=None).to(half).float(), act).to(half).float()
+    else:
+        y = gemm(col, wk, b.contiguous(), act=None if pool > 1 else act)
+        if half is not None:
+            y = y.to(half).float()
     ctx = {'col': col, 'strides': strides, 'dims': (nb, C, H, W, k, cout), 'pool': pool,
            'act': act, 'y': y, 'clast': clast, 'wk': wk}
     if pool == 1:
@@ -1044,6 +1058,8 @@ def conv2d_periodic_gemm_train(x: torch.Tensor, layout: str, w: torch.Tensor, b:
     else:
         out = torch.empty((nb, Ho // pool, Wo // pool, cout), dtype=torch.float32, device=x.device)
         N.call('l2q_maxpool_act_nhwc_f32', y, nb, Ho, Wo, cout, pool, N.ACT[act], out)
+        if half is not None:
+            out = out.to(half).float()
     ctx['out'] = out
     return out, ctx
 

@@ -84,6 +84,23 @@ class BaseConfig(ABC):
     def to_dict(self) -> dict:
         return deepcopy(self.__dict__)
 
+    def to_file(self, fpath) -> None:
+        """the JSON text of the config, as a JSON string (configs.py:169-171 dumps `to_json()`'s string)"""
+        with open(fpath, 'w') as f:
+            json.dump(self.to_json(), f, indent=4)
+
+    def from_file(self, fpath) -> None:
+        """re-initialise from a file written by `to_file`.  (The reference's version opens the file for
+        writing first and so truncates it, configs.py:173-178; this one reads it.)"""
+        with open(fpath, 'r') as f:
+            config = json.load(f)
+        if isinstance(config, str):
+            config = json.loads(config)
+        fields = getattr(self, '__dataclass_fields__', None)
+        if fields is not None:
+            config = {k: v for k, v in config.items() if k in fields and fields[k].init}
+        self.__init__(**config)
+
     def __getitem__(self, key):
         return super().__getattribute__(key)
 
@@ -174,6 +191,15 @@ class Steps(BaseConfig):
 
     def to_str(self) -> str:
         return f'nera-{self.nera}_nepoch-{self.nepoch}'
+
+    def update(self, nera: Optional[int] = None, nepoch: Optional[int] = None, test: Optional[int] = None,
+               log: Optional[int] = None, print: Optional[int] = None,
+               extend_last_era: Optional[int] = None) -> 'Steps':
+        """a copy with the given fields replaced (configs.py:371-388)"""
+        pick = lambda new, old: old if new is None else new
+        return Steps(nera=pick(nera, self.nera), nepoch=pick(nepoch, self.nepoch), test=pick(test, self.test),
+                     log=pick(log, self.log), print=pick(print, self.print),
+                     extend_last_era=pick(extend_last_era, self.extend_last_era))
 
 
 @dataclass

@@ -162,3 +162,59 @@ def vec_to_su3(v: Tensor) -> Tensor:
         torch.stack([x01, v11, -x12.conj()], -1),
         torch.stack([x02, x12, v22], -1),
     ], -1)
+
+
+# ------------------------------------------------------------------ module-level names a notebook may import
+# (utils.py:26-47, 144-154, 448-514 of the reference; none of them is on the leapfrog path)
+SQRT1by2, SQRT1by3, SQRT3 = NP_SQRT1by2, NP_SQRT1by3, float(np.sqrt(3.0))
+TWO_PI = 2.0 * np.pi
+EPS = 1e-12
+# non-zero structure constants of [T^a, T^b] = f^abc T^c in the basis of su3_to_vec / vec_to_su3
+f012, f036, f045, f135, f146, f234, f256 = +1.0, +0.5, -0.5, +0.5, +0.5, +0.5, -0.5
+f347 = f567 = float(np.sqrt(0.75))
+_F_NONZERO = {(0, 1, 2): f012, (0, 3, 6): f036, (0, 4, 5): f045, (1, 3, 5): f135, (1, 4, 6): f146,
+              (2, 3, 4): f234, (2, 5, 6): f256, (3, 4, 7): f347, (5, 6, 7): f567}
+
+
+def _structure_constants(dtype, device) -> Tensor:
+    """f^abc [8, 8, 8], totally antisymmetric, from the nine independent non-zero entries."""
+    f = torch.zeros(8, 8, 8, dtype=dtype, device=device)
+    for (a, b, c), val in _F_NONZERO.items():
+        for (i, j, k), sgn in (((a, b, c), 1), ((b, c, a), 1), ((c, a, b), 1),
+                               ((b, a, c), -1), ((a, c, b), -1), ((c, b, a), -1)):
+            f[i, j, k] = sgn * val
+    return f
+
+
+def su3fabc(v: Tensor) -> Tensor:
+    """f^{abc} v[..., c] as an [..., 8, 8] matrix, laid out like the reference's nested stack
+    (utils.py:448-488: entry [..., a, b] holds f^{abc} v_c; checked against the reference's table)."""
+    f = _structure_constants(v.dtype, v.device)
+    return torch.einsum('abc,...c->...ab', f, v)
+
+
+def eye_like(x: Tensor) -> Tensor:
+    """identity with the (2-D) shape, dtype and device of x (utils.py:144-145)"""
+    return torch.eye(*x.size(), out=torch.empty_like(x)).to(DEVICE)
+
+
+def expm(m: Tensor, order: int = 12) -> Tensor:
+    """Taylor polynomial of exp(m) of the given order, evaluated by Horner's rule (utils.py:148-154) --
+    the reference's own truncated series, NOT the integrator's exponential (the x-update uses
+    torch.matrix_exp there and l2q_su3_expm_mul here)."""
+    eye = eyeOf(m).to(m.dtype)
+    acc = eye + m / order
+    for i in range(order - 1, 0, -1):
+        acc = eye + torch.matmul(m, acc) / i
+    return acc
+
+
+def SU3Gradient(f, x: Tensor, create_graph: bool = True) -> tuple[Tensor, Tensor]:
+    """(f(x), df/dx) by autograd for a per-chain real f (utils.py:491-514).  With f = LatticeSU3.action the
+    derivative comes from l2q_su3_plaq_bwd through l2hmc/_autograd.py; those nodes are first-order, so
+    `create_graph` only matters for an f written in differentiable torch ops."""
+    x.requires_grad_(True)
+    y = f(x)
+    ones = torch.ones(x.shape[0], device=y.device, dtype=y.dtype)
+    dydx, = torch.autograd.grad(y, x, create_graph=create_graph, retain_graph=True, grad_outputs=ones)
+    return y, dydx

@@ -359,7 +359,9 @@ class ConvStack(nn.Module):
                         lin.bias.detach(), act=self.act)
 
     # ---- training path: forward keeping what the backward needs, and the backward itself
-    def forward_train(self, x: Tensor) -> tuple[Tensor, dict]:
+    def forward_train(self, x: Tensor, half: Optional[torch.dtype] = None) -> tuple[Tensor, dict]:
+        """half: the stack under torch.autocast(dtype=half) -- every Conv2d / Linear with 16-bit operands
+        and outputs (ops.conv2d_periodic_gemm_train's `half`), values kept in fp32 containers for the tape."""
         x = x.to(DEVICE)
         nb = x.shape[0]
         x = x.reshape(nb, self.in_channels, self.nt, self.nx).contiguous()
@@ -369,7 +371,7 @@ class ConvStack(nn.Module):
         for ci, k, pool, act in self.plan:
             conv = self.layers[ci]
             x, c = ops.conv2d_periodic_gemm_train(x, layout, conv.weight.detach(),
-                                                  conv.bias.detach(), pool, act)
+                                                  conv.bias.detach(), pool, act, half=half)
             ctxs.append(c)
             layout = 'nhwc'
         nhwc_shape = None
@@ -379,7 +381,12 @@ class ConvStack(nn.Module):
             x = ops.transpose(x.reshape(nb, H * W, C), nb, H * W, C)
         flat = x.reshape(nb, -1).contiguous()
         lin = self.layers[self.linear_index]
-        y = ops.gemm(flat, lin.weight.detach(), lin.bias.detach(), act=self.act)
+        if half is not None:
+            y = ops.gemm_h(flat, lin.weight.detach().to(half).contiguous(),
+                           lin.bias.detach().to(half).float().contiguous(), act=self.act,
+                           out_dtype=torch.float32)
+        else:
+            y = ops.gemm(flat, lin.weight.detach(), lin.bias.detach(), act=self.act)
         return y, {'convs': ctxs, 'nhwc_shape': nhwc_shape, 'flat': flat, 'y': y}
 
     def backward(self, ctx: dict, dy: Tensor) -> Tensor:
@@ -900,22 +907,23 @@ class LeapfrogLayer(nn.Module):
         on the fp32 master weights, in fp32 -- the reference runs those products in 16 bit; the difference is
         below its own fp16-vs-fp32 distance, which is what the tests pin."""
         il = self.input_layer
-        if isinstance(il.conv_stack, ConvStack):
-            raise NotImplementedError('half-precision training: dense networks (conv=none) only -- train the '
-                                      'conv stack with precision=float32')
         if self.act == 'swish':
             raise NotImplementedError('half-precision training: swish keeps pre-activations; use another activation_fn')
         hd = self.half_dtype
         nb = x.shape[0]
         h = self._half_train_weights()
-        xf = x.reshape(nb, -1).float().contiguous()
+        conv_ctx = None
+        if isinstance(il.conv_stack, ConvStack):
+            xf, conv_ctx = il.conv_stack.forward_train(x, half=hd)
+        else:
+            xf = x.reshape(nb, -1).float().contiguous()
         vf = v.reshape(nb, -1).float().contiguous()
         z = ops.gemm_h(xf, h['wx'], h['bx'], a2=vf, w2=h['wv'], bias2=h['bv'], act=self.act)
         acts = [z.float()]
         for hw, hb in h['hidden']:
             z = ops.gemm_h(z, hw, hb, act=self.act)
             acts.append(z.float())
-        ctx: dict = {'xf': xf, 'vf': vf, 'acts': acts, 'pre': None, 'conv': None,
+        ctx: dict = {'xf': xf, 'vf': vf, 'acts': acts, 'pre': None, 'conv': conv_ctx,
                      'xshape': tuple(x.shape), 'vshape': tuple(v.shape), 'native': False}
         zf = acts[-1]
         p = float(self.net_config.dropout_prob)

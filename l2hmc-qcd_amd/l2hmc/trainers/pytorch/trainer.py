@@ -343,6 +343,70 @@ class Trainer:
             x, stuck = self._redraw_if_stuck(x, avgs, stuck, patience, step)
         return {'history': history, 'x': x, 'timer': timer}
 
+    # -- single steps with timing / bookkeeping, and the loss-driven beta schedule
+    #    (trainer.py:1369-1476, 1840-1927 without the wandb / aim / rich side effects)
+    def train_step_detailed(self, x: Optional[Tensor] = None, beta=None, era: int = 0, epoch: int = 0,
+                            verbose: bool = True, **_unused) -> tuple[Tensor, dict]:
+        """One timed train_step; the record (era / epoch / tstep / dt / beta / loss / dQ* / metrics) goes
+        into histories['train'] and comes back with its per-key averages under 'avgs'."""
+        x = self.lattice.random() if x is None else x
+        beta = self.config.annealing_schedule.beta_init if beta is None else beta
+        self.timers['train'].start()
+        xout, metrics = self.train_step((x, float(beta)))
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dt = self.timers['train'].stop()
+        record = {'era': era, 'epoch': epoch, 'tstep': self._gstep, 'dt': dt, 'beta': float(beta),
+                  'loss': metrics.pop('loss', None), 'dQsin': metrics.pop('dQsin', None),
+                  'dQint': metrics.pop('dQint', None), **metrics}
+        record['avgs'] = self.histories['train'].update({k: v for k, v in record.items() if v is not None})
+        return xout, record
+
+    def eval_step_detailed(self, job_type: str, x: Optional[Tensor] = None, beta: Optional[float] = None,
+                           verbose: bool = True) -> tuple[Tensor, dict]:
+        if job_type not in ('eval', 'hmc'):
+            raise ValueError(f'Job type should be eval or hmc, got: {job_type}')
+        x = self.lattice.random() if x is None else x
+        beta = self.config.annealing_schedule.beta_init if beta is None else beta
+        self.timers[job_type].start()
+        xout, metrics = (self.eval_step if job_type == 'eval' else self.hmc_step)((x, beta))
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dt = self.timers[job_type].stop()
+        record = {'dt': dt, 'beta': beta, 'loss': metrics.pop('loss', None),
+                  'dQsin': metrics.pop('dQsin', None), 'dQint': metrics.pop('dQint', None), **metrics}
+        record['avgs'] = self.histories[job_type].update({k: v for k, v in record.items() if v is not None})
+        return xout, record
+
+    def train_dynamic(self, x: Optional[Tensor] = None, nera: Optional[int] = None,
+                      nepoch: Optional[int] = None, beta=None, **_unused) -> dict:
+        """Eras at a beta that follows the loss instead of the fixed ladder (trainer.py:1840-1927): start from
+        the schedule's first value; after each era, with `annealing_schedule.dynamic`, beta moves by a tenth of
+        itself -- down when the loss rose on average over the era, up when it fell -- until it reaches
+        beta_final.  (Without `dynamic` the reference's loop never changes beta; `nera` bounds it here.)"""
+        self.dynamics.train()
+        nera = self.config.steps.nera if nera is None else nera
+        nepoch = self.config.steps.nepoch if nepoch is None else nepoch
+        sched = self.config.annealing_schedule
+        betas = sched.setup(nera=nera, nepoch=nepoch)
+        beta_final = float(sched.beta_final)
+        b = float(betas.get('0', beta_final)) if beta is None else float(beta)
+        x = self.lattice.random() if x is None else x
+        out: dict = {'history': {}, 'betas': [], 'x': x, 'timer': self.timers['train']}
+        era = 0
+        while b < beta_final and era < nera:
+            res = self.train(x=out['x'], beta=b, nsteps=nepoch)
+            out['x'] = res['x']
+            for k, v in res['history'].items():
+                out['history'].setdefault(k, []).extend(v)
+            out['history'].setdefault('era', []).extend([era] * nepoch)
+            out['betas'].append(b)
+            losses = torch.as_tensor([float(l) for l in res['history']['loss'][1:]])
+            if getattr(sched, 'dynamic', False) and losses.numel() > 1:
+                b = b - b / 10.0 if float((losses[1:] - losses[:-1]).mean()) > 0 else b + b / 10.0
+            era += 1
+        return out
+
     def _redraw_if_stuck(self, x: Tensor, avgs: dict, stuck: int, patience: int, step: int):
         """The reference's stuck-chain rescue (trainers/pytorch/trainer.py:1209-1215 in `eval`,
         :1594-1600 in `train_epoch`): at logging steps, a mean acceptance below 1e-5 counts as

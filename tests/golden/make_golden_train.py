@@ -265,6 +265,9 @@ if __name__ == '__main__':
                    loss_cfg=lc, half=torch.float16, init_scale=16.0)
         train_case('u1_train_bf16', (4, 6), 5, 3, [8], 'tanh', None, beta=3.0, seed=640, bn=False,
                    loss_cfg=cfgs.LossConfig(use_mixed_loss=False, charge_weight=0.5), half=torch.bfloat16)
+        train_case('u1_train_fp16_conv', (4, 6), 5, 2, [8, 6], 'leaky_relu',
+                   {'filters': [2, 3, 4], 'sizes': [3, 2, 2], 'pool': [2, 2, 2]}, beta=2.5, seed=660, bn=False,
+                   loss_cfg=lc, half=torch.float16, init_scale=16.0)
         # default GradScaler scale 2^16: the fp16 backward overflows, the step is skipped, the scale halves
         train_case('u1_train_fp16_overflow', (4, 8), 8, 2, [16, 16], 'relu', None, beta=2.0, seed=600, bn=False,
                    loss_cfg=lc, half=torch.float16, init_scale=65536.0)

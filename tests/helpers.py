@@ -709,7 +709,7 @@ def assert_half_train_step(g, name, route, out):
     assert out['acc'] <= max(3.0 * out['acc_ref16_vs_ref32'], 2e-3), out
     assert out['x_prop'] <= max(3.0 * out['x_prop_ref16_vs_ref32'], 1e-3), out
     assert out['loss'] <= 1e-2, out
-    if name == 'u1_train_fp16':
+    if name in ('u1_train_fp16', 'u1_train_fp16_conv'):
         assert out['grad_vs_ref16'] <= 5e-4 and out['param_abs'] <= 1e-6, out
     else:
         assert out['param_abs'] <= 2.1 * float(g['lr']), out        # Adam's first step: lr * sign(g)

@@ -85,3 +85,45 @@ def test_get_experiment(monkeypatch):
     assert not ex4.trainer.dynamics._networks_built
     x, m = ex.trainer.eval_step((ex.lattice.random(), 2.0))
     assert x.shape == (4, 32) and np.isfinite(m['loss'])
+
+
+def test_config_file_roundtrip_and_steps_update(tmp_path):
+    """BaseConfig.to_file / from_file, Steps.update (configs.py:169-178, 371-388)"""
+    import l2hmc.configs as cfgs
+    s = cfgs.Steps(nera=2, nepoch=10, test=5)
+    s2 = s.update(nepoch=20, log=7)
+    assert (s2.nera, s2.nepoch, s2.test, s2.log, s2.total) == (2, 20, 5, 7, 40) and s.nepoch == 10
+    f = tmp_path / 'steps.json'
+    s2.to_file(f)
+    s3 = cfgs.Steps(nera=1, nepoch=1, test=1)
+    s3.from_file(f)
+    assert s3 == s2
+
+
+def test_su3_utils_module_names():
+    """names a notebook may import from group/su3/pytorch/utils.py (reference :39-47, 144-154, 448-514):
+    structure constants against the commutators of the basis vec_to_su3 defines, the truncated Taylor expm
+    against matrix_exp, eye_like, SU3Gradient on a torch-written function."""
+    import torch
+    from l2hmc.group.su3.pytorch import utils as U
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        T = [U.vec_to_su3(torch.eye(8)[a]) for a in range(8)]          # generators T^a
+        v = torch.randn(8, generator=torch.Generator().manual_seed(0))
+        F = U.su3fabc(v)                                                   # [a, b] = f^abc v_c
+        for a in range(8):
+            for b in range(8):
+                comm = T[a] @ T[b] - T[b] @ T[a]                           # = f^abc T^c
+                fc = U.su3_to_vec(comm)
+                assert abs(float(F[a, b]) - float((fc * v).sum())) < 1e-12, (a, b)
+        assert float((F + F.T).abs().max()) == 0.0
+        m = 0.2 * U.vec_to_su3(torch.randn(3, 8, generator=torch.Generator().manual_seed(1)))
+        assert float((U.expm(m, order=16) - torch.matrix_exp(m)).abs().max()) < 1e-13
+        assert torch.equal(U.eye_like(torch.zeros(3, 3)).cpu(), torch.eye(3))
+        x = torch.randn(4, 5)
+        y, g = U.SU3Gradient(lambda t: (t ** 2).sum(1), x, create_graph=False)
+        assert torch.allclose(g, 2 * x.detach()) and y.shape == (4,)
+        assert U.f012 == 1.0 and abs(U.f347 - 0.75 ** 0.5) < 1e-15
+    finally:
+        torch.set_default_dtype(old)

@@ -455,7 +455,7 @@ def test_micro_batched_single_direction_training_host_logic(inject_dir, monkeypa
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
 @pytest.mark.parametrize('route', ['trainer', 'autograd'])
-@pytest.mark.parametrize('name', ['u1_train_fp16', 'u1_train_fp16_bn', 'u1_train_bf16'])
+@pytest.mark.parametrize('name', ['u1_train_fp16', 'u1_train_fp16_bn', 'u1_train_bf16', 'u1_train_fp16_conv'])
 def test_half_precision_train_step_host_logic(name, route, golden, monkeypatch):
     """autocast + GradScaler training (trainers/pytorch/trainer.py:211-219, 1276-1280, 1303-1313) against the
     real reference run that way: accept masks bit-equal, gradients within a multiple of the reference's OWN
@@ -465,3 +465,34 @@ def test_half_precision_train_step_host_logic(name, route, golden, monkeypatch):
     out = helpers.check_half_train_step(g, route)
     print(name, route, out)
     helpers.assert_half_train_step(g, name, route, out)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='host-logic test for the CPU container')
+def test_trainer_detailed_steps_and_train_dynamic_host_logic(monkeypatch):
+    """Trainer.train_step_detailed / eval_step_detailed / train_dynamic (trainers/pytorch/trainer.py:1369-1476,
+    1840-1927): records with dt / loss / averages; beta follows the loss by tenths of itself."""
+    import l2hmc.configs as cfgs
+    from l2hmc.trainers.pytorch.trainer import Trainer
+    emu_native.install(monkeypatch)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = cfgs.get_config(['dynamics.group=U1', 'dynamics.latvolume=[4,4]', 'dynamics.nchains=4',
+                           'dynamics.nleapfrog=2', 'dynamics.verbose=true', 'network.units=[4]',
+                           'network.dropout_prob=0.0', 'network.use_batch_norm=false', 'conv=none',
+                           'annealing_schedule.beta_init=1.0', 'annealing_schedule.beta_final=1.5',
+                           'annealing_schedule.dynamic=true', 'steps.nera=3', 'steps.nepoch=3', 'steps.log=1'])
+    tr = Trainer(cfg)
+    x, rec = tr.train_step_detailed(era=1, epoch=2)
+    assert rec['era'] == 1 and rec['epoch'] == 2 and rec['tstep'] == 1 and rec['dt'] > 0
+    assert np.isfinite(rec['loss']) and 'avgs' in rec and 'dQint' in rec
+    x, rec = tr.eval_step_detailed('eval', x=x, beta=1.0)
+    assert rec['dt'] > 0 and np.isfinite(rec['loss'])
+    x, rec = tr.eval_step_detailed('hmc', x=x, beta=1.0)
+    assert np.isfinite(rec['loss'])
+    with pytest.raises(ValueError):
+        tr.eval_step_detailed('train')
+    out = tr.train_dynamic(x=x)
+    assert 1 <= len(out['betas']) <= 3 and out['betas'][0] == 1.0
+    for b0, b1 in zip(out['betas'], out['betas'][1:]):
+        assert abs(abs(b1 - b0) - b0 / 10.0) < 1e-12
+    assert len(out['history']['loss']) == 3 * len(out['betas'])
