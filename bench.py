@@ -940,6 +940,22 @@ def main():
         dt = per_rank[-1]
     acc = m['acc']
     assert torch.isfinite(acc).all() and torch.isfinite(x).all(), 'non-finite trajectory'
+    blocking_ms = None
+    if train and dist is not None:
+        # A/B of the gradient exchange: the same K steps with ONE blocking all-reduce after the reverse sweep
+        # instead of the slab-by-slab exchange that overlaps it (Trainer.overlap_grad_exchange); the
+        # difference is what the overlap hides of the collective
+        tr.overlap_grad_exchange = False
+        step(x)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            x, _m2 = step(x)
+        barrier()
+        tb = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        blocking_ms = float(tb.item()) / args.steps * 1e3
+        tr.overlap_grad_exchange = True
     ar = allreduce_probe(tr, dist, world) if train else None
     probe = None
     nprobe = None
@@ -1090,6 +1106,8 @@ def main():
             out['grad_allreduce_probe_native'] = nprobe
         if train:
             out['train'] = {'params_trained': tr.arena.numel(), 'grad_allreduce': ar,
+                            'grad_exchange': tr.last_exchange,
+                            'blocking_exchange_ms_per_step': None if blocking_ms is None else round(blocking_ms, 3),
                             'micro_batch': args.micro_batch, 'loss': m.get('loss'),
                             'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
         if world == 1 and not train:

@@ -171,6 +171,104 @@ class ParamArena:
         ops.PARAM_GENERATION[0] += 1
 
 
+class GradReducer:
+    """The data-parallel gradient exchange of ONE optimiser step, overlapped with the reverse sweep.
+
+    The reference gets this from DistributedDataParallel: bucketed all-reduces that start while
+    `loss.backward()` is still running (trainers/pytorch/trainer.py:246-257, 1296-1304).  Here the
+    gradients live in the flat `ParamArena`; whenever the sweep has FINISHED a set of parameters --
+    a network whose last tape entry has been reversed, a weight matrix whose deferred-gradient GEMM
+    and native-order scatter are done -- `ready()` starts the all-reduce of their contiguous arena
+    range on the communication stream (RCCL over xGMI), and the sweep carries on.  `finish()` reduces
+    what is left in as few contiguous ranges as possible and makes the compute stream wait for all
+    of it: only the last slab's exchange is exposed.  Sums are element-wise, so the result is the one
+    blocking all-reduce's bit for bit."""
+
+    def __init__(self, arena: 'ParamArena', comm=None, force: bool = False):
+        import torch.distributed as dist
+        self.arena, self.comm = arena, comm
+        self.world = 1
+        if comm is not None:
+            self.world = comm.world_size
+        elif dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size()
+        self.active = self.world > 1 or force
+        self.done: dict = {dt: [] for dt in arena.groups}        # dtype -> [(lo, hi)] ranges already launched
+        self.handles: list = []
+        self.side = None
+        self.launched = 0                                        # collectives started before finish()
+        self._where = None
+
+    def _ranges(self, params) -> dict:
+        if self._where is None:
+            self._where = {id(p): (g['flat'].dtype, off, n) for p, g, off, n in self.arena._param_slices()}
+        out: dict = {}
+        for p in params:
+            w = self._where.get(id(p))
+            if w is not None:
+                out.setdefault(w[0], []).append((w[1], w[1] + w[2]))
+        return out
+
+    @staticmethod
+    def _merge(ranges: list, slack: int) -> list:
+        """sorted, with neighbours closer than the arena's alignment padding joined (the padding is zero)"""
+        merged: list = []
+        for lo, hi in sorted(ranges):
+            if merged and lo <= merged[-1][1] + slack:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        return [(a, b) for a, b in merged]
+
+    def _launch(self, view: Tensor) -> None:
+        import torch.distributed as dist
+        if self.comm is not None:
+            # C-ABI route: the collective runs on a side stream that waits for the producer kernels
+            if view.is_cuda:
+                if self.side is None:
+                    self.side = torch.cuda.Stream(device=view.device)
+                self.side.wait_stream(torch.cuda.current_stream(view.device))
+                with torch.cuda.stream(self.side):
+                    self.comm.all_reduce_(view)
+            else:
+                self.comm.all_reduce_(view)
+            return
+        if dist.is_available() and dist.is_initialized():
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def ready(self, params) -> None:
+        """the gradients of `params` are final for this step: start their exchange"""
+        if not self.active:
+            return
+        for dt, rs in self._ranges(params).items():
+            g = self.arena.groups[dt]
+            q = 16 // g['flat'].element_size()
+            for lo, hi in self._merge(rs, q):
+                if any(a <= lo and hi <= b for a, b in self.done[dt]):
+                    continue
+                self._launch(g['grad'][lo:hi])
+                self.done[dt].append((lo, hi))
+                self.launched += 1
+
+    def finish(self) -> float:
+        """exchange the rest, wait for everything; returns the 1 / world factor for the optimiser"""
+        if not self.active:
+            return 1.0
+        for dt, g in self.arena.groups.items():
+            n = g['grad'].numel()
+            pos = 0
+            for lo, hi in self._merge(self.done[dt], 0) + [(n, n)]:
+                if lo > pos:
+                    self._launch(g['grad'][pos:lo])
+                pos = max(pos, hi)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        return 1.0 / self.world
+
+
 class LossScaler:
     """torch.amp.GradScaler's bookkeeping (defaults included: init 2^16, growth x2 every 2000 clean steps,
     backoff x0.5) for the flat-arena trainer: the reference scales the loss of its mixed-precision steps,
@@ -541,18 +639,35 @@ def _loss_and_seeds_su3(dyn, loss_fn, xn_init, x_prop, v_prop, tape, sumlogdet, 
 
 
 # ------------------------------------------------------------------------------ reverse sweep
-def backward(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float) -> None:
+def _first_use(tape: Tape) -> dict:
+    """tape index -> networks whose FIRST recorded call sits there: once the reverse sweep has passed that
+    entry, those networks' gradients are final for this trajectory"""
+    first: dict = {}
+    for i, e in enumerate(tape.entries):
+        n = e.get('net')
+        if n is not None and id(n) not in first:
+            first[id(n)] = (i, n)
+    out: dict = {}
+    for i, n in first.values():
+        out.setdefault(i, []).append(n)
+    return out
+
+
+def backward(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float, on_final=None) -> None:
     """Replay the tape in reverse, accumulating every parameter's .grad (networks, xeps, veps).
     gx / gv: cotangents of the proposed state; gl [nb]: cotangent of sum logdet (every
-    sub-update's logdet enters the sum with weight 1)."""
+    sub-update's logdet enters the sum with weight 1).  on_final(params): called as soon as the sweep
+    has finished a set of parameters (GradReducer.ready: the gradient exchange overlaps the rest)."""
     if dyn.group == 'SU3':
-        return _backward_su3(dyn, tape, gx, gv, gl, beta)
+        return _backward_su3(dyn, tape, gx, gv, gl, beta, on_final)
     lat = dyn.latvolume
     nb = gx.shape[0]
     gx = gx.reshape(nb, -1).contiguous()
     gv = gv.reshape(nb, -1).contiguous()
     eps_acc: dict = {}
-    for e in reversed(tape.entries):
+    finals = _first_use(tape) if on_final is not None else {}
+    for idx in range(len(tape.entries) - 1, -1, -1):
+        e = tape.entries[idx]
         kind = e['kind']
         if kind == 'flip':
             gv = -gv
@@ -577,10 +692,12 @@ def backward(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float) -
             ops.u1_masked_cos_sin_bwd_(dx, x, e['mask'], e['complement'], dxm.contiguous())
             gx = dx
             eps_acc.setdefault(('x', e['step']), []).append(deps)
+        for net in finals.get(idx, ()):
+            on_final(list(net.parameters()))
     _accumulate_eps_grads(dyn, eps_acc)
 
 
-def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float) -> None:
+def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: float, on_final=None) -> None:
     lat = dyn.latvolume
     nb, _, _, V = gx.shape
     gx, gv = gx.contiguous(), gv.contiguous()
@@ -666,6 +783,9 @@ def _backward_su3(dyn, tape: Tape, gx: Tensor, gv: Tensor, gl: Tensor, beta: flo
     assert not pend and not paired
     for net in {id(e['net']): e['net'] for e in tape.entries if e.get('kind') == 'v'}.values():
         net.flush_deferred()
+        if on_final is not None and not net.native_active():
+            # (native-order shadows: the matrices become final one by one in native_train_end)
+            on_final(list(net.parameters()))
     _accumulate_eps_grads(dyn, eps_acc)
 
 
@@ -697,7 +817,7 @@ def _cat_metrics(parts: list, sizes: list) -> dict:
 
 
 def train_forward_backward_chunked(dyn, loss_fn, x: Tensor, beta, micro_batch: int,
-                                   loss_weight: float = 1.0):
+                                   loss_weight: float = 1.0, reducer: Optional[GradReducer] = None):
     """train_forward_backward over micro-batches of chains.  The loss is a mean over chains and
     the chains are independent, so the gradient is the size-weighted sum of the micro-batch
     gradients; the trajectory tape then holds `micro_batch` chains at a time (what makes the
@@ -734,10 +854,13 @@ def train_forward_backward_chunked(dyn, loss_fn, x: Tensor, beta, micro_batch: i
             mets.append(m)
             sizes.append(hi - lo)
             loss = loss + l * ((hi - lo) / nb)
+        done = True
     finally:
         dyn._inject = inj
+        # (gradients accumulate over the micro-batches: only the closing scatter can hand slabs to the exchange)
+        cb = reducer.ready if (reducer is not None and reducer.active and locals().get('done')) else None
         for n in nets:
-            n.native_train_end()
+            n.native_train_end(on_ready=cb)
     return torch.cat(outs, 0), _cat_metrics(mets, sizes), loss
 
 
@@ -782,10 +905,12 @@ def _native_begin(dyn, nb: Optional[int] = None) -> list:
     return nets
 
 
-def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1.0):
+def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1.0,
+                           reducer: Optional[GradReducer] = None):
     """forward_step + calc_loss + loss.backward() of the reference's train_step for one input
     batch: returns (x_out [nb, xdim], metrics, loss).  Gradients are ACCUMULATED into the
-    parameters' .grad (zero them first)."""
+    parameters' .grad (zero them first).  reducer: this call completes the step's gradients -- their
+    data-parallel exchange starts slab by slab while the sweep is still running (GradReducer)."""
     from l2hmc.dynamics.pytorch.dynamics import _beta
     b = _beta(beta)
     merged = bool(dyn.config.merge_directions)
@@ -798,6 +923,7 @@ def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1
     xn = dyn._pack(x)
     vn = dyn._momentum_n(xn.shape[0])
     nets = _native_begin(dyn, xn.shape[0])
+    cb = None
     try:
         if merged:
             x_, v_, hist, tape = trajectory_fb_train(dyn, xn, vn, b)
@@ -806,9 +932,13 @@ def train_forward_backward(dyn, loss_fn, x: Tensor, beta, loss_weight: float = 1
         loss, gx, gv, gl = loss_and_seeds(dyn, loss_fn, xn, x_, v_, tape, hist['sumlogdet'], b)
         if loss_weight != 1.0:
             gx, gv, gl = gx * loss_weight, gv * loss_weight, gl * loss_weight
-        backward(dyn, tape, gx, gv, gl, b)
+        cb = reducer.ready if (reducer is not None and reducer.active) else None
+        backward(dyn, tape, gx, gv, gl, b, cb)
+    except BaseException:
+        cb = None
+        raise
     finally:
         for n in nets:
-            n.native_train_end()
+            n.native_train_end(on_ready=cb if nets else None)
     xout, metrics = dyn._finish(xn, vn, x_, v_, beta, hist, with_sumlogdet=True)
     return xout, metrics, loss

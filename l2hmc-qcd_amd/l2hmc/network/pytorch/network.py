@@ -739,11 +739,13 @@ class LeapfrogLayer(nn.Module):
             nat['defer']['seen'] = set()
         nat['active'] = True
 
-    def native_train_end(self, keep_active: bool = False, scatter: bool = True) -> None:
+    def native_train_end(self, keep_active: bool = False, scatter: bool = True, on_ready=None) -> None:
         """Scatter-add the native-order gradients into the parameters' .grad, leave native mode.
         keep_active: flush only (the gradient buffers are zeroed, the weight shadows stay: another
         recorded trajectory of the same optimiser step still needs them -- dynamics/pytorch/autograd.py);
-        scatter=False: leave without touching .grad (a recorded trajectory that was never reversed)."""
+        scatter=False: leave without touching .grad (a recorded trajectory that was never reversed);
+        on_ready([param]): called per matrix right after ITS deferred-gradient GEMM and scatter -- the
+        data-parallel exchange of that slab then overlaps the next matrix's GEMM (training.GradReducer)."""
         nat = getattr(self, '_nat', None)
         if nat is None or not nat.get('active'):
             return
@@ -754,10 +756,21 @@ class LeapfrogLayer(nn.Module):
                 d['seen'] = set()
             nat['active'] = False
             return
-        self.flush_deferred()                  # (a no-op when the reverse sweep has flushed already)
+        # the deferred weight-gradient GEMMs run matrix by matrix, each just in front of its scatter (all at
+        # once here when nobody listens; a no-op when the reverse sweep has flushed already)
+        jobs = self._deferred_jobs()
+        if on_ready is None:
+            for run in jobs.values():
+                run()
+            jobs = {}
         with torch.no_grad():
             inv = nat.setdefault('inv', {})
-            for k, (par, dim, perm) in nat['src'].items():
+            # big matrices first: their exchange takes longest, the small vectors ride in its shadow
+            order = sorted(nat['src'].items(), key=lambda kv: -kv[1][0].numel()) if on_ready is not None \
+                else list(nat['src'].items())
+            for k, (par, dim, perm) in order:
+                if k in jobs:
+                    jobs.pop(k)()
                 g = nat['g'][k]
                 if par.grad is None:
                     if keep_active:
@@ -776,6 +789,12 @@ class LeapfrogLayer(nn.Module):
                     par.grad.add_(torch.index_select(g, dim, ip))
                 if keep_active:
                     g.zero_()
+                if on_ready is not None:
+                    on_ready([par])
+            if on_ready is not None:
+                # the layers that never had shadows (hidden layers, the input layer's biases, BatchNorm)
+                shadowed = {id(par) for par, _d, _p in nat['src'].values()}
+                on_ready([q for q in self.parameters() if id(q) not in shadowed])
         nat['active'] = bool(keep_active)
 
     def native_active(self) -> bool:
@@ -999,25 +1018,34 @@ class LeapfrogLayer(nn.Module):
         d['i'] += 1
         return i, d['xv'][i], d['fv'][i]
 
-    def flush_deferred(self) -> None:
-        """W.grad of the five big matrices from the arenas filled by this step's backward calls."""
+    def _deferred_jobs(self) -> dict:
+        """matrix key -> thunk forming that matrix's W.grad from the arenas filled by this step's backward
+        calls (one GEMM with K = calls x chains each); the arenas are marked consumed."""
         nat = getattr(self, '_nat', None)
         d = None if nat is None else nat.get('defer')
         if d is None or d.get('off') or not d['seen']:
-            return
+            return {}
         n = d['i']
         if d['seen'] != set(range(n)):
             raise RuntimeError(f'flush_deferred: backward ran for calls {sorted(d["seen"])} of {n}')
         nb = d['key'][0]
         ng_ = nat['g']
         rows = lambda a: a[:n].reshape(n * nb, -1)
-        for tag in 'stq':
-            ops.gemm_ex(rows(d['dpre'][tag]), rows(d['z']), a_trans=True, w_trans=True, out=ng_['w' + tag],
-                        accumulate=True)
-        ops.gemm_ex(rows(d['dpre_in']), rows(d['xv']), a_trans=True, w_trans=True, out=ng_['wx'], accumulate=True)
-        ops.gemm_ex(rows(d['dpre_in']), rows(d['fv']), a_trans=True, w_trans=True, out=ng_['wv'], accumulate=True)
+
+        def job(dpre, act, key):
+            return lambda: ops.gemm_ex(rows(dpre), rows(act), a_trans=True, w_trans=True, out=ng_[key],
+                                       accumulate=True)
+        jobs = {'w' + tag: job(d['dpre'][tag], d['z'], 'w' + tag) for tag in 'stq'}
+        jobs['wx'] = job(d['dpre_in'], d['xv'], 'wx')
+        jobs['wv'] = job(d['dpre_in'], d['fv'], 'wv')
         d['i'] = 0
         d['seen'] = set()
+        return jobs
+
+    def flush_deferred(self) -> None:
+        """W.grad of the five big matrices from the arenas filled by this step's backward calls."""
+        for run in self._deferred_jobs().values():
+            run()
 
     # ---- the heads of the training tape on the int8-sliced kernel (csrc/heads_sliced.hip, TAPE instances)
     def sliced_train_image(self):

@@ -66,6 +66,11 @@ class Trainer:
         # chains per training micro-batch (None: all at once).  Not a reference option: bounds the
         # trajectory tape so that large lattices train within HBM (exact without BatchNorm).
         self.micro_batch: Optional[int] = None
+        # gradient exchange: slab by slab while the reverse sweep is still running (False: ONE blocking
+        # all-reduce of the flat arena after it); `comm`: a utils.dist.NativeComm for the C-ABI route
+        self.overlap_grad_exchange = True
+        self.comm = None
+        self.last_exchange: Optional[dict] = None
 
     # -- construction (trainer.py:490-562, trainers/trainer.py:292-309)
     def build_lattice(self):
@@ -210,21 +215,32 @@ class Trainer:
         self.arena.zero_grad()
         mb = self.micro_batch
 
-        def fwd_bwd(xin, w=1.0):
+        # data-parallel exchange overlapped with the reverse sweep (what DDP's buckets do for the reference,
+        # trainer.py:246-257): the sweep that COMPLETES the step's gradients hands finished slabs to RCCL
+        reducer = T.GradReducer(self.arena, comm=self.comm) if self.overlap_grad_exchange else None
+
+        def fwd_bwd(xin, w=1.0, last=True):
+            red = reducer if last else None
             if mb is not None and 0 < mb < xin.shape[0]:
                 return T.train_forward_backward_chunked(self.dynamics, self.loss_fn, xin, beta, mb,
-                                                        loss_weight=w)
-            return T.train_forward_backward(self.dynamics, self.loss_fn, xin, beta, loss_weight=w)
+                                                        loss_weight=w, reducer=red)
+            return T.train_forward_backward(self.dynamics, self.loss_fn, xin, beta, loss_weight=w,
+                                            reducer=red)
         # mixed precision: `grad_scaler.scale(loss).backward()` = the seeds of the sweep times the scale
         ls = 1.0 if self.grad_scaler is None else self.grad_scaler.get_scale()
-        xout, metrics, loss = fwd_bwd(xinit, ls)
+        aw = self.config.loss.aux_weight
+        xout, metrics, loss = fwd_bwd(xinit, ls, last=not aw > 0)
         loss_tot = loss
-        if (aw := self.config.loss.aux_weight) > 0:
+        if aw > 0:
             # the reference's `aux_loss += aw * aux_loss` (trainer.py:1343-1353)
             yinit = self.g.random(list(xinit.shape)).to(self.device)
             _, _m, aux = fwd_bwd(yinit, (1.0 + aw) * ls)
             loss_tot = loss + (1.0 + aw) * aux
-        scale = self.arena.all_reduce() / ls               # `unscale_`: folded into the fused Adam
+        if reducer is not None:
+            scale = reducer.finish() / ls
+            self.last_exchange = {'collectives_overlapped': reducer.launched, 'ranks': reducer.world}
+        else:
+            scale = self.arena.all_reduce(comm=self.comm) / ls     # `unscale_`: folded into the fused Adam
         clip = float(self.config.learning_rate.clip_norm)
         found_inf = False
         if clip > 0.0 or self.grad_scaler is not None:
