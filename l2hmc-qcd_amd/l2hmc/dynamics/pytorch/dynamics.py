@@ -250,6 +250,9 @@ class Dynamics(nn.Module):
         # train mode + grad mode: forward() records the trajectory and returns tensors with a grad_fn
         # (the reference's forward_step / loss.backward() contract); False keeps the graph-free sampler
         self.autograd_forward = True
+        # eval mode, small U(1) lattices: whole transitions replayed from a HIP graph (_auto_graphed)
+        self.auto_graph = True
+        self._graphs: dict = {}
 
     # ------------------------------------------------------------------ construction
     def set_net_precision(self, precision) -> None:
@@ -1312,9 +1315,59 @@ class Dynamics(nn.Module):
                      'mc_states': MonteCarloStates(init=init, proposed=prop, out=out)})
         return xout, hist
 
+    # ---- launch-bound lattices: transitions replayed from a HIP graph, transparently
+    AUTO_GRAPH_MAX_ELEMS = 1 << 21      # chains x links up to which a U(1) trajectory is launch-bound
+
+    def _auto_graphed(self, mode: str, x: Tensor, beta, eps=None, nleapfrog=None):
+        """The small U(1) lattices (BASELINE cfg-1 / cfg-2, the reference's published 16 x 16 runs) spend
+        more host time launching their ~30 us kernels than the GPU spends running them (cfg-2 eager: 3.7 ms
+        per trajectory for 1.9 ms of kernels).  In eval mode such a transition is captured once per
+        (batch, beta, step size) as a HIP graph (`GraphedTransition`: re-captured when the model changes)
+        and replayed; the outputs are COPIED out of the graph's static buffers, so the contract of
+        `forward` / `apply_transition_hmc` -- fresh tensors the caller owns -- is unchanged.  Not taken
+        with injected / host-generator draws (parity runs), in train mode, or for larger lattices, whose
+        kernels hide the launches.  `dyn.auto_graph = False` restores eager launches."""
+        if not (self.auto_graph and self.group == 'U1' and not self.training and self._inject is None
+                and (self._networks_built or mode == 'hmc') and not getattr(self, '_capturing', False)
+                and isinstance(x, Tensor) and x.is_cuda and self.rng_device == DEVICE
+                and x.numel() <= self.AUTO_GRAPH_MAX_ELEMS
+                and not torch.cuda.is_current_stream_capturing()):
+            return None
+        b = _beta(beta)
+        key = (mode, tuple(x.shape), b, None if eps is None else float(eps), nleapfrog)
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 4:                           # (an annealed beta: keep the recent ones)
+                self._graphs.pop(next(iter(self._graphs)))
+            self._capturing = True
+            try:
+                g = GraphedTransition(self, x.detach(), b, mode, eps, nleapfrog, warmup=2)
+            finally:
+                self._capturing = False
+            self._graphs[key] = g
+        self._capturing = True
+        try:
+            xo, m = g(x.detach())
+        finally:
+            self._capturing = False
+        own = lambda t: t.clone() if isinstance(t, Tensor) else t
+        out = {}
+        for k, v in m.items():
+            if isinstance(v, MonteCarloStates):
+                out[k] = MonteCarloStates(*(State(x=own(s.x), v=own(s.v), beta=beta)
+                                            for s in (v.init, v.proposed, v.out)))
+            else:
+                out[k] = own(v)
+        if 'beta' in out:
+            out['beta'] = beta
+        return own(xo), out
+
     def apply_transition_hmc(self, inputs: tuple[Tensor, Tensor], eps: Optional[float] = None,
                              nleapfrog: Optional[int] = None) -> tuple[Tensor, dict]:
         x, beta = inputs
+        hit = self._auto_graphed('hmc', x, beta, eps, nleapfrog)
+        if hit is not None:
+            return hit
         xn = self._pack_input(x)
         vn = self._momentum_n(xn.shape[0])
         x_, v_, hist = self._kernel_hmc_n(xn, vn, beta, eps, nleapfrog)
@@ -1322,6 +1375,9 @@ class Dynamics(nn.Module):
 
     def apply_transition_fb(self, inputs: tuple[Tensor, Tensor]) -> tuple[Tensor, dict]:
         x, beta = inputs
+        hit = self._auto_graphed('fb', x, beta)
+        if hit is not None:
+            return hit
         xn = self._pack_input(x)
         vn = self._momentum_n(xn.shape[0])
         x_, v_, hist = self._kernel_fb_n(xn, vn, beta)
