@@ -100,6 +100,11 @@ int l2q_transpose(const void* in, void* out, long batch, int rows, int cols, int
 /* x[nb][4][V][3][3] c128 <-> xn[nb][4][9][V] c128 */
 int l2q_su3_pack(const void* x_ref, void* x_nat, int nb, long V, void* stream);
 int l2q_su3_unpack(const void* x_nat, void* x_ref, int nb, long V, void* stream);
+/* x_ref[c] = unpack(mask[c] != 0 ? a_nat[c] : b_nat[c]): the accept / reject select of a transition
+ * (x_out = ma x_prop + mr x_init, dynamics.py:677-682) fused into the native -> reference transpose of its
+ * result; mask [nb] float32 (the acc_mask of l2q_accept) */
+int l2q_su3_unpack_select(const void* a_nat, const void* b_nat, const float* mask, void* x_ref, int nb,
+                          long V, void* stream);
 
 /* ---------------------------------------------------------------- SU(3) lattice kernels */
 /* Per-chain plaquette sums: out[c][0] = sum_{sites, 6 planes} Re tr P, out[c][1] = Im.

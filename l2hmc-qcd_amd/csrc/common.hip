@@ -73,6 +73,36 @@ __global__ __launch_bounds__(kBlock) void transpose_kernel(const T* __restrict__
   }
 }
 
+// The accept / reject select of a transition fused into its native -> reference transpose: batch item b
+// (a link direction of chain b / per_chain) is read from `a` where mask[chain] != 0 and from `b` otherwise.
+// One pass over the field instead of select_rows (read 2, write 1) + transpose (read 1, write 1).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void transpose_select_kernel(const T* __restrict__ a,
+                                                                  const T* __restrict__ bsrc,
+                                                                  const float* __restrict__ mask,
+                                                                  int per_chain, T* __restrict__ out,
+                                                                  int rows, int cols, long tiles_r,
+                                                                  long tiles_c) {
+  __shared__ T tile[32][33];
+  long b = blockIdx.x;
+  const long tc = b % tiles_c; b /= tiles_c;
+  const long tr = b % tiles_r; b /= tiles_r;
+  const T* src = (mask[b / per_chain] != 0.0f ? a : bsrc) + b * (long)rows * cols;
+  T* dst = out + b * (long)rows * cols;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long r = tr * 32 + ty + 8 * k, c = tc * 32 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long c = tc * 32 + ty + 8 * k, r = tr * 32 + tx;
+    if (r < rows && c < cols) dst[c * rows + r] = tile[tx][ty + 8 * k];
+  }
+}
+
 template <typename T>
 static int launch_transpose(const void* in, void* out, long batch, int rows, int cols,
                             hipStream_t st) {
@@ -226,6 +256,20 @@ int l2q_su3_pack(const void* x_ref, void* x_nat, int nb, long V, void* stream) {
 int l2q_su3_unpack(const void* x_nat, void* x_ref, int nb, long V, void* stream) {
   L2Q_REQUIRE(V > 0 && V <= 0x7fffffffL, L2Q_EINVAL, "bad volume");
   return l2q_transpose(x_nat, x_ref, (long)nb * 4, 9, (int)V, 16, stream);
+}
+
+int l2q_su3_unpack_select(const void* a_nat, const void* b_nat, const float* mask, void* x_ref, int nb,
+                          long V, void* stream) {
+  L2Q_REQUIRE(a_nat && b_nat && mask && x_ref, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && V > 0 && V <= 0x7fffffffL, L2Q_EINVAL, "bad size");
+  L2Q_REQUIRE(x_ref != a_nat && x_ref != b_nat, L2Q_EINVAL, "in-place transpose not supported");
+  const long tiles_r = 1, tiles_c = cdiv(V, 32);
+  const long nblocks = (long)nb * 4 * tiles_r * tiles_c;
+  if (nblocks > 0x7fffffffL) { set_error("l2q_su3_unpack_select: grid too large"); return L2Q_ESHAPE; }
+  hipLaunchKernelGGL(transpose_select_kernel<double2>, dim3((unsigned)nblocks), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)a_nat, (const double2*)b_nat, mask, 4,
+                     (double2*)x_ref, 9, (int)V, tiles_r, tiles_c);
+  return check_launch("l2q_su3_unpack_select");
 }
 
 static int v_update_launch(const void* vin, void* v, const void* force, const void* s, const void* t,

@@ -58,6 +58,9 @@ constexpr int OZ_CHUNK = OZ_NS * OZ_KB * OZ_FRAG;         // 16 vectors x 256 x 
 #ifndef L2Q_SL_PROF
 #define L2Q_SL_PROF 0      // 1: per-wavefront cycle counters (barrier wait, total) into SlicedArgs::dbg
 #endif
+#ifndef L2Q_SL_V2
+#define L2Q_SL_V2 1        // A/B: 0 = both tanh evaluations in the q head's period, degree-12 step-size exponentials
+#endif
 #ifndef L2Q_SL_SKIP
 #define L2Q_SL_SKIP 0      // timing experiments (bits): 1 no epilogue arithmetic, 2 one MFMA per fragment group,
                            // 4 no LDS-DMA after the first images, 8 no Horner chain, 16 no ring writes
@@ -428,6 +431,32 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
   double es_[4], eq_[4], es2_[4], eq2_[4], s_[4], q_[4], t_[4];
   const double eps = a.eps, heps = 0.5 * a.eps, h2 = 0.5 * a.eps2;
   const bool same2 = PAIR && a.eps2 == a.eps && a.fwd2 == (int)FWD;
+#if L2Q_SL_V2
+  // The three periods of a tile end at barriers shared with the matrix wavefronts, so the LONGEST period sets
+  // the pace: with both tanh evaluations in the period of the q head it was 2 x 112 + 24 + the 56 of the
+  // Horner chain = 304 fp64 instructions against 176 / 112 in the other two.  The s head of a tile arrives two
+  // periods before its q head: its tanh moves into the (lightest) period right after its arrival -- the last
+  // period of the PREVIOUS tile -- and rides in sn_ until the tile's own epilogue: 192 / 176 / 224.
+  double sn_[4];
+  auto tanh_s = [&](const Operands& q, const double (&fs)[4], double (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double zs = fma(fs[r], q.w0, q.b0);
+      out[r] = (L2Q_SL_SKIP & 1) ? zs : q.pcs * tanh_bf(zs);
+    }
+  };
+  auto stage_a = [&](const Operands& q, const double (&fs)[4], const double (&ft)[4], const double (&fq)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double zt = fma(ft[r], q.w1, q.b1);
+      const double zq = fma(fq[r], q.w2, q.b2);
+      s_[r] = sn_[r];
+      if (L2Q_SL_SKIP & 1) { q_[r] = zq; t_[r] = zt; continue; }
+      t_[r] = a.st * zt;
+      q_[r] = q.pcq * tanh_bf(zq);
+    }
+  };
+#else
   auto stage_a = [&](const Operands& q, const double (&fs)[4], const double (&ft)[4], const double (&fq)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -440,6 +469,7 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
       q_[r] = q.pcq * tanh_bf(zq);
     }
   };
+#endif
   // exp of the step-size-scaled arguments: when every lane's |x| < 0.34 (k = rint(x log2 e) = 0) the
   // range reduction of exp_bf is the identity -- the polynomial alone gives the same bits
   auto exp_poly = [](double r) {
@@ -457,10 +487,33 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
     p = fma(p, r, 1.0);
     return fma(p, r, 1.0);
   };
+#if L2Q_SL_V2
+  // step-size-scaled arguments are ~1e-2: below 2^-6 the degree-7 polynomial is exact to 9e-20
+  auto exp_poly7 = [](double r) {
+    double p = 1.0 / 5040.0;
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    return fma(p, r, 1.0);
+  };
+#endif
   auto exp4x2 = [&](const double (&xa)[4], const double (&xb)[4], double (&ya)[4], double (&yb)[4]) {
     bool small = true;
 #pragma unroll
     for (int r = 0; r < 4; ++r) small = small && fabs(xa[r]) < 0.34 && fabs(xb[r]) < 0.34;
+#if L2Q_SL_V2
+    bool tiny = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tiny = tiny && fabs(xa[r]) < 0x1p-6 && fabs(xb[r]) < 0x1p-6;
+    if (__all(tiny)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ya[r] = exp_poly7(xa[r]); yb[r] = exp_poly7(xb[r]); }
+      return;
+    }
+#endif
     if (__all(small)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ya[r] = exp_poly(xa[r]); yb[r] = exp_poly(xb[r]); }
@@ -575,6 +628,9 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
     L2Q_SL_CBAR(0);                                    // B(1): chunk 0 is in the ring
     issue(3, L2Q_SL_NPD);
     conv(0, fs);
+#if L2Q_SL_V2
+    tanh_s(cur, fs, sn_);
+#endif
     L2Q_SL_CBAR(0);                                    // B(2)
     issue(4, L2Q_SL_NPD);
     conv(1, ft);
@@ -598,6 +654,9 @@ __global__ __launch_bounds__(512, 1) void heads_sliced_kernel(HeadsArgs a, Slice
         L2Q_SL_T(prof_conv, conv(3 * u + 4, gt));
       }
       stage_c(t, cur, outv);
+#if L2Q_SL_V2
+      if (more) tanh_s(nxt, gs, sn_);
+#endif
       if (more) {
         cur = nxt;
 #pragma unroll

@@ -64,6 +64,16 @@ def su3_unpack(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
     return out
 
 
+def su3_unpack_select(an: torch.Tensor, bn: torch.Tensor, mask: torch.Tensor,
+                      lat: Sequence[int]) -> torch.Tensor:
+    """reference-layout x_out[c] = mask[c] ? an[c] : bn[c] from two native fields in one pass"""
+    nb, _, _, V = an.shape
+    out = torch.empty((nb, 4, *[int(i) for i in lat], 3, 3), dtype=C128, device=an.device)
+    N.call('l2q_su3_unpack_select', an.contiguous(), bn.contiguous(), mask.to(torch.float32).contiguous(),
+           out, nb, V)
+    return out
+
+
 def pack_entries(a: torch.Tensor, V: int, ncomp: int = 9) -> torch.Tensor:
     """per-entry quantity [nb, 4*V*ncomp] in reference order -> native order [nb, 4*ncomp*V]."""
     nb = a.shape[0]

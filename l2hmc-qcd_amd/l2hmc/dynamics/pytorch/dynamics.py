@@ -1219,11 +1219,18 @@ class Dynamics(nn.Module):
         acc = hist['acc']
         u = self._uniform(acc)
         ma = (acc > u).to(torch.float32)
-        xo_n = ops.select_rows(x_.reshape(nb, -1), xn.reshape(nb, -1), ma).reshape(xn.shape)
+        fuse = self.group == 'SU3' and not self.cache_native_output
+        if fuse:
+            # select + native -> reference transpose in ONE pass (the native x_out is only needed by the
+            # opt-in native-output cache)
+            xo_n = None
+            xout = ops.su3_unpack_select(x_, xn, ma, self.latvolume).reshape(nb, -1)
+        else:
+            xo_n = ops.select_rows(x_.reshape(nb, -1), xn.reshape(nb, -1), ma).reshape(xn.shape)
+            xout = self._unpack(xo_n).reshape(nb, -1)
         # reference-layout copies of the init / proposed / out states are made on first access
         init = self._state_from_n(xn, vn, beta, lazy=True)
         prop = self._state_from_n(x_, v_, beta, lazy=True)
-        xout = self._unpack(xo_n).reshape(nb, -1)
         if self.group == 'SU3':
             # the selected momentum is formed on first access as well (nothing in a sampler loop
             # reads it); v_ / vn are this trajectory's own tensors and are not written again
@@ -1231,7 +1238,7 @@ class Dynamics(nn.Module):
                 v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)).reshape(nb, -1),
                 beta=beta, xshape=xout.shape)
             # (kept only while it is small next to the HBM: the 16^4 shard would pin 9.7 GB)
-            keep = (self.cache_native_output
+            keep = (self.cache_native_output and xo_n is not None
                     and xo_n.numel() * xo_n.element_size() <= (1 << 30))
             self._xcache = (xout, xout._version, xo_n) if keep else None
         else:

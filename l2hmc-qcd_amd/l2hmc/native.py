@@ -34,6 +34,7 @@ SIGNATURES = {
     'l2q_transpose': (I, [P, P, L, I, I, I, P]),
     'l2q_su3_pack': (I, [P, P, I, L, P]),
     'l2q_su3_unpack': (I, [P, P, I, L, P]),
+    'l2q_su3_unpack_select': (I, [P, P, P, P, I, L, P]),
     'l2q_su3_plaq_reduce': (I, [P, I, I, I, I, I, P, P, Z, P]),
     'l2q_su3_plaq_planes': (I, [P, I, I, I, I, I, P, P, Z, P]),
     'l2q_diff_norm2_reduce': (I, [P, P, I, L, P, P, Z, P]),

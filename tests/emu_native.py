@@ -523,6 +523,12 @@ def l2q_su3_unpack(xn, out, nb, V):
     out.copy_(_mats(xn.reshape(nb, 4, 9, V)).reshape(out.shape))
 
 
+def l2q_su3_unpack_select(an, bn, mask, out, nb, V):
+    pick = (mask.reshape(nb, 1, 1, 1) != 0)
+    xn = torch.where(pick, an.reshape(nb, 4, 9, V), bn.reshape(nb, 4, 9, V))
+    out.copy_(_mats(xn).reshape(out.shape))
+
+
 def l2q_su3_plaq_reduce(xn, nb, T, X, Y, Z, out, ws, wsn):
     p = _su3_planes(_mats(xn.reshape(nb, 4, 9, -1)).reshape(nb, 4, T, X, Y, Z, 3, 3)).sum(1)
     out[:, 0] = p.real

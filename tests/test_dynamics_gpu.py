@@ -1170,3 +1170,55 @@ def test_from_seed_trajectory(golden, name):
         else:
             d = np.abs(np.angle(np.exp(1j * (host(xo) - g['x_out'].reshape(nb, -1)))))
             assert d.max() < tx, (kv, d.max())
+
+
+def test_auto_graphed_small_u1_transitions(golden):
+    """Dynamics.auto_graph: eval-mode transitions of a launch-bound U(1) lattice replay a HIP graph behind the
+    ordinary `forward` / `apply_transition_hmc` calls.  The caller owns the outputs (a second call does not
+    touch them), the same device seed gives the same result as the captured graph itself, a changed model is
+    re-captured, and injected draws / train mode / `auto_graph = False` stay on eager launches."""
+    torch.set_default_dtype(torch.float32)
+    from l2hmc import _ops as ops
+    g = golden('u1_c1')
+    dyn, lat = build_u1_dynamics(g, verbose=False)
+    dyn.eval()
+    x, beta = dev(g['x']), float(g['beta'])
+    assert dyn._inject is None and not dyn._graphs
+    xo1, m1 = dyn((x, beta))
+    assert len(dyn._graphs) == 1
+    gt = next(iter(dyn._graphs.values()))
+    keep = {k: v.clone() for k, v in (('x', xo1), ('acc', m1['acc']), ('px', m1['mc_states'].proposed.x))}
+    xo2, m2 = dyn((x, beta))
+    assert err(host(xo1), host(keep['x'])) == 0.0 and err(host(m1['acc']), host(keep['acc'])) == 0.0
+    assert err(host(m1['mc_states'].proposed.x), host(keep['px'])) == 0.0
+    assert err(host(m2['mc_states'].proposed.x), host(keep['px'])) > 0.0          # fresh momenta
+    assert xo1.data_ptr() != xo2.data_ptr() != gt.out_x.data_ptr()
+    # same device seed -> the captured graph's own result, copied out
+    torch.cuda.manual_seed(11)
+    xo_a, m_a = dyn((x, beta))
+    torch.cuda.manual_seed(11)
+    xo_g, m_g = gt(x)
+    assert err(host(xo_a), host(xo_g)) == 0.0 and err(host(m_a['acc']), host(m_g['acc'])) == 0.0
+    assert gt.captures == 1
+    # the model changes: re-captured, still one graph
+    with torch.no_grad():
+        for p in dyn.vnet.parameters():
+            p.mul_(0.5)
+    ops.PARAM_GENERATION[0] += 1
+    dyn((x, beta))
+    assert gt.captures == 2 and len(dyn._graphs) == 1
+    # HMC flavour gets its own graph
+    xh, mh = dyn.apply_transition_hmc((x, beta), eps=0.1, nleapfrog=4)
+    assert len(dyn._graphs) == 2 and bool(torch.isfinite(mh['acc']).all())
+    # eager routes: injected draws (parity), the switch, train mode
+    n = len(dyn._graphs)
+    dyn._inject = {'normals': dev(g['normals']), 'u': dev(g['u'])}
+    xo_e, m_e = dyn((x, beta))
+    dyn._inject = None
+    dyn.auto_graph = False
+    dyn((x, beta))
+    dyn.auto_graph = True
+    dyn.train()
+    assert dyn._auto_graphed('fb', x, beta) is None
+    dyn.eval()
+    assert len(dyn._graphs) == n and gt.captures == 2

@@ -1052,3 +1052,20 @@ def test_heads_sliced_tape(ops, cplx, shape):
         # and the update from them is the v_update kernel's
         v2, l2 = ops.v_update(v, f, s, t, q, 0.07, fwd)
         assert float((v2 - vt).abs().max()) < 2e-14 and err(host(l2), host(ld)) < 1e-12
+
+
+@pytest.mark.parametrize('lat', [(2, 3, 2, 4), (4, 4, 4, 4), (3, 5, 2, 7)])
+def test_su3_unpack_select_equals_select_then_unpack(lat):
+    """l2q_su3_unpack_select: the accept / reject select fused into the native -> reference transpose is
+    bit-identical to l2q_select_rows followed by l2q_su3_unpack (all-accept, all-reject and mixed masks)."""
+    from l2hmc import _ops as ops
+    V = int(np.prod(lat))
+    nb = 5
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(nb, 4, 9, V, dtype=torch.complex128, generator=g).cuda()
+    b = torch.randn(nb, 4, 9, V, dtype=torch.complex128, generator=g).cuda()
+    for mask in ([1, 0, 1, 1, 0], [0] * 5, [1] * 5):
+        m = torch.tensor(mask, dtype=torch.float32, device='cuda')
+        ref = ops.su3_unpack(ops.select_rows(a.reshape(nb, -1), b.reshape(nb, -1), m).reshape(a.shape), lat)
+        got = ops.su3_unpack_select(a, b, m, lat)
+        assert got.shape == ref.shape and torch.equal(got, ref)
