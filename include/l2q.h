@@ -87,6 +87,12 @@ int l2q_comm_unique_id(void* id_out);
 int l2q_comm_init(const void* id, int nranks, int rank, void** comm_out);
 int l2q_allreduce_grads(void* comm, void* grad, long n, int elem_bytes, void* stream);
 int l2q_comm_destroy(void* comm);
+/* teardown without a handshake with the peers (ncclCommAbort; falls back to destroy): for garbage collection
+ * and interpreter shutdown, when the other ranks may be gone */
+int l2q_comm_abort(void* comm);
+/* version code of the RCCL library that was resolved (ncclGetVersion: major * 10000 + minor * 100 + patch), or a
+ * negative error.  The wrapper declares the 2.x ABI by hand and refuses a library that reports another major. */
+int l2q_comm_version(void);
 
 /* bytes of scratch the reductions need for `nb` chains of `n_per_chain` work items */
 size_t l2q_reduce_ws_bytes(int nb, long n_per_chain);

@@ -33,6 +33,9 @@ struct Rccl {
                             hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional: teardown without a handshake
+  int version = 0;
   bool ok = false;
   char why[256] = "librccl not loaded";
 };
@@ -61,8 +64,25 @@ Rccl& rccl() {
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.h, "ncclCommAbort");
     r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy && r.GetErrorString;
-    if (!r.ok) snprintf(r.why, sizeof r.why, "librccl: missing symbols");
+    if (!r.ok) { snprintf(r.why, sizeof r.why, "librccl: missing symbols"); return; }
+    // The declarations above are spelled out by hand (ncclUniqueId = 128 bytes, ncclFloat32 = 7,
+    // ncclFloat64 = 8, ncclSum = 0: the ABI of NCCL / RCCL 2.x).  Whatever library was loaded must say it
+    // speaks that ABI: ncclGetVersion's code is major * 10000 + minor * 100 + patch (major * 1000 + ... before
+    // 2.9); anything but major 2 is refused instead of being called with a guessed layout.
+    if (!r.GetVersion || r.GetVersion(&r.version) != ncclSuccess) {
+      r.ok = false;
+      snprintf(r.why, sizeof r.why, "librccl: ncclGetVersion missing or failing (cannot verify the ABI)");
+      return;
+    }
+    const int major = r.version >= 10000 ? r.version / 10000 : r.version / 1000;
+    if (major != 2) {
+      r.ok = false;
+      snprintf(r.why, sizeof r.why, "librccl reports version code %d (major %d); this wrapper declares the "
+               "2.x ABI by hand and refuses anything else", r.version, major);
+    }
   });
   if (!r.ok) set_error("%s", r.why);
   return r;
@@ -147,6 +167,22 @@ int l2q_comm_destroy(void* comm) {
   ncclResult_t e = r.CommDestroy((ncclComm_t)comm);
   if (e != ncclSuccess) return rccl_fail("ncclCommDestroy", e);
   return L2Q_OK;
+}
+
+int l2q_comm_abort(void* comm) {
+  L2Q_REQUIRE(comm, L2Q_EINVAL, "null pointer");
+  Rccl& r = rccl();
+  if (!r.ok) return L2Q_EHIP;
+  // ncclCommAbort frees the communicator without waiting for the peers (garbage collection / interpreter
+  // shutdown, when they may be gone already); a library without it falls back to the orderly destroy
+  ncclResult_t e = r.CommAbort ? r.CommAbort((ncclComm_t)comm) : r.CommDestroy((ncclComm_t)comm);
+  if (e != ncclSuccess) return rccl_fail("ncclCommAbort", e);
+  return L2Q_OK;
+}
+
+int l2q_comm_version(void) {
+  Rccl& r = rccl();
+  return r.ok ? r.version : L2Q_EHIP;
 }
 
 }  // extern "C"

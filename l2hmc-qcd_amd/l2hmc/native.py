@@ -30,6 +30,8 @@ SIGNATURES = {
     'l2q_comm_init': (I, [P, I, I, C.POINTER(P)]),
     'l2q_allreduce_grads': (I, [P, P, L, I, P]),
     'l2q_comm_destroy': (I, [P]),
+    'l2q_comm_abort': (I, [P]),
+    'l2q_comm_version': (I, []),
     'l2q_reduce_ws_bytes': (Z, [I, L]),
     'l2q_transpose': (I, [P, P, L, I, I, I, P]),
     'l2q_su3_pack': (I, [P, P, I, L, P]),

@@ -216,11 +216,13 @@ class NativeComm:
         native.call('l2q_allreduce_grads', self._comm, flat, flat.numel(), flat.element_size())
         return flat
 
-    def close(self) -> None:
+    def close(self, abort: bool = False) -> None:
+        """orderly ncclCommDestroy; abort=True: ncclCommAbort (no handshake with the peers)"""
         comm, self._comm = getattr(self, '_comm', None), None
         if comm is not None and comm.value:
             from l2hmc import native
-            native.load().l2q_comm_destroy(comm)
+            lib = native.load()
+            (lib.l2q_comm_abort if abort else lib.l2q_comm_destroy)(comm)
 
     # a communicator is a device-side resource: release it with the object / the `with` block
     def __enter__(self) -> 'NativeComm':
@@ -230,8 +232,10 @@ class NativeComm:
         self.close()
 
     def __del__(self):
+        # garbage collection / interpreter shutdown: the peers may be gone and ncclCommDestroy could wait for
+        # them -- abort instead unless this is a lone rank (use the context manager for an orderly close)
         try:
-            self.close()
+            self.close(abort=getattr(self, 'world_size', 1) > 1)
         except Exception:      # noqa: BLE001  (interpreter shutdown: the library may be gone)
             pass
 

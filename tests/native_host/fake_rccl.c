@@ -87,6 +87,13 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
 }
 
 int ncclCommDestroy(ncclComm_t c) { free(c); return 0; }
+int ncclCommAbort(ncclComm_t c) { free(c); return 0; }
+/* version code major * 10000 + minor * 100 + patch; FAKE_RCCL_VERSION overrides it (an ABI the wrapper refuses) */
+int ncclGetVersion(int* v) {
+  const char* e = getenv("FAKE_RCCL_VERSION");
+  *v = e ? atoi(e) : 22105;
+  return 0;
+}
 
 const char* ncclGetErrorString(int e) {
   switch (e) {

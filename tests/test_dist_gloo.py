@@ -361,3 +361,30 @@ def test_rccl_resolution_failure_reports_its_reason_every_time(tmp_path):
         "assert e1 == e2 and 'libdoes_not_exist' in e1, (e1, e2)\n" % os.path.join(ROOT, 'l2hmc-qcd_amd'))
     env = dict(os.environ, L2Q_RCCL_LIB='libdoes_not_exist.so')
     subprocess.run([sys.executable, '-c', code], check=True, env=env)
+
+
+def test_rccl_abi_version_is_checked(tmp_path):
+    """the wrapper declares RCCL's types by hand, so the library it resolves must SAY it speaks that
+    ABI -- ncclGetVersion with major 2 is accepted (l2q_comm_version reports the code), anything else refused
+    with the reason; l2q_comm_abort tears a communicator down without a handshake."""
+    import subprocess
+    so = _fake_rccl(str(tmp_path))
+    code = (
+        "import sys, os, ctypes as C; sys.path.insert(0, %r)\n"
+        "from l2hmc import native\n"
+        "lib = native.load(); buf = C.create_string_buffer(128)\n"
+        "want = os.environ['WANT']\n"
+        "rc = lib.l2q_comm_unique_id(buf)\n"
+        "if want == 'ok':\n"
+        "    assert rc == 0 and lib.l2q_comm_version() == 22105\n"
+        "    c = C.c_void_p(); assert lib.l2q_comm_init(buf, 1, 0, C.byref(c)) == 0\n"
+        "    assert lib.l2q_comm_abort(c) == 0\n"
+        "else:\n"
+        "    assert rc != 0 and lib.l2q_comm_version() < 0\n"
+        "    assert 'refuses' in lib.l2q_last_error().decode(), lib.l2q_last_error().decode()\n"
+        % os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    for want, ver in (('ok', None), ('bad', '30100')):
+        env = dict(os.environ, L2Q_RCCL_LIB=so, WANT=want)
+        if ver:
+            env['FAKE_RCCL_VERSION'] = ver
+        subprocess.run([sys.executable, '-c', code], check=True, env=env)
