@@ -505,6 +505,48 @@ SLICED_K = 256
 SLICED_IMAGE_MAX_FREE_FRACTION = [0.25]     # heads_sliced_build: largest share of the free device memory
 
 
+# ---- memory gates: ONE helper for every "take the faster path only while it fits comfortably" decision
+# (ADVICE r04).  The int8-sliced and the fp64 kernels agree to rounding, not bit for bit, so a gate that
+# silently flips with the allocator's state would make a run irreproducible from its seed and could put the
+# ranks of a data-parallel job on different paths.  Every refusal is therefore RECORDED (MEM_GATE_LOG) and logged
+# once per gate; `MEM_GATE_POLICY[0]` makes the choice explicit: 'auto' (default: gate on free + idle memory),
+# 'always' (take the path, let the allocator fail loudly if it cannot), 'never' (the fp64 / un-deferred path).
+# `mem_gate_signature()` is what a distributed job compares across ranks (Trainer does, and warns).
+MEM_GATE_POLICY = ['auto']
+MEM_GATE_LOG: dict = {}
+
+
+def device_headroom(device) -> int:
+    """bytes a new allocation can count on: free device memory + the caching allocator's idle blocks"""
+    if not (isinstance(device, torch.device) and device.type == 'cuda'):
+        return 1 << 62
+    free, _total = torch.cuda.mem_get_info(device)
+    return int(free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+
+
+def mem_gate(what: str, need_bytes: int, fraction: float, device) -> bool:
+    """True: `need_bytes` may be taken for `what` (at most `fraction` of the headroom)."""
+    pol = MEM_GATE_POLICY[0]
+    if pol == 'always':
+        ok = True
+    elif pol == 'never':
+        ok = False
+    else:
+        ok = need_bytes <= fraction * device_headroom(device)
+    prev = MEM_GATE_LOG.get(what)
+    MEM_GATE_LOG[what] = ok
+    if not ok and prev is not False:
+        import logging
+        logging.getLogger('l2hmc').warning(
+            'memory gate: %s not taken (%.2f GiB wanted, policy %s) -- the slower equivalent path runs; '
+            'results agree with the faster one to rounding only', what, need_bytes / 2 ** 30, pol)
+    return ok
+
+
+def mem_gate_signature() -> tuple:
+    return tuple(sorted(MEM_GATE_LOG.items()))
+
+
 def heads_sliced_build(heads: dict):
     """int8 slice image of the three head weight matrices (include/l2q.h: l2q_heads_sliced_build).
     Returns the uint8 device buffer, or None when the weights do not qualify (dtype, K, dynamic range)."""
@@ -516,9 +558,7 @@ def heads_sliced_build(heads: dict):
     nbytes = int(N.load().l2q_heads_sliced_bytes(k, n))
     # the image lives NEXT TO the fp64 weights (+87 % of their size: 0.7 GB per vnet at 8^4, 11 GB at 16^4):
     # built only while it is a small part of what the device still has (free + the allocator's idle blocks)
-    free, _total = torch.cuda.mem_get_info(ws_.device)
-    idle = torch.cuda.memory_reserved(ws_.device) - torch.cuda.memory_allocated(ws_.device)
-    if nbytes > SLICED_IMAGE_MAX_FREE_FRACTION[0] * (free + idle):
+    if not mem_gate('sliced heads image', nbytes, SLICED_IMAGE_MAX_FREE_FRACTION[0], ws_.device):
         return None
     buf = torch.empty(nbytes, dtype=torch.uint8, device=ws_.device)
     usable = ctypes.c_int(0)
@@ -535,9 +575,8 @@ def heads_sliced_build_into(ws_: torch.Tensor, wt: torch.Tensor, wq: torch.Tenso
     n, k = ws_.shape
     nbytes = int(N.load().l2q_heads_sliced_bytes(k, n))
     if buf is None or buf.numel() != nbytes or buf.device != ws_.device:
-        free, _total = torch.cuda.mem_get_info(ws_.device)
-        idle = torch.cuda.memory_reserved(ws_.device) - torch.cuda.memory_allocated(ws_.device)
-        if nbytes > SLICED_IMAGE_MAX_FREE_FRACTION[0] * (free + idle):
+        if not mem_gate('sliced heads image (training tape)', nbytes, SLICED_IMAGE_MAX_FREE_FRACTION[0],
+                        ws_.device):
             return None, False                       # (same memory gate as heads_sliced_build)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=ws_.device)
     usable = ctypes.c_int(0)

@@ -254,6 +254,18 @@ class Dynamics(nn.Module):
         self.auto_graph = True
         self._graphs: dict = {}
 
+    def train(self, mode: bool = True):
+        """nn.Module.train; leaving train mode also releases the training-only device buffers of the
+        networks (native-order shadows, deferred-gradient arenas, tape slice images: ADVICE r04)."""
+        was = self.training
+        super().train(mode)
+        if was and not mode and self._networks_built:
+            from l2hmc.network.pytorch.network import LeapfrogLayer
+            for m in self.networks.modules():
+                if isinstance(m, LeapfrogLayer):
+                    m.native_train_release()
+        return self
+
     # ------------------------------------------------------------------ construction
     def set_net_precision(self, precision) -> None:
         """'fp16' / 'bf16' (or the torch dtype): every LeapfrogLayer's Linear layers run in

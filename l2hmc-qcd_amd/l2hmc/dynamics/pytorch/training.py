@@ -895,11 +895,8 @@ def _native_begin(dyn, nb: Optional[int] = None) -> list:
                 il.xlayer.weight, il.vlayer.weight, n.scale.layer.weight, n.transl.weight,
                 n.transf.layer.weight))
             dev = il.vlayer.weight.device
-            if dev.type == 'cuda':
-                free, _t = torch.cuda.mem_get_info(dev)
-                idle = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                if 3 * wbytes > 0.5 * (free + idle):
-                    continue
+            if dev.type == 'cuda' and not ops.mem_gate('native-order weight shadows', 3 * wbytes, 0.5, dev):
+                continue
         n.native_train_begin(p['in'], p['out'])
         nets.append(n)
     return nets

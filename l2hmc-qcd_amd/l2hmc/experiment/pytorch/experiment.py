@@ -13,9 +13,21 @@ from l2hmc.utils import dist as D
 
 class Experiment:
     def __init__(self, cfg: dict | cfgs.ExperimentConfig, build_networks: bool = True,
-                 keep=None, skip=None) -> None:
+                 keep=None, skip=None, seed: Optional[int | bool] = None) -> None:
+        """seed (not a reference argument): an int, or True for `cfg.seed`, seeds torch / numpy /
+        random right here -- for a direct caller (a script, a test) that wants `Experiment(cfg)` alone to be
+        reproducible.  None keeps the reference's contract (the caller has seeded); a generator that was never
+        seeded in this process is reported once, because such a run cannot be reproduced from `cfg.seed`."""
         self.cfg = cfg
         self.config = cfgs.instantiate(cfg) if isinstance(cfg, dict) else cfg
+        if seed is not None and seed is not False:
+            D.seed_everything(int(self.config.seed if seed is True else seed))
+        elif not D.SEEDED[0] and not getattr(Experiment, '_warned_unseeded', False):
+            import logging
+            logging.getLogger('l2hmc').info(
+                'Experiment: the host generator has not been seeded through l2hmc.utils.dist (seed_everything / '
+                'setup_torch); like the reference, Experiment does not seed -- pass seed=True to use cfg.seed')
+            Experiment._warned_unseeded = True
         # Seeding is the CALLER's job, like in the reference: its Experiment never seeds
         # (experiment/pytorch/experiment.py:141-225); `python -m l2hmc` seeds with cfg.seed through
         # setup_torch right before it builds the Experiment (__main__.py:78-92) and a script such

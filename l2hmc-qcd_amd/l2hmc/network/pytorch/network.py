@@ -680,7 +680,7 @@ class LeapfrogLayer(nn.Module):
                 # at 16^4): built only while that leaves most of the free memory alone
                 need = 2 * (w['wx'].numel() + w['wv'].numel()) * 8
                 ix = iv = None
-                if not x.is_cuda or torch.cuda.mem_get_info(x.device)[0] > 4 * need:
+                if not x.is_cuda or ops.mem_gate('sliced input-layer images', need, 0.25, x.device):
                     ix, iv = ops.gemm_sliced_build(w['wx']), ops.gemm_sliced_build(w['wv'])
                 w['input_img'] = (ix, iv) if ix is not None and iv is not None else None
             if w['input_img'] is not None:
@@ -796,6 +796,16 @@ class LeapfrogLayer(nn.Module):
                 shadowed = {id(par) for par, _d, _p in nat['src'].values()}
                 on_ready([q for q in self.parameters() if id(q) not in shadowed])
         nat['active'] = bool(keep_active)
+
+    def native_train_release(self) -> None:
+        """Drop what native-order training keeps between optimiser steps -- weight / gradient shadows,
+        the deferred-gradient arenas (8 GB at cfg-4), the slice images of the tape -- when the layer leaves
+        training (`Dynamics.eval()`): a sampler that runs next must not find that memory pinned (its own
+        slice images are gated on free memory).  A later train step allocates them again."""
+        nat = getattr(self, '_nat', None)
+        if nat is None or nat.get('active'):
+            return                                   # (never inside a step)
+        self._nat = None
 
     def native_active(self) -> bool:
         nat = getattr(self, '_nat', None)
@@ -998,10 +1008,8 @@ class LeapfrogLayer(nn.Module):
             es = 8 if dt == torch.float64 else 4
             extra = 3 * capacity * nb * n_out * es
             total = extra + capacity * nb * (kx + kv + units + units_in) * es
-            free, _t = torch.cuda.mem_get_info(nat['w']['ws'].device) if nat['w']['ws'].is_cuda else (1 << 62, 0)
-            idle = (torch.cuda.memory_reserved(nat['w']['ws'].device)
-                    - torch.cuda.memory_allocated(nat['w']['ws'].device)) if nat['w']['ws'].is_cuda else 0
-            if total > self.DEFER_MAX_FREE_FRACTION * (free + idle):
+            if not ops.mem_gate('deferred weight-gradient arenas', total, self.DEFER_MAX_FREE_FRACTION,
+                                nat['w']['ws'].device):
                 nat['defer'] = {'key': key, 'off': True}
                 return None
             dev = nat['w']['ws'].device
@@ -1089,8 +1097,7 @@ class LeapfrogLayer(nn.Module):
         if (ops.USE_SLICED_INPUT[0] and wx.dtype == torch.float64 and wx.is_cuda
                 and ops.gemm_sliced_pays(nb, wx.shape[0], wx.shape[1], wv.shape[1])):
             need = 2 * (wx.numel() + wv.numel()) * 8
-            if torch.cuda.mem_get_info(wx.device)[0] + torch.cuda.memory_reserved(wx.device) \
-                    - torch.cuda.memory_allocated(wx.device) > 4 * need:
+            if ops.mem_gate('sliced input-layer images (training tape)', need, 0.25, wx.device):
                 ix, iv = ops.gemm_sliced_build(wx), ops.gemm_sliced_build(wv)
                 imgs = (ix, iv) if ix is not None and iv is not None else None
         nat['input_img'] = imgs

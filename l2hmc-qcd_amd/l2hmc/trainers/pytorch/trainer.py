@@ -256,12 +256,31 @@ class Trainer:
             metrics['loss_scale'] = ls
         if not (found_inf and self.grad_scaler is not None):
             self.arena.adam_step(lr=float(self.config.learning_rate.lr_init), grad_scale=scale)
+        if self._gstep == 0:
+            self._check_paths_across_ranks()
         metrics.pop('mc_states', None)
         metrics['loss'] = float(loss_tot)
         if self.config.dynamics.verbose:
             metrics.update(self.loss_fn.lattice_metrics(xinit=xinit, xout=xout))
         self._gstep += 1
         return xout.detach(), metrics
+
+    @staticmethod
+    def _check_paths_across_ranks() -> None:
+        """The memory gates of l2hmc._ops pick between kernels that agree to rounding only; in a data-parallel
+        job every rank must have picked alike or the replicas drift apart bit by bit.  Compared once, after the
+        first step; a difference is reported with both tables."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        from l2hmc import _ops as ops
+        sigs = [None] * dist.get_world_size()
+        dist.all_gather_object(sigs, ops.mem_gate_signature())
+        if len(set(sigs)) > 1:
+            import logging
+            logging.getLogger('l2hmc').warning(
+                'ranks took different memory-gated kernel paths: %s -- set l2hmc._ops.MEM_GATE_POLICY[0] to '
+                "'always' or 'never' to pin the choice", sigs)
 
     def _new_arena(self):
         from l2hmc.dynamics.pytorch import training as T

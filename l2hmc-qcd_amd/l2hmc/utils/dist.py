@@ -26,6 +26,9 @@ def query_environment() -> dict[str, int]:
             'world_size': int(os.environ.get('WORLD_SIZE', 1))}
 
 
+SEEDED = [False]          # set by seed_everything: lets Experiment tell an unseeded direct caller
+
+
 def seed_everything(seed: int) -> None:
     """random / numpy / torch, like common.py:115-121 of the reference"""
     random.seed(seed)
@@ -33,6 +36,7 @@ def seed_everything(seed: int) -> None:
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+    SEEDED[0] = True
 
 
 def setup_torch_distributed(backend: Optional[str] = None, port: str = '2345') -> dict[str, int]:

@@ -195,9 +195,13 @@ def test_two_rank_train_step_equals_single_process(tmp_path):
     port = _free_port()
     mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     old = torch.get_default_dtype()
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    from l2hmc import native
+    keep = native.call                       # (the in-process run swaps in the emulator: put it back)
     try:
         _train_worker(0, 1, port, str(tmp_path))
     finally:
+        native.call = keep
         torch.set_default_dtype(old)
     r0, r1 = (torch.load(tmp_path / f't2_{i}.pt') for i in range(2))
     one = torch.load(tmp_path / 't1_0.pt')
