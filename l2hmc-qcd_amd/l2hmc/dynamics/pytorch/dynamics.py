@@ -169,9 +169,15 @@ class Dynamics(nn.Module):
             if self.group == 'SU3':
                 # The SU(3) xnet is built (its tensors are state_dict / checkpoint keys) but never
                 # called (dynamics.py:1420-1425): 264 M of the 446 M parameters at
-                # 8^4 / units [256], 34 GB at 16^4.  It keeps its freshly initialised values but
-                # lives in host memory, not HBM.
-                self.xnet.to('cpu')
+                # 8^4 / units [256], 34 GB at 16^4.  It keeps its freshly initialised values.  While it is a
+                # small part of the device's headroom (2.1 GB at 8^4) it stays in HBM, so that the module is
+                # on ONE device type -- what `DistributedDataParallel(dynamics, find_unused_parameters=True)`,
+                # the reference's wrapper (trainers/pytorch/trainer.py:246-257), requires; the 34 GB of the
+                # 16^4 shard go to host memory (`dynamics.xnet.to(DEVICE)` brings them back for a DDP wrap).
+                nbytes = sum(p.numel() * p.element_size() for p in self.xnet.parameters())
+                dev = DEVICE if isinstance(DEVICE, torch.device) else torch.device(DEVICE)
+                if not ops.mem_gate('SU(3) xnet (never called) kept on the device', nbytes, 0.05, dev):
+                    self.xnet.to('cpu')
         else:
             self._networks_built = False
             self.xnet = dummy_network

@@ -392,3 +392,66 @@ def test_rccl_abi_version_is_checked(tmp_path):
         if ver:
             env['FAKE_RCCL_VERSION'] = ver
         subprocess.run([sys.executable, '-c', code], check=True, env=env)
+
+
+def _ddp_worker(rank, world, port, out):
+    """The reference's data-parallel wrapper as it uses it (trainers/pytorch/trainer.py:246-257, 1276-1304):
+    `DistributedDataParallel(dynamics)`, forward through the wrapper, `loss.backward()` -- the gradient
+    all-reduce is DDP's own, fired by the accumulation hooks of the parameters this build's Transition node
+    hands its gradients to."""
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import numpy as np
+    torch.set_default_dtype(torch.float64)
+    import emu_native
+    import helpers
+    from l2hmc import native
+    from l2hmc.utils import dist as D
+    native.call = emu_native.call
+    import l2hmc._ops as ops
+    ops.N.call = emu_native.call
+    if world > 1:
+        assert D.setup_torch(seed=1234, backend='gloo') == rank
+    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'u1_train_f64_plain.npz')))
+    nb = g['x'].shape[0] - 1
+    lo, hi = (rank * nb // world, (rank + 1) * nb // world)
+    gs = dict(g)
+    for k in ('x', 'normals', 'u'):
+        gs[k] = g[k][lo:hi]
+    dyn, lat, loss_fn = helpers.build_u1_train_dynamics(gs)
+    model = dyn
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        model = DDP(dyn, find_unused_parameters=True)
+    dyn._inject = {'normals': gs['normals'], 'u': gs['u']}
+    x = dyn.g.compat_proj(dyn.unflatten(torch.from_numpy(gs['x'])))
+    x.requires_grad_(True)
+    xout, m = model((x, torch.tensor(float(g['beta']))))
+    loss = loss_fn(x, m['mc_states'].proposed.x, m['acc'])
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in dyn.parameters()])
+    torch.save({'grads': grads, 'loss': float(loss)}, os.path.join(out, f'd{world}_{rank}.pt'))
+    if world > 1:
+        D.cleanup()
+
+
+def test_reference_ddp_wrapper_drives_dynamics(tmp_path):
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    old = torch.get_default_dtype()
+    sys.path.insert(0, os.path.join(ROOT, 'l2hmc-qcd_amd'))
+    from l2hmc import native
+    import l2hmc._ops as ops
+    keep = (native.call, ops.N.call)
+    try:
+        _ddp_worker(0, 1, port, str(tmp_path))
+    finally:
+        native.call, ops.N.call = keep
+        torch.set_default_dtype(old)
+    r0, r1 = (torch.load(tmp_path / f'd2_{i}.pt') for i in range(2))
+    one = torch.load(tmp_path / 'd1_0.pt')
+    assert torch.equal(r0['grads'], r1['grads'])                   # DDP averaged them
+    gn = float(one['grads'].abs().max())
+    assert gn > 0 and float((r0['grads'] - one['grads']).abs().max()) < 1e-12 * max(gn, 1.0)
