@@ -300,7 +300,11 @@ def cpu_baseline(dyn, args):
         single = {'value': round(units / dt, 2), 'cores': threads, 'seconds': round(dt, 2)}
         nproc = max(1, ncpu // threads)
         multi = None
-        if nproc > 1 and os.environ.get('L2Q_BENCH_CPU_SINGLE') != '1':
+        # measured on the 256-CPU GPU host (profiles/r05f_bench_l2hmc.json): 16 processes x 16 threads give 14.6
+        # chain*LF/s in 70 s against 26.3 for ONE process x 16 threads -- every process streams the 1.4 GB of
+        # network weights per layer call and they saturate the host memory system -- so the all-cores attempt
+        # only runs on request (L2Q_BENCH_CPU_ALL=1) and the default line stays within its time budget
+        if nproc > 1 and os.environ.get('L2Q_BENCH_CPU_ALL') == '1':
             ctx = mp.get_context('spawn')
             q = ctx.Queue()
             start = time.time() + 20.0                  # interpreter + torch import of the workers
@@ -332,8 +336,11 @@ def cpu_baseline(dyn, args):
                'sample': f'{args.cpu_chains} chains x {nsteps} LF steps of the same {args.mode} trajectory per '
                          f'process (SU(3) {"x".join(map(str, L))}, units {args.units}); oracle/torch_cpu.py, '
                          f'{best.get("processes", 1)} process(es) x {threads} torch threads in '
-                         f'{best["seconds"]} s (more threads per process are slower: the 3x3 batches do not '
-                         f'scale past ~16)'}
+                         f'{best["seconds"]} s.  Not os.cpu_count() threads: one process scales to ~16 threads '
+                         f'(35 / 45 / 54 / 33 / 19 / 8 chain*LF/s at 4 / 8 / 16 / 32 / 64 / 128 threads), and '
+                         f'cpu_count/16 processes x 16 threads on independent chains were measured SLOWER on the '
+                         f'256-CPU host (14.6 vs 26.3: memory-bound on the network weights; L2Q_BENCH_CPU_ALL=1 '
+                         f're-runs that, profiles/r05f_bench_l2hmc.json holds the record)'}
     finally:
         if tmp is not None:
             try:
