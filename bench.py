@@ -79,6 +79,8 @@ def parse():
     ap.add_argument('--no-comm-probe', action='store_true')
     ap.add_argument('--no-u1', action='store_true', help='skip the untimed U(1) cfg-2 / cfg-3 block')
     ap.add_argument('--cpu-chains', type=int, default=32)
+    ap.add_argument('--settle', type=int, default=12,
+                    help='graph-replayed sampler: set-up trajectories before the warm-up (clock settling)')
     ap.add_argument('--fp64-input-layer', action='store_true',
                     help='A/B: the vnet input layer on the fp64 MFMA kernel instead of the int8-sliced one')
     ap.add_argument('--fp64-train-heads', action='store_true',
@@ -481,14 +483,16 @@ def secondary(dyn, x, beta, args, nlf_exec):
     baseline sampler (apply_transition_hmc), each over 2 steps after 1 warm-up."""
     res = {}
 
-    def rate(fn):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2):
+    def rate(fn, warm=8, n=4):
+        # (a graph-replayed sampler needs ~10 trajectories to settle in its clock state, DESIGN.md section 5)
+        for _ in range(warm):
             fn()
         torch.cuda.synchronize()
-        return round(args.nchains * nlf_exec * 2 / (time.perf_counter() - t0), 1)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return round(args.nchains * nlf_exec * n / (time.perf_counter() - t0), 1)
     old = dyn.config.verbose
     try:
         dyn.config.verbose = True
@@ -535,8 +539,16 @@ def secondary(dyn, x, beta, args, nlf_exec):
                         l.bias.copy_(b0)
         res['hmc'] = rate(lambda: dyn.apply_transition_hmc((x, beta), eps=0.01,
                                                            nleapfrog=nlf_exec))
-        # the headline trajectory replayed from a HIP graph (Dynamics.make_graphed): what the
-        # host-side launch gaps cost
+        # the headline trajectory on EAGER launches (Dynamics.auto_graph = False): the default replays a HIP graph
+        # behind forward(); the same kernels launched one by one run ~10 % slower (clock state)
+        try:
+            dyn.auto_graph = False
+            res['l2hmc_eager_launches'] = rate(lambda: dyn((x, beta)))
+            res['hmc_eager_launches'] = rate(lambda: dyn.apply_transition_hmc((x, beta), eps=0.01,
+                                                                              nleapfrog=nlf_exec))
+        finally:
+            dyn.auto_graph = True
+        # an explicit graph (Dynamics.make_graphed): outputs are views of its static buffers, nothing copied out
         try:
             g = dyn.make_graphed(x, beta=float(beta))
             res['l2hmc_hip_graph'] = rate(lambda: g(x))
@@ -970,6 +982,18 @@ def main():
     for _ in range(1 if train else 2):
         step(x)
     torch.cuda.synchronize()
+    setup_steps = 1 if train else 2
+    graphed = bool(getattr(dyn, '_graphs', None))
+    if graphed:
+        # The default Dynamics replays its eval-mode transitions from a HIP graph (Dynamics._auto_graphed), and a
+        # gap-free kernel stream takes ~10 trajectories (~0.2 s) to settle in the clock state it then keeps
+        # (profiles/r05h_graph_feed_probe.txt: 21.7 ms for the first ten, 19.2 ms from then on).  `value` is the
+        # sampler's steady state, so the settling belongs to the set-up, like the allocator growth above; the W
+        # warm-up and K timed steps of the contract follow unchanged.  (--settle 0 times the cold state.)
+        for _ in range(args.settle):
+            x, m = step(x)
+        setup_steps += args.settle
+        torch.cuda.synchronize()
     timer = KernelTimer()
     timer.install()
     for _ in range(args.warmup):
@@ -992,12 +1016,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = os.environ.get('L2Q_BENCH_NO_KTIMER') != '1'     # (experiment switch: no kernel table)
+    # (HIP events cannot be recorded inside a graph replay -- torch: "External events are disallowed in rocm" --
+    # so the instrumented pass launches the SAME kernels eagerly: its per-kernel durations are those of the lower
+    # clock state, i.e. an upper bound of what ran in the timed region; the rocprofv3 table of the graph replay
+    # itself is profiles/r05*_bench_l2hmc_kernel_stats.txt)
+    if graphed:
+        dyn.auto_graph = False
+        step(x)
     t1 = time.perf_counter()
     for _ in range(args.steps):
         x, m = step(x)
     barrier()
     dt_instr = time.perf_counter() - t1
     timer.enabled = False
+    if graphed:
+        dyn.auto_graph = True
     per_rank = None
     ranks_check = None
     if dist is not None:
@@ -1172,6 +1205,11 @@ def main():
             'roofline': roofline,
             'rooflines': rooflines,
             'instrumented_ms_per_step': round(dt_instr / args.steps * 1e3, 3),
+            'launch_path': ('HIP-graph replay behind Dynamics.forward (Dynamics.auto_graph, default); the kernel '
+                            'table / rooflines below come from the instrumented pass on eager launches of the same '
+                            'kernels (HIP events cannot be recorded inside a replay): an upper bound of the '
+                            'durations in the timed region') if graphed else 'eager launches',
+            'setup_steps': setup_steps,
             'kernel_time_fraction_of_wall': round(total_k / dt_instr, 4),
             'kernels': kernels,
             'accept_prob_mean': round(float(acc.mean()), 4),

