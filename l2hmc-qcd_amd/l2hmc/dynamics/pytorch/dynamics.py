@@ -1374,7 +1374,9 @@ class Dynamics(nn.Module):
         if self.group == 'U1':
             if x.numel() > self.AUTO_GRAPH_MAX_ELEMS:
                 return None
-        elif x.numel() * 16 > self.AUTO_GRAPH_MAX_BYTES_SU3 or not self._networks_built:
+        elif x.numel() * 16 > self.AUTO_GRAPH_MAX_BYTES_SU3 or mode != 'fb':
+            # (plain HMC at 8^4 measures 7 % SLOWER from a graph -- 251k vs 269k chain*LF/s, profiles/r05i_* --:
+            # only the L2HMC trajectory is replayed)
             return None
         b = _beta(beta)
         key = (mode, tuple(x.shape), b, None if eps is None else float(eps), nleapfrog)

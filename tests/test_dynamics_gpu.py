@@ -1243,6 +1243,7 @@ def test_auto_graphed_su3_transitions(golden):
     keep = xo1.clone()
     torch.cuda.manual_seed(4)
     xo2, m2 = dyn((x, beta))
+    px2 = m2['mc_states'].proposed.x                      # (formed now: the caller's tensor from here on)
     assert err(host(xo1), host(keep)) == 0.0 and xo1.data_ptr() != xo2.data_ptr() != gt.out_x.data_ptr()
     with pytest.raises(RuntimeError, match='NEXT transition'):
         m1['mc_states'].init.v                           # first access after the sampler moved on
@@ -1251,8 +1252,7 @@ def test_auto_graphed_su3_transitions(golden):
     torch.cuda.manual_seed(4)
     xo_g, m_g = gt(x)
     assert err(host(xo2), host(xo_g)) == 0.0 and err(host(m2['acc']), host(m_g['acc'])) == 0.0
-    assert err(host(m2['mc_states'].proposed.x), host(m_g['mc_states'].proposed.x)) == 0.0
-    assert float(lat.g.checkSU(m2['mc_states'].init.x)[1].max()) < 1e-10 or True
+    assert err(host(px2), host(m_g['mc_states'].proposed.x)) == 0.0
     # eager routes
     n = len(dyn._graphs)
     dyn._inject = {'normals': dev(g['normals']), 'u': dev(g['u'])}
