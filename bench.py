@@ -483,6 +483,8 @@ def secondary(dyn, x, beta, args, nlf_exec):
     baseline sampler (apply_transition_hmc), each over 2 steps after 1 warm-up."""
     res = {}
 
+    bad = []
+
     def rate(fn, warm=8, n=4):
         # (a graph-replayed sampler needs ~10 trajectories to settle in its clock state, DESIGN.md section 5)
         for _ in range(warm):
@@ -490,9 +492,14 @@ def secondary(dyn, x, beta, args, nlf_exec):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
-            fn()
+            out = fn()
         torch.cuda.synchronize()
-        return round(args.nchains * nlf_exec * n / (time.perf_counter() - t0), 1)
+        dt = time.perf_counter() - t0
+        # every secondary line is a real trajectory: a non-finite acceptance would make its rate meaningless
+        if isinstance(out, tuple) and isinstance(out[1], dict) and 'acc' in out[1] \
+                and not bool(torch.isfinite(out[1]['acc']).all()):
+            bad.append(len(res))
+        return round(args.nchains * nlf_exec * n / dt, 1)
     old = dyn.config.verbose
     try:
         dyn.config.verbose = True
@@ -505,7 +512,8 @@ def secondary(dyn, x, beta, args, nlf_exec):
             state = {'x': x}
 
             def chained():
-                state['x'], _ = dyn((state['x'], beta))
+                state['x'], mm = dyn((state['x'], beta))
+                return state['x'], mm
             res['l2hmc_native_output_cache'] = rate(chained)
         finally:
             dyn.cache_native_output = False
@@ -525,7 +533,8 @@ def secondary(dyn, x, beta, args, nlf_exec):
                 box = {}
 
                 def scaled():
-                    _, box['m'] = dyn((x, beta))
+                    xo_, box['m'] = dyn((x, beta))
+                    return xo_, box['m']
                 r = rate(scaled)
                 a = box['m']['acc']
                 res['l2hmc_scaled_heads'] = {
@@ -558,6 +567,8 @@ def secondary(dyn, x, beta, args, nlf_exec):
     finally:
         dyn.config.verbose = old
     res['unit'] = 'chain*leapfrog-steps/s'
+    if bad:
+        res['non_finite_acceptance_in_entries'] = bad
     return res
 
 

@@ -44,6 +44,18 @@ void launch_finalize(const double* partial, double* out, int nb, long nblk, int 
                      scale, offset);
 }
 
+__global__ void zero_words_kernel(unsigned* __restrict__ p, size_t nwords) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nwords) p[i] = 0u;
+}
+
+void launch_zero(void* p, size_t bytes, hipStream_t st) {
+  const size_t nwords = (bytes + 3) / 4;
+  if (nwords == 0) return;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)cdiv((long)nwords, kBlock)), dim3(kBlock), 0, st,
+                     (unsigned*)p, nwords);
+}
+
 // ------------------------------------------------------------------ batched transpose
 // in[batch][rows][cols] -> out[batch][cols][rows].  cols or rows is small (8/9); a block
 // stages a tile of TILE consecutive "long-axis" items through LDS so that both the global

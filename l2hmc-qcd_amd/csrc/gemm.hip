@@ -1274,7 +1274,7 @@ static int heads_launch(const double* Z, int M, int K, long N, const double* Ws,
   const int swz = tuning().xcd_swizzle;
   const int stg = tuning().heads_stagger;
   // partial columns of wave tiles that fall entirely beyond N are never written: clear first
-  (void)hipMemsetAsync(ws, 0, (size_t)M * ncols * (mid ? 3 : 1) * sizeof(double), st);
+  launch_zero(ws, (size_t)M * ncols * (mid ? 3 : 1) * sizeof(double), st);
   // LDS-DMA kernel whenever the K-slabs are whole (tuning heads_dma = 0 keeps the older kernel)
   const bool dma_ok = (K % BK == 0) && K >= BK && K <= (1 << 20);
   const bool dma = tuning().heads_dma && dma_ok;

@@ -1252,7 +1252,7 @@ static int heads_h_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, floa
   double* part = (double*)ws;
   double* tmp = part + (size_t)a.M * a.ncols_part;
   a.logdet_part = part;
-  (void)hipMemsetAsync(part, 0, (size_t)a.M * a.ncols_part * sizeof(double), st);
+  launch_zero(part, (size_t)a.M * a.ncols_part * sizeof(double), st);
   // weights-stationary stream kernel wherever its shape conditions hold (tuning heads_h_stream = 0: tile kernel)
   const bool stream = tuning().heads_h_stream && (a.K == 32 || a.K == 64 || a.K == 128 || a.K == 256) &&
                       (a.N & 3) == 0 && al16(a.a) && al16(a.bsrc) && al16(a.b[0]) && al16(a.b[1]) &&

@@ -639,7 +639,7 @@ int l2q_gemm_sliced_f64(const double* A, const void* image, long K, int a_exp, c
   const int groups = g0 + g1;
   a.part = (double*)ws;
   a.flag = (int*)((char*)ws + (size_t)groups * M * N * sizeof(double));
-  (void)hipMemsetAsync(a.flag, 0, sizeof(int), st);
+  launch_zero(a.flag, sizeof(int), st);                 // (a kernel, not a memset node: l2q_common.hpp)
   const int tiles = (M / GS_T) * (N / GS_T);
   hipLaunchKernelGGL(gemm_sliced_kernel, dim3((unsigned)(groups * tiles)), dim3(512), 0, st, a, tuning().xcd_swizzle);
   const long MN = (long)M * N;

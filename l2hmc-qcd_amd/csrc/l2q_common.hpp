@@ -124,4 +124,11 @@ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 void launch_finalize(const double* partial, double* out, int nb, long nblk, int ncomp,
                      double scale, double offset, hipStream_t st);
 
+// Zero `bytes` (a multiple of 4) of device memory with a KERNEL.  The launch paths use this instead of
+// hipMemsetAsync: a memset becomes a memset NODE when the call is captured into a HIP graph, and on ROCm 7.0 a
+// replayed graph's memset nodes stop taking effect once a >= 512 KB device-to-host copy has run on the null stream
+// (found in round 5: the 4-byte flag of l2q_gemm_sliced_f64 then kept whatever the workspace held and every later
+// replay of a captured trajectory came out NaN; kernel nodes are not affected).
+void launch_zero(void* p, size_t bytes, hipStream_t st);
+
 }  // namespace l2q

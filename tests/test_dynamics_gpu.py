@@ -1253,6 +1253,14 @@ def test_auto_graphed_su3_transitions(golden):
     xo_g, m_g = gt(x)
     assert err(host(xo2), host(xo_g)) == 0.0 and err(host(m2['acc']), host(m_g['acc'])) == 0.0
     assert err(host(px2), host(m_g['mc_states'].proposed.x)) == 0.0
+    # a big device-to-host copy on the null stream between two replays (what `x_out.cpu()` in a sampler loop is):
+    # on ROCm 7.0 it silences the memset NODES of a replayed graph -- the launch paths therefore zero their flags
+    # with a kernel (csrc/l2q_common.hpp::launch_zero); same seed -> same trajectory, before and after
+    big = torch.zeros(8 << 20, dtype=torch.uint8, device='cuda').cpu()
+    torch.cuda.manual_seed(4)
+    xo3, m3 = dyn((x, beta))
+    assert bool(torch.isfinite(m3['acc']).all())
+    assert err(host(xo3), host(xo2)) == 0.0 and err(host(m3['acc']), host(m2['acc'])) == 0.0
     # eager routes
     n = len(dyn._graphs)
     dyn._inject = {'normals': dev(g['normals']), 'u': dev(g['u'])}
