@@ -524,22 +524,56 @@ __device__ __forceinline__ double gs_act(double z, int act) {
   }
 }
 
+// The "operand out of range" flag of a call and the ticket that clears it: device symbols (zero at module load), NOT a
+// workspace word reset by the launcher with hipMemsetAsync.  Captured into a HIP graph that memset is a memset NODE,
+// and on ROCm 7.0 such a node makes the replayed graph unsafe: after a >= 512 KB device-to-host copy on the null
+// stream every later replay of a captured SU(3) trajectory came out NaN, even with this self-cleaning flag in place
+// (the node itself scribbles), while the same graph ran 10 % FASTER than eager launches -- an effect that exists only
+// with the node present (19.2 vs 21.2-21.8 ms per trajectory with a zeroing kernel, with no reset at all, or with the
+// node anywhere else: profiles/r05k_graph_memset_node.txt) and is therefore not something to build on.  The flag cleans
+// up after itself instead: the LAST block of gs_reduce_kernel to have read it puts flag and ticket back to zero for
+// the next call.  One flag per device: calls on different streams of one device would share it (the library
+// launches on one stream).
+__device__ int gs_flag_dev[2];
+static int* gs_flag_ptr() {
+  static int* cache[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!cache[dev]) {
+    int* p = nullptr;
+    if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(gs_flag_dev)) != hipSuccess) return nullptr;
+    cache[dev] = p;
+  }
+  return cache[dev];
+}
+
 __global__ __launch_bounds__(256) void gs_reduce_kernel(const double* __restrict__ part, int groups, long MN, int N,
                                                          const double* __restrict__ bias,
                                                          const double* __restrict__ bias2,
                                                          const double* __restrict__ coeff, double scale, int act,
-                                                         const int* __restrict__ flag, double* __restrict__ C) {
+                                                         int* flag, double* __restrict__ C) {
   const long i = blockIdx.x * 256L + threadIdx.x;
-  if (i >= MN) return;
-  double s = 0.0;
-  for (int g = 0; g < groups; ++g) s += part[(long)g * MN + i];
-  const int n = (int)(i % N);
-  double b = 0.0;
-  if (bias) b += bias[n];
-  if (bias2) b += bias2[n];
-  double y = (coeff ? scale * exp(coeff[n]) : scale) * gs_act(s + b, act);
-  if (*flag) y = __longlong_as_double(0x7ff8000000000000LL);
-  C[i] = y;
+  const int raised = __atomic_load_n(flag, __ATOMIC_RELAXED);
+  if (i < MN) {
+    double s = 0.0;
+    for (int g = 0; g < groups; ++g) s += part[(long)g * MN + i];
+    const int n = (int)(i % N);
+    double b = 0.0;
+    if (bias) b += bias[n];
+    if (bias2) b += bias2[n];
+    double y = (coeff ? scale * exp(coeff[n]) : scale) * gs_act(s + b, act);
+    if (raised) y = __longlong_as_double(0x7ff8000000000000LL);
+    C[i] = y;
+  }
+  // every thread of the block has read the flag: take a ticket; the last block clears flag and ticket
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(flag + 1, 1) == (int)gridDim.x - 1) {
+      __atomic_store_n(flag, 0, __ATOMIC_RELAXED);
+      __atomic_store_n(flag + 1, 0, __ATOMIC_RELAXED);
+    }
+  }
 }
 
 static inline size_t gs_image_bytes(int N, long K) {
@@ -638,13 +672,13 @@ int l2q_gemm_sliced_f64(const double* A, const void* image, long K, int a_exp, c
   a.groups0 = g0; a.klen = klen; a.M = M; a.N = N;
   const int groups = g0 + g1;
   a.part = (double*)ws;
-  a.flag = (int*)((char*)ws + (size_t)groups * M * N * sizeof(double));
-  launch_zero(a.flag, sizeof(int), st);                 // (a kernel, not a memset node: l2q_common.hpp)
+  a.flag = gs_flag_ptr();
+  L2Q_REQUIRE(a.flag, L2Q_EHIP, "device symbol gs_flag_dev not found");
   const int tiles = (M / GS_T) * (N / GS_T);
   hipLaunchKernelGGL(gemm_sliced_kernel, dim3((unsigned)(groups * tiles)), dim3(512), 0, st, a, tuning().xcd_swizzle);
   const long MN = (long)M * N;
   hipLaunchKernelGGL(gs_reduce_kernel, dim3((unsigned)cdiv(MN, 256)), dim3(256), 0, st, (const double*)ws, groups, MN,
-                     N, bias, bias2, coeff, scale, act, (const int*)a.flag, C);
+                     N, bias, bias2, coeff, scale, act, a.flag, C);
   return check_launch("l2q_gemm_sliced_f64");
 }
 

@@ -124,11 +124,10 @@ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 void launch_finalize(const double* partial, double* out, int nb, long nblk, int ncomp,
                      double scale, double offset, hipStream_t st);
 
-// Zero `bytes` (a multiple of 4) of device memory with a KERNEL.  The launch paths use this instead of
-// hipMemsetAsync: a memset becomes a memset NODE when the call is captured into a HIP graph, and on ROCm 7.0 a
-// replayed graph's memset nodes stop taking effect once a >= 512 KB device-to-host copy has run on the null stream
-// (found in round 5: the 4-byte flag of l2q_gemm_sliced_f64 then kept whatever the workspace held and every later
-// replay of a captured trajectory came out NaN; kernel nodes are not affected).
+// Zero `bytes` of device memory with a KERNEL.  The launch paths use this instead of hipMemsetAsync: a memset becomes
+// a memset NODE when the call is captured into a HIP graph, and on ROCm 7.0 a replayed graph that contains one is
+// corrupted by a >= 512 KB device-to-host copy on the null stream (round 5: every later replay of a captured SU(3)
+// trajectory came out NaN; profiles/r05k_graph_memset_node.txt).  No launch path of this library records a memset node.
 void launch_zero(void* p, size_t bytes, hipStream_t st);
 
 }  // namespace l2q

@@ -258,6 +258,7 @@ class Dynamics(nn.Module):
         self.autograd_forward = True
         # eval mode, small U(1) lattices: whole transitions replayed from a HIP graph (_auto_graphed)
         self.auto_graph = True
+        self.auto_graph_su3 = False        # SU(3): kernel-bound, a replay is worth ~1 % (opt-in)
         self._graphs: dict = {}
 
     def train(self, mode: bool = True):
@@ -1351,20 +1352,19 @@ class Dynamics(nn.Module):
         (`GraphedTransition`: re-captured when the model changes) and replayed behind the ordinary
         `forward` / `apply_transition_hmc` calls.
           * small U(1) lattices (BASELINE cfg-1 / cfg-2, the reference's published 16 x 16 runs) spend more
-            host time launching their ~30 us kernels than the GPU spends running them (cfg-2: 3.7 ms per
-            trajectory eager for 1.9 ms of kernels);
-          * SU(3) 8^4 is kernel-bound either way, but every kernel of the SAME trajectory runs ~10 % faster
-            from a graph (rocprofv3, same box: heads 0.83 -> 0.72 ms, input layer 0.47 -> 0.38, force 0.40 ->
-            0.36, x-update 0.41 -> 0.37; 21.2 -> 19.2 ms per trajectory after ~10 replays): gap-free
-            dispatch lets the part settle in a higher clock state than eagerly launched kernels ever reach
-            (profiles/r05h_*).
+            host time launching their ~30 us kernels than the GPU spends running them (cfg-2: 3.4 ms per
+            trajectory eager for 1.9 ms of kernels): default ON (`auto_graph`);
+          * SU(3) 8^4 is kernel-bound: a replay is worth ~1 % (21.2 vs 21.5 ms per trajectory), so it is
+            OPT-IN (`auto_graph_su3 = True`).  (A 10 % gain measured earlier in round 5 turned out to hinge on a
+            memset node whose presence also corrupted replays after a large device-to-host copy on the null
+            stream -- profiles/r05k_graph_memset_node.txt -- and the library records no memset node any more.)
         The caller's contract is unchanged: x_out and the [nb]-sized metrics are COPIED out of the graph's
         static buffers; the SU(3) `mc_states` fields, which are formed on first access anyway, read the
         graph's native buffers and therefore must be read before the NEXT transition of this sampler (they
         raise afterwards instead of returning another trajectory's data).  Not taken with injected /
         host-generator draws (parity runs), in train mode, with the native-output cache, or where the pinned
         temporaries would be large (SU(3) fields > 1 GiB: the 16^4 shard).  `dyn.auto_graph = False`
-        restores eager launches."""
+        restores eager launches everywhere."""
         if not (self.auto_graph and not self.training and self._inject is None
                 and (self._networks_built or mode == 'hmc') and not getattr(self, '_capturing', False)
                 and isinstance(x, Tensor) and x.is_cuda and self.rng_device == DEVICE
@@ -1374,9 +1374,9 @@ class Dynamics(nn.Module):
         if self.group == 'U1':
             if x.numel() > self.AUTO_GRAPH_MAX_ELEMS:
                 return None
-        elif x.numel() * 16 > self.AUTO_GRAPH_MAX_BYTES_SU3 or mode != 'fb':
+        elif not self.auto_graph_su3 or x.numel() * 16 > self.AUTO_GRAPH_MAX_BYTES_SU3 or mode != 'fb':
             # (plain HMC at 8^4 measures 7 % SLOWER from a graph -- 251k vs 269k chain*LF/s, profiles/r05i_* --:
-            # only the L2HMC trajectory is replayed)
+            # only the L2HMC trajectory is replayed, and only on request)
             return None
         b = _beta(beta)
         key = (mode, tuple(x.shape), b, None if eps is None else float(eps), nleapfrog)

@@ -1225,7 +1225,7 @@ def test_auto_graphed_small_u1_transitions(golden):
 
 
 def test_auto_graphed_su3_transitions(golden):
-    """Dynamics.auto_graph for SU(3) (fields <= 1 GiB): eval-mode `forward` replays a HIP graph; x_out and the
+    """Dynamics.auto_graph_su3 (opt-in; fields <= 1 GiB): eval-mode `forward` replays a HIP graph; x_out and the
     [nb] metrics are the caller's own copies, the lazily formed mc_states read the replay's native buffers -- equal
     to the captured graph's own result under the same device seed -- and REFUSE to be read once the sampler has
     moved on; injected draws and `auto_graph = False` stay eager."""
@@ -1235,6 +1235,9 @@ def test_auto_graphed_su3_transitions(golden):
     dyn.eval()
     x, beta = dev(g['x']), float(g['beta'])
     assert dyn._inject is None and not dyn._graphs
+    dyn((x, beta))
+    assert not dyn._graphs                               # SU(3): opt-in
+    dyn.auto_graph_su3 = True
     torch.cuda.manual_seed(3)
     xo1, m1 = dyn((x, beta))
     assert len(dyn._graphs) == 1
@@ -1254,8 +1257,8 @@ def test_auto_graphed_su3_transitions(golden):
     assert err(host(xo2), host(xo_g)) == 0.0 and err(host(m2['acc']), host(m_g['acc'])) == 0.0
     assert err(host(px2), host(m_g['mc_states'].proposed.x)) == 0.0
     # a big device-to-host copy on the null stream between two replays (what `x_out.cpu()` in a sampler loop is):
-    # on ROCm 7.0 it silences the memset NODES of a replayed graph -- the launch paths therefore zero their flags
-    # with a kernel (csrc/l2q_common.hpp::launch_zero); same seed -> same trajectory, before and after
+    # on ROCm 7.0 it corrupts replayed graphs that contain a memset NODE -- the launch paths record none
+    # (csrc/l2q_common.hpp::launch_zero, gemm_sliced.hip::gs_flag_dev); same seed -> same trajectory, before and after
     big = torch.zeros(8 << 20, dtype=torch.uint8, device='cuda').cpu()
     torch.cuda.manual_seed(4)
     xo3, m3 = dyn((x, beta))

@@ -14,14 +14,15 @@ python bench.py --mode hmc --no-u1 > "$o/bench_hmc.json" 2>> "$o/bench_l2hmc.err
 python bench.py --mode train --no-u1 --no-cpu-baseline --no-spot-check --no-comm-probe > "$o/bench_train.json" 2> "$o/bench_train.err"
 python bench.py --lattice 16 16 16 16 --beta 6.2 --steps 3 --warmup 2 --no-cpu-baseline --no-spot-check --no-u1 > "$o/bench_cfg5_shard.json" 2> "$o/bench_cfg5.err"
 L2Q_BENCH_SHARE_GPU=1 L2Q_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --nchains 64 --no-u1 > "$o/bench_2ranks_gloo_shared_gpu.json" 2> "$o/bench_2ranks.err"
-KSTATS_MARKER=$M KSTATS_LAST=5 bash tools/kstats.sh "$o/bench_l2hmc_kernel_stats.txt" python bench.py --no-cpu-baseline --no-spot-check --no-u1 --no-comm-probe > "$o/kstats_l2hmc.log" 2>&1
+L2Q_BENCH_SKIP_INSTRUMENTED=1 KSTATS_MARKER=$M KSTATS_LAST=5 bash tools/kstats.sh "$o/bench_l2hmc_kernel_stats.txt" python bench.py --no-cpu-baseline --no-spot-check --no-u1 --no-comm-probe > "$o/kstats_l2hmc.log" 2>&1
+KSTATS_MARKER=$M KSTATS_LAST=5 bash tools/kstats.sh "$o/bench_l2hmc_eager_instrumented_kernel_stats.txt" python bench.py --no-cpu-baseline --no-spot-check --no-u1 --no-comm-probe > "$o/kstats_l2hmc_eager.log" 2>&1
 KSTATS_MARKER=$M KSTATS_LAST=5 bash tools/kstats.sh "$o/bench_train_kernel_stats.txt" python bench.py --mode train --no-cpu-baseline --no-spot-check --no-u1 --no-comm-probe > "$o/kstats_train.log" 2>&1
 bash tools/pmc_collect.sh "$tag" > "$o/pmc.log" 2>&1
 L2Q_KPROF_LATTICE="16 16 16 16" L2Q_KPROF_NB=256 bash tools/pmc_collect.sh "${tag}_16x4" > "$o/pmc16.log" 2>&1
 cp profiles/${tag}_pmc_counters.txt profiles/${tag}_16x4_pmc_counters.txt profiles/pmc_traffic.json "$o/" 2>/dev/null
 python bench.py --no-cpu-baseline --no-spot-check --no-u1 --no-comm-probe > "$o/bench_l2hmc_after_pmc.json" 2>/dev/null
 python bench.py --lattice 16 16 16 16 --beta 6.2 --steps 3 --warmup 2 --no-cpu-baseline --no-spot-check --no-u1 --no-comm-probe > "$o/bench_cfg5_shard_after_pmc.json" 2>/dev/null
-head -16 "$o/bench_l2hmc_kernel_stats.txt"; head -12 "$o/bench_train_kernel_stats.txt"
+head -16 "$o/bench_l2hmc_kernel_stats.txt"; head -8 "$o/bench_l2hmc_eager_instrumented_kernel_stats.txt"; head -12 "$o/bench_train_kernel_stats.txt"
 python - "$o" <<'PY'
 import json, sys
 o = sys.argv[1]
