@@ -602,7 +602,7 @@ def _u1_flops(name, a):
     return 0.0
 
 
-def secondary_u1(steps=3):
+def secondary_u1(steps=3, only=None):
     """Untimed-region block (rank 0, N = 1): the other two single-GPU BASELINE configs run as
     themselves -- cfg-2 (2D U(1) 16x16, beta 4, 2048 chains, nleapfrog 8, fp32) and cfg-3 (64x64,
     beta 6, 8192 chains, nleapfrog 8, fp16 nets / fp32 action), each with the reference's default
@@ -628,6 +628,8 @@ def secondary_u1(steps=3):
     out = {}
     orig_native, orig_ops = native.call, ops.N.call
     for tag, L, nb, beta, units, conv, prec in cases:
+        if only and tag not in only:
+            continue
         try:
             torch.manual_seed(9992)
             np.random.seed(9992)

@@ -357,6 +357,10 @@ int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M,
                const float* coeff, float scale, int act, void* C, int c_is_f32, void* ws,
                size_t ws_bytes, void* stream);
 size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2);
+/* K-splits the streaming input-layer kernel (fp32 A / A2, N <= 256, wide K: csrc/gemm_f16_skinny.hip) takes for
+ * this shape under the current `gemm_h_skinny` tuning; 0: the tile kernels run it.  K as passed to l2q_gemm_h
+ * (u1x: 2 xdim). */
+int l2q_gemm_h_skinny_splits(int M, int N, long K, long K2, int u1x);
 /* The U(1) xnet's input layer in half precision with its [cos(m x), sin(m x)] input
  * (dynamics.py:1161-1185, network.py:430-451) formed inside the GEMM's tile loader:
  *   C = r16(act(r16([cos(keep x) | sin(keep x)] . W^T + A2 . W2^T + bias + bias2))),

@@ -312,6 +312,14 @@ static int pick_config_h(int M, int N, long Kt, bool* wide) {
 }
 
 
+// gemm_f16_skinny.hip: the streaming kernel of the wide-K fp32-operand input layer (N <= 256); false -> not its case
+int gemm_h_skinny_splits(int M, int N, long raw1, long K2, int want);
+size_t gemm_h_skinny_ws_bytes(int M, int N, long K, long K2);
+template <typename HT>
+bool gemm_h_skinny_launch(const float* A, const void* W, int M, int N, long K, const float* A2,
+                          const void* W2, long K2, void* ws, size_t ws_bytes, hipStream_t st,
+                          const float* cs_mask, int cs_compl, int want, int* splits_out);
+
 template <typename HT, typename AS, typename CT>
 static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, const void* A2_,
                          const void* W2_, long K2, EpiH epi, void* C_, void* ws, size_t ws_bytes,
@@ -322,6 +330,17 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
   const HT* W2 = (const HT*)W2_;
   CT* C = (CT*)C_;
   const long Kt = K + K2;
+  if constexpr (std::is_same<AS, float>::value) {
+    const int sk = tuning().gemm_h_skinny;
+    int S = 0;
+    if (sk != 0 && gemm_h_skinny_launch<HT>((const float*)A_, W_, M, N, K, (const float*)A2_, W2_, K2, ws,
+                                            ws_bytes, st, cs_mask, cs_compl, sk == 1 ? 0 : sk, &S)) {
+      const long MN = (long)M * N;
+      hipLaunchKernelGGL((splitk_reduce_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN, kBlock)), dim3(kBlock), 0,
+                         st, (const float*)ws, S, MN, N, epi, C);
+      return check_launch("l2q_gemm_h");
+    }
+  }
   bool wide = false;
   int splits = pick_config_h(M, N, Kt, &wide);
   long kchunk = cdiv(cdiv(Kt, splits), HBK) * HBK;
@@ -1307,8 +1326,21 @@ size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2) {
   if (M <= 0 || N <= 0 || K + K2 <= 0) return 0;
   bool wide = false;
   const int splits = pick_config_h(M, N, K + K2, &wide);
-  if (wide && splits == 1 && (long)M * N >= 1024L * 1024L) return 0;      // fused wide tile
-  return (splits == 1 && !wide) ? 0 : (size_t)(splits + 1) * M * N * sizeof(float);
+  size_t need = (splits == 1 && !wide) ? 0 : (size_t)(splits + 1) * M * N * sizeof(float);
+  if (wide && splits == 1 && (long)M * N >= 1024L * 1024L) need = 0;     // fused wide tile
+  // the streaming input-layer kernel (fp32 operands, N <= 256): up to 8 K-splits of partial sums.  The
+  // element type and the U1X form are not known here: sized for any of them.
+  if (tuning().gemm_h_skinny != 0 && N <= 256 && K + K2 >= 4096 && M >= 1024) {
+    const size_t sk = gemm_h_skinny_ws_bytes(M, N, K, K2);     // partial sums + the slab-major copy of W
+    if (sk > need) need = sk;
+  }
+  return need;
+}
+
+int l2q_gemm_h_skinny_splits(int M, int N, long K, long K2, int u1x) {
+  const int sk = tuning().gemm_h_skinny;
+  if (sk == 0 || M <= 0 || N <= 0 || K <= 0 || K2 < 0 || (u1x && (K & 1))) return 0;
+  return gemm_h_skinny_splits(M, N, u1x ? K / 2 : K, K2, sk == 1 ? 0 : sk);
 }
 
 int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M, int N, long K,

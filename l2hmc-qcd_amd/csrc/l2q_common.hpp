@@ -32,6 +32,8 @@ struct Tuning {
   int conv_stream = 0;        // half conv: 1 = persistent whole-K kernel (conv_stream_f16.hip; measured slower at cfg-3:
                               // 3.7 / 1.8 ms against the gather kernel's 2.6 / 1.2 ms), 0 = gather kernel
   int gemm_h_dma = 1;         // big half GEMMs (M, N % 256 == 0, K % 64 == 0): LDS-DMA 256 x 256 kernel (0: off)
+  int gemm_h_skinny = 1;      // wide-K fp32-operand input layer, N <= 256: streaming kernel (gemm_f16_skinny.hip);
+                              // 0 off, 1 on (split count chosen), 2 / 4 / 8: that split count (A/B)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
   int heads_h_stream = 0; // half-precision heads+update: 1 = weights-stationary stream kernel (measured slower at
                           // cfg-3: 0.475 vs 0.420 ms, see u1_heads_stream_h_kernel), 0 = tile kernel

@@ -82,6 +82,7 @@ SIGNATURES = {
     'l2q_gemm_ex': (I, [P, I, P, I, I, I, L, I, I, P, P, Z, P]),
     'l2q_gemm_h': (I, [I, P, I, P, I, I, L, P, P, L, P, P, P, F, I, P, I, P, Z, P]),
     'l2q_gemm_h_ws_bytes': (Z, [I, I, L, L]),
+    'l2q_gemm_h_skinny_splits': (I, [I, I, L, L, I]),
     'l2q_gemm_h_u1x': (I, [I, P, P, I, P, I, I, L, P, P, L, P, P, I, P, P, Z, P]),
     'l2q_u1_heads_update_h': (I, [I, P, I, I, L, P, P, P, P, P, F, P, P, P, I, P, P, P, I, F, I, I, P,
                                   I, P, Z, P]),

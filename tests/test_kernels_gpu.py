@@ -932,6 +932,86 @@ def test_gemm_h_u1x(hd, dims):
             assert float((d > 0).float().mean()) < 0.25
 
 
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(1100, 256, 2048, 2048, 1), (1024, 192, 4096, 0, 4), (1030, 64, 3072, 1024, 1),
+                                   (2048, 256, 2048, 2048, 8), (1500, 250, 2048, 2048, 2)])
+def test_gemm_h_skinny(hd, shape):
+    """The streaming kernel of the wide-K fp32-operand input layer (gemm_f16_skinny.hip; N <= 256, K and K2
+    multiples of 32) against the emulator's restatement and against the register-staged kernel (tuning
+    gemm_h_skinny = 0): same rounding points, another accumulation order over K; ragged M (clamped rows),
+    N below the tile width, every split count."""
+    import emu_native
+    from l2hmc import _ops as ops, native
+    m, n, k, k2, sk = shape
+    g = torch.Generator().manual_seed(23)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd)
+    b = torch.randn(n, generator=g).to(hd).float()
+    a2 = w2 = b2 = None
+    if k2:
+        a2 = torch.randn(m, k2, generator=g)
+        w2 = (torch.randn(n, k2, generator=g) / k2 ** 0.5).to(hd)
+        b2 = torch.randn(n, generator=g).to(hd).float()
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    cu = lambda t: None if t is None else t.cuda()
+    try:
+        for act, odt in ((None, hd), ('leaky_relu', hd), ('tanh', torch.float32)):
+            assert native.set_tuning('gemm_h_skinny', sk) >= 0
+            assert native.load().l2q_gemm_h_skinny_splits(m, n, k, k2, 0) == (sk if sk > 1 else 8)
+            got = ops.gemm_h(cu(a), cu(w), cu(b), a2=cu(a2), w2=cu(w2), bias2=cu(b2), act=act, out_dtype=odt)
+            native.set_tuning('gemm_h_skinny', 0)
+            old = ops.gemm_h(cu(a), cu(w), cu(b), a2=cu(a2), w2=cu(w2), bias2=cu(b2), act=act, out_dtype=odt)
+            want = torch.empty(m, n, dtype=odt)
+            emu_native.l2q_gemm_h(ops.HALF_TYPES[hd], a, 1, w, m, n, k, a2, w2, k2, b, b2, None, 1.0,
+                                  N_ACT[act], want, int(odt == torch.float32), None, 0)
+            for other in (want, old.cpu()):
+                d = (got.cpu().float() - other.float()).abs()
+                tol = 2.5 * ulp * other.float().abs().clamp(min=1.0)
+                assert bool((d <= tol).all()), (act, shape, float((d / tol).max()))
+                assert float((d > 0).float().mean()) < 0.2, (act, shape)
+    finally:
+        native.set_tuning('gemm_h_skinny', 1)
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('dims', [(1100, 256, 2048, 1), (1024, 128, 4096, 4), (2050, 200, 2048, 2)])
+def test_gemm_h_u1x_skinny(hd, dims):
+    """l2q_gemm_h_u1x on the streaming kernel: cos and sin slabs of the same links adjacent in the K order,
+    against the emulator and the K-ordered loader of the register-staged kernel."""
+    import emu_native
+    from l2hmc import _ops as ops, native
+    m, n, xdim, sk = dims
+    g = torch.Generator().manual_seed(41)
+    x = 2 * np.pi * torch.rand(m, xdim, generator=g) - np.pi
+    v = torch.randn(m, xdim, generator=g)
+    mask = (torch.rand(xdim, generator=g) < 0.5).float()
+    w = (torch.randn(n, 2 * xdim, generator=g) / (2 * xdim) ** 0.5).to(hd)
+    w2 = (torch.randn(n, xdim, generator=g) / xdim ** 0.5).to(hd)
+    b = torch.randn(n, generator=g).to(hd).float()
+    b2 = torch.randn(n, generator=g).to(hd).float()
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    try:
+        for complement in (False, True):
+            for act in (None, 'leaky_relu'):
+                assert native.set_tuning('gemm_h_skinny', sk) >= 0
+                assert native.load().l2q_gemm_h_skinny_splits(m, n, 2 * xdim, xdim, 1) == (sk if sk > 1 else 8)
+                got = ops.gemm_h_u1x(x.cuda(), mask.cuda(), complement, w.cuda(), b.cuda(), v.cuda(),
+                                     w2.cuda(), b2.cuda(), act)
+                native.set_tuning('gemm_h_skinny', 0)
+                old = ops.gemm_h_u1x(x.cuda(), mask.cuda(), complement, w.cuda(), b.cuda(), v.cuda(),
+                                     w2.cuda(), b2.cuda(), act)
+                want = torch.empty(m, n, dtype=hd)
+                emu_native.l2q_gemm_h_u1x(ops.HALF_TYPES[hd], x, mask, int(complement), w, m, n, xdim, v,
+                                          w2, xdim, b, b2, N_ACT[act], want, None, 0)
+                for other in (want, old.cpu()):
+                    d = (got.cpu().float() - other.float()).abs()
+                    tol = 2.5 * ulp * other.float().abs().clamp(min=1.0)
+                    assert bool((d <= tol).all()), (complement, act, float((d / tol).max()))
+                    assert float((d > 0).float().mean()) < 0.25
+    finally:
+        native.set_tuning('gemm_h_skinny', 1)
+
+
 def test_lattice_edge_shapes_vs_oracle():
     """Degenerate and ragged lattices: extent 1 in some or all directions (a link is its own
     neighbour), a single chain, odd extents, kernel blocks far from full -- action, plaquette,
