@@ -16,6 +16,7 @@
 #include <type_traits>
 #include "half_common.hpp"
 #include "u1_math.hpp"
+#include "heads_h_common.hpp"
 
 namespace l2q {
 
@@ -413,69 +414,7 @@ static int gemm_h_dispatch(const void* A, int a_f32, const void* W, int M, int N
 // v_sin / v_cos / v_rcp, ~1e-6 absolute): three orders of magnitude inside the 16-bit rounding
 // the heads already carry, and ~4x fewer VALU cycles than the libm forms, which matter here
 // because the epilogue (not the K = units[-1] MFMA loop) is the long part of this kernel.
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float fast_tanh_h(float x) {
-  return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);      // saturates to +-1; v_rcp_f32 (1 ulp),
-                                                                       // not the 10-instruction IEEE division
-}
-
-// timing-only builds of u1_heads_update_h_kernel (tools/ab_build.sh -DL2Q_HH_SKIP=n): 1 no K-loop,
-// 2 no epilogue math, 4 no field traffic.  0 in the product.
-#ifndef L2Q_HH_SKIP
-#define L2Q_HH_SKIP 0
-#endif
-
-struct HeadsHArgs {
-  const void* Z;          // [M][K]  16 bit
-  const void* W[3];       // s, t, q weights [N][K]  16 bit
-  const float* b[3];      // biases [N]
-  const float* cs;        // nw.s * exp(coeff_s[n])
-  const float* cq;
-  float st;               // nw.t
-  float eps;
-  float* a;               // v (v-update) or x (x-update), [M][N], in place
-  const float* bsrc;      // force (v-update) or v (x-update)
-  const float* mask;      // x-update: [N] keep mask (complement flips it)
-  int complement;
-  double* logdet_part;    // [M][ncols_part]
-  int M, N, K, ncols_part;
-};
-
-// One entry of the half-precision heads + update epilogue (the arithmetic both kernels below share):
-// head pre-activations (fp32 accumulators) -> s, t, q with autocast's rounding points -> v- or x-update.
-// Returns the new field value; `ldterm` is the entry's contribution to the chain's log-Jacobian.
-template <typename HT, bool XUPD, bool FWD, bool NCP>
-__device__ __forceinline__ float hh_element(float as, float at, float aq, float bs, float bt, float bq,
-                                            float cs, float cq, float st, float eps, float a0, float b0,
-                                            float keep, float& ldterm) {
-  const float s = cs * rnd<HT>(fast_tanh_h(rnd<HT>(as + bs)));
-  const float t = rnd<HT>(st * rnd<HT>(at + bt));
-  const float q = cq * rnd<HT>(fast_tanh_h(rnd<HT>(aq + bq)));
-  if (!XUPD) {
-    const float lj = FWD ? (eps * s * 0.5f) : (-eps * s * 0.5f);
-    ldterm = lj;
-    const float es = fast_exp(lj), eq = fast_exp(eps * q);
-    const float f = b0 * eq + t;
-    return FWD ? (es * a0 - 0.5f * eps * f) : (es * (a0 + 0.5f * eps * f));
-  }
-  const float xj = a0, mb = 1.f - keep;
-  const float sj = FWD ? eps * s : -eps * s;
-  const float es = fast_exp(sj), eq = fast_exp(eps * q);
-  const float tr = b0 * eq + t;
-  float xp, l;
-  if (NCP) {
-    const float hx = xj * 0.5f;                    // |hx| <= pi/2 (x is wrapped)
-    const float ch = __cosf(hx), sh = es * __sinf(hx);
-    const float x1 = 2.f * atan2f(sh, ch);         // = 2 atan(tan(hx) es), no division
-    xp = FWD ? (x1 + eps * tr) : (x1 - es * eps * tr);
-    l = sj - __logf(ch * ch + sh * sh);            // log(es / (ch^2 + sh^2))
-  } else {
-    xp = FWD ? (xj * es + eps * tr) : (es * (xj - eps * tr));
-    l = sj;
-  }
-  ldterm = mb * l;
-  return wrap_angle<float>(keep * xj + mb * xp);
-}
+// (HeadsHArgs, fast_exp / fast_tanh_h, hh_element: heads_h_common.hpp)
 
 template <typename HT, bool XUPD, bool FWD, bool NCP, int BM>
 __global__ __launch_bounds__(kBlock, BM == 128 ? 2 : 3) void u1_heads_update_h_kernel(HeadsHArgs a, int swz,
@@ -1259,6 +1198,11 @@ __global__ void cast_f64_f32_kernel(const double* __restrict__ in, float* __rest
   if (i < n) out[i] = accumulate ? out[i] + (float)in[i] : (float)in[i];
 }
 
+// heads_kstream_f16.hip: K-split stream kernel (tuning heads_h_stream = 2); false -> not its case
+template <typename HT>
+bool heads_h_kstream_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, int swz, float* logdet,
+                            int accumulate, hipStream_t st, bool any_length);
+
 template <typename HT>
 static int heads_h_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, float* logdet,
                           int accumulate, void* ws, hipStream_t st) {
@@ -1271,9 +1215,13 @@ static int heads_h_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, floa
   double* part = (double*)ws;
   double* tmp = part + (size_t)a.M * a.ncols_part;
   a.logdet_part = part;
+  // K-split stream kernel (writes every partial it sums: no zeroing, its own finalize)
+  if (tuning().heads_h_stream >= 2 &&
+      heads_h_kstream_launch<HT>(a, xupd, forward, use_ncp, swz, logdet, accumulate, st, tuning().heads_h_stream == 3))
+    return check_launch("l2q_u1_heads_update_h");
   launch_zero(part, (size_t)a.M * a.ncols_part * sizeof(double), st);
   // weights-stationary stream kernel wherever its shape conditions hold (tuning heads_h_stream = 0: tile kernel)
-  const bool stream = tuning().heads_h_stream && (a.K == 32 || a.K == 64 || a.K == 128 || a.K == 256) &&
+  const bool stream = tuning().heads_h_stream == 1 && (a.K == 32 || a.K == 64 || a.K == 128 || a.K == 256) &&
                       (a.N & 3) == 0 && al16(a.a) && al16(a.bsrc) && al16(a.b[0]) && al16(a.b[1]) &&
                       al16(a.b[2]) && al16(a.cs) && al16(a.cq) && (!xupd || al16(a.mask)) && al16(a.Z) &&
                       al16(a.W[0]) && al16(a.W[1]) && al16(a.W[2]);

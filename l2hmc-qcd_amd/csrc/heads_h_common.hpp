@@ -1,0 +1,107 @@
+// heads_h_common.hpp -- shared by the half-precision heads + update kernels of the U(1) LeapfrogLayer
+// (gemm_f16.hip: tile and stream kernels; heads_kstream_f16.hip: K-split stream kernel): arguments, the hardware
+// transcendentals of the 16-bit epilogue, and the per-entry arithmetic (autocast's rounding points -> v- or x-update).
+#pragma once
+#include "half_common.hpp"
+#include "u1_math.hpp"
+
+namespace l2q {
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_tanh_h(float x) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);      // saturates to +-1; v_rcp_f32 (1 ulp),
+                                                                       // not the 10-instruction IEEE division
+}
+
+// atan2(y, x) for x >= 0 (the half-angle form of the x-update: x = cos(theta / 2) of a wrapped angle; a cosine that
+// rounds to -1e-7 at theta = +-pi is handled by the same formula to first order).  atan(t) = t P(t^2) on [0, 1],
+// P of degree 7 fitted at Chebyshev nodes: |error| < 1.5e-7 in fp32 Horner form (checked on 2e5 points); the
+// libm atan2f is ~60 instructions with an IEEE division, and the epilogue of the x-update is VALU-bound.
+__device__ __forceinline__ float fast_atan2_px(float y, float x) {
+  const float ay = fabsf(y);
+  const float mx = fmaxf(x, ay), mn = fminf(x, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float u = t * t;
+  float p = -0.00455979211255908f;
+  p = fmaf(p, u, 0.023780519142746925f);
+  p = fmaf(p, u, -0.05882975459098816f);
+  p = fmaf(p, u, 0.09868865460157394f);
+  p = fmaf(p, u, -0.14003290235996246f);
+  p = fmaf(p, u, 0.19966961443424225f);
+  p = fmaf(p, u, -0.3333181142807007f);
+  p = fmaf(p, u, 0.9999998807907104f);
+  float r = p * t;
+  r = ay > x ? 1.5707963267948966f - r : r;
+  return copysignf(r, y);
+}
+
+// ((x + pi) mod 2 pi) - pi for |x| of a few pi (a wrapped angle plus one leapfrog increment): floor form instead of
+// the exact fmodf loop of wrap_angle<float> (u1_math.hpp); differs from it by the rounding of one fp32 fma (~5e-7).
+__device__ __forceinline__ float fast_wrap_angle(float x) {
+  const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
+  const float t = x + pi;
+  float r = fmaf(-two_pi, floorf(t * 0.15915494309189535f), t);
+  r = r < 0.f ? r + two_pi : r;
+  r = r >= two_pi ? r - two_pi : r;
+  return r - pi;
+}
+
+// timing-only builds of u1_heads_update_h_kernel (tools/ab_build.sh -DL2Q_HH_SKIP=n): 1 no K-loop,
+// 2 no epilogue math, 4 no field traffic.  0 in the product.
+#ifndef L2Q_HH_SKIP
+#define L2Q_HH_SKIP 0
+#endif
+
+struct HeadsHArgs {
+  const void* Z;          // [M][K]  16 bit
+  const void* W[3];       // s, t, q weights [N][K]  16 bit
+  const float* b[3];      // biases [N]
+  const float* cs;        // nw.s * exp(coeff_s[n])
+  const float* cq;
+  float st;               // nw.t
+  float eps;
+  float* a;               // v (v-update) or x (x-update), [M][N], in place
+  const float* bsrc;      // force (v-update) or v (x-update)
+  const float* mask;      // x-update: [N] keep mask (complement flips it)
+  int complement;
+  double* logdet_part;    // [M][ncols_part]
+  int M, N, K, ncols_part;
+};
+
+// One entry of the half-precision heads + update epilogue (the arithmetic both kernels below share):
+// head pre-activations (fp32 accumulators) -> s, t, q with autocast's rounding points -> v- or x-update.
+// Returns the new field value; `ldterm` is the entry's contribution to the chain's log-Jacobian.
+template <typename HT, bool XUPD, bool FWD, bool NCP>
+__device__ __forceinline__ float hh_element(float as, float at, float aq, float bs, float bt, float bq,
+                                            float cs, float cq, float st, float eps, float a0, float b0,
+                                            float keep, float& ldterm) {
+  const float s = cs * rnd<HT>(fast_tanh_h(rnd<HT>(as + bs)));
+  const float t = rnd<HT>(st * rnd<HT>(at + bt));
+  const float q = cq * rnd<HT>(fast_tanh_h(rnd<HT>(aq + bq)));
+  if (!XUPD) {
+    const float lj = FWD ? (eps * s * 0.5f) : (-eps * s * 0.5f);
+    ldterm = lj;
+    const float es = fast_exp(lj), eq = fast_exp(eps * q);
+    const float f = b0 * eq + t;
+    return FWD ? (es * a0 - 0.5f * eps * f) : (es * (a0 + 0.5f * eps * f));
+  }
+  const float xj = a0, mb = 1.f - keep;
+  const float sj = FWD ? eps * s : -eps * s;
+  const float es = fast_exp(sj), eq = fast_exp(eps * q);
+  const float tr = b0 * eq + t;
+  float xp, l;
+  if (NCP) {
+    const float hx = xj * 0.5f;                    // |hx| <= pi/2 (x is wrapped)
+    const float ch = __cosf(hx), sh = es * __sinf(hx);
+    const float x1 = 2.f * fast_atan2_px(sh, ch);  // = 2 atan(tan(hx) es), no division
+    xp = FWD ? (x1 + eps * tr) : (x1 - es * eps * tr);
+    l = sj - __logf(ch * ch + sh * sh);            // log(es / (ch^2 + sh^2))
+  } else {
+    xp = FWD ? (xj * es + eps * tr) : (es * (xj - eps * tr));
+    l = sj;
+  }
+  ldterm = mb * l;
+  return fast_wrap_angle(keep * xj + mb * xp);
+}
+
+}  // namespace l2q

@@ -35,8 +35,10 @@ struct Tuning {
   int gemm_h_skinny = 1;      // wide-K fp32-operand input layer, N <= 256: streaming kernel (gemm_f16_skinny.hip);
                               // 0 off, 1 on (split count chosen), 2 / 4 / 8: that split count (A/B)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
-  int heads_h_stream = 0; // half-precision heads+update: 1 = weights-stationary stream kernel (measured slower at
-                          // cfg-3: 0.475 vs 0.420 ms, see u1_heads_stream_h_kernel), 0 = tile kernel
+  int heads_h_stream = 2; // half-precision heads+update: 2 = K-split stream kernel where its shape conditions hold
+                          // (heads_kstream_f16.hip: K = 256, long streams; cfg-3: 0.22 / 0.32 ms per v- / x-update
+                          // against the tile kernel's 0.36 / 0.42), 1 = round 3's weights-stationary stream kernel
+                          // (0.475 ms), 0 = tile kernel only, 3 = as 2 for streams of any length (tests)
   int heads_h_bm = 128;   // chains per workgroup of the half-precision heads+update kernel (64 | 128)
   int heads_h_order = 1;  // half-precision heads+update kernel: 0 m-tiles fastest, 1 n-tiles fastest (consecutive
                           // workgroups walk along the rows of the fp32 field: 0.50 -> 0.41 ms at cfg-3)

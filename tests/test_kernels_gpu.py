@@ -1086,7 +1086,52 @@ def test_u1_heads_update_h_stream_equals_tile(hd, dims):
                 dl = float((res[0][1] - res[1][1]).abs().max())
                 assert dl < (1e-5 * max(1.0, float(res[0][1].abs().max())) + 2 * ulp * 0.17) * n ** 0.5, dl
     finally:
-        native.set_tuning('heads_h_stream', 0)
+        native.set_tuning('heads_h_stream', 2)
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('dims', [(1024, 512, 3), (1100, 260, 3), (2085, 1028, 3), (37, 64, 3), (4100, 1028, 2)])
+def test_u1_heads_update_h_kstream_equals_tile(hd, dims):
+    """Tuning `heads_h_stream` = 2 (the default; heads_kstream_f16.hip: weights stationary, K = 256 split over
+    wavefront pairs; 3 = the same for streams of any length) against the tile kernel: the K sum is (k < 128) + (k >= 128) instead of one running accumulator, so
+    a head can differ by an fp32 rounding in front of its 16-bit rounding (rare 1-ulp16 flips); ragged chain
+    counts (clamped rows, masked stores) and entry counts that are not multiples of 64."""
+    from l2hmc import _ops as ops, native
+    m, n, kind = dims
+    k = 256
+    g = torch.Generator().manual_seed(31)
+    z = torch.randn(m, k, generator=g).to(hd).cuda()
+    heads = {}
+    for nm in 'stq':
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd).cuda()
+        b = (0.1 * torch.randn(n, generator=g)).cuda()
+        c = None if nm == 't' else (0.7 * torch.exp(0.3 * torch.randn(n, generator=g))).cuda()
+        heads[nm] = (w, b, c)
+    mask = (torch.rand(n, generator=g) < 0.5).float().cuda()
+    try:
+        for xupd in (False, True):
+            for forward in (True, False):
+                a0 = (torch.randn(m, n, generator=g) if not xupd
+                      else (2 * np.pi * torch.rand(m, n, generator=g) - np.pi)).cuda()
+                b0 = torch.randn(m, n, generator=g).cuda()
+                res = {}
+                for stream in (0, 2):
+                    assert native.set_tuning('heads_h_stream', kind if stream else 0) >= 0
+                    a = a0.clone()
+                    ld = ops.u1_heads_update_h_(z, heads, 0.9, a, b0, 0.17, forward,
+                                                mask=mask if xupd else None, complement=xupd and forward)
+                    res[stream] = (a, ld)
+                d = res[0][0] - res[2][0]
+                if xupd:
+                    d = torch.remainder(d + np.pi, 2 * np.pi) - np.pi
+                ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+                scale = max(1.0, float(res[0][0].abs().max()))
+                assert float(d.abs().max()) < 2 * ulp * scale, (xupd, forward, float(d.abs().max()))
+                assert float((d != 0).float().mean()) < 0.05, (xupd, forward, float((d != 0).float().mean()))
+                dl = float((res[0][1] - res[2][1]).abs().max())
+                assert dl < (1e-5 * max(1.0, float(res[0][1].abs().max())) + 2 * ulp * 0.17) * n ** 0.5, dl
+    finally:
+        native.set_tuning('heads_h_stream', 2)
 
 
 @pytest.mark.parametrize('cplx', [True, False])
