@@ -26,6 +26,11 @@
 //   * U1X (the xnet's [cos(m x), sin(m x)] input, dynamics.py:1161-1185): the cos slab and the sin slab of
 //     the same 32 links are ADJACENT in the K order, so the second request of x hits L2 (the K-ordered
 //     loader of gemm_nt_h_kernel read x from HBM twice: 805 MB per launch instead of 537).
+// Measured at cfg-3 (vnet / xnet input layer, kernel alone): 138 / 190 us (+ 7 us re-ordering W + 11 us split-K
+// reduce) against gemm_nt_h_kernel's 243 / 420; by parts (SK_SKIP builds): loop skeleton 21 / 45 us, W + MFMA 74, A +
+// MFMA 109, A + W without MFMA 105 (= the speed of a plain float4 read of A on this machine), everything 138.  A
+// variant with the A stream on two producer wavefronts and the MFMAs on four consumers (so that W requests do not
+// queue behind HBM misses in a wavefront's in-order vmcnt) was measured slower (149 / 194 us) and is not kept.
 // fp32 partial sums go to part[splits][M][N]; splitk_reduce_h_kernel (gemm_f16.hip) adds them in fixed
 // order and applies the epilogue with autocast's rounding points.  The accumulation order over K differs
 // from gemm_nt_h_kernel's (fp32 accumulators, both inside the 16-bit rounding that follows).

@@ -67,6 +67,47 @@ __global__ __launch_bounds__(kBlock) void u1_force_kernel(const T* __restrict__ 
   }
 }
 
+// The same force for fp32 lattices of 1024 .. 4096 sites with X % 4 == 0 (32 x 32, 64 x 64: BASELINE cfg-3), staged:
+// the chain's links come in as float4 (one pass over HBM, 32 KB into LDS), sin(theta) of every plaquette is formed
+// from LDS, and the force leaves as float4 rows.  Same expressions in the same order as u1_force_kernel (identical
+// bits); that kernel reads each link with four scalar loads per plaquette and writes scalars: 153 us per launch at
+// cfg-3 (537 MB, 3.5 TB/s).
+constexpr int kU1StageMax = 4096;
+__global__ __launch_bounds__(kBlock) void u1_force_staged_f32_kernel(const float* __restrict__ x, float beta,
+                                                                     float* __restrict__ force, float* v,
+                                                                     float coef, int Tn, int Xn) {
+  __shared__ __attribute__((aligned(16))) float xs[2 * kU1StageMax];
+  __shared__ __attribute__((aligned(16))) float sth[kU1StageMax];
+  const int c = blockIdx.x, V = Tn * Xn;
+  const long o = (long)c * 2 * V;
+  const float4* xc4 = reinterpret_cast<const float4*>(x + o);
+  for (int i = threadIdx.x; i < V / 2; i += kBlock) reinterpret_cast<float4*>(xs)[i] = xc4[i];
+  __syncthreads();
+  for (int s = threadIdx.x; s < V; s += kBlock) sth[s] = sinf(plaq_angle<float>(xs, s / Xn, s % Xn, Tn, Xn));
+  __syncthreads();
+  for (int i = threadIdx.x; i < V / 4; i += kBlock) {
+    const int s = 4 * i, t = s / Xn, xx = s - t * Xn;          // four sites of one row
+    const int tm = (t == 0) ? Tn - 1 : t - 1;
+    const float4 s0 = *reinterpret_cast<const float4*>(sth + s);
+    const float4 stm = *reinterpret_cast<const float4*>(sth + tm * Xn + xx);
+    const float sl = sth[t * Xn + (xx == 0 ? Xn - 1 : xx - 1)];
+    const float4 f0 = make_float4(beta * (s0.x - sl), beta * (s0.y - s0.x), beta * (s0.z - s0.y), beta * (s0.w - s0.z));
+    const float4 f1 = make_float4(beta * (-s0.x + stm.x), beta * (-s0.y + stm.y), beta * (-s0.z + stm.z),
+                                  beta * (-s0.w + stm.w));
+    if (force) {
+      *reinterpret_cast<float4*>(force + o + s) = f0;
+      *reinterpret_cast<float4*>(force + o + V + s) = f1;
+    }
+    if (v) {
+      float4 a = *reinterpret_cast<float4*>(v + o + s), b = *reinterpret_cast<float4*>(v + o + V + s);
+      a.x += coef * f0.x; a.y += coef * f0.y; a.z += coef * f0.z; a.w += coef * f0.w;
+      b.x += coef * f1.x; b.y += coef * f1.y; b.z += coef * f1.z; b.w += coef * f1.w;
+      *reinterpret_cast<float4*>(v + o + s) = a;
+      *reinterpret_cast<float4*>(v + o + V + s) = b;
+    }
+  }
+}
+
 template <typename T, bool FWD, bool NCP>
 __global__ __launch_bounds__(kBlock) void u1_x_update_kernel(T* x, const T* __restrict__ v,
                                                              const T* __restrict__ s,
@@ -274,6 +315,14 @@ int l2q_u1_force(const void* x, double beta, void* force, void* v, double coef, 
   L2Q_REQUIRE(x && (force || v), L2Q_EINVAL, "null pointer");
   L2Q_REQUIRE(nb > 0 && T_ > 0 && X_ > 0, L2Q_EINVAL, "non-positive size");
   hipStream_t st = (hipStream_t)stream;
+  const long V = (long)T_ * X_;
+  if (elem_bytes == 4 && X_ % 4 == 0 && V >= 1024 && V <= kU1StageMax &&
+      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(force) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(v) & 15) == 0) {
+    hipLaunchKernelGGL(u1_force_staged_f32_kernel, dim3(nb), dim3(kBlock), 0, st, (const float*)x, (float)beta,
+                       (float*)force, (float*)v, (float)coef, T_, X_);
+    return check_launch("l2q_u1_force");
+  }
   L2Q_DISPATCH_T(elem_bytes,
                  hipLaunchKernelGGL(u1_force_kernel<T>, dim3(nb), dim3(kBlock), 0, st, (const T*)x,
                                     (T)beta, (T*)force, (T*)v, (T)coef, T_, X_));

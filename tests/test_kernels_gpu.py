@@ -233,6 +233,25 @@ def test_gemm(ops, dtype, shape):
     assert err(host(got), a.astype(np.float64) @ w.astype(np.float64).T) < tol * 10
 
 
+@pytest.mark.parametrize('L', [(32, 32), (64, 64), (16, 64), (64, 36), (24, 44)])
+def test_u1_force_staged_f32_vs_oracle(ops, L):
+    """fp32 lattices of 1024 .. 4096 sites with X % 4 == 0 take the LDS-staged force kernel (float4 rows in and
+    out); (24, 44) stays on the scalar kernel.  Force and the fused kick v += coef F against the oracle."""
+    from oracle import u1 as ou1
+    rng = np.random.default_rng(5)
+    nb = 7
+    xh = rng.uniform(-np.pi, np.pi, size=(nb, 2, *L))
+    vh = rng.normal(size=(nb, 2, *L))
+    want = ou1.grad_action(xh, 3.7).reshape(nb, -1)
+    x = torch.from_numpy(xh).float().cuda()
+    got = ops.u1_force(x, 3.7, L).reshape(nb, -1)
+    assert got.dtype == torch.float32
+    assert err(host(got), want) < 2e-5
+    v = torch.from_numpy(vh).float().cuda().reshape(nb, -1).clone()
+    ops.u1_force_kick_(x, 3.7, -0.07, v, L)
+    assert err(host(v), vh.reshape(nb, -1) - 0.07 * want) < 2e-5
+
+
 @pytest.mark.parametrize('name', ['u1_conv', 'u1_c1'])
 def test_u1_ops_golden(ops, golden, name):
     g = golden(name)
