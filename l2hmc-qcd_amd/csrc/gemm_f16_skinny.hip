@@ -23,9 +23,11 @@
 //     (16 row pieces of 64 B per instruction) cost 125 us for W alone against 87 slab-major;
 //   * split-K with the split index = blockIdx % splits: one XCD sees one K-range of W (<= 3 MB at cfg-3,
 //     resident in its 4 MB L2) and every A tile once;
-//   * U1X (the xnet's [cos(m x), sin(m x)] input, dynamics.py:1161-1185): the cos slab and the sin slab of
-//     the same 32 links are ADJACENT in the K order, so the second request of x hits L2 (the K-ordered
-//     loader of gemm_nt_h_kernel read x from HBM twice: 805 MB per launch instead of 537).
+//   * U1X (the xnet's [cos(m x), sin(m x)] input, dynamics.py:1161-1185): ONE request of a slab of links makes two
+//     LDS tiles, cos and sin, multiplied by the W slabs K columns apart (the K-ordered loader of gemm_nt_h_kernel
+//     read x from HBM twice: 805 MB per launch instead of 537; so did a first version of this kernel with the cos
+//     and sin slabs adjacent in the K order -- 886 MB of fabric reads in the PMC pass: two slabs later x has left
+//     the 4 MB L2 of an XCD that streams 64 workgroups x 32 KB per slab).
 // Measured at cfg-3 (vnet / xnet input layer, kernel alone): 138 / 190 us (+ 7 us re-ordering W + 11 us split-K
 // reduce) against gemm_nt_h_kernel's 243 / 420; by parts (SK_SKIP builds): loop skeleton 21 / 45 us, W + MFMA 74, A +
 // MFMA 109, A + W without MFMA 105 (= the speed of a plain float4 read of A on this machine), everything 138.  A
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
   typedef HT hv4 __attribute__((ext_vector_type(4)));
   constexpr int NT = kSkNT, BM = kSkBM;
   constexpr int AR = NT / 32, AP = BM / AR;         // A slab: 32 lanes x 16 B per row, AP = 8 passes of AR = 8 rows
-  __shared__ __attribute__((aligned(16))) HT As[2][BM][kSkLD];
+  constexpr int NTL = U1X ? 2 : 1;                  // LDS tiles one A slab turns into (U1X: cos and sin of the links)
+  __shared__ __attribute__((aligned(16))) HT As[2][NTL][BM][kSkLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
   const int wn = wave * 64;
@@ -88,9 +91,12 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
   const long z = blockIdx.x % S, mt = blockIdx.x / S;
   const long m0 = mt * BM;
   const long q1 = a.K / ((long)kSkBKA * S), q2 = a.K2 / ((long)kSkBKA * S);  // this split's A slabs per segment
-  const long nq1 = (U1X ? 2 : 1) * q1, nq = nq1 + q2;
+  const long nq = q1 + q2;
+  // W slabs (32 columns) of this split in the order they are multiplied: segment-1 slab Q contributes NTL x 4 (U1X:
+  // its four cos slabs, then the four sin slabs K columns further), segment-2 slabs 4 each
+  const long nv1 = (long)NTL * kSkSub * q1, nv = nv1 + kSkSub * q2;
   const HT* Wp = (const HT*)a.Wp;
-  const long kw = (U1X ? 2 : 1) * a.K;             // columns of W in front of W2 in the packed copy
+  const long kw = (long)NTL * a.K;                  // columns of W in front of W2 in the packed copy
 
   const int ac = (tid & 31) * 4;
   int wrow[4];
@@ -104,18 +110,11 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
   vec_t rw[2][4];
   float4 rk[2];
 
-  // A slab Q of this split: segment 1 (Q < nq1; U1X: raw slab Q >> 1 as cos (even) / sin (odd)), then segment 2.
-  // Returns through the references where its columns start in A / A2 and in [W | W2].
-  auto locate = [&](long Q, bool& s1, long& acol, long& wcol) {
-    if (Q >= nq) Q = nq - 1;                       // past the end: the last slab again (nobody reads it)
-    s1 = Q < nq1;
-    const long r = s1 ? (U1X ? (Q >> 1) : Q) : Q - nq1;
-    acol = ((s1 ? q1 : q2) * z + r) * kSkBKA;
-    wcol = s1 ? acol + ((U1X && (Q & 1)) ? a.K : 0) : kw + acol;
-  };
+  // A slab Q of this split: segment 1 (Q < q1), then segment 2
   auto fetch_a = [&](int e, long Q) {
-    bool s1; long acol, wcol;
-    locate(Q, s1, acol, wcol);
+    if (Q >= nq) Q = nq - 1;                       // past the end: the last slab again (nobody reads it)
+    const bool s1 = Q < q1;
+    const long acol = s1 ? (q1 * z + Q) * kSkBKA : (q2 * z + (Q - q1)) * kSkBKA;
     const float* Ab = s1 ? a.A : a.A2;
     const long lda = s1 ? a.K : a.K2;
 #pragma unroll
@@ -127,11 +126,18 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
     }
     if (U1X) rk[e] = *reinterpret_cast<const float4*>(a.mask + (s1 ? acol : 0) + ac);
   };
-  // W slab v = 4 Q + s as MFMA operands: lane (row wn + 16 j + l15, k-group grp) holds k = 8 grp .. 8 grp + 7
+  // W slab v as MFMA operands: lane (row wn + 16 j + l15, k-group grp) holds k = 8 grp .. 8 grp + 7
   auto fetch_w = [&](int e, long v) {
-    bool s1; long acol, wcol;
-    locate(v >> 2, s1, acol, wcol);
-    const HT* src = Wp + (wcol / kSkBK + (v & 3)) * ((long)a.N * kSkBK);
+    if (v >= nv) v = nv - 1;
+    long wcol;                                     // first column of the slab in [W | W2]
+    if (v < nv1) {
+      const long Q = v / (NTL * kSkSub), r = v % (NTL * kSkSub);   // r >= 4: the sin slabs
+      wcol = (q1 * z + Q) * kSkBKA + (r & 3) * kSkBK + (r >> 2) * a.K;
+    } else {
+      const long w = v - nv1;
+      wcol = kw + (q2 * z + (w >> 2)) * kSkBKA + (w & 3) * kSkBK;
+    }
+    const HT* src = Wp + (wcol / kSkBK) * ((long)a.N * kSkBK);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (SK_SKIP & 2) {
@@ -143,9 +149,10 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
     }
   };
 
-  // `sin_slab`: compile-time parity of the slab inside segment 1 of a U1X launch
-  auto store_a = [&](int e, long Q, int buf, bool sin_slab) {
-    const bool trig = U1X && Q < nq1;                              // wavefront-uniform
+  // registers of slab Q -> LDS buffer `buf`, rounded to 16 bit; U1X segment 1: tile 0 = cos(keep x), tile 1 = sin(keep x)
+  // from ONE request of x
+  auto store_a = [&](int e, long Q, int buf) {
+    const bool trig = U1X && Q < q1;                               // wavefront-uniform
     float keep[4] = {1.f, 1.f, 1.f, 1.f};
     if (U1X) {
       const float m[4] = {rk[e].x, rk[e].y, rk[e].z, rk[e].w};
@@ -154,13 +161,20 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
     }
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      float f[4] = {ra[e][p].x, ra[e][p].y, ra[e][p].z, ra[e][p].w};
+      const float f[4] = {ra[e][p].x, ra[e][p].y, ra[e][p].z, ra[e][p].w};
+      const int row = (tid >> 5) + p * AR;
       if (trig) {
+        float c[4], sn[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = sin_slab ? __sinf(keep[j] * f[j]) : __cosf(keep[j] * f[j]);
+        for (int j = 0; j < 4; ++j) { c[j] = __cosf(keep[j] * f[j]); sn[j] = __sinf(keep[j] * f[j]); }
+        const hv4 hc = {(HT)c[0], (HT)c[1], (HT)c[2], (HT)c[3]};
+        const hv4 hs = {(HT)sn[0], (HT)sn[1], (HT)sn[2], (HT)sn[3]};
+        *reinterpret_cast<hv4*>(&As[buf][0][row][ac]) = hc;
+        *reinterpret_cast<hv4*>(&As[buf][NTL - 1][row][ac]) = hs;
+      } else {
+        const hv4 h = {(HT)f[0], (HT)f[1], (HT)f[2], (HT)f[3]};
+        *reinterpret_cast<hv4*>(&As[buf][0][row][ac]) = h;
       }
-      const hv4 h = {(HT)f[0], (HT)f[1], (HT)f[2], (HT)f[3]};
-      *reinterpret_cast<hv4*>(&As[buf][(tid >> 5) + p * AR][ac]) = h;
     }
   };
 
@@ -172,36 +186,42 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4f32){0.f, 0.f, 0.f, 0.f};
 
-  auto mfma = [&](int buf, int sub, int e) {
+  auto mfma = [&](int buf, int tile, int sub, int e) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const vec_t fa = *reinterpret_cast<const vec_t*>(&As[buf][16 * i + l15][kSkBK * sub + 8 * grp]);
+      const vec_t fa = *reinterpret_cast<const vec_t*>(&As[buf][tile][16 * i + l15][kSkBK * sub + 8 * grp]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = MfmaH<HT>::run(rw[e][j], fa, acc[i][j]);
     }
   };
 
   // A ring, entry Q & 1: slab Q until it has been stored to LDS buffer Q & 1 (during slab Q - 1), then slab
-  // Q + 2.  W ring, entry v & 1: W slab v until it has been multiplied, then v + 2.  In segment 1 of a U1X launch
-  // slab Q is the sin slab iff Q is odd.
+  // Q + 2.  W ring, entry v & 1: W slab v until it has been multiplied, then v + 2 (every A slab takes an even
+  // number of W slabs, so the entry of its sub-slab `sub` is sub & 1).
   fetch_a(0, 0);
   fetch_a(1, 1);
   fetch_w(0, 0);
   fetch_w(1, 1);
-  store_a(0, 0, 0, false);
+  store_a(0, 0, 0);
   fetch_a(0, 2);
   __syncthreads();
+  long v = 0;                                       // next W slab to multiply
   for (long qb = 0; qb < nq; qb += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const long Q = qb + u;
+      const int ntile = (U1X && Q < q1) ? 2 : 1;    // wavefront-uniform
+      if (Q < nq) {
+        for (int tile = 0; tile < ntile; ++tile) {
 #pragma unroll
-      for (int sub = 0; sub < kSkSub; ++sub) {
-        const long v = kSkSub * Q + sub;
-        if (Q < nq && !(SK_SKIP & 1)) mfma(u, sub, sub & 1);
-        fetch_w(sub & 1, v + 2);
+          for (int sub = 0; sub < kSkSub; ++sub) {
+            if (!(SK_SKIP & 1)) mfma(u, U1X ? tile : 0, sub, sub & 1);
+            fetch_w(sub & 1, v + 2);
+            ++v;
+          }
+        }
       }
-      store_a(u ^ 1, Q + 1, u ^ 1, u == 0);
+      store_a(u ^ 1, Q + 1, u ^ 1);
       fetch_a(u ^ 1, Q + 3);
       __syncthreads();
     }

@@ -38,6 +38,10 @@ ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'gemm_sliced_kernel': 'l2q_gemm_sliced_f64',
     'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_expm_mul_kernel<true, false>': 'l2q_su3_expm_mul2',
     'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
+    # cfg-3 (tools/kprof_u1_cfg3.py)
+    'u1_heads_kstream_h_kernel<_Float16, false': 'l2q_u1_heads_update_h:v', 'u1_heads_kstream_h_kernel<_Float16, true': 'l2q_u1_heads_update_h:x',
+    'gemm_skinny_h_kernel<_Float16, false': 'l2q_gemm_h:input', 'gemm_skinny_h_kernel<_Float16, true': 'l2q_gemm_h_u1x',
+    'u1_force_staged_f32_kernel': 'l2q_u1_force',
 }
 
 
@@ -51,8 +55,9 @@ def main():
     for f in files:
         for r in csv.DictReader(open(f)):
             agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
-    lines = ['# rocprofv3 --pmc passes (separate runs per counter group) of tools/kprof.py:',
-             f'# SU(3) {"x".join(map(str, LAT))}, {NB} chains, fp64.  FETCH_SIZE / WRITE_SIZE in KiB as reported; on gfx950',
+    desc = os.environ.get('L2Q_KPROF_DESC', f'SU(3) {"x".join(map(str, LAT))}, {NB} chains, fp64')
+    lines = [f'# rocprofv3 --pmc passes (separate runs per counter group) of {os.environ.get("L2Q_KPROF_SCRIPT", "tools/kprof.py")}:',
+             f'# {desc}.  FETCH_SIZE / WRITE_SIZE in KiB as reported; on gfx950',
              '# FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM',
              '# section) -> read bytes = 2 * FETCH_SIZE * 1024.  Means over the launches of a run.', '']
     traffic = {}
