@@ -35,15 +35,13 @@ __device__ __forceinline__ float fast_atan2_px(float y, float x) {
   return copysignf(r, y);
 }
 
-// ((x + pi) mod 2 pi) - pi for |x| of a few pi (a wrapped angle plus one leapfrog increment): floor form instead of
-// the exact fmodf loop of wrap_angle<float> (u1_math.hpp); differs from it by the rounding of one fp32 fma (~5e-7).
+// ((x + pi) mod 2 pi) - pi for |x| of a few pi (a wrapped angle plus one leapfrog increment) on v_fract_f32: the
+// result is in [-pi, pi) by construction (fract < 1), no fix-up compares; differs from the exact fmodf loop of
+// wrap_angle<float> (u1_math.hpp) by the rounding of one fp32 multiply (~5e-7).
 __device__ __forceinline__ float fast_wrap_angle(float x) {
   const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
-  const float t = x + pi;
-  float r = fmaf(-two_pi, floorf(t * 0.15915494309189535f), t);
-  r = r < 0.f ? r + two_pi : r;
-  r = r >= two_pi ? r - two_pi : r;
-  return r - pi;
+  const float y = (x + pi) * 0.15915494309189535f;
+  return fmaf(two_pi, __builtin_amdgcn_fractf(y), -pi);
 }
 
 // timing-only builds of u1_heads_update_h_kernel (tools/ab_build.sh -DL2Q_HH_SKIP=n): 1 no K-loop,

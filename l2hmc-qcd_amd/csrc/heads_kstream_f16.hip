@@ -170,8 +170,8 @@ __global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs
         vec_t fa[2];
         const int chunk = (4 * (4 * kh + kk) + grp) ^ fsw;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          fa[i] = *reinterpret_cast<const vec_t*>(sb + (frow + 16 * i) * ROWB + (chunk << 4));
+        for (int i = 0; i < 2; ++i)      // accumulator i = row tile i ^ kh: acc[h][0] is the tile this wavefront finishes
+          fa[i] = *reinterpret_cast<const vec_t*>(sb + (frow + 16 * (i ^ kh)) * ROWB + (chunk << 4));
 #pragma unroll
         for (int h = 0; h < 3; ++h)
 #pragma unroll
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs
       const bool ok = ncok && m < mend;
       const float4 ta = av[slot], tb = bv[slot];
       const float a4[4] = {ta.x, ta.y, ta.z, ta.w}, b4[4] = {tb.x, tb.y, tb.z, tb.w};
+      const float okf = ok ? 1.f : 0.f;
       float out[4], ld = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs
           out[r] = hh_element<HT, XUPD, FWD, NCP>(pre[0][r], pre[1][r], pre[2][r], bs[r], bt[r], bq[r], cs[r],
                                                   cq[r], a.st, eps, a4[r], b4[r], keep[r], ldt);
         }
-        if (ok) ld += ldt;
+        ld = fmaf(okf, ldt, ld);
       }
       if ((L2Q_HH_SKIP & 4) && out[0] + out[1] + out[2] + out[3] != 12345.678f) {
       } else if (ok) *reinterpret_cast<float4*>(pa + m * (long)a.N + nb4) = make_float4(out[0], out[1], out[2], out[3]);
@@ -215,9 +216,8 @@ __global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs
       // partial sums of the other row tile -> partner (cg, 1 - kh); this wavefront's own tile is carried
 #pragma unroll
       for (int h = 0; h < 3; ++h) {
-        const v4f32 p = kh ? acc[h][0] : acc[h][1];
-        xb[s & 1][wave][h][lane] = make_float4(p[0], p[1], p[2], p[3]);
-        mine[h] = kh ? acc[h][1] : acc[h][0];
+        xb[s & 1][wave][h][lane] = make_float4(acc[h][1][0], acc[h][1][1], acc[h][1][2], acc[h][1][3]);
+        mine[h] = acc[h][0];
       }
     }
   };
