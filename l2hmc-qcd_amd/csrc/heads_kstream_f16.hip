@@ -28,22 +28,28 @@
 
 namespace l2q {
 
-constexpr int kKsRows = 32, kKsK = 256, kKsRowB = kKsK * 2, kKsStage = kKsRows * kKsRowB, kKsNT = 512;
+#ifndef KS_NCG
+#define KS_NCG 4           // column groups of 16 entries per workgroup (4: 8 wavefronts, one workgroup per CU; 2: 4
+                           // wavefronts, two workgroups per CU with their own barriers -- measured slower at cfg-3,
+                           // 0.259 / 0.347 ms against 0.216 / 0.323: 128-byte field rows and twice the Z staging)
+#endif
+constexpr int kKsNCG = KS_NCG, kKsCols = 16 * kKsNCG, kKsWaves = 2 * kKsNCG;
+constexpr int kKsRows = 32, kKsK = 256, kKsRowB = kKsK * 2, kKsStage = kKsRows * kKsRowB, kKsNT = 64 * kKsWaves;
 
 template <typename HT, bool XUPD, bool FWD, bool NCP>
-__global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs a, int swz, int rows_per_wg) {
+__global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel(HeadsHArgs a, int swz, int rows_per_wg) {
   using vec_t = typename MfmaH<HT>::vec_t;
   constexpr int ROWS = kKsRows, ROWB = kKsRowB, STAGE = kKsStage;
   __shared__ __attribute__((aligned(1024))) char zs[2 * STAGE];
-  __shared__ __attribute__((aligned(16))) float4 xb[2][8][3][64];   // partial sums for the partner wavefront
-  __shared__ float red[2][8][16];
+  __shared__ __attribute__((aligned(16))) float4 xb[2][kKsWaves][3][64];   // partial sums for the partner wavefront
+  __shared__ float red[2][kKsWaves][16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wave & 3, kh = wave >> 2;
+  const int cg = wave % kKsNCG, kh = wave / kKsNCG;
   const int l15 = lane & 15, grp = lane >> 4;
-  const long ntiles = (a.N + 63) / 64;
+  const long ntiles = (a.N + kKsCols - 1) / kKsCols;
   const long w = xcd_swizzle(blockIdx.x, gridDim.x, swz);
-  const long n0 = (w % ntiles) * 64;              // n-tiles fastest: neighbours walk the same rows
+  const long n0 = (w % ntiles) * kKsCols;         // n-tiles fastest: neighbours walk the same rows
   const long mbeg = (w / ntiles) * rows_per_wg;
   long mend = mbeg + rows_per_wg;
   if (mend > a.M) mend = a.M;
@@ -92,20 +98,32 @@ __global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs
   // t >> 4.  Chunk c of row r sits at slot c ^ (r & 15) of its row: the ds_read_b128 fragments (16 rows, one
   // chunk index) touch 16 different bank groups.
   const char* zbase = reinterpret_cast<const char*>(a.Z);
+  constexpr int ZP = ROWS / (kKsNT / 16);          // passes of NT / 16 rows (1 | 2)
   const int zrow = tid >> 4, zc = 2 * (tid & 15);
-  uint4 zr0, zr1;                                 // (two scalars: hipcc moved a `uint4 zr[2]` to LDS and waited
-                                                  // vmcnt(0) behind every request)
+  uint4 zr0, zr1, zr2, zr3;                       // (scalars: hipcc moved a `uint4 zr[2]` to LDS and waited vmcnt(0)
+                                                  // behind every request)
   auto zfetch = [&](int s) {
     long m = mbeg + (long)s * ROWS + zrow;
     if (m >= a.M) m = a.M - 1;                    // rows past the end re-read a valid one (never stored)
     const char* p = zbase + m * (long)ROWB + (zc << 4);
     zr0 = *reinterpret_cast<const uint4*>(p);
     zr1 = *reinterpret_cast<const uint4*>(p + 16);
+    if (ZP == 2) {
+      long m2 = mbeg + (long)s * ROWS + zrow + 16;
+      if (m2 >= a.M) m2 = a.M - 1;
+      const char* p2 = zbase + m2 * (long)ROWB + (zc << 4);
+      zr2 = *reinterpret_cast<const uint4*>(p2);
+      zr3 = *reinterpret_cast<const uint4*>(p2 + 16);
+    }
   };
   auto zstore = [&](int st) {
     char* row = zs + st * STAGE + zrow * ROWB;
     *reinterpret_cast<uint4*>(row + ((zc ^ (zrow & 15)) << 4)) = zr0;
     *reinterpret_cast<uint4*>(row + (((zc + 1) ^ (zrow & 15)) << 4)) = zr1;
+    if (ZP == 2) {                                // row zrow + 16: the same swizzle key
+      *reinterpret_cast<uint4*>(row + 16 * ROWB + ((zc ^ (zrow & 15)) << 4)) = zr2;
+      *reinterpret_cast<uint4*>(row + 16 * ROWB + (((zc + 1) ^ (zrow & 15)) << 4)) = zr3;
+    }
   };
 
   // ---- field operands of the row tile this wavefront finishes: chain 16 kh + l15 of the step, entries nb4 .. + 3
@@ -140,10 +158,10 @@ __global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs
     if (tid < ROWS) {
       const long m = mbeg + (long)q * ROWS + tid;
       if (m < mend) {
-        const int pr = q & 1, hw = 4 * (tid >> 4), rr = tid & 15;
-        const double x = ((double)red[pr][hw][rr] + (double)red[pr][hw + 1][rr]) +
-                         ((double)red[pr][hw + 2][rr] + (double)red[pr][hw + 3][rr]);
-        a.logdet_part[m * a.ncols_part + (n0 >> 6)] = x;
+        const int pr = q & 1, hw = kKsNCG * (tid >> 4), rr = tid & 15;
+        double x = (double)red[pr][hw][rr] + (double)red[pr][hw + 1][rr];
+        if (kKsNCG == 4) x += (double)red[pr][hw + 2][rr] + (double)red[pr][hw + 3][rr];
+        a.logdet_part[m * a.ncols_part + n0 / kKsCols] = x;
       }
     }
   };
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(kKsNT, 1) void u1_heads_kstream_h_kernel(HeadsHArgs
       float pre[3][4];
 #pragma unroll
       for (int h = 0; h < 3; ++h) {
-        const float4 q = xb[(s - 1) & 1][wave ^ 4][h][lane];
+        const float4 q = xb[(s - 1) & 1][wave ^ kKsNCG][h][lane];
         // (k < 128) + (k >= 128): fp32 addition commutes exactly, so both wavefronts of a pair form the same sum
 #pragma unroll
         for (int r = 0; r < 4; ++r) pre[h][r] = mine[h][r] + (r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w);
@@ -266,14 +284,15 @@ bool heads_h_kstream_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, in
   // pipeline fill are paid per workgroup)
   if (a.K != kKsK || (a.N & 3) != 0) return false;
   if (!any_length && (a.M < 1024 || (long)a.M * cdiv(a.N, 64) < 65536)) return false;
+  const long slots = 256L * (8 / kKsWaves);       // workgroups the chip runs at a time
   if (!al16(a.a) || !al16(a.bsrc) || !al16(a.b[0]) || !al16(a.b[1]) || !al16(a.b[2]) || !al16(a.cs) ||
       !al16(a.cq) || (xupd && !al16(a.mask)) || !al16(a.Z) || !al16(a.W[0]) || !al16(a.W[1]) || !al16(a.W[2]))
     return false;
-  const long nt = cdiv(a.N, 64);
+  const long nt = cdiv(a.N, kKsCols);
   a.ncols_part = (int)nt;                         // one partial per (chain, column block), each written exactly once
   // one workgroup per CU at a time (8 wavefronts, > 128 VGPRs): rounds of 256
-  long msplit = cdiv(256, nt);
-  if (nt < 256 && 256 % nt == 0) msplit = 256 / nt;
+  long msplit = cdiv(slots, nt);
+  if (nt < slots && slots % nt == 0) msplit = slots / nt;
   const long maxsplit = cdiv(a.M, 4 * kKsRows);
   if (msplit > maxsplit) msplit = maxsplit;
   if (msplit < 1) msplit = 1;
