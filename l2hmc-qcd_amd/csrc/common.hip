@@ -233,6 +233,7 @@ int l2q_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "conv_patch")) { slot = &t.conv_patch; ok = value >= 0 && value <= 2; }
   else if (!strcmp(key, "gemm_h_dma")) { slot = &t.gemm_h_dma; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "gemm_h_skinny")) { slot = &t.gemm_h_skinny; ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 8; }
+  else if (!strcmp(key, "gemm_h_small")) { slot = &t.gemm_h_small; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "gemm_h_patch")) { slot = &t.gemm_h_patch; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "heads_h_bm")) { slot = &t.heads_h_bm; ok = value == 64 || value == 128; }
   else if (!strcmp(key, "heads_h_stream")) { slot = &t.heads_h_stream; ok = value >= 0 && value <= 3; }

@@ -1128,6 +1128,10 @@ __global__ __launch_bounds__(kBlock) void nchw_to_nhwc_pad_h_kernel(const float*
   for (int c = 0; c < CP; ++c) dst[c] = c < C ? (HT)src[c * HW] : (HT)0.f;
 }
 
+// gemm_f16_small.hip: K, N <= 256 on many rows; false -> not its case
+template <typename HT>
+bool gemm_h_small_launch(const void* A, const void* W, int M, int N, long K, const EpiH& epi, void* C, int c_is_f32,
+                         hipStream_t st);
 // gemm_f16_dma.hip: 256 x 256 LDS-DMA kernel when the shape fits it; false -> the kernels here
 template <typename HT>
 bool gemm_h_dma_launch(const void* A, const void* W, int M, int N, long K, const EpiH& epi, void* C,
@@ -1303,6 +1307,13 @@ int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M,
   L2Q_REQUIRE(coeff == nullptr || c_is_f32, L2Q_EINVAL, "exp(coeff) scaling needs an fp32 output");
   const EpiH epi{bias, bias2, coeff, scale, act};
   const hipStream_t st = (hipStream_t)stream;
+  // hidden layers on many chains (K, N <= 256): one pass, all N columns per workgroup (gemm_f16_small.hip)
+  if (tuning().gemm_h_small && !a_is_f32 && K2 == 0) {
+    const bool done = half_type == L2Q_HALF_F16
+                          ? gemm_h_small_launch<_Float16>(A, W, M, N, K, epi, C, c_is_f32, st)
+                          : gemm_h_small_launch<__bf16>(A, W, M, N, K, epi, C, c_is_f32, st);
+    if (done) return check_launch("l2q_gemm_h");
+  }
   // big 16-bit x 16-bit layers: 256 x 256 tiles on LDS-DMA staging (gemm_f16_dma.hip)
   if (tuning().gemm_h_dma && !a_is_f32 && K2 == 0) {
     const bool done = half_type == L2Q_HALF_F16

@@ -34,6 +34,7 @@ struct Tuning {
   int gemm_h_dma = 1;         // big half GEMMs (M, N % 256 == 0, K % 64 == 0): LDS-DMA 256 x 256 kernel (0: off)
   int gemm_h_skinny = 1;      // wide-K fp32-operand input layer, N <= 256: streaming kernel (gemm_f16_skinny.hip);
                               // 0 off, 1 on (split count chosen), 2 / 4 / 8: that split count (A/B)
+  int gemm_h_small = 1;       // 16-bit layers with K, N <= 256 on >= 2048 rows: one-pass kernel (gemm_f16_small.hip; 0: off)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
   int heads_h_stream = 2; // half-precision heads+update: 2 = K-split stream kernel where its shape conditions hold
                           // (heads_kstream_f16.hip: K = 256, long streams; cfg-3: 0.22 / 0.32 ms per v- / x-update

@@ -952,6 +952,42 @@ def test_gemm_h_u1x(hd, dims):
 
 
 @pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2048, 256, 256), (2100, 200, 128), (4096, 16, 32), (2050, 250, 96), (8192, 64, 224)])
+def test_gemm_h_small(hd, shape):
+    """The one-pass kernel of the hidden layers (gemm_f16_small.hip: 16-bit activations, K, N <= 256, >= 2048 rows)
+    against the emulator's restatement and against the tile kernel (tuning gemm_h_small = 0): ragged rows, N that
+    is not a multiple of 64 or of 4, every epilogue form."""
+    import emu_native
+    from l2hmc import _ops as ops, native
+    m, n, k = shape
+    g = torch.Generator().manual_seed(43)
+    a = torch.randn(m, k, generator=g).to(hd)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd)
+    b = torch.randn(n, generator=g).to(hd).float()
+    co = 0.3 * torch.randn(n, generator=g)
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    try:
+        for act, coeff, odt in ((None, None, hd), ('tanh', co, torch.float32), ('leaky_relu', None, hd),
+                                ('swish', None, torch.float32)):
+            native.set_tuning('gemm_h_small', 1)
+            got = ops.gemm_h(a.cuda(), w.cuda(), b.cuda(), coeff=None if coeff is None else coeff.cuda(),
+                             scale=0.7, act=act, out_dtype=odt)
+            native.set_tuning('gemm_h_small', 0)
+            old = ops.gemm_h(a.cuda(), w.cuda(), b.cuda(), coeff=None if coeff is None else coeff.cuda(),
+                             scale=0.7, act=act, out_dtype=odt)
+            want = torch.empty(m, n, dtype=odt)
+            emu_native.l2q_gemm_h(ops.HALF_TYPES[hd], a, 0, w, m, n, k, None, None, 0, b, None, coeff,
+                                  0.7, N_ACT[act], want, int(odt == torch.float32), None, 0)
+            for other in (want, old.cpu()):
+                d = (got.cpu().float() - other.float()).abs()
+                tol = 2.5 * ulp * other.float().abs().clamp(min=1.0)
+                assert bool((d <= tol).all()), (act, shape, float((d / tol).max()))
+                assert float((d > 0).float().mean()) < 0.2, (act, shape)
+    finally:
+        native.set_tuning('gemm_h_small', 1)
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(1100, 256, 2048, 2048, 1), (1024, 192, 4096, 0, 4), (1030, 64, 3072, 1024, 1),
                                    (2048, 256, 2048, 2048, 8), (1500, 250, 2048, 2048, 2)])
 def test_gemm_h_skinny(hd, shape):
