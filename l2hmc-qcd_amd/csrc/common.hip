@@ -240,6 +240,7 @@ int l2q_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "heads_h_order")) { slot = &t.heads_h_order; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "u1_fused_ch")) { slot = &t.u1_fused_ch; ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 8; }
   else if (!strcmp(key, "heads_dma")) { slot = &t.heads_dma; ok = value == 0 || value == 1; }
+  else if (!strcmp(key, "force_tsplit")) { slot = &t.force_tsplit; ok = value >= 0 && value <= 64; }
   else if (!strcmp(key, "force_stagger")) { slot = &t.force_stagger; ok = value >= 0 && value <= 64; }
   else if (!strcmp(key, "heads_stagger")) { slot = &t.heads_stagger; ok = value >= 0 && value <= 64; }
   if (!slot || !ok) { set_error("l2q_set_tuning: bad key/value %s=%d", key, value); return L2Q_EINVAL; }

@@ -18,6 +18,7 @@ struct Tuning {
                           // with the six planes split over wavefronts (su3_plaq_nu.hip; measured slower),
                           // 1: L2 t-sweep, 0: flat
   int heads_dma = 1;      // heads + v-update: LDS-DMA staged kernel (0: register-staged kernel of round 1)
+  int force_tsplit = 0;   // su3_force_link.hip: 0 = t-range chunks chosen by the launcher, n = that many chunks per chain
   int force_stagger = 0;  // x ~2k cycles initial delay of the 2nd resident workgroup set (su3_force_link.hip)
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
   int force_tile = 5;     // 6: as 5 with two adjacent x-planes per workgroup (su3_force_pair.hip: half the x-halo),

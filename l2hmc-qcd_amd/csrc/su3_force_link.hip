@@ -428,6 +428,7 @@ void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef
   const int Vs = d.X * d.Y * d.Z;
   const int nsb = Vs / kRS;
   int tsplit = (int)cdiv(1024, (long)nb * nsb);        // >= ~2 resident rounds of 2 x 256 workgroups
+  if (tuning().force_tsplit > 0) tsplit = tuning().force_tsplit;
   if (tsplit > d.T) tsplit = d.T;
   if (tsplit < 1) tsplit = 1;
   const int tlen = (int)cdiv(d.T, tsplit);
