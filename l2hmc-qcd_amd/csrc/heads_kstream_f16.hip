@@ -1,6 +1,6 @@
 // heads_kstream_f16.hip -- the three 16-bit heads of a U(1) LeapfrogLayer + the sub-update that consumes them
 // (the operation of u1_heads_update_h_kernel, gemm_f16.hip) as a STREAM over the chains with the weights
-// stationary in registers and the K dimension split over wavefront pairs.  K = units[-1] = 256.
+// stationary in registers and the K dimension split over wavefront pairs.  K = units[-1] = 256, 128 or 64.
 //
 // Why: the tile kernel stages 160 KB of Z and W through registers into LDS for every 128 x 64 tile (1.3 GB of
 // L2 -> LDS traffic per launch against 805 MB of HBM traffic) and runs at 0.25 of the HBM roofline; round 3's
@@ -34,12 +34,14 @@ namespace l2q {
                            // 0.259 / 0.347 ms against 0.216 / 0.323: 128-byte field rows and twice the Z staging)
 #endif
 constexpr int kKsNCG = KS_NCG, kKsCols = 16 * kKsNCG, kKsWaves = 2 * kKsNCG;
-constexpr int kKsRows = 32, kKsK = 256, kKsRowB = kKsK * 2, kKsStage = kKsRows * kKsRowB, kKsNT = 64 * kKsWaves;
+constexpr int kKsRows = 32, kKsNT = 64 * kKsWaves;
 
-template <typename HT, bool XUPD, bool FWD, bool NCP>
+// KH: MFMA k-steps (of 32) per wavefront = K / 64: K = 256, 128, 64
+template <typename HT, bool XUPD, bool FWD, bool NCP, int KH>
 __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel(HeadsHArgs a, int swz, int rows_per_wg) {
   using vec_t = typename MfmaH<HT>::vec_t;
-  constexpr int ROWS = kKsRows, ROWB = kKsRowB, STAGE = kKsStage;
+  constexpr int KK = 64 * KH;                      // K
+  constexpr int ROWS = kKsRows, ROWB = KK * 2, STAGE = ROWS * ROWB;
   __shared__ __attribute__((aligned(1024))) char zs[2 * STAGE];
   __shared__ __attribute__((aligned(16))) float4 xb[2][kKsWaves][3][64];   // partial sums for the partner wavefront
   __shared__ float red[2][kKsWaves][16];
@@ -60,12 +62,12 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
   const long nw0 = n0 + 16 * cg;
   const long ncol = nw0 + l15;
   const long nrow = ncol < a.N ? ncol : a.N - 1;
-  vec_t wf[3][4];
+  vec_t wf[3][KH];
 #pragma unroll
   for (int h = 0; h < 3; ++h) {
-    const HT* W = (const HT*)a.W[h] + nrow * (long)kKsK + 128 * kh + 8 * grp;
+    const HT* W = (const HT*)a.W[h] + nrow * (long)KK + 32 * KH * kh + 8 * grp;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) wf[h][kk] = *reinterpret_cast<const vec_t*>(W + 32 * kk);
+    for (int kk = 0; kk < KH; ++kk) wf[h][kk] = *reinterpret_cast<const vec_t*>(W + 32 * kk);
   }
   const long nb4 = nw0 + 4 * grp;                 // this lane's four consecutive entries
   const bool ncok = nb4 < a.N;                    // (N % 4 == 0: all four or none)
@@ -98,8 +100,12 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
   // t >> 4.  Chunk c of row r sits at slot c ^ (r & 15) of its row: the ds_read_b128 fragments (16 rows, one
   // chunk index) touch 16 different bank groups.
   const char* zbase = reinterpret_cast<const char*>(a.Z);
-  constexpr int ZP = ROWS / (kKsNT / 16);          // passes of NT / 16 rows (1 | 2)
-  const int zrow = tid >> 4, zc = 2 * (tid & 15);
+  constexpr int TPR = KK / 16;                     // threads per Z row (32 bytes each)
+  constexpr int RPP = kKsNT / TPR;                 // rows per pass
+  constexpr int ZP = RPP >= ROWS ? 1 : ROWS / RPP; // passes (1 | 2); RPP > ROWS: the surplus threads carry copies
+  constexpr int SWM = (KK / 8 < 16 ? KK / 8 : 16) - 1;     // chunk swizzle mask (chunks per row: a power of two)
+  const bool zact = tid / TPR < ROWS;
+  const int zrow = zact ? tid / TPR : ROWS - 1, zc = 2 * (tid % TPR);
   uint4 zr0, zr1, zr2, zr3;                       // (scalars: hipcc moved a `uint4 zr[2]` to LDS and waited vmcnt(0)
                                                   // behind every request)
   auto zfetch = [&](int s) {
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
     zr0 = *reinterpret_cast<const uint4*>(p);
     zr1 = *reinterpret_cast<const uint4*>(p + 16);
     if (ZP == 2) {
-      long m2 = mbeg + (long)s * ROWS + zrow + 16;
+      long m2 = mbeg + (long)s * ROWS + zrow + RPP;
       if (m2 >= a.M) m2 = a.M - 1;
       const char* p2 = zbase + m2 * (long)ROWB + (zc << 4);
       zr2 = *reinterpret_cast<const uint4*>(p2);
@@ -118,11 +124,12 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
   };
   auto zstore = [&](int st) {
     char* row = zs + st * STAGE + zrow * ROWB;
-    *reinterpret_cast<uint4*>(row + ((zc ^ (zrow & 15)) << 4)) = zr0;
-    *reinterpret_cast<uint4*>(row + (((zc + 1) ^ (zrow & 15)) << 4)) = zr1;
+    if (!zact) return;
+    *reinterpret_cast<uint4*>(row + ((zc ^ (zrow & SWM)) << 4)) = zr0;
+    *reinterpret_cast<uint4*>(row + (((zc + 1) ^ (zrow & SWM)) << 4)) = zr1;
     if (ZP == 2) {                                // row zrow + 16: the same swizzle key
-      *reinterpret_cast<uint4*>(row + 16 * ROWB + ((zc ^ (zrow & 15)) << 4)) = zr2;
-      *reinterpret_cast<uint4*>(row + 16 * ROWB + (((zc + 1) ^ (zrow & 15)) << 4)) = zr3;
+      *reinterpret_cast<uint4*>(row + RPP * ROWB + ((zc ^ (zrow & SWM)) << 4)) = zr2;
+      *reinterpret_cast<uint4*>(row + RPP * ROWB + (((zc + 1) ^ (zrow & SWM)) << 4)) = zr3;
     }
   };
 
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
     bv[slot] = *reinterpret_cast<const float4*>(pb + o);
   };
   const float eps = a.eps;
-  const int frow = l15, fsw = l15;                // fragment rows frow + 16 i; (row + 16 i) & 15 == row & 15
+  const int frow = l15, fsw = l15 & SWM;          // fragment rows frow + 16 i; (row + 16 i) & SWM == row & SWM
 
   zfetch(0);
   fetch(0, 0);                                    // slot of step q: q % 3
@@ -184,9 +191,9 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
         for (int i = 0; i < 2; ++i) acc[h][i] = (v4f32){0, 0, 0, 0};
       const char* sb = zs + (s & 1) * STAGE;
 #pragma unroll
-      for (int kk = 0; kk < ((L2Q_HH_SKIP & 1) ? 0 : 4); ++kk) {
+      for (int kk = 0; kk < ((L2Q_HH_SKIP & 1) ? 0 : KH); ++kk) {
         vec_t fa[2];
-        const int chunk = (4 * (4 * kh + kk) + grp) ^ fsw;
+        const int chunk = (4 * (KH * kh + kk) + grp) ^ fsw;
 #pragma unroll
         for (int i = 0; i < 2; ++i)      // accumulator i = row tile i ^ kh: acc[h][0] is the tile this wavefront finishes
           fa[i] = *reinterpret_cast<const vec_t*>(sb + (frow + 16 * (i ^ kh)) * ROWB + (chunk << 4));
@@ -282,7 +289,7 @@ bool heads_h_kstream_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, in
                             int accumulate, hipStream_t st, bool any_length) {
   // (short streams -- fewer than ~8 steps per workgroup -- stay on the tile kernel: the stationary weights and the
   // pipeline fill are paid per workgroup)
-  if (a.K != kKsK || (a.N & 3) != 0) return false;
+  if ((a.K != 256 && a.K != 128 && a.K != 64) || (a.N & 3) != 0) return false;
   if (!any_length && (a.M < 1024 || (long)a.M * cdiv(a.N, 64) < 65536)) return false;
   const long slots = 256L * (8 / kKsWaves);       // workgroups the chip runs at a time
   if (!al16(a.a) || !al16(a.bsrc) || !al16(a.b[0]) || !al16(a.b[1]) || !al16(a.b[2]) || !al16(a.cs) ||
@@ -299,7 +306,12 @@ bool heads_h_kstream_launch(HeadsHArgs a, int xupd, int forward, int use_ncp, in
   const int rows_per_wg = (int)(cdiv(cdiv(a.M, msplit), kKsRows) * kKsRows);
   msplit = cdiv(a.M, rows_per_wg);
   const dim3 grid((unsigned)(nt * msplit)), block(kKsNT);
-#define L2Q_KS(X, F, C) hipLaunchKernelGGL((u1_heads_kstream_h_kernel<HT, X, F, C>), grid, block, 0, st, a, swz, rows_per_wg)
+#define L2Q_KS(X, F, C)                                                                                             \
+  do {                                                                                                              \
+    if (a.K == 256) hipLaunchKernelGGL((u1_heads_kstream_h_kernel<HT, X, F, C, 4>), grid, block, 0, st, a, swz, rows_per_wg);      \
+    else if (a.K == 128) hipLaunchKernelGGL((u1_heads_kstream_h_kernel<HT, X, F, C, 2>), grid, block, 0, st, a, swz, rows_per_wg); \
+    else hipLaunchKernelGGL((u1_heads_kstream_h_kernel<HT, X, F, C, 1>), grid, block, 0, st, a, swz, rows_per_wg);                 \
+  } while (0)
   if (!xupd) { if (forward) L2Q_KS(false, true, false); else L2Q_KS(false, false, false); }
   else if (use_ncp) { if (forward) L2Q_KS(true, true, true); else L2Q_KS(true, false, true); }
   else { if (forward) L2Q_KS(true, true, false); else L2Q_KS(true, false, false); }

@@ -38,7 +38,7 @@ struct Tuning {
   int gemm_h_small = 1;       // 16-bit layers with K, N <= 256 on >= 2048 rows: one-pass kernel (gemm_f16_small.hip; 0: off)
   int gemm_h_patch = 1;       // half GEMM: 8 x 8 tile patches per XCD (0: row-major tile order)
   int heads_h_stream = 2; // half-precision heads+update: 2 = K-split stream kernel where its shape conditions hold
-                          // (heads_kstream_f16.hip: K = 256, long streams; cfg-3: 0.22 / 0.32 ms per v- / x-update
+                          // (heads_kstream_f16.hip: K = 256 / 128 / 64, long streams; cfg-3: 0.22 / 0.32 ms per v- / x-update
                           // against the tile kernel's 0.36 / 0.42), 1 = round 3's weights-stationary stream kernel
                           // (0.475 ms), 0 = tile kernel only, 3 = as 2 for streams of any length (tests)
   int heads_h_bm = 128;   // chains per workgroup of the half-precision heads+update kernel (64 | 128)

@@ -1145,15 +1145,15 @@ def test_u1_heads_update_h_stream_equals_tile(hd, dims):
 
 
 @pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('k', [256, 128, 64])
 @pytest.mark.parametrize('dims', [(1024, 512, 3), (1100, 260, 3), (2085, 1028, 3), (37, 64, 3), (4100, 1028, 2)])
-def test_u1_heads_update_h_kstream_equals_tile(hd, dims):
+def test_u1_heads_update_h_kstream_equals_tile(hd, dims, k):
     """Tuning `heads_h_stream` = 2 (the default; heads_kstream_f16.hip: weights stationary, K = 256 split over
-    wavefront pairs; 3 = the same for streams of any length) against the tile kernel: the K sum is (k < 128) + (k >= 128) instead of one running accumulator, so
+    wavefront pairs, K = 256 / 128 / 64; 3 = the same for streams of any length) against the tile kernel: the K sum is formed in two halves instead of one running accumulator, so
     a head can differ by an fp32 rounding in front of its 16-bit rounding (rare 1-ulp16 flips); ragged chain
     counts (clamped rows, masked stores) and entry counts that are not multiples of 64."""
     from l2hmc import _ops as ops, native
     m, n, kind = dims
-    k = 256
     g = torch.Generator().manual_seed(31)
     z = torch.randn(m, k, generator=g).to(hd).cuda()
     heads = {}
