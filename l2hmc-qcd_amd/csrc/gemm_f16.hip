@@ -286,6 +286,41 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_h_kernel(const float* __
   C[i] = (CT)epilogue_h<HT>(s, cb, cs, epi.coeff != nullptr, epi.act);
 }
 
+// four consecutive outputs per thread (N % 4 == 0: one row): 16-byte loads of every partial, one 8- / 16-byte store
+template <typename HT, typename CT>
+__global__ __launch_bounds__(kBlock) void splitk_reduce4_h_kernel(const float* __restrict__ part, int splits, long MN,
+                                                                  int N, EpiH epi, CT* __restrict__ C) {
+  const long i = ((long)blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (i >= MN) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < splits; ++z) {                               // fixed order
+    const float4 p = *reinterpret_cast<const float4*>(part + (long)z * MN + i);
+    s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+  }
+  const int n = (int)(i % N);
+  typedef CT cv __attribute__((ext_vector_type(4)));
+  cv o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float cs = epi.coeff ? epi.scale * expf(epi.coeff[n + r]) : epi.scale;
+    float cb = 0.f;
+    if (epi.bias) cb += epi.bias[n + r];
+    if (epi.bias2) cb += epi.bias2[n + r];
+    o[r] = (CT)epilogue_h<HT>(s[r], cb, cs, epi.coeff != nullptr, epi.act);
+  }
+  *reinterpret_cast<cv*>(C + i) = o;
+}
+
+template <typename HT, typename CT>
+static void launch_splitk_reduce_h(const float* part, int splits, long MN, int N, const EpiH& epi, CT* C, hipStream_t st) {
+  if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0)
+    hipLaunchKernelGGL((splitk_reduce4_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN / 4, kBlock)), dim3(kBlock), 0, st, part,
+                       splits, MN, N, epi, C);
+  else
+    hipLaunchKernelGGL((splitk_reduce_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN, kBlock)), dim3(kBlock), 0, st, part,
+                       splits, MN, N, epi, C);
+}
+
 static int pick_splits_h(int M, int N, long Kt) {
   const long tiles = cdiv(M, 128) * cdiv(N, 128);
   if (tiles >= 256 || Kt <= 8 * HBK) return 1;
@@ -336,9 +371,7 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
     int S = 0;
     if (sk != 0 && gemm_h_skinny_launch<HT>((const float*)A_, W_, M, N, K, (const float*)A2_, W2_, K2, ws,
                                             ws_bytes, st, cs_mask, cs_compl, sk == 1 ? 0 : sk, &S)) {
-      const long MN = (long)M * N;
-      hipLaunchKernelGGL((splitk_reduce_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN, kBlock)), dim3(kBlock), 0,
-                         st, (const float*)ws, S, MN, N, epi, C);
+      launch_splitk_reduce_h<HT, CT>((const float*)ws, S, (long)M * N, N, epi, C, st);
       return check_launch("l2q_gemm_h");
     }
   }
@@ -378,9 +411,7 @@ static int gemm_h_launch(const void* A_, const void* W_, int M, int N, long K, c
                        A2, W2, M, N, K, K2, kchunk, splits, epi, veca, vecw, C, part, patch, cs_mask, cs_compl);
   }
   if (splits > 1 || (wide && !wide_fused)) {
-    const long MN = (long)M * N;
-    hipLaunchKernelGGL((splitk_reduce_h_kernel<HT, CT>), dim3((unsigned)cdiv(MN, kBlock)),
-                       dim3(kBlock), 0, st, (const float*)part, splits, MN, N, epi, C);
+    launch_splitk_reduce_h<HT, CT>((const float*)part, splits, (long)M * N, N, epi, C, st);
   }
   return check_launch("l2q_gemm_h");
 }
