@@ -733,6 +733,17 @@ def secondary_u1(steps=3, only=None):
                         'steps': steps, 'accept_prob_mean': round(float(m['acc'].mean()), 4),
                         'kernel_time_fraction_of_wall': round(tot / (dt * steps), 4),
                         'dominant_kernel': dom, 'kernels': top, 'hip_graph': graphed}
+            # HBM / fabric bytes per launch of the dominant kernel from the PMC passes taken at exactly this shape
+            # (tools/pmc_collect.sh with tools/kprof_u1_cfg3.py): the v- and the x-update are two instantiations
+            try:
+                pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_u1_cfg3.json')))
+                ent = [v for k, v in pj.items() if k.split('@')[0].split(':')[0] == dom.get('kernel')
+                       and v.get('lattice') == L and v.get('nchains') == nb]
+                if tag == 'cfg3_dense256_fp16' and ent:
+                    dom['traffic'] = round(sum(e['total_bytes'] for e in ent) / len(ent), 1)
+                    dom['traffic_source'] = '; '.join(sorted({e['source'].split(' ')[0] for e in ent}))
+            except Exception:  # noqa: BLE001
+                pass
         except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
             import traceback
             out[tag] = f'failed: {type(e).__name__}: {e} | ' + traceback.format_exc()[-400:]

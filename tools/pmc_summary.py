@@ -39,8 +39,9 @@ ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'su3_expm_mul_kernel<true>': 'l2q_su3_expm_mul2', 'su3_expm_mul_kernel<true, false>': 'l2q_su3_expm_mul2',
     'su3_project_kernel<1>': 'l2q_su3_projsu_vec8',
     # cfg-3 (tools/kprof_u1_cfg3.py)
-    'u1_heads_kstream_h_kernel<_Float16, false': 'l2q_u1_heads_update_h:v', 'u1_heads_kstream_h_kernel<_Float16, true': 'l2q_u1_heads_update_h:x',
-    'gemm_skinny_h_kernel<_Float16, false': 'l2q_gemm_h:input', 'gemm_skinny_h_kernel<_Float16, true': 'l2q_gemm_h_u1x',
+    # (rocprofv3 leaves the _Float16 instantiations mangled)
+    'u1_heads_kstream_h_kernelIDF16_Lb0': 'l2q_u1_heads_update_h:v', 'u1_heads_kstream_h_kernelIDF16_Lb1': 'l2q_u1_heads_update_h:x',
+    'gemm_skinny_h_kernelIDF16_Lb0': 'l2q_gemm_h:input', 'gemm_skinny_h_kernelIDF16_Lb1': 'l2q_gemm_h_u1x',
     'u1_force_staged_f32_kernel': 'l2q_u1_force',
 }
 
