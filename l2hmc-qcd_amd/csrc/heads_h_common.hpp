@@ -102,4 +102,75 @@ __device__ __forceinline__ float hh_element(float as, float at, float aq, float 
   return fast_wrap_angle(keep * xj + mb * xp);
 }
 
+// ---- the same arithmetic on TWO entries at a time (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 issue two fp32
+// operations per lane and cycle; the transcendentals, conversions and selects stay per entry).  Used by the stream
+// kernel, whose x-update is bound by the VALU issue of its epilogue.  Not bit-identical to hh_element (the compiler
+// contracts other mul / add pairs; exp(2 x) and exp(eps q) take their scale factors in one packed multiply).
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define L2Q_V2(expr_x, expr_y) ((v2f){(expr_x), (expr_y)})
+template <typename HT> __device__ __forceinline__ v2f rnd2(v2f x) { return L2Q_V2(rnd<HT>(x.x), rnd<HT>(x.y)); }
+__device__ __forceinline__ v2f exp2_2(v2f x) { return L2Q_V2(__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)); }
+__device__ __forceinline__ v2f rcp_2(v2f x) { return L2Q_V2(__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)); }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float a) { return L2Q_V2(a, a); }
+__device__ __forceinline__ v2f tanh2_h(v2f x) {                       // 1 - 2 / (exp(2 x) + 1)
+  const v2f e = exp2_2(x * splat2(2.885390081777927f));                // 2 log2(e)
+  return fma2(splat2(-2.f), rcp_2(e + splat2(1.f)), splat2(1.f));
+}
+__device__ __forceinline__ v2f atan2_px_2(v2f y, v2f x) {
+  const v2f ay = L2Q_V2(fabsf(y.x), fabsf(y.y));
+  const v2f mx = L2Q_V2(fmaxf(x.x, ay.x), fmaxf(x.y, ay.y)), mn = L2Q_V2(fminf(x.x, ay.x), fminf(x.y, ay.y));
+  const v2f t = mn * rcp_2(mx);
+  const v2f u = t * t;
+  v2f p = splat2(-0.00455979211255908f);
+  p = fma2(p, u, splat2(0.023780519142746925f));
+  p = fma2(p, u, splat2(-0.05882975459098816f));
+  p = fma2(p, u, splat2(0.09868865460157394f));
+  p = fma2(p, u, splat2(-0.14003290235996246f));
+  p = fma2(p, u, splat2(0.19966961443424225f));
+  p = fma2(p, u, splat2(-0.3333181142807007f));
+  p = fma2(p, u, splat2(0.9999998807907104f));
+  const v2f r = p * t, rc = splat2(1.5707963267948966f) - r;
+  return L2Q_V2(copysignf(ay.x > x.x ? rc.x : r.x, y.x), copysignf(ay.y > x.y ? rc.y : r.y, y.y));
+}
+
+template <typename HT, bool XUPD, bool FWD, bool NCP>
+__device__ __forceinline__ v2f hh_element2(v2f as, v2f at, v2f aq, v2f bs, v2f bt, v2f bq, v2f cs, v2f cq, float st,
+                                           float eps, v2f a0, v2f b0, v2f keep, v2f& ldterm) {
+  const float l2e = 1.4426950408889634f;
+  const v2f s = cs * rnd2<HT>(tanh2_h(rnd2<HT>(as + bs)));
+  const v2f t = rnd2<HT>(splat2(st) * rnd2<HT>(at + bt));
+  const v2f q = cq * rnd2<HT>(tanh2_h(rnd2<HT>(aq + bq)));
+  const v2f eq = exp2_2(q * splat2(eps * l2e));
+  if (!XUPD) {
+    const v2f lj = s * splat2(FWD ? 0.5f * eps : -0.5f * eps);
+    ldterm = lj;
+    const v2f es = exp2_2(lj * splat2(l2e));
+    const v2f f = fma2(b0, eq, t);
+    return FWD ? fma2(es, a0, splat2(-0.5f * eps) * f) : es * fma2(splat2(0.5f * eps), f, a0);
+  }
+  const v2f xj = a0, mb = splat2(1.f) - keep;
+  const v2f sj = s * splat2(FWD ? eps : -eps);
+  const v2f es = exp2_2(sj * splat2(l2e));
+  const v2f tr = fma2(b0, eq, t);
+  v2f xp, l;
+  if (NCP) {
+    const v2f hx = xj * splat2(0.5f);
+    const v2f ch = L2Q_V2(__cosf(hx.x), __cosf(hx.y));
+    const v2f sh = es * L2Q_V2(__sinf(hx.x), __sinf(hx.y));
+    const v2f x1 = splat2(2.f) * atan2_px_2(sh, ch);
+    xp = FWD ? fma2(splat2(eps), tr, x1) : fma2(es * splat2(-eps), tr, x1);
+    const v2f d = fma2(ch, ch, sh * sh);
+    l = sj - L2Q_V2(__logf(d.x), __logf(d.y));
+  } else {
+    xp = FWD ? fma2(xj, es, splat2(eps) * tr) : es * fma2(splat2(-eps), tr, xj);
+    l = sj;
+  }
+  ldterm = mb * l;
+  const v2f w = fma2(keep, xj, mb * xp);
+  const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
+  const v2f y = (w + splat2(pi)) * splat2(0.15915494309189535f);
+  return fma2(splat2(two_pi), L2Q_V2(__builtin_amdgcn_fractf(y.x), __builtin_amdgcn_fractf(y.y)), splat2(-pi));
+}
+
 }  // namespace l2q

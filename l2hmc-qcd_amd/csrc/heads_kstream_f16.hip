@@ -28,6 +28,9 @@
 
 namespace l2q {
 
+#ifndef KS_PACKED
+#define KS_PACKED 1        // epilogue on two entries at a time (packed fp32 math); 0: the scalar hh_element
+#endif
 #ifndef KS_NCG
 #define KS_NCG 4           // column groups of 16 entries per workgroup (4: 8 wavefronts, one workgroup per CU; 2: 4
                            // wavefronts, two workgroups per CU with their own barriers -- measured slower at cfg-3,
@@ -218,6 +221,19 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
       const float a4[4] = {ta.x, ta.y, ta.z, ta.w}, b4[4] = {tb.x, tb.y, tb.z, tb.w};
       const float okf = ok ? 1.f : 0.f;
       float out[4], ld = 0.f;
+#if KS_PACKED
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {              // two entries per call: packed fp32 math (heads_h_common.hpp)
+        v2f ldt;
+        const v2f o = hh_element2<HT, XUPD, FWD, NCP>(
+            L2Q_V2(pre[0][r], pre[0][r + 1]), L2Q_V2(pre[1][r], pre[1][r + 1]), L2Q_V2(pre[2][r], pre[2][r + 1]),
+            L2Q_V2(bs[r], bs[r + 1]), L2Q_V2(bt[r], bt[r + 1]), L2Q_V2(bq[r], bq[r + 1]), L2Q_V2(cs[r], cs[r + 1]),
+            L2Q_V2(cq[r], cq[r + 1]), a.st, eps, L2Q_V2(a4[r], a4[r + 1]), L2Q_V2(b4[r], b4[r + 1]),
+            L2Q_V2(keep[r], keep[r + 1]), ldt);
+        out[r] = o.x; out[r + 1] = o.y;
+        ld = fmaf(okf, ldt.x + ldt.y, ld);
+      }
+#else
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float ldt;
@@ -230,6 +246,7 @@ __global__ __launch_bounds__(kKsNT, 8 / kKsWaves) void u1_heads_kstream_h_kernel
         }
         ld = fmaf(okf, ldt, ld);
       }
+#endif
       if ((L2Q_HH_SKIP & 4) && out[0] + out[1] + out[2] + out[3] != 12345.678f) {
       } else if (ok) *reinterpret_cast<float4*>(pa + m * (long)a.N + nb4) = make_float4(out[0], out[1], out[2], out[3]);
       // row sums over this wavefront's 16 columns (four lane groups of 4 entries)

@@ -1182,7 +1182,10 @@ def test_u1_heads_update_h_kstream_equals_tile(hd, dims, k):
                 ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
                 scale = max(1.0, float(res[0][0].abs().max()))
                 assert float(d.abs().max()) < 2 * ulp * scale, (xupd, forward, float(d.abs().max()))
-                assert float((d != 0).float().mean()) < 0.05, (xupd, forward, float((d != 0).float().mean()))
+                # the stream kernel's epilogue runs on packed fp32 math (other contractions: fp32-rounding-level
+                # differences anywhere); a flipped 16-bit rounding of a head is ~1e-4 .. 1e-3 and must stay rare
+                flips = float((d.abs() > 4e-6 * scale).float().mean())
+                assert flips < 0.05, (xupd, forward, flips)
                 dl = float((res[0][1] - res[2][1]).abs().max())
                 assert dl < (1e-5 * max(1.0, float(res[0][1].abs().max())) + 2 * ulp * 0.17) * n ** 0.5, dl
     finally:
