@@ -108,7 +108,11 @@ __device__ __forceinline__ float hh_element(float as, float at, float aq, float 
 // contracts other mul / add pairs; exp(2 x) and exp(eps q) take their scale factors in one packed multiply).
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define L2Q_V2(expr_x, expr_y) ((v2f){(expr_x), (expr_y)})
-template <typename HT> __device__ __forceinline__ v2f rnd2(v2f x) { return L2Q_V2(rnd<HT>(x.x), rnd<HT>(x.y)); }
+// both entries through one v_cvt_pk_{f16,bf16}_f32 (round to nearest even, like the scalar conversion)
+template <typename HT> __device__ __forceinline__ v2f rnd2(v2f x) {
+  typedef HT h2 __attribute__((ext_vector_type(2)));
+  return __builtin_convertvector(__builtin_convertvector(x, h2), v2f);
+}
 __device__ __forceinline__ v2f exp2_2(v2f x) { return L2Q_V2(__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)); }
 __device__ __forceinline__ v2f rcp_2(v2f x) { return L2Q_V2(__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)); }
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -119,7 +123,9 @@ __device__ __forceinline__ v2f tanh2_h(v2f x) {                       // 1 - 2 /
 }
 __device__ __forceinline__ v2f atan2_px_2(v2f y, v2f x) {
   const v2f ay = L2Q_V2(fabsf(y.x), fabsf(y.y));
-  const v2f mx = L2Q_V2(fmaxf(x.x, ay.x), fmaxf(x.y, ay.y)), mn = L2Q_V2(fminf(x.x, ay.x), fminf(x.y, ay.y));
+  // (compare + select instead of fmaxf / fminf: those canonicalise both operands first -- two more VALU instructions)
+  const bool bx = ay.x > x.x, by = ay.y > x.y;
+  const v2f mx = L2Q_V2(bx ? ay.x : x.x, by ? ay.y : x.y), mn = L2Q_V2(bx ? x.x : ay.x, by ? x.y : ay.y);
   const v2f t = mn * rcp_2(mx);
   const v2f u = t * t;
   v2f p = splat2(-0.00455979211255908f);
@@ -131,7 +137,7 @@ __device__ __forceinline__ v2f atan2_px_2(v2f y, v2f x) {
   p = fma2(p, u, splat2(-0.3333181142807007f));
   p = fma2(p, u, splat2(0.9999998807907104f));
   const v2f r = p * t, rc = splat2(1.5707963267948966f) - r;
-  return L2Q_V2(copysignf(ay.x > x.x ? rc.x : r.x, y.x), copysignf(ay.y > x.y ? rc.y : r.y, y.y));
+  return L2Q_V2(copysignf(bx ? rc.x : r.x, y.x), copysignf(by ? rc.y : r.y, y.y));
 }
 
 template <typename HT, bool XUPD, bool FWD, bool NCP>
@@ -160,8 +166,8 @@ __device__ __forceinline__ v2f hh_element2(v2f as, v2f at, v2f aq, v2f bs, v2f b
     const v2f sh = es * L2Q_V2(__sinf(hx.x), __sinf(hx.y));
     const v2f x1 = splat2(2.f) * atan2_px_2(sh, ch);
     xp = FWD ? fma2(splat2(eps), tr, x1) : fma2(es * splat2(-eps), tr, x1);
-    const v2f d = fma2(ch, ch, sh * sh);
-    l = sj - L2Q_V2(__logf(d.x), __logf(d.y));
+    const v2f d = fma2(ch, ch, sh * sh);           // cos^2 + es^2 sin^2: never denormal -> the bare v_log_f32
+    l = fma2(splat2(-0.6931471805599453f), L2Q_V2(__builtin_amdgcn_logf(d.x), __builtin_amdgcn_logf(d.y)), sj);
   } else {
     xp = FWD ? fma2(xj, es, splat2(eps) * tr) : es * fma2(splat2(-eps), tr, xj);
     l = sj;

@@ -22,7 +22,8 @@
 //     0.285 / 0.408 ms per v- / x-update, of which 0.116 ms were barriers, LDS hand-overs and their latencies.)
 //   * the epilogue handles two entries at a time on packed fp32 math (hh_element2, heads_h_common.hpp): the x-update
 //     is bound by the VALU issue of its epilogue (97 instructions per entry, 10 of them quarter-rate, two wavefronts
-//     per SIMD in lockstep); 399 -> 325 VALU instructions per 4 entries, 0.324 -> 0.297 ms.
+//     per SIMD in lockstep); with packed conversions, the bare v_log_f32 and compare-select min / max: 399 -> 259 VALU
+//     instructions per 4 entries, 0.324 -> 0.274 ms.
 // Same MFMA instruction and operand roles as the other two kernels; the K = 256 sum is formed as (k < 128) +
 // (k >= 128) in fp32 instead of one running accumulator: a rounding-level difference in front of the 16-bit
 // rounding of the head (rare 1-ulp16 flips, as between the tile and the stream kernel).
