@@ -19,7 +19,8 @@ __device__ __forceinline__ float fast_tanh_h(float x) {
 // libm atan2f is ~60 instructions with an IEEE division, and the epilogue of the x-update is VALU-bound.
 __device__ __forceinline__ float fast_atan2_px(float y, float x) {
   const float ay = fabsf(y);
-  const float mx = fmaxf(x, ay), mn = fminf(x, ay);
+  const bool big = ay > x;                         // (compare + select: fmaxf / fminf canonicalise their operands first)
+  const float mx = big ? ay : x, mn = big ? x : ay;
   const float t = mn * __builtin_amdgcn_rcpf(mx);
   const float u = t * t;
   float p = -0.00455979211255908f;
@@ -31,7 +32,7 @@ __device__ __forceinline__ float fast_atan2_px(float y, float x) {
   p = fmaf(p, u, -0.3333181142807007f);
   p = fmaf(p, u, 0.9999998807907104f);
   float r = p * t;
-  r = ay > x ? 1.5707963267948966f - r : r;
+  r = big ? 1.5707963267948966f - r : r;
   return copysignf(r, y);
 }
 
@@ -93,7 +94,8 @@ __device__ __forceinline__ float hh_element(float as, float at, float aq, float 
     const float ch = __cosf(hx), sh = es * __sinf(hx);
     const float x1 = 2.f * fast_atan2_px(sh, ch);  // = 2 atan(tan(hx) es), no division
     xp = FWD ? (x1 + eps * tr) : (x1 - es * eps * tr);
-    l = sj - __logf(ch * ch + sh * sh);            // log(es / (ch^2 + sh^2))
+    // log(es / (ch^2 + sh^2)); the argument is never denormal: the bare v_log_f32 (log2) without __logf's scaling
+    l = sj - 0.6931471805599453f * __builtin_amdgcn_logf(ch * ch + sh * sh);
   } else {
     xp = FWD ? (xj * es + eps * tr) : (es * (xj - eps * tr));
     l = sj;
