@@ -37,6 +37,37 @@ def test_argument_validation_without_gpu():
     assert lib.l2q_reduce_ws_bytes(4, 1000) > 0 and lib.l2q_gemm_ws_bytes(256, 256, 262144, 0) > 0
 
 
+def test_half_layer_kernel_plan_host_logic():
+    """Host-side choices of the half-precision layer kernels (no GPU work): which shapes the streaming input-layer
+    kernel takes and with how many K-splits (csrc/gemm_f16_skinny.hip), and that the workspace the caller is told
+    to bring covers its partial sums and the slab-major copy of the weights."""
+    from l2hmc import native
+    lib = native.load()
+    q = lib.l2q_gemm_h_skinny_splits
+    prev = lib.l2q_set_tuning(b'gemm_h_skinny', 1)
+    try:
+        assert q(8192, 256, 8192, 8192, 0) == 4            # BASELINE cfg-3 vnet: 128 row tiles x 4 = one round of 512
+        assert q(8192, 256, 16384, 8192, 1) == 4           # xnet: K counts the cos and the sin columns
+        assert q(2048, 256, 2048, 2048, 0) == 8            # 32 row tiles: the largest admissible split count
+        assert q(65536, 128, 8192, 0, 0) == 1              # more row tiles than workgroup slots: no split-K
+        assert q(8192, 256, 8192 + 64, 8192, 0) == 0       # K not a multiple of the 128-column slab
+        assert q(8192, 512, 8192, 8192, 0) == 0            # wider than one workgroup's columns
+        assert q(512, 256, 8192, 8192, 0) == 0             # too few chains
+        assert q(8192, 256, 1024, 1024, 0) == 0            # short K: the tile kernels
+        assert q(8192, 256, 16385, 8192, 1) == 0           # odd K for the cos | sin form
+        lib.l2q_set_tuning(b'gemm_h_skinny', 8)
+        assert q(8192, 256, 8192, 8192, 0) == 8
+        need = lib.l2q_gemm_h_ws_bytes(8192, 256, 8192, 8192)
+        assert need >= 8 * 8192 * 256 * 4 + 256 * 16384 * 2
+        lib.l2q_set_tuning(b'gemm_h_skinny', 0)
+        assert q(8192, 256, 8192, 8192, 0) == 0
+        assert lib.l2q_gemm_h_ws_bytes(8192, 256, 8192, 8192) < need
+    finally:
+        lib.l2q_set_tuning(b'gemm_h_skinny', prev if prev >= 0 else 1)
+    assert lib.l2q_set_tuning(b'heads_h_stream', 4) == -1 and lib.l2q_set_tuning(b'heads_h_stream', 2) in (0, 1, 2, 3)
+    assert lib.l2q_set_tuning(b'gemm_h_small', 1) in (0, 1)
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
