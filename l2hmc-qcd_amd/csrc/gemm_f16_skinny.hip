@@ -46,7 +46,12 @@ namespace l2q {
 #ifndef SK_SKIP
 #define SK_SKIP 0          // timing-only builds (tools/ab_build.sh): 1 no MFMA, 2 no W requests, 4 no A requests
 #endif
-constexpr int kSkBM = 64, kSkBN = 256, kSkBK = 32, kSkNT = 256;
+#ifndef SK_RH
+#define SK_RH 1            // row halves per workgroup: 1 = 64 chains x 4 wavefronts; 2 = 128 chains x 8 wavefronts (the two
+                           // wavefronts of a column group request the same W slabs, half the L2 traffic of W if L1
+                           // catches the second request) -- measured slower at cfg-3: 158 / 201 us against 150 / 191
+#endif
+constexpr int kSkRH = SK_RH, kSkBM = 64 * kSkRH, kSkBN = 256, kSkBK = 32, kSkNT = 256 * kSkRH;
 constexpr int kSkBKA = 128, kSkSub = kSkBKA / kSkBK;     // A slab: 128 columns = 4 W slabs of 32
 constexpr int kSkLD = kSkBKA + 16;           // LDS row stride 288 B: conflict-free ds_read_b128 of 16-row fragments
 
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
   __shared__ __attribute__((aligned(16))) HT As[2][NTL][BM][kSkLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
-  const int wn = wave * 64;
+  const int wn = (wave & 3) * 64, rbase = (wave >> 2) * 64;
   const int S = a.splits;
   const long z = blockIdx.x % S, mt = blockIdx.x / S;
   const long m0 = mt * BM;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
   auto mfma = [&](int buf, int tile, int sub, int e) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const vec_t fa = *reinterpret_cast<const vec_t*>(&As[buf][tile][16 * i + l15][kSkBK * sub + 8 * grp]);
+      const vec_t fa = *reinterpret_cast<const vec_t*>(&As[buf][tile][rbase + 16 * i + l15][kSkBK * sub + 8 * grp]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = MfmaH<HT>::run(rw[e][j], fa, acc[i][j]);
     }
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(kSkNT, SK_OCC) void gemm_skinny_h_kernel(SkArgs a) 
     if (nb4 >= a.N) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long m = m0 + 16 * i + l15;
+      const long m = m0 + rbase + 16 * i + l15;
       if (m >= a.M) continue;
       float* dst = a.part + (z * a.M + m) * a.N + nb4;
       if (vecc) {
@@ -254,7 +259,7 @@ int gemm_h_skinny_splits(int M, int N, long raw1, long K2, int want) {
   if (N > kSkBN || N < 64 || M < 1024 || raw1 % kSkBKA != 0 || K2 % kSkBKA != 0 || raw1 + K2 < 4096) return 0;
   const long s1 = raw1 / kSkBKA, s2 = K2 / kSkBKA;
   const long mt = cdiv(M, kSkBM);
-  const long slots = 256L * 2;                         // a full first round of workgroups, two per CU
+  const long slots = 256L * 2 / kSkRH;                 // a full first round of workgroups (8 wavefronts per CU)
   int fits = 0, smallest = 0;
   for (int s = 8; s >= 1; s >>= 1) {
     if (s1 % s != 0 || s2 % s != 0) continue;
