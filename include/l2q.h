@@ -125,6 +125,10 @@ int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, doub
  * (loss/pytorch/loss.py:57-70).  ws >= nb * ceil(V/256) * 12 doubles. */
 int l2q_su3_plaq_planes(const void* xn, int nb, int T, int X, int Y, int Z, double* out, void* ws,
                         size_t ws_bytes, void* stream);
+/* The trace field itself: out[p][c][site] = tr P_p(site), complex128, planes ordered as above -- the tensor
+ * [6, nb, T, X, Y, Z] that LatticeSU3.wilson_loops returns (lattice/su3/pytorch/lattice.py:157-174, 242-244)
+ * for callers that reduce it themselves (loss/pytorch/loss.py:57-110). */
+int l2q_su3_wilson_loops(const void* xn, int nb, int T, int X, int Y, int Z, void* out, void* stream);
 /* out[c] = sum_j (a[c][j] - b[c][j])^2 over n doubles (rmse loss, loss.py:131-148). */
 int l2q_diff_norm2_reduce(const double* a, const double* b, int nb, long n, double* out, void* ws,
                           size_t ws_bytes, void* stream);
@@ -417,6 +421,11 @@ int l2q_nchw_to_nhwc_pad_h(int half_type, const float* in, int nb, int C, int H,
  *   action = beta (V - out0); plaqs = out0/V; sinQ = out1/2pi; intQ = out2/2pi. */
 int l2q_u1_plaq_reduce(const void* x, int nb, int T, int X, int elem_bytes, void* out,
                        void* stream);
+/* The plaquette-angle field out[c][t][x] = U0(t,x) + U1(t+1,x) - U0(t,x+1) - U1(t,x): the tensor [nb, T, X]
+ * that LatticeU1.wilson_loops returns (lattice/u1/pytorch/lattice.py:154-159). */
+int l2q_u1_wilson_loops(const void* x, int nb, int T, int X, int elem_bytes, void* out, void* stream);
+/* its adjoint (VJP): dx0(t,x) += g(t,x) - g(t,x-1), dx1(t,x) += g(t-1,x) - g(t,x);  g [nb][T][X] */
+int l2q_u1_wilson_loops_bwd(const void* g, int nb, int T, int X, int elem_bytes, void* dx, void* stream);
 /* F0 = beta [sin th - sin th(t,x-1)], F1 = beta [-sin th + sin th(t-1,x)]
  * (autograd of the action, lattice.py:102-117).  If v != NULL: v += coef * F (fused kick)
  * and `force` may be NULL. */
@@ -626,6 +635,10 @@ int l2q_su3_force_bwd(const void* xn, const void* gf, double beta, void* gx, int
  * as l2q_su3_plaq_planes.  gx += dL/dx. */
 int l2q_su3_plaq_bwd(const void* xn, const double* w, void* gx, int nb, int T, int X, int Y, int Z,
                      void* stream);
+/* VJP of l2q_su3_wilson_loops: L = sum_{p, c, site} Re(conj(w[p][c][site]) tr P_p(site)), w complex128 laid
+ * out like that function's output (torch's cotangent of a complex tensor: dL/dRe + i dL/dIm).  gx += dL/dx. */
+int l2q_su3_wilson_loops_bwd(const void* xn, const void* w, void* gx, int nb, int T, int X, int Y, int Z,
+                             void* stream);
 /* ---- improved gauge actions (c1 != 0: Iwasaki / DBW2 rectangles), lattice/su3/pytorch/lattice.py
  * :83-112 (coeffs, _rectangles), :180-196 (rectangle traces of _wilson_loops), :252-269 (action):
  *   S = -(1/3) [ beta (1 - 8 c1) sum_P Re tr P + beta c1 sum_R Re tr R ],  12 planar 2x1 loops R

@@ -153,6 +153,39 @@ __global__ __launch_bounds__(kBlock, 2) void su3_plaq_planes_kernel(const double
   }
 }
 
+// The trace FIELD itself, out[plane][chain][site] = tr P_plane(site) (complex): the tensor the reference's
+// `LatticeSU3.wilson_loops` returns, [6, nb, T, X, Y, Z] (lattice/su3/pytorch/lattice.py:157-174, 242-244).
+// The sampler never needs it (action / plaquette / charges are the per-chain sums above); callers that
+// reduce the field themselves (loss/pytorch/loss.py:57-110) do.  864 B read + 96 B written per site.
+__global__ __launch_bounds__(kBlock, 2) void su3_wloops_kernel(const double2* __restrict__ xn, Dims d,
+                                                               long nblk, long nb,
+                                                               double2* __restrict__ out) {
+  const long c = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int s = (int)blk * kBlock + threadIdx.x;
+  if (s >= d.V) return;
+  const double2* xc = xn + c * 36L * d.V;
+  const Site p = site_coords(s, d);
+  const int V = d.V;
+  int plane = 0;
+#pragma unroll 1
+  for (int u = 1; u < 4; ++u) {
+    const int s_pu = fwd(s, coord_of(p, u), d, u);
+#pragma unroll 1
+    for (int v = 0; v < u; ++v, ++plane) {
+      const int s_pv = fwd(s, coord_of(p, v), d, v);
+      double sr = 0.0, si = 0.0;
+      M3 a, b, yuv;
+      load_link(a, xc + u * 9 * V, V, s);
+      load_link(b, xc + v * 9 * V, V, s_pu);
+      m3_mul_nn(yuv, a, b);
+      load_link(a, xc + v * 9 * V, V, s);
+      load_link(b, xc + u * 9 * V, V, s_pv);
+      m3_trace_y_abh(sr, si, yuv, a, b);
+      out[(plane * nb + c) * V + s] = make_double2(sr, si);
+    }
+  }
+}
+
 // per-chain sum |a - b|^2 over n doubles (complex fields pass 2n)
 __global__ __launch_bounds__(kBlock) void diff_norm2_kernel(const double* __restrict__ a,
                                                             const double* __restrict__ b, long n,
@@ -1199,6 +1232,16 @@ int l2q_su3_plaq_reduce(const void* xn, int nb, int T, int X, int Y, int Z, doub
   }
   launch_finalize(partial, out, nb, nblk, 2, 1.0, 0.0, st);
   return check_launch("l2q_su3_plaq_reduce");
+}
+
+int l2q_su3_wilson_loops(const void* xn, int nb, int T, int X, int Y, int Z, void* out, void* stream) {
+  L2Q_REQUIRE(xn && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  hipLaunchKernelGGL(su3_wloops_kernel, dim3((unsigned)(nb * nblk)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const double2*)xn, d, nblk, (long)nb, (double2*)out);
+  return check_launch("l2q_su3_wilson_loops");
 }
 
 int l2q_su3_plaq_planes(const void* xn, int nb, int T, int X, int Y, int Z, double* out, void* ws,

@@ -277,6 +277,9 @@ void launch_force_link_bwd(const double2* xn, Dims d, int nb, double coef, const
 // MODE 1 (plaquette-sum VJP, L = sum_p Re(conj(w_p) tr P_p), planes p = (u > v) in the order
 //   (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)):
 //   mu > nu: g_x += w_p S_up^H + conj(w_p) S_dn^H;   mu < nu: g_x += conj(w_p) S_up^H + w_p S_dn^H
+// MODE 2 (VJP of the per-site trace FIELD of LatticeSU3.wilson_loops, lattice.py:242-244): as MODE 1 with a
+//   weight per (plane, chain, site), w[(p nb + c) V + site] complex: the up staple closes the plaquette based
+//   at s, the down staple the one based at s - nu
 __device__ __forceinline__ int plane_index(int u, int v) { return u * (u - 1) / 2 + v; }
 
 __device__ __forceinline__ void mac_scaled_adjoint(M3& acc, double wr, double wi, const M3& sm) {
@@ -318,11 +321,21 @@ __global__ __launch_bounds__(kBlock, 2) void su3_staple_bwd_kernel(
     const int s_mnu = bwd(s, cnu, d, nu);
     const int s_pmu_mnu = bwd(s_pmu, cnu, d, nu);
     double wr = 1.0, wi = 0.0;
+    double wdr = 1.0, wdi = 0.0;                       // the down staple's weight (MODE 2: another site)
     if (MODE == 1) {
       const int pl = mu > nu ? plane_index(mu, nu) : plane_index(nu, mu);
       wr = w[(c * 6 + pl) * 2 + 0];
       wi = w[(c * 6 + pl) * 2 + 1];
       if (mu < nu) wi = -wi;                           // conj(w) multiplies S_up^H when mu < nu
+      wdr = wr; wdi = wi;
+    }
+    if (MODE == 2) {
+      const int pl = mu > nu ? plane_index(mu, nu) : plane_index(nu, mu);
+      const long nbl = (long)(total / (4 * nblk));
+      const double* wp = w + ((pl * nbl + c) * V) * 2;
+      wr = wp[2L * s]; wi = wp[2L * s + 1];
+      wdr = wp[2L * s_mnu]; wdi = wp[2L * s_mnu + 1];
+      if (mu < nu) { wi = -wi; wdi = -wdi; }
     }
     M3 a, b, t, st;
     load_link(a, fn, V, s_pmu);
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(kBlock, 2) void su3_staple_bwd_kernel(
     m3_mul_aa(t, a, b);
     load_link(a, fn, V, s_mnu);
     m3_mul_nn(st, t, a);                               // S_dn
-    mac_scaled_adjoint(acc, wr, -wi, st);
+    mac_scaled_adjoint(acc, wdr, -wdi, st);
   }
   M3 g;
   if (MODE == 0) {
@@ -572,6 +585,18 @@ int l2q_su3_plaq_bwd(const void* xn, const double* w, void* gx, int nb, int T, i
                      (hipStream_t)stream, (const double2*)xn, d, nblk, tuning().xcd_swizzle, 1.0,
                      (const double2*)nullptr, w, (double2*)gx);
   return check_launch("l2q_su3_plaq_bwd");
+}
+
+int l2q_su3_wilson_loops_bwd(const void* xn, const void* w, void* gx, int nb, int T, int X, int Y, int Z,
+                             void* stream) {
+  L2Q_REQUIRE(xn && w && gx, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(dims_ok4(nb, T, X, Y, Z), L2Q_EINVAL, "non-positive size");
+  Dims d{T, X, Y, Z, T * X * Y * Z};
+  const long nblk = cdiv(d.V, kBlock);
+  hipLaunchKernelGGL(su3_staple_bwd_kernel<2>, dim3((unsigned)(nb * nblk * 4)), dim3(kBlock), 0,
+                     (hipStream_t)stream, (const double2*)xn, d, nblk, tuning().xcd_swizzle, 1.0,
+                     (const double2*)nullptr, (const double*)w, (double2*)gx);
+  return check_launch("l2q_su3_wilson_loops_bwd");
 }
 
 int l2q_v_update_bwd_c128(const void* v, const void* force, const double* s, const double* t,

@@ -29,6 +29,36 @@ __global__ __launch_bounds__(kBlock) void u1_plaq_kernel(const T* __restrict__ x
   if (threadIdx.x == 0) { out[c * 3 + 0] = (T)a; out[c * 3 + 1] = (T)b; out[c * 3 + 2] = (T)p; }
 }
 
+// The plaquette-angle FIELD theta[chain][t][x] itself: the tensor the reference's `LatticeU1.wilson_loops`
+// returns (lattice/u1/pytorch/lattice.py:154-159; same left-to-right sum, so fp32 results are the same bits).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void u1_wloops_kernel(const T* __restrict__ x, int Tn, int Xn,
+                                                           long total, T* __restrict__ out) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= total) return;
+  const int V = Tn * Xn;
+  const long c = i / V;
+  const int s = (int)(i % V);
+  out[i] = plaq_angle(x + c * 2 * V, s / Xn, s % Xn, Tn, Xn);
+}
+
+// its adjoint (theta is linear in the links): dx0(t, x) += g(t, x) - g(t, x-1), dx1(t, x) += g(t-1, x) - g(t, x)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void u1_wloops_bwd_kernel(const T* __restrict__ g, int Tn, int Xn,
+                                                               long total, T* dx) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= total) return;
+  const int V = Tn * Xn;
+  const long c = i / V;
+  const int s = (int)(i % V);
+  const int t = s / Xn, xx = s % Xn;
+  const int tm = t == 0 ? Tn - 1 : t - 1, xm = xx == 0 ? Xn - 1 : xx - 1;
+  const T* gc = g + c * V;
+  T* dc = dx + c * 2 * V;
+  dc[s] += gc[s] - gc[t * Xn + xm];
+  dc[V + s] += gc[tm * Xn + xx] - gc[s];
+}
+
 // force written and/or fused kick v += coef * F.  One workgroup per chain: sin(theta) of every
 // plaquette is computed ONCE into LDS (each one enters 4 force components), then the force
 // is two differences of LDS values.  Lattices beyond kU1MaxLds sites recompute instead.
@@ -308,6 +338,26 @@ int l2q_u1_plaq_reduce(const void* x, int nb, int T_, int X_, int elem_bytes, vo
   L2Q_DISPATCH_T(elem_bytes, hipLaunchKernelGGL(u1_plaq_kernel<T>, dim3(nb), dim3(kBlock), 0, st,
                                                 (const T*)x, T_, X_, (T*)out));
   return check_launch("l2q_u1_plaq_reduce");
+}
+
+int l2q_u1_wilson_loops(const void* x, int nb, int T_, int X_, int elem_bytes, void* out, void* stream) {
+  L2Q_REQUIRE(x && out, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && T_ > 0 && X_ > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)nb * T_ * X_;
+  L2Q_DISPATCH_T(elem_bytes, hipLaunchKernelGGL(u1_wloops_kernel<T>, dim3((unsigned)cdiv(total, kBlock)),
+                                                dim3(kBlock), 0, st, (const T*)x, T_, X_, total, (T*)out));
+  return check_launch("l2q_u1_wilson_loops");
+}
+
+int l2q_u1_wilson_loops_bwd(const void* g, int nb, int T_, int X_, int elem_bytes, void* dx, void* stream) {
+  L2Q_REQUIRE(g && dx, L2Q_EINVAL, "null pointer");
+  L2Q_REQUIRE(nb > 0 && T_ > 0 && X_ > 0, L2Q_EINVAL, "non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)nb * T_ * X_;
+  L2Q_DISPATCH_T(elem_bytes, hipLaunchKernelGGL(u1_wloops_bwd_kernel<T>, dim3((unsigned)cdiv(total, kBlock)),
+                                                dim3(kBlock), 0, st, (const T*)g, T_, X_, total, (T*)dx));
+  return check_launch("l2q_u1_wilson_loops_bwd");
 }
 
 int l2q_u1_force(const void* x, double beta, void* force, void* v, double coef, int nb, int T_,

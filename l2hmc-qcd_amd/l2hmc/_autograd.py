@@ -64,6 +64,41 @@ class SU3PlaqPlanes(torch.autograd.Function):
         return ops.su3_unpack(gx, ctx.lat).reshape(ctx.shape), None
 
 
+class SU3WilsonLoops(torch.autograd.Function):
+    """x -> [6, nb, T, X, Y, Z] complex: the trace field of the reference's `wilson_loops`
+    (lattice/su3/pytorch/lattice.py:242-244); `l2q_su3_wilson_loops` / `l2q_su3_wilson_loops_bwd`."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, lat: Sequence[int]):
+        xn = su3_pack_cached(x)
+        ctx.save_for_backward(xn)
+        ctx.lat, ctx.shape = tuple(int(i) for i in lat), x.shape
+        return ops.su3_wilson_loops_n(xn, lat)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xn,) = ctx.saved_tensors
+        gx = torch.zeros_like(xn)
+        ops.su3_wilson_loops_bwd_(gx, xn, g, ctx.lat)
+        return ops.su3_unpack(gx, ctx.lat).reshape(ctx.shape), None
+
+
+class U1WilsonLoops(torch.autograd.Function):
+    """x [nb, 2, T, X] -> theta [nb, T, X] (lattice/u1/pytorch/lattice.py:154-159), a linear map:
+    `l2q_u1_wilson_loops` forward, its adjoint `l2q_u1_wilson_loops_bwd` backward."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, lat: Sequence[int]):
+        ctx.lat, ctx.shape, ctx.dtype = tuple(int(i) for i in lat), x.shape, x.dtype
+        return ops.u1_wilson_loops(x.detach().contiguous(), lat)
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = torch.zeros((g.shape[0], 2, *ctx.lat), dtype=ctx.dtype, device=g.device)
+        ops.u1_wilson_loops_bwd_(dx, g, ctx.lat)
+        return dx.reshape(ctx.shape), None
+
+
 class SU3RectSums(torch.autograd.Function):
     """x -> [nb] sum Re tr R over the 12 planar 2x1 loops per site (c1 != 0 actions)."""
 

@@ -112,6 +112,15 @@ def su3_plaq_planes_n(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
     return out
 
 
+def su3_wilson_loops_n(xn: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    """[6, nb, T, X, Y, Z] complex128: tr P per plane and site (the reference's `wilson_loops` tensor)."""
+    nb = xn.shape[0]
+    T, X, Y, Z = (int(i) for i in lat)
+    out = torch.empty((6, nb, T, X, Y, Z), dtype=C128, device=xn.device)
+    N.call('l2q_su3_wilson_loops', xn, nb, T, X, Y, Z, out)
+    return out
+
+
 def diff_norm2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """per-chain sum |a - b|^2 (float64 / complex128 tensors of equal shape)."""
     nb = a.shape[0]
@@ -724,6 +733,21 @@ def u1_plaq_sums(x: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
     return out
 
 
+def u1_wilson_loops(x: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    """[nb, T, X]: the plaquette angles theta (the reference's `wilson_loops` tensor)."""
+    T, X = (int(i) for i in lat)
+    out = torch.empty((x.shape[0], T, X), dtype=x.dtype, device=x.device)
+    N.call('l2q_u1_wilson_loops', x, x.shape[0], T, X, x.element_size(), out)
+    return out
+
+
+def u1_wilson_loops_bwd_(dx: torch.Tensor, g: torch.Tensor, lat: Sequence[int]) -> torch.Tensor:
+    """dx [nb, 2, T, X] += adjoint of the plaquette-angle map applied to g [nb, T, X]."""
+    T, X = (int(i) for i in lat)
+    N.call('l2q_u1_wilson_loops_bwd', g.to(dx.dtype).contiguous(), dx.shape[0], T, X, dx.element_size(), dx)
+    return dx
+
+
 def u1_force(x: torch.Tensor, beta: float, lat: Sequence[int]) -> torch.Tensor:
     T, X = (int(i) for i in lat)
     f = torch.empty_like(x)
@@ -1203,6 +1227,14 @@ def su3_plaq_bwd_(gx: torch.Tensor, xn: torch.Tensor, w: torch.Tensor,
     """w [nb, 6, 2] float64: complex plane weights (re, im)."""
     T, X, Y, Z = (int(i) for i in lat)
     N.call('l2q_su3_plaq_bwd', xn, w.to(torch.float64).contiguous(), gx, xn.shape[0], T, X, Y, Z)
+    return gx
+
+
+def su3_wilson_loops_bwd_(gx: torch.Tensor, xn: torch.Tensor, w: torch.Tensor,
+                          lat: Sequence[int]) -> torch.Tensor:
+    """w [6, nb, T, X, Y, Z] complex128: the cotangent of `su3_wilson_loops_n`'s output."""
+    T, X, Y, Z = (int(i) for i in lat)
+    N.call('l2q_su3_wilson_loops_bwd', xn, w.to(C128).contiguous(), gx, xn.shape[0], T, X, Y, Z)
     return gx
 
 

@@ -40,12 +40,19 @@ def mat_adj(mat: np.ndarray) -> np.ndarray:
 
 
 class PlaqSums:
-    """What the reference calls ``wloops`` ([6, nb, T, X, Y, Z] complex traces) is only ever
-    reduced over everything but the chain; this carries the two per-chain sums instead."""
+    """Per-chain (sum Re tr P, sum Im tr P): what the sampler's own consumers (action, plaquette,
+    charges) reduce the reference's ``wloops`` field to.  ``LatticeSU3.plaq_sums`` returns it from ONE
+    pass of `l2q_su3_plaq_reduce`; ``wilson_loops`` returns the field itself as the reference does, and
+    every ``_plaqs / _charges / ...`` helper below accepts either."""
 
     def __init__(self, sums: Tensor):
         self.re = sums[:, 0].contiguous()
         self.im = sums[:, 1].contiguous()
+
+
+def _site_sum(w: Tensor) -> Tensor:
+    """the reference's reduction of a trace field [nplanes, nb, T, X, Y, Z] to [nb] (lattice.py:209, 228)"""
+    return w.sum(tuple(range(2, len(w.shape)))).sum(0)
 
 
 class LatticeSU3(Lattice):
@@ -96,32 +103,68 @@ class LatticeSU3(Lattice):
     def coeffs(self, beta: Tensor) -> dict[str, Tensor]:
         return {'plaq': beta * (1.0 - 8.0 * self.c1), 'rect': beta * self.c1}
 
-    def wilson_loops(self, x: Tensor) -> PlaqSums:
+    def wilson_loops(self, x: Tensor) -> Tensor:
+        """tr P for the 6 planes (u > v) and every site: [6, nb, T, X, Y, Z] complex, the tensor the
+        reference returns (lattice.py:242-244), from `l2q_su3_wilson_loops` (differentiable:
+        `l2q_su3_wilson_loops_bwd`).  The sampler itself never materialises it (`plaq_sums`)."""
+        if AG.wants_grad(x):
+            return AG.SU3WilsonLoops.apply(x.to(DEVICE), self._lattice_shape)
+        return ops.su3_wilson_loops_n(self.pack(x), self._lattice_shape)
+
+    def plaq_sums(self, x: Tensor) -> PlaqSums:
+        """the per-chain reductions of `wilson_loops(x)` in one fused pass (no field written)"""
         if AG.wants_grad(x):
             # differentiable route (loss.backward() of an autograd caller): l2q_su3_plaq_bwd behind it
             return PlaqSums(AG.SU3PlaqPlanes.apply(x.to(DEVICE), self._lattice_shape).sum(1))
         return PlaqSums(self.plaq_sums_n(self.pack(x)))
 
-    def _wilson_loops(self, x: Tensor, needs_rect: bool = False):
-        """(plaquette sums, rectangle sum or None): the per-chain reductions of the reference's
-        ([6, ...], [12, ...]) trace fields (lattice.py:157-199)."""
-        xn = self.pack(x)
-        return PlaqSums(self.plaq_sums_n(xn)), (self.rect_sums_n(xn) if needs_rect else None)
+    def _wilson_loops(self, x: Tensor, needs_rect: bool = False) -> tuple[Tensor, Tensor]:
+        """(plaquette traces [6, nb, T, X, Y, Z], rectangle traces [12, nb, T, X, Y, Z]) like the
+        reference (lattice.py:157-199); without `needs_rect` the second is zeros (a broadcast view)."""
+        ps = self.wilson_loops(x)
+        if not needs_rect:
+            return ps, torch.zeros((), dtype=ps.dtype, device=ps.device).expand(12, *ps.shape[1:])
+        rects = []
+        for u in range(1, self.dim):
+            for v in range(u):
+                rects.extend(self.g.trace(r) for r in self._rectangles(x, u, v))
+        return ps, torch.stack(rects)
 
     def _plaquettes(self, x: Tensor) -> Tensor:
-        return self._plaqs(self.wilson_loops(x))
+        return self._plaqs(self.plaq_sums(x))
 
-    def _plaqs(self, wloops: PlaqSums) -> Tensor:
-        return wloops.re / (6 * 3 * self.volume)
+    def plaqs(self, x: Optional[Tensor] = None, wloops=None) -> Tensor:
+        return self._plaqs(self.plaq_sums(x) if wloops is None else wloops)
 
-    def _charges(self, wloops: PlaqSums) -> Charges:
+    def charges(self, x: Optional[Tensor] = None, wloops=None) -> Charges:
+        return self._charges(self.plaq_sums(x) if wloops is None else wloops)
+
+    def int_charges(self, x: Optional[Tensor] = None, wloops=None) -> Tensor:
+        return self._int_charges(self.plaq_sums(x) if wloops is None else wloops)
+
+    def sin_charges(self, x: Optional[Tensor] = None, wloops=None) -> Tensor:
+        return self._sin_charges(self.plaq_sums(x) if wloops is None else wloops)
+
+    # the helpers take the reference's trace field (a Tensor, lattice.py:208-240) or a PlaqSums
+    @staticmethod
+    def _re_sum(wloops) -> Tensor:
+        return wloops.re if isinstance(wloops, PlaqSums) else _site_sum(wloops.real)
+
+    @staticmethod
+    def _im_sum(wloops) -> Tensor:
+        return wloops.im if isinstance(wloops, PlaqSums) else _site_sum(wloops.imag)
+
+    def _plaqs(self, wloops) -> Tensor:
+        return self._re_sum(wloops) / (6 * 3 * self.volume)
+
+    def _charges(self, wloops) -> Charges:
         return Charges(intQ=self._int_charges(wloops), sinQ=self._sin_charges(wloops))
 
-    def _int_charges(self, wloops: PlaqSums) -> Tensor:
-        return wloops.im / (32 * (np.pi ** 2))
+    def _int_charges(self, wloops) -> Tensor:
+        return self._im_sum(wloops) / (32 * (np.pi ** 2))
 
-    def _sin_charges(self, wloops: PlaqSums) -> Tensor:
-        return wloops.im / (6 * 3 * self.volume)
+    def _sin_charges(self, wloops) -> Tensor:
+        return self._im_sum(wloops) / (6 * 3 * self.volume)
 
     def kinetic_energy(self, v: Tensor) -> Tensor:
         return self.g.kinetic_energy(v)
@@ -175,9 +218,9 @@ class LatticeSU3(Lattice):
         """The reference's unused opposite-sign variant (lattice.py:271-285): +coeff sum Re tr P / 3."""
         ps, rs = wloops if isinstance(wloops, tuple) else (wloops, None)
         c = self.coeffs(torch.as_tensor(_beta(beta)))
-        action = c['plaq'] * ps.re
+        action = c['plaq'] * self._re_sum(ps)
         if self.c1 != 0 and rs is not None:
-            action = action + c['rect'] * rs
+            action = action + c['rect'] * (_site_sum(rs.real) if rs.dim() > 1 else rs)
         return action / 3.0
 
     def plaq_loss(self, acc: Tensor, x1=None, x2=None, wloops1=None, wloops2=None):
@@ -207,7 +250,7 @@ class LatticeSU3(Lattice):
 
     def calc_metrics(self, x: Tensor, beta: Optional[Tensor] = None,
                      xinit: Optional[Tensor] = None) -> dict[str, Tensor]:
-        w = self.wilson_loops(x)
+        w = self.plaq_sums(x)
         q = self._charges(w)
         metrics = {'plaqs': self._plaqs(w), 'sinQ': q.sinQ, 'intQ': q.intQ}
         if beta is not None:
@@ -217,7 +260,7 @@ class LatticeSU3(Lattice):
                 s_, dsdx_ = self.action_with_grad(xinit, beta)
                 metrics.update({'daction': (s - s_).abs(), 'dsdx': (dsdx - dsdx_).abs()})
         if xinit is not None:
-            w_ = self.wilson_loops(xinit)
+            w_ = self.plaq_sums(xinit)
             q_ = self._charges(w_)
             metrics.update({'dplaqs': (metrics['plaqs'] - self._plaqs(w_)).abs(),
                             'dQint': (q.intQ - q_.intQ).abs(),

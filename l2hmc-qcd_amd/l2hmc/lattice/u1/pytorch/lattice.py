@@ -38,8 +38,10 @@ def _beta(beta) -> float:
 
 
 class PlaqSumsU1:
-    """per-chain sums of cos / sin / project_angle of the plaquette angle (what every
-    consumer of the reference's ``wloops`` reduces to)."""
+    """per-chain sums of cos / sin / project_angle of the plaquette angle: what the sampler's own
+    consumers reduce the reference's ``wloops`` field to (``LatticeU1.plaq_sums``, one pass of
+    `l2q_u1_plaq_reduce`).  ``wilson_loops`` returns the field itself as the reference does; every
+    ``_plaqs / _charges / ...`` helper accepts either."""
 
     def __init__(self, sums: Tensor):
         self.cos, self.sin, self.proj = (sums[:, i].contiguous() for i in range(3))
@@ -57,8 +59,15 @@ class LatticeU1(Lattice):
     def _x(self, x: Tensor) -> Tensor:
         return x.to(DEVICE).reshape(-1, *self.xshape).contiguous()
 
-    def wilson_loops(self, x: Tensor) -> PlaqSumsU1:
-        """theta = U0(t,x) + U1(t+1,x) - U0(t,x+1) - U1(t,x), reduced per chain."""
+    def wilson_loops(self, x: Tensor) -> Tensor:
+        """theta = U0(t,x) + U1(t+1,x) - U0(t,x+1) - U1(t,x): [nb, T, X], the tensor the reference
+        returns (lattice.py:154-159), from `l2q_u1_wilson_loops` (differentiable: its adjoint kernel)."""
+        if AG.wants_grad(x):
+            return AG.U1WilsonLoops.apply(x.to(DEVICE).reshape(-1, *self.xshape), self._lattice_shape)
+        return ops.u1_wilson_loops(self._x(x), self._lattice_shape)
+
+    def plaq_sums(self, x: Tensor) -> PlaqSumsU1:
+        """the per-chain reductions of `wilson_loops(x)` in one fused pass (no field written)"""
         if AG.wants_grad(x):
             # differentiable route (loss.backward() of an autograd caller): l2q_u1_plaq_bwd behind it
             return PlaqSumsU1(AG.U1PlaqSums.apply(x.to(DEVICE).reshape(-1, *self.xshape),
@@ -68,7 +77,7 @@ class LatticeU1(Lattice):
     def _get_wloops(self, x: Optional[Tensor] = None) -> PlaqSumsU1:
         if x is None:
             raise ValueError('One of `x` or `wloops` must be specified.')
-        return self.wilson_loops(x)
+        return self.plaq_sums(x)
 
     def draw_uniform_batch(self, requires_grad: bool = True) -> Tensor:
         """uniform in (-pi, pi) (lattice.py:67-71)"""
@@ -79,9 +88,11 @@ class LatticeU1(Lattice):
 
     def action(self, x: Tensor, beta: Tensor) -> Tensor:
         """beta * sum(1 - cos theta) (lattice.py:80-86)"""
-        return self._action(self.wilson_loops(x), beta)
+        return self._action(self.plaq_sums(x), beta)
 
-    def _action(self, wloops: PlaqSumsU1, beta: Tensor) -> Tensor:
+    def _action(self, wloops, beta: Tensor) -> Tensor:
+        if isinstance(wloops, Tensor):                   # the reference's field (lattice.py:80-86)
+            return _beta(beta) * (1. - wloops.cos()).sum((1, 2))
         return _beta(beta) * (self.volume - wloops.cos)
 
     def action_with_grad(self, x: Tensor, beta: Tensor) -> tuple[Tensor, Tensor]:
@@ -100,12 +111,12 @@ class LatticeU1(Lattice):
         return plaq_exact(torch.as_tensor(beta)).to(plaqs.device) * torch.ones_like(plaqs) - plaqs
 
     def calc_metrics(self, x: Tensor, beta: Optional[Tensor] = None) -> dict[str, Tensor]:
-        w = self.wilson_loops(x)
+        w = self.plaq_sums(x)
         return {'plaqs': self._plaqs(w), 'intQ': self._int_charges(w),
                 'sinQ': self._sin_charges(w)}
 
     def observables(self, x: Tensor) -> LatticeMetrics:
-        w = self.wilson_loops(x)
+        w = self.plaq_sums(x)
         return LatticeMetrics(p4x4=self.plaqs4x4(x=x), plaqs=self._plaqs(w),
                               charges=self._charges(w))
 
@@ -113,10 +124,12 @@ class LatticeU1(Lattice):
         if wloops is None:
             if x is None:
                 raise ValueError('One of `x` or `wloops` must be specified.')
-            wloops = self.wilson_loops(x)
+            wloops = self.plaq_sums(x)
         return self._plaqs(wloops)
 
-    def _plaqs(self, wloops: PlaqSumsU1) -> Tensor:
+    def _plaqs(self, wloops) -> Tensor:
+        if isinstance(wloops, Tensor):                   # (lattice.py:200-203)
+            return wloops.cos().mean((1, 2))
         return wloops.cos / self.volume
 
     def wilson_loops4x4(self, x: Tensor) -> Tensor:
@@ -146,12 +159,18 @@ class LatticeU1(Lattice):
 
     def plaq_loss(self, acc: Tensor, x1: Optional[Tensor] = None, x2: Optional[Tensor] = None,
                   wl1=None, wl2=None) -> Tensor:
-        """-(acc * sum 2 (1 - cos(theta_2 - theta_1)) + 1e-4).mean()  (lattice.py:278-292).  The
-        plaquette angle is linear in the links, so theta_2 - theta_1 = theta(x2 - x1) and one
-        reduction over the difference field gives the sum."""
+        """-(acc * sum 2 (1 - cos(theta_2 - theta_1)) + 1e-4).mean()  (lattice.py:278-292).  From
+        configurations: the plaquette angle is linear in the links, so theta_2 - theta_1 = theta(x2 - x1)
+        and one reduction over the difference field gives the sum.  From `wilson_loops` tensors: the
+        reference's expression."""
+        if isinstance(wl1, Tensor) or isinstance(wl2, Tensor):
+            w1 = self.wilson_loops(x1) if wl1 is None else wl1
+            w2 = self.wilson_loops(x2) if wl2 is None else wl2
+            ploss = acc.to(w1.device) * (2. * (1. - (w2 - w1).cos())).sum((1, 2)) + 1e-4
+            return -ploss.mean(0)
         if x1 is None or x2 is None:
-            raise ValueError('plaq_loss needs the configurations x1, x2 (the per-chain sums '
-                             'this build keeps instead of the plaquette field do not suffice)')
+            raise ValueError('plaq_loss needs the configurations x1, x2 or `wilson_loops` tensors '
+                             '(per-chain PlaqSumsU1 do not determine it)')
         d = self._x(x2) - self._x(x1)
         cosd = ops.u1_plaq_sums(d.contiguous(), self._lattice_shape)[:, 0]
         ploss = acc.to(cosd.device) * (2. * (self.volume - cosd)) + 1e-4
@@ -165,10 +184,14 @@ class LatticeU1(Lattice):
         dq = (self._sin_charges(w2) - self._sin_charges(w1)) ** 2
         return -(acc.to(dq.device) * dq + 1e-4).mean(0)
 
-    def _sin_charges(self, wloops: PlaqSumsU1) -> Tensor:
+    def _sin_charges(self, wloops) -> Tensor:
+        if isinstance(wloops, Tensor):                   # (lattice.py:221-224)
+            return wloops.sin().sum((1, 2)) / TWOPI
         return wloops.sin / TWOPI
 
-    def _int_charges(self, wloops: PlaqSumsU1) -> Tensor:
+    def _int_charges(self, wloops) -> Tensor:
+        if isinstance(wloops, Tensor):                   # (lattice.py:226-228)
+            return project_angle(wloops).sum((1, 2)) / TWOPI
         return wloops.proj / TWOPI
 
     def sin_charges(self, x: Optional[Tensor] = None,

@@ -77,8 +77,8 @@ class LatticeLoss:
 
     def charge_loss(self, x_init: Tensor, x_prop: Tensor, acc: Tensor,
                     use_mixed_loss: Optional[bool] = None) -> Tensor:
-        q1 = self.lattice._sin_charges(self.lattice.wilson_loops(x_init))
-        q2 = self.lattice._sin_charges(self.lattice.wilson_loops(x_prop))
+        q1 = self.lattice._sin_charges(self.lattice.plaq_sums(x_init))
+        q2 = self.lattice._sin_charges(self.lattice.plaq_sums(x_prop))
         return self._mixed(acc.to(DEVICE) * (q2 - q1) ** 2, self.charge_weight, use_mixed_loss)
 
     def rmse_loss(self, x_init: Tensor, x_prop: Tensor, acc: Tensor,
@@ -97,11 +97,21 @@ class LatticeLoss:
         return self._mixed(acc.to(DEVICE) * (d2 / nelem).to(acc.dtype), self.rmse_weight,
                            use_mixed_loss)
 
-    # ---- the reference's wloops-based helpers (loss.py:57-92, 166-192) on this build's per-chain
-    # reductions (PlaqSums / PlaqSumsU1 objects returned by lattice.wilson_loops)
-    def _plaq_loss(self, w1, w2, acc: Tensor, use_mixed_loss: Optional[bool] = None) -> Tensor:
-        raise NotImplementedError('_plaq_loss needs per-plane (SU3) / per-row (U1) sums, not the '
-                                  'per-chain wloops reductions: use plaq_loss(x_init, x_prop, acc)')
+    # ---- the reference's wloops-based helpers (loss.py:57-92, 166-192): w1, w2 are the tensors
+    # `lattice.wilson_loops` returns (or, for the charge term, the per-chain PlaqSums of `plaq_sums`)
+    def _plaq_loss(self, w1: Tensor, w2: Tensor, acc: Tensor,
+                   use_mixed_loss: Optional[bool] = None) -> Tensor:
+        """(loss.py:57-70) on `wilson_loops` tensors; `use_mixed_loss` is taken literally (None -> not
+        mixed) like the reference"""
+        if not isinstance(w1, Tensor) or not isinstance(w2, Tensor):
+            raise TypeError('_plaq_loss takes the tensors of lattice.wilson_loops (per-chain PlaqSums do '
+                            'not determine the per-plane sums): or use plaq_loss(x_init, x_prop, acc)')
+        p1 = w1.real.sum(list(range(2, len(w1.shape))))
+        p2 = w2.real.sum(list(range(2, len(w2.shape))))
+        ploss = acc.to(p1.device) * (p2 - p1) ** 2
+        if use_mixed_loss:
+            return self.mixed_loss(ploss + 1e-4, self.plaq_weight.to(ploss.device)).mean()
+        return (-ploss / self.plaq_weight.to(ploss.device)).mean()
 
     def _charge_loss(self, w1, w2, acc: Tensor, use_mixed_loss: Optional[bool] = None) -> Tensor:
         dq = (self.lattice._sin_charges(w2) - self.lattice._sin_charges(w1)) ** 2
@@ -162,7 +172,7 @@ class LatticeLoss:
     def lattice_metrics(self, xinit: Tensor, xout: Optional[Tensor] = None) -> dict[str, Tensor]:
         metrics = self.lattice.calc_metrics(x=xinit)
         if xout is not None:
-            w = self.lattice.wilson_loops(x=xout.reshape(xinit.shape))
+            w = self.lattice.plaq_sums(xout.reshape(xinit.shape))
             metrics.update({'dQint': (self.lattice._int_charges(w) - metrics['intQ']).abs(),
                             'dQsin': (self.lattice._sin_charges(w) - metrics['sinQ']).abs()})
         return metrics

@@ -39,6 +39,7 @@ SIGNATURES = {
     'l2q_su3_unpack_select': (I, [P, P, P, P, I, L, P]),
     'l2q_su3_plaq_reduce': (I, [P, I, I, I, I, I, P, P, Z, P]),
     'l2q_su3_plaq_planes': (I, [P, I, I, I, I, I, P, P, Z, P]),
+    'l2q_su3_wilson_loops': (I, [P, I, I, I, I, I, P, P]),
     'l2q_diff_norm2_reduce': (I, [P, P, I, L, P, P, Z, P]),
     'l2q_su3_force': (I, [P, D, P, I, I, I, I, I, P]),
     'l2q_su3_force_kick': (I, [P, D, D, P, I, I, I, I, I, P]),
@@ -92,6 +93,8 @@ SIGNATURES = {
     'l2q_maxpool_act_nhwc_h': (I, [I, P, I, I, I, I, I, I, P, P]),
     'l2q_nchw_to_nhwc_pad_h': (I, [I, P, I, I, I, I, I, P, P]),
     'l2q_u1_plaq_reduce': (I, [P, I, I, I, I, P, P]),
+    'l2q_u1_wilson_loops': (I, [P, I, I, I, I, P, P]),
+    'l2q_u1_wilson_loops_bwd': (I, [P, I, I, I, I, P, P]),
     'l2q_u1_force': (I, [P, D, P, P, D, I, I, I, I, P]),
     'l2q_u1_x_update': (I, [P, P, P, P, P, P, I, D, I, I, I, I, L, P, P]),
     'l2q_u1_wrap': (I, [P, P, L, I, P]),
@@ -131,6 +134,7 @@ SIGNATURES = {
     'l2q_su3_projsu_vec8_bwd': (I, [P, P, P, L, L, P]),
     'l2q_su3_force_bwd': (I, [P, P, D, P, I, I, I, I, I, P]),
     'l2q_su3_plaq_bwd': (I, [P, P, P, I, I, I, I, I, P]),
+    'l2q_su3_wilson_loops_bwd': (I, [P, P, P, I, I, I, I, I, P]),
     'l2q_su3_rect_reduce': (I, [P, I, I, I, I, I, P, P, Z, P]),
     'l2q_su3_rect_force_add': (I, [P, D, P, I, I, I, I, I, P]),
     'l2q_su3_rect_bwd': (I, [P, P, P, I, I, I, I, I, P]),

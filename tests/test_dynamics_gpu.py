@@ -742,9 +742,12 @@ def test_su3_improved_action_c1(golden):
     assert err(host(lat.grad_action(x, beta)), g['force']) < 1e-12
     s, f = lat.action_with_grad(x, beta)
     assert err(host(s), g['action']) < 1e-11 and err(host(f), g['force']) < 1e-12
-    ps, rs = lat._wilson_loops(x, needs_rect=True)
-    assert err(host(ps.re), g['plaq_sum']) < 1e-11 and err(host(rs), g['rect_sum']) < 1e-11
+    ps, rs = lat._wilson_loops(x, needs_rect=True)              # the reference's trace fields [6, ...], [12, ...]
+    assert tuple(rs.shape) == g['rects'].shape and err(host(rs), g['rects']) < 1e-13
+    assert err(host(lat._re_sum(ps)), g['plaq_sum']) < 1e-11
+    assert err(host(rs.real.sum(tuple(range(2, rs.dim()))).sum(0)), g['rect_sum']) < 1e-11
     assert err(host(lat._action((ps, rs), beta)), -g['action']) < 1e-11
+    assert err(host(lat._action((lat.plaq_sums(x), lat.rect_sums_n(xn)), beta)), -g['action']) < 1e-11
     urul, uuud = lat._rectangles(x, 2, 1)
     assert err(host(urul), g['rect_21_urul']) < 1e-13 and err(host(uuud), g['rect_21_uuud']) < 1e-13
     _, rects = lat._plaquette_field(x, needs_rect=True)

@@ -59,6 +59,120 @@ def test_lattice_loss_u1(golden):
         LatticeLoss(lat, cfgs.LossConfig(rmse_weight=1.0)).rmse_loss(x, xp, acc)
 
 
+def test_wilson_loops_tensor_su3(golden):
+    """`LatticeSU3.wilson_loops` returns the reference's tensor ([6, nb, T, X, Y, Z] complex,
+    lattice/su3/pytorch/lattice.py:242-244): the expressions reference callers apply to it
+    (loss/pytorch/loss.py:57-110, lattice.py:208-240) give the reference's values, and it is differentiable."""
+    torch.set_default_dtype(torch.float64)
+    import l2hmc.configs as cfgs
+    from l2hmc.lattice.su3.pytorch.lattice import LatticeSU3, PlaqSums
+    from l2hmc.loss.pytorch.loss import LatticeLoss
+    go = golden('su3_ops')
+    lat0 = LatticeSU3(go['x'].shape[0], [int(i) for i in go['latvolume']])
+    w = lat0.wilson_loops(dev(go['x']))
+    assert isinstance(w, torch.Tensor) and w.dtype == torch.complex128 and tuple(w.shape) == go['wloops'].shape
+    assert np.abs(w.cpu().numpy() - go['wloops']).max() < 1e-13
+    assert np.abs(lat0._plaqs(wloops=w).cpu().numpy() - go['plaqs']).max() < 1e-14
+    assert np.abs(lat0._sin_charges(wloops=w).cpu().numpy() - go['sinQ']).max() < 1e-14
+    assert np.abs(lat0._int_charges(wloops=w).cpu().numpy() - go['intQ']).max() < 1e-13
+    assert np.abs(lat0.plaqs(wloops=w).cpu().numpy() - go['plaqs']).max() < 1e-14
+    assert np.abs(lat0.charges(wloops=w).intQ.cpu().numpy() - go['intQ']).max() < 1e-13
+    ps, rs = lat0._wilson_loops(dev(go['x']))
+    assert torch.equal(ps, w) and tuple(rs.shape) == (12, *w.shape[1:]) and float(rs.abs().max()) == 0.0
+    assert isinstance(lat0.plaq_sums(dev(go['x'])), PlaqSums)
+
+    g, want = golden('su3_l2hmc'), golden('loss_su3')
+    L = [int(i) for i in g['latvolume']]
+    x, xp, acc = dev(g['x']), dev(g['x_prop']), dev(g['acc'])
+    lat = LatticeSU3(x.shape[0], L)
+    w1, w2 = lat.wilson_loops(x), lat.wilson_loops(xp)
+    # loss.py:64-70 (`_plaq_loss`, not mixed) written out on the returned tensors
+    p1 = w1.real.sum(list(range(2, len(w1.shape))))
+    p2 = w2.real.sum(list(range(2, len(w2.shape))))
+    ploss = acc * (p2 - p1) ** 2
+    pw = torch.tensor(0.1, dtype=torch.float).cuda()              # the reference keeps its weights in fp32
+    assert abs(float((-ploss / pw).mean()) - float(want['su3_plaq'])) < 1e-8
+    assert abs(float((-ploss / 0.5).mean()) - float(want['mix_plaq'])) < 1e-8
+    lf = LatticeLoss(lat, cfgs.LossConfig(use_mixed_loss=False, charge_weight=0.3, rmse_weight=1.0,
+                                          plaq_weight=0.5))
+    assert abs(float(lf._plaq_loss(w1, w2, acc)) - float(want['mix_plaq'])) < 1e-8
+    # loss.py:79-92 (`_charge_loss`)
+    q1, q2 = lat._sin_charges(wloops=w1), lat._sin_charges(wloops=w2)
+    qw = torch.tensor(0.3, dtype=torch.float).cuda()
+    assert abs(float((-(acc * (q2 - q1) ** 2) / qw).mean()) - float(want['mix_charge'])) < 1e-14
+    assert abs(float(lf._charge_loss(w1, w2, acc)) - float(want['mix_charge'])) < 1e-14
+    # loss.py:100-110 (`lattice_metrics`)
+    m = lat.calc_metrics(x=x)
+    wo = lat.wilson_loops(x=dev(g['x_out']).reshape(x.shape))
+    assert np.abs((lat._int_charges(wloops=wo) - m['intQ']).abs().cpu().numpy() - want['dQint']).max() < 1e-10
+    assert np.abs((lat._sin_charges(wloops=wo) - m['sinQ']).abs().cpu().numpy() - want['dQsin']).max() < 1e-10
+    # gradients: the reference's loss through the tensor == through the fused per-plane sums; and an arbitrary
+    # per-site cotangent against torch autograd over the roll / matmul construction of the same traces
+    xa = xp.clone().requires_grad_(True)
+    wa = lat.wilson_loops(xa)
+    pa = wa.real.sum(list(range(2, len(wa.shape))))
+    la = (-(acc * (pa - p1) ** 2) / 0.5).mean() + (-(acc * (lat._sin_charges(wloops=wa) - q1) ** 2) / 0.3).mean()
+    la.backward()
+    xb = xp.clone().requires_grad_(True)
+    lb = lf.plaq_loss(x, xb, acc) + lf.charge_loss(x, xb, acc)
+    lb.backward()
+    assert abs(float(la) - float(lb)) < 1e-10 * max(1.0, abs(float(lb)))
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-10 * max(1.0, float(xb.grad.abs().max()))
+    gen = torch.Generator().manual_seed(3)
+    cot = torch.complex(torch.randn(w2.shape, generator=gen), torch.randn(w2.shape, generator=gen)).cuda()
+    xc = xp.clone().requires_grad_(True)
+    (lat.wilson_loops(xc) * cot.conj()).real.sum().backward()
+    xd = xp.clone().requires_grad_(True)
+    ref = torch.stack([lat._trace_plaquette(xd, u, v) for u in range(1, 4) for v in range(u)])
+    (ref * cot.conj()).real.sum().backward()
+    assert float((xc.grad - xd.grad).abs().max()) < 1e-11 * max(1.0, float(xd.grad.abs().max()))
+
+
+def test_wilson_loops_tensor_u1(golden):
+    """`LatticeU1.wilson_loops` returns the reference's [nb, T, X] plaquette angles (lattice/u1/pytorch/
+    lattice.py:154-159); the reference's expressions on it (lattice.py:188-308) and its gradient."""
+    torch.set_default_dtype(torch.float32)
+    import l2hmc.configs as cfgs
+    from l2hmc.lattice.u1.pytorch.lattice import LatticeU1, project_angle
+    from l2hmc.loss.pytorch.loss import LatticeLoss
+    g, want = golden('u1_c1'), golden('loss_u1')
+    L = [int(i) for i in g['latvolume']]
+    x, xp, acc = dev(g['x']), dev(g['x_prop']), dev(g['acc'])
+    lat = LatticeU1(x.shape[0], L)
+    w = lat.wilson_loops(x)
+    assert isinstance(w, torch.Tensor) and tuple(w.shape) == g['wloops'].shape
+    assert np.array_equal(w.cpu().numpy(), g['wloops'])              # same left-to-right fp32 sum
+    assert np.abs(w.cos().mean((1, 2)).cpu().numpy() - g['plaqs']).max() < 1e-6
+    assert np.abs(lat._plaqs(wloops=w).cpu().numpy() - g['plaqs']).max() < 1e-6
+    assert np.abs(lat._sin_charges(wloops=w).cpu().numpy() - g['sinQ']).max() < 1e-5
+    assert np.abs(lat._int_charges(wloops=w).cpu().numpy() - g['intQ']).max() < 1e-5
+    assert np.abs((project_angle(w).sum((1, 2)) / (2 * np.pi)).cpu().numpy() - g['intQ']).max() < 1e-5
+    assert np.abs(lat._action(w, torch.tensor(float(g['beta']))).cpu().numpy() - g['action']).max() < 1e-3
+    assert np.abs(lat.sin_charges(wloops=w).cpu().numpy() - g['sinQ']).max() < 1e-5
+    # LatticeLoss._charge_loss / lattice.charge_loss / plaq_loss on tensors (loss.py:72-92, lattice.py:278-308)
+    w2 = lat.wilson_loops(xp)
+    lf = LatticeLoss(lat, cfgs.LossConfig(use_mixed_loss=False, charge_weight=0.5))
+    rel = abs(float(lf._charge_loss(w, w2, acc)) - float(want['plain_loss'])) / abs(float(want['plain_loss']))
+    assert rel < 1e-3, rel
+    dq = (lat._sin_charges(wloops=w2) - lat._sin_charges(wloops=w)) ** 2
+    assert abs(float(lat.charge_loss(acc, wl1=w, wl2=w2)) - float(-(acc * dq + 1e-4).mean(0))) < 1e-6
+    pl = -(acc * (2. * (1. - (w2 - w).cos())).sum((1, 2)) + 1e-4).mean(0)
+    assert abs(float(lat.plaq_loss(acc, wl1=w, wl2=w2)) - float(pl)) < 1e-5 * abs(float(pl))
+    assert abs(float(lat.plaq_loss(acc, x1=x, x2=xp)) - float(pl)) < 1e-4 * abs(float(pl))
+    wo = lat.wilson_loops(x=dev(g['x_out']).reshape(x.shape))
+    m = lat.calc_metrics(x=x)
+    assert np.abs((lat._int_charges(wloops=wo) - m['intQ']).abs().cpu().numpy() - want['dQint']).max() < 1e-4
+    assert np.abs((lat._sin_charges(wloops=wo) - m['sinQ']).abs().cpu().numpy() - want['dQsin']).max() < 1e-4
+    # gradient of a non-linear functional of the field against torch autograd over the roll construction
+    xa = xp.double().clone().requires_grad_(True)
+    cot = torch.randn(w.shape, generator=torch.Generator().manual_seed(5)).double().cuda()
+    (lat.wilson_loops(xa).sin() * cot).sum().backward()
+    xb = xp.double().clone().requires_grad_(True)
+    th = xb[:, 0] + xb[:, 1].roll(-1, dims=1) - xb[:, 0].roll(-1, dims=2) - xb[:, 1]
+    (th.sin() * cot).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-12
+
+
 def test_experiment_from_config_su3():
     import l2hmc.configs as cfgs
     from l2hmc.experiment.pytorch.experiment import Experiment
@@ -123,8 +237,10 @@ def test_minor_lattice_group_helpers():
     ls = LatticeSU3(2, L)
     x = ls.random().cuda()
     tot = sum(ls._trace_plaquette(x, u, v).sum((1, 2, 3, 4)) for u in range(1, 4) for v in range(u))
-    w = ls.wilson_loops(x)
+    w = ls.plaq_sums(x)
     assert float((tot.real - w.re).abs().max()) < 1e-9 and float((tot.imag - w.im).abs().max()) < 1e-9
+    wt = ls.wilson_loops(x)
+    assert float((wt.sum((0, 2, 3, 4, 5)) - tot).abs().max()) < 1e-9
     field, rect = ls._plaquette_field(x)
     assert field.shape == (6, 2, *L, 3, 3) and rect is None
     # X^{-1/2} of a positive Hermitian matrix
