@@ -1067,16 +1067,23 @@ def main():
         except Exception:  # noqa: BLE001
             uid = f'device-{torch.cuda.current_device()}'
         info = [None] * world
+        from l2hmc import _ops as _l2q_ops
         dist.all_gather_object(info, {'rank': rank, 'device': torch.cuda.current_device(), 'uuid': uid,
-                                      'model': msum, 'chains': xsum})
+                                      'model': msum, 'chains': xsum,
+                                      'paths': _l2q_ops.mem_gate_signature()})
         if len({i['model'] for i in info}) != 1:
             raise RuntimeError(f'bench.py: ranks hold different models: {info}')
         if len({i['chains'] for i in info}) != world:
             raise RuntimeError(f'bench.py: ranks run the same chains: {info}')
         if not share and len({i['uuid'] for i in info}) != world:
             raise RuntimeError(f'bench.py: ranks share a device: {info}')
+        # the memory-gated kernel choices (int8-sliced vs fp64 MFMA ...) are made by all ranks together before the
+        # first kernel that depends on them (l2hmc._ops.mem_gate): every rank must report the same table
+        if len({i['paths'] for i in info}) != 1:
+            raise RuntimeError(f'bench.py: ranks took different memory-gated kernel paths: {info}')
         ranks_check = {'distinct_devices': len({i['uuid'] for i in info}), 'same_model': True,
-                       'distinct_chain_sets': world}
+                       'distinct_chain_sets': world, 'same_kernel_paths': True,
+                       'kernel_paths': [list(kv) for kv in info[0]['paths']]}
     if dist is not None:
         # every rank's own time for its K steps (rank 0 reports min / median / max of the per-rank
         # rates next to the contract's max-over-ranks value)
@@ -1202,6 +1209,21 @@ def main():
         roofline = dict(max(rooflines, key=lambda r: r['time_s'])) if rooflines else None
         for r in rooflines + ([roofline] if roofline else []):
             r.pop('time_s', None)
+        if roofline is not None:
+            # BASELINE's metric has a second half, "plaquette-kernel HBM GB/s": the lattice kernels' own lines sit
+            # INSIDE `roofline` (the record the driver keeps), next to the int8 pricing of the sliced GEMMs
+            short = {'l2q_su3_plaq_reduce': 'plaq', 'l2q_su3_force': 'force', 'l2q_su3_force_vec8': 'force_vec8',
+                     'l2q_su3_force_kick': 'force_kick'}
+            roofline['hbm_kernels'] = {
+                short[r['kernel']]: {'symbol': r['symbol'], 'GB/s': r['achieved'], 'peak': r['peak'],
+                                     'frac': r['frac'], 'avg_ms': r['avg_ms'], 'launches': r['launches'],
+                                     'traffic': r['traffic'],
+                                     'algorithmic_bytes_per_launch': r['algorithmic_bytes_per_launch']}
+                for r in rooflines if r['bound'] == 'hbm' and r['kernel'] in short}
+            i8 = {('heads' if 'heads' in r['kernel'] else 'input_layer'): dict(r['int8'], avg_ms=r['avg_ms'])
+                  for r in rooflines if 'int8' in r}
+            if i8:
+                roofline['int8'] = i8
         nchain_lf = world * args.nchains * nlf_exec * args.steps
         what = {'l2hmc': 'Dynamics.forward merged L2HMC', 'hmc': 'apply_transition_hmc',
                 'train': 'Trainer.train_step (tape + reverse sweep + all-reduce + Adam)'}[args.mode]
@@ -1266,6 +1288,15 @@ def main():
                 out['spot_check'] = spot_check(dyn, lat, x, args)
             if not args.no_cpu_baseline:
                 out['secondary'] = secondary(dyn, x, beta, args, nlf_exec)
+                sh = out['secondary'].get('l2hmc_scaled_heads')
+                if isinstance(sh, dict):
+                    # the representative sampling line beside the headline's all-reject one (same kernels and shapes)
+                    out['config']['workload'] += (
+                        f'; acceptance {out["accept_prob_mean"]} with random-init heads (every chain rejects), '
+                        f'{sh["accept_prob_mean"]} with the heads scaled by {sh["head_scale"]}: '
+                        f'{sh["value"]} chain*LF/s (secondary.l2hmc_scaled_heads)')
+                    out['config']['scaled_heads'] = {'value': sh['value'], 'accept_prob_mean': sh['accept_prob_mean'],
+                                                     'accepted_fraction': sh['accepted_fraction']}
                 out['cpu_baseline'] = cpu_baseline(dyn, args)
             if not args.no_u1:
                 del dyn, lat, x, m

@@ -533,6 +533,34 @@ def device_headroom(device) -> int:
     return int(free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
 
 
+# In a data-parallel job the ranks must take the SAME path (the overlapped gradient exchange launches
+# one collective per finished parameter range, and which ranges exist depends on these gates -- ranks that
+# disagree would issue mismatched all-reduces).  With torch.distributed initialised and more than one rank, an
+# 'auto' decision is therefore made ONCE per (gate, size) by all ranks together -- the path is taken only if
+# every rank can afford it (all-reduce MIN, before the first kernel that depends on it) -- and kept for the rest
+# of the process.  Every rank reaches a gate in the same program order, so the collective matches up.
+MEM_GATE_CONSENSUS = [True]
+_MEM_GATE_AGREED: dict = {}
+
+
+def _multi_rank() -> bool:
+    import torch.distributed as dist
+    return bool(MEM_GATE_CONSENSUS[0] and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1)
+
+
+def _ranks_agree(ok: bool, device) -> bool:
+    """all-reduce MIN of one rank-local yes / no"""
+    import torch.distributed as dist
+    backend = str(dist.get_backend())
+    on_dev = 'nccl' in backend and isinstance(device, torch.device) and device.type == 'cuda'
+    if not on_dev and 'gloo' not in backend:
+        return ok                                     # (an RCCL-only group and a host-side decision: nothing to compare)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_dev else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def mem_gate(what: str, need_bytes: int, fraction: float, device) -> bool:
     """True: `need_bytes` may be taken for `what` (at most `fraction` of the headroom)."""
     pol = MEM_GATE_POLICY[0]
@@ -541,7 +569,13 @@ def mem_gate(what: str, need_bytes: int, fraction: float, device) -> bool:
     elif pol == 'never':
         ok = False
     else:
-        ok = need_bytes <= fraction * device_headroom(device)
+        key = (what, int(need_bytes))
+        if key in _MEM_GATE_AGREED:
+            ok = _MEM_GATE_AGREED[key]
+        else:
+            ok = need_bytes <= fraction * device_headroom(device)
+            if _multi_rank():
+                ok = _MEM_GATE_AGREED[key] = _ranks_agree(ok, device)
     prev = MEM_GATE_LOG.get(what)
     MEM_GATE_LOG[what] = ok
     if not ok and prev is not False:

@@ -184,6 +184,9 @@ class GradReducer:
     of it: only the last slab's exchange is exposed.  Sums are element-wise, so the result is the one
     blocking all-reduce's bit for bit."""
 
+    _paths_checked = False          # the once-per-process comparison of the ranks' memory-gated paths
+    _paths_differ = False
+
     def __init__(self, arena: 'ParamArena', comm=None, force: bool = False):
         import torch.distributed as dist
         self.arena, self.comm = arena, comm
@@ -193,15 +196,21 @@ class GradReducer:
         elif dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size()
         self.active = self.world > 1 or force
-        self.done: dict = {dt: [] for dt in arena.groups}        # dtype -> [(lo, hi)] ranges already launched
+        self.done: dict = {dt: [] for dt in arena.groups}        # dtype -> disjoint [lo, hi) ranges already launched
         self.handles: list = []
         self.side = None
         self.launched = 0                                        # collectives started before finish()
+        self.blocking = False                                    # ranks disagree on their paths: one exchange in finish()
         self._where = None
+        self._slices: dict = {}
 
     def _ranges(self, params) -> dict:
         if self._where is None:
             self._where = {id(p): (g['flat'].dtype, off, n) for p, g, off, n in self.arena._param_slices()}
+            for dt, off, n in self._where.values():
+                self._slices.setdefault(dt, []).append((off, off + n))
+            for v in self._slices.values():
+                v.sort()
         out: dict = {}
         for p in params:
             w = self._where.get(id(p))
@@ -209,16 +218,62 @@ class GradReducer:
                 out.setdefault(w[0], []).append((w[1], w[1] + w[2]))
         return out
 
-    @staticmethod
-    def _merge(ranges: list, slack: int) -> list:
-        """sorted, with neighbours closer than the arena's alignment padding joined (the padding is zero)"""
+    def _gap_is_padding(self, dt, a: int, b: int) -> bool:
+        """no arena parameter of this dtype lies in [a, b): the gap is alignment padding (zeros)"""
+        import bisect
+        sl = self._slices.get(dt, [])
+        i = bisect.bisect_left(sl, (a, a))
+        if i > 0 and sl[i - 1][1] > a:
+            return False
+        return not (i < len(sl) and sl[i][0] < b)
+
+    def _merge(self, dt, ranges: list, slack: int) -> list:
+        """sorted, with neighbours joined when the gap between them is nothing but the arena's alignment
+        padding (at most `slack` elements that belong to no parameter); overlapping ranges are joined too"""
         merged: list = []
         for lo, hi in sorted(ranges):
-            if merged and lo <= merged[-1][1] + slack:
+            if merged and (lo <= merged[-1][1]
+                           or (lo <= merged[-1][1] + slack and self._gap_is_padding(dt, merged[-1][1], lo))):
                 merged[-1][1] = max(merged[-1][1], hi)
             else:
                 merged.append([lo, hi])
         return [(a, b) for a, b in merged]
+
+    def _uncovered(self, dt, lo: int, hi: int) -> list:
+        """the parts of [lo, hi) that no launched range covers (every element is exchanged exactly once)"""
+        out, pos = [], lo
+        for a, b in sorted(self.done[dt]):
+            if b <= pos:
+                continue
+            if a >= hi:
+                break
+            if a > pos:
+                out.append((pos, a))
+            pos = max(pos, b)
+        if pos < hi:
+            out.append((pos, hi))
+        return out
+
+    def _check_paths_once(self) -> None:
+        """Before the FIRST overlapped collective of the process: every rank reports which memory-gated paths it
+        took (`ops.mem_gate_signature`; the gates themselves already decide by consensus).  If the tables differ
+        the number, order and size of the per-range collectives could differ as well: this step and all later
+        ones then use ONE blocking exchange of the whole arena in `finish()`, which is rank-invariant."""
+        if GradReducer._paths_checked:
+            self.blocking = GradReducer._paths_differ
+            return
+        GradReducer._paths_checked, GradReducer._paths_differ = True, False
+        import torch.distributed as dist
+        if self.comm is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            sigs = [None] * dist.get_world_size()
+            dist.all_gather_object(sigs, ops.mem_gate_signature())
+            if len(set(sigs)) > 1:
+                import logging
+                logging.getLogger('l2hmc').warning(
+                    'ranks took different memory-gated paths %s: gradient exchange falls back to one blocking '
+                    'all-reduce per step', sigs)
+                GradReducer._paths_differ = True
+        self.blocking = GradReducer._paths_differ
 
     def _launch(self, view: Tensor) -> None:
         import torch.distributed as dist
@@ -240,15 +295,18 @@ class GradReducer:
         """the gradients of `params` are final for this step: start their exchange"""
         if not self.active:
             return
+        if self.launched == 0 and not self.blocking:
+            self._check_paths_once()
+        if self.blocking:
+            return
         for dt, rs in self._ranges(params).items():
             g = self.arena.groups[dt]
             q = 16 // g['flat'].element_size()
-            for lo, hi in self._merge(rs, q):
-                if any(a <= lo and hi <= b for a, b in self.done[dt]):
-                    continue
-                self._launch(g['grad'][lo:hi])
-                self.done[dt].append((lo, hi))
-                self.launched += 1
+            for lo, hi in self._merge(dt, rs, q):
+                for a, b in self._uncovered(dt, lo, hi):
+                    self._launch(g['grad'][a:b])
+                    self.done[dt].append((a, b))
+                    self.launched += 1
 
     def finish(self) -> float:
         """exchange the rest, wait for everything; returns the 1 / world factor for the optimiser"""
@@ -257,7 +315,7 @@ class GradReducer:
         for dt, g in self.arena.groups.items():
             n = g['grad'].numel()
             pos = 0
-            for lo, hi in self._merge(self.done[dt], 0) + [(n, n)]:
+            for lo, hi in self._merge(dt, self.done[dt], 0) + [(n, n)]:
                 if lo > pos:
                     self._launch(g['grad'][pos:lo])
                 pos = max(pos, hi)
