@@ -123,7 +123,14 @@ def test_wilson_loops_tensor_su3(golden):
     xc = xp.clone().requires_grad_(True)
     (lat.wilson_loops(xc) * cot.conj()).real.sum().backward()
     xd = xp.clone().requires_grad_(True)
-    ref = torch.stack([lat._trace_plaquette(xd, u, v) for u in range(1, 4) for v in range(u)])
+
+    def tr_plaq(xx, u, v):           # plain torch ops (autograd), the reference's construction lattice.py:164-174
+        xu, xv = xx[:, u], xx[:, v]
+        yuv = xu @ xv.roll(-1, dims=u + 1)
+        yvu = xv @ xu.roll(-1, dims=v + 1)
+        return torch.diagonal(yuv @ yvu.adjoint(), dim1=-2, dim2=-1).sum(-1)
+    ref = torch.stack([tr_plaq(xd, u, v) for u in range(1, 4) for v in range(u)])
+    assert float((ref.detach() - w2).abs().max()) < 1e-12
     (ref * cot.conj()).real.sum().backward()
     assert float((xc.grad - xd.grad).abs().max()) < 1e-11 * max(1.0, float(xd.grad.abs().max()))
 
