@@ -254,6 +254,8 @@ class Trainer:
             # `grad_scaler.step(optimizer)` skips the update when a gradient is inf / nan; `update()`
             self.grad_scaler.update(found_inf)
             metrics['loss_scale'] = ls
+            #  the loss of a skipped step is still finite: say that no update was made
+            metrics['step_skipped'] = bool(found_inf)
         if not (found_inf and self.grad_scaler is not None):
             self.arena.adam_step(lr=float(self.config.learning_rate.lr_init), grad_scale=scale)
         if self._gstep == 0:
