@@ -646,8 +646,9 @@ def secondary_u1(steps=3, only=None):
             dyn.set_net_precision(prec)
             x = lat.random()
             bt = torch.tensor(beta)
-            xo, m = dyn((x, bt))                                   # warm-up (weight copies, pool)
-            x = dyn.g.compat_proj(xo.reshape(x.shape))
+            for _ in range(max(1, int(dyn.auto_graph_after))):     # warm-up (weight copies, pool; the default
+                xo, m = dyn((x, bt))                               # Dynamics captures its graph on the 3rd sighting)
+                x = dyn.g.compat_proj(xo.reshape(x.shape))
             torch.cuda.synchronize()
             recs = []
 
@@ -791,8 +792,8 @@ def published_u1(steps=10):
             return (time.perf_counter() - t0) / n, x, m
         dt_tr, x, m = clock(lambda xx: tr.train_step((xx, beta)), x, steps, 3)
         x128 = x[:128].contiguous()
-        dt_ev, _x, me = clock(lambda xx: tr.eval_step((xx, beta)), x128, steps, 2)
-        dt_h, _x, mh = clock(lambda xx: tr.hmc_step((xx, beta), nleapfrog=8, eps=0.25), x128, steps, 2)
+        dt_ev, _x, me = clock(lambda xx: tr.eval_step((xx, beta)), x128, steps, 3)
+        dt_h, _x, mh = clock(lambda xx: tr.hmc_step((xx, beta), nleapfrog=8, eps=0.25), x128, steps, 3)
         nlf = 4
         out = {
             'workload': '2D U(1) 16x16, beta=4, nleapfrog=4 (8 LF steps), precision fp16 (16-bit layers, fp32 '

@@ -39,6 +39,7 @@ class _Session:
     def __init__(self, dyn, nb: int):
         self.nets = T._native_begin(dyn, nb)
         self.stamp = _param_stamp(dyn)
+        self.nb = nb
         self.live = 0
 
     def join(self):
@@ -83,6 +84,11 @@ def trained_parameters(dyn) -> list:
 def _session(dyn, nb: int) -> _Session:
     s: Optional[_Session] = getattr(dyn, '_ag_session', None)
     if s is not None and s.live > 0 and s.stamp == _param_stamp(dyn):
+        if s.nb != nb:
+            # the deferred-gradient arenas of the live session are keyed and sized by its batch: a second
+            # batch size would re-key them under the first tape's slots
+            raise RuntimeError(f'Dynamics.forward: a recorded trajectory of {s.nb} chains has not been reversed '
+                               f'yet; reverse (or drop) it before recording one of {nb} chains')
         return s
     if s is not None and s.live > 0:
         # parameters changed under a recorded trajectory that was never reversed: its shadows are stale
@@ -113,8 +119,11 @@ class Transition(torch.autograd.Function):
         ctx.params = params
         ctx.set_materialize_grads(False)
         # what the caller sees: reference layout, plus the native originals for the wrappers
-        xp = AG.attach_native(dyn._unpack(x_), x_)
-        vp = dyn._unpack(v_) if dyn.group == 'SU3' else v_.reshape(nb, -1)
+        # (U(1): the reference layout IS the native one -- hand out copies, so that an in-place wrap / projection
+        # of the proposal before loss.backward() cannot corrupt the fields the reverse sweep differentiates)
+        su3 = dyn.group == 'SU3'
+        xp = AG.attach_native(dyn._unpack(x_) if su3 else dyn._unpack(x_).clone(), x_)
+        vp = dyn._unpack(v_) if su3 else v_.reshape(nb, -1).clone()
         # native originals / per-step history for the caller (Dynamics._forward_train), not kept here
         side.update({'xn': xn, 'vn': vn, 'x_': x_, 'v_': v_, 'hist': hist})
         return xp, vp, hist['sumlogdet'].clone(), hist['acc'].clone()

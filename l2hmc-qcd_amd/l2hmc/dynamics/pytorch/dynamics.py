@@ -259,7 +259,12 @@ class Dynamics(nn.Module):
         # eval mode, small U(1) lattices: whole transitions replayed from a HIP graph (_auto_graphed)
         self.auto_graph = True
         self.auto_graph_su3 = False        # SU(3): kernel-bound, a replay is worth ~1 % (opt-in)
+        # a (shape, beta, step size) is captured the `auto_graph_after`-th time it is seen: a capture costs two
+        # warm-up trajectories + the captured one + a device sync, which a sampler that sweeps beta or the HMC step
+        # size would pay on every call; the most recently used `AUTO_GRAPH_KEEP` graphs are kept
+        self.auto_graph_after = 3
         self._graphs: dict = {}
+        self._graph_seen: dict = {}
 
     def train(self, mode: bool = True):
         """nn.Module.train; leaving train mode also releases the training-only device buffers of the
@@ -1347,6 +1352,8 @@ class Dynamics(nn.Module):
     AUTO_GRAPH_MAX_ELEMS = 1 << 21      # U(1): chains x links up to which a trajectory is launch-bound
     AUTO_GRAPH_MAX_BYTES_SU3 = 1 << 30  # SU(3): a graph pins every temporary of a trajectory; not at 16^4
 
+    AUTO_GRAPH_KEEP = 8
+
     def _auto_graphed(self, mode: str, x: Tensor, beta, eps=None, nleapfrog=None):
         """Eval-mode transitions are captured once per (batch, beta, step size) as a HIP graph
         (`GraphedTransition`: re-captured when the model changes) and replayed behind the ordinary
@@ -1380,16 +1387,26 @@ class Dynamics(nn.Module):
             return None
         b = _beta(beta)
         key = (mode, tuple(x.shape), b, None if eps is None else float(eps), nleapfrog)
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
-            if len(self._graphs) >= (4 if self.group == 'U1' else 2):     # (an annealed beta: the recent ones)
-                self._graphs.pop(next(iter(self._graphs)))
+            seen = self._graph_seen.get(key, 0) + 1
+            if len(self._graph_seen) > 64:
+                self._graph_seen.clear()
+            self._graph_seen[key] = seen
+            if seen < int(self.auto_graph_after):
+                return None                                   # eager until the key has proved recurrent
+            while len(self._graphs) >= (self.AUTO_GRAPH_KEEP if self.group == 'U1' else 2):
+                self._graphs.pop(next(iter(self._graphs)))     # least recently used (dict order = use order)
+            # the warm-up trajectories and the capture draw from the device generator: put its state back
+            # afterwards, so that the random stream the caller sees does not depend on WHEN a graph was captured
+            rng = torch.cuda.get_rng_state(x.device)
             self._capturing = True
             try:
                 g = GraphedTransition(self, x.detach(), b, mode, eps, nleapfrog, warmup=2)
             finally:
                 self._capturing = False
-            self._graphs[key] = g
+                torch.cuda.set_rng_state(rng, x.device)
+        self._graphs[key] = g                                  # (re-inserted: most recently used last)
         self._capturing = True
         try:
             xo, m = g(x.detach())

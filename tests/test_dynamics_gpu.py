@@ -1187,6 +1187,22 @@ def test_auto_graphed_small_u1_transitions(golden):
     dyn.eval()
     x, beta = dev(g['x']), float(g['beta'])
     assert dyn._inject is None and not dyn._graphs
+    # a key is captured the third time it is seen (a beta / step-size sweep never pays for captures), and the
+    # capture leaves the device generator where it was: the draw after it is the one an eager run would make
+    assert dyn.auto_graph_after == 3
+    dyn((x, beta))
+    dyn((x, beta))
+    assert not dyn._graphs
+    torch.cuda.manual_seed(5)
+    xo_c, _ = dyn((x, beta))                              # captures (2 warm-up trajectories + 1), then replays
+    assert len(dyn._graphs) == 1
+    after_capture = torch.rand(4, device='cuda')
+    torch.cuda.manual_seed(5)
+    xo_r, _ = dyn((x, beta))                              # replays only
+    assert torch.equal(xo_c, xo_r) and torch.equal(after_capture, torch.rand(4, device='cuda'))
+    dyn._graphs.clear()
+    dyn._graph_seen.clear()
+    dyn.auto_graph_after = 1
     xo1, m1 = dyn((x, beta))
     assert len(dyn._graphs) == 1
     gt = next(iter(dyn._graphs.values()))
@@ -1241,6 +1257,7 @@ def test_auto_graphed_su3_transitions(golden):
     dyn((x, beta))
     assert not dyn._graphs                               # SU(3): opt-in
     dyn.auto_graph_su3 = True
+    dyn.auto_graph_after = 1
     torch.cuda.manual_seed(3)
     xo1, m1 = dyn((x, beta))
     assert len(dyn._graphs) == 1
