@@ -59,7 +59,11 @@ int l2q_version(void);
  * calling thread's current HIP device -- the library's only state besides the last-error text
  * is this per-device table: "plaq_occ" / "force_occ" in {2,3,4} pick
  * the register-allocation variant (min waves per SIMD) of the stencil kernels; "xcd_swizzle"
- * in {0,1}.  Returns the previous value, or L2Q_EINVAL for an unknown key/value. */
+ * in {0,1}; "force_tile" in 0..7 picks the SU(3) force kernel design (5, the default: thread per link,
+ * su3_force_link.hip; 7: plaquettes shared between their four links, su3_force_plaq.hip; the others
+ * are the earlier designs kept as A/B variants), "plaq_sweep" in 0..3 the plaquette kernel.  Results agree to
+ * rounding across variants.  Returns the previous value, or L2Q_EINVAL for an unknown key/value.
+ * (The Python binding applies L2Q_TUNING="key=value,..." from the environment when it loads the library.) */
 int l2q_set_tuning(const char* key, int value);
 /* Name (template instantiation as rocprofv3 prints it, without the l2q:: prefix) of the device
  * kernel that `entry` ("l2q_su3_force", "l2q_su3_force_kick", "l2q_su3_plaq_reduce",

@@ -227,7 +227,7 @@ int l2q_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "force_occ")) { slot = &t.force_occ; ok = value >= 2 && value <= 4; }
   else if (!strcmp(key, "xcd_swizzle")) { slot = &t.xcd_swizzle; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "plaq_sweep")) { slot = &t.plaq_sweep; ok = value >= 0 && value <= 3; }
-  else if (!strcmp(key, "force_tile")) { slot = &t.force_tile; ok = value >= 0 && value <= 6; }
+  else if (!strcmp(key, "force_tile")) { slot = &t.force_tile; ok = value >= 0 && value <= 7; }
   else if (!strcmp(key, "gemm_h_wide_fused")) { slot = &t.gemm_h_wide_fused; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "conv_stream")) { slot = &t.conv_stream; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "conv_patch")) { slot = &t.conv_patch; ok = value >= 0 && value <= 2; }

@@ -21,7 +21,9 @@ struct Tuning {
   int force_tsplit = 0;   // su3_force_link.hip: 0 = t-range chunks chosen by the launcher, n = that many chunks per chain
   int force_stagger = 0;  // x ~2k cycles initial delay of the 2nd resident workgroup set (su3_force_link.hip)
   int heads_stagger = 0;  // x ~8k cycles initial delay of the 2nd resident block set (heads kernel)
-  int force_tile = 5;     // 6: as 5 with two adjacent x-planes per workgroup (su3_force_pair.hip: half the x-halo),
+  int force_tile = 5;     // 7: plaquettes shared between their four links, one 8-wavefront workgroup per CU (su3_force_plaq.hip;
+                          //    plain force on lattices whose (y, z) plane is the 64-site tile: 1.17x HBM traffic, not faster),
+                          // 6: as 5 with two adjacent x-planes per workgroup (su3_force_pair.hip: half the x-halo),
                           // 5: slice-resident thread-per-link, streamed factors, 2 workgroups / CU
                           // (su3_force_link.hip), 4: staples split by plane over wavefronts (su3_force_nu.hip), 3: rows
                           // split over wavefronts (su3_force_rows.hip), 2: slice-resident

@@ -1029,6 +1029,9 @@ bool force_link_applicable(const Dims& d);
 int force_link_inmask(const Dims& d);
 void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
                        hipStream_t st, const double2* vin = nullptr);
+// su3_force_plaq.hip
+bool force_plaq_applicable(const Dims& d);
+void launch_force_plaq(const double2* xn, Dims d, int nb, double coef, double2* out, hipStream_t st);
 // su3_force_pair.hip
 bool force_pair_applicable(const Dims& d);
 int force_pair_inmask(const Dims& d);
@@ -1056,6 +1059,10 @@ static void launch_force(const double2* xn, Dims d, int nb, long nblk, double co
   constexpr int kFS = KICK ? kFSKick : kFSPlain;
   constexpr int kVar = KICK ? 2 : 0;
   constexpr int kLpt = KICK ? 1 : kLptPlain;
+  if (!KICK && tuning().force_tile == 7 && force_plaq_applicable(d)) {
+    launch_force_plaq(xn, d, nb, coef, out, st);               // plaquettes shared between their four links
+    return;
+  }
   if (tuning().force_tile == 6 && force_pair_applicable(d)) {
     launch_force_pair(KICK, xn, d, nb, coef, out, st);
     return;
@@ -1133,7 +1140,9 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
     const bool kick = !strcmp(entry, "l2q_su3_force_kick");
     const int fs = kick ? kFSKick : kFSPlain;
     const Dims dd{T, X, Y, Z, T * X * Y * Z};
-    if (t.force_tile == 6 && force_pair_applicable(dd))
+    if (!kick && t.force_tile == 7 && force_plaq_applicable(dd))
+      snprintf(buf, buf_bytes, "su3_force_plaq_kernel");
+    else if (t.force_tile == 6 && force_pair_applicable(dd))
       snprintf(buf, buf_bytes, "su3_force_pair_kernel<%d, %d>", kick ? 1 : 0, force_pair_inmask(dd));
     else if (t.force_tile >= 5 && force_link_applicable(dd))
       snprintf(buf, buf_bytes, "su3_force_link_kernel<%d, %d>", kick ? 1 : 0, force_link_inmask(dd));

@@ -165,6 +165,12 @@ def load() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        # L2Q_TUNING="force_tile=7,plaq_sweep=2": tuning knobs of include/l2q.h (l2q_set_tuning) for a whole process --
+        # A/B runs of bench.py / the tests without code changes (the table is per device: applies to the current one)
+        for kv in filter(None, os.environ.get('L2Q_TUNING', '').split(',')):
+            k, _, v = kv.partition('=')
+            if lib.l2q_set_tuning(k.strip().encode(), int(v)) < 0:      # (returns the previous value)
+                raise L2QError(f'L2Q_TUNING: unknown knob or value out of range: {kv!r}')
     return _lib
 
 

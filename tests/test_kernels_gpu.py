@@ -95,7 +95,7 @@ def test_su3_ops_golden(ops, golden):
 
 @pytest.mark.parametrize('L', [(2, 2, 2, 2), (1, 3, 2, 5), (4, 4, 4, 4), (3, 5, 2, 7), (2, 2, 8, 8),
                                (3, 2, 4, 16), (3, 8, 8, 8), (2, 4, 8, 16), (1, 2, 8, 8),
-                               (2, 4, 4, 12), (2, 16, 4, 4), (5, 4, 4, 4), (2, 2, 2, 32)])
+                               (2, 4, 4, 12), (2, 16, 4, 4), (5, 4, 4, 4), (2, 2, 2, 32), (4, 3, 8, 8)])
 def test_su3_stencils_vs_oracle(ops, L):
     """edge shapes: extent 1 and 2 (forward == backward neighbour), odd sizes, V not a
     multiple of the block size."""
@@ -111,14 +111,21 @@ def test_su3_stencils_vs_oracle(ops, L):
     from l2hmc import native
     # every kernel variant (register budget, flat vs t-sweep plaquette, flat vs LDS-tiled
     # force, with / without the XCD remap) must give the same numbers
-    # (force_tile 6 = two x-planes per workgroup, su3_force_pair.hip -- (3,8,8,8), (2,2,8,8), (1,2,8,8) with
+    # (force_tile 7 = plaquettes shared between their four links, one 8-wavefront workgroup per CU,
+    # su3_force_plaq.hip: taken where the (y, z) plane is the 64-site tile and T >= 2 -- (3,8,8,8), (2,2,8,8),
+    # (4,3,8,8): x extent 8, 2 (both x neighbours are the same plane) and odd -- and falls back to 5 elsewhere;
+    # force_tile 6 = two x-planes per workgroup, su3_force_pair.hip -- (3,8,8,8), (2,2,8,8), (1,2,8,8) with
     # whole (y,z) planes per group, (2,4,8,16) with half planes; it falls back to 5 elsewhere;
+    # force_tile 7 = plaquettes shared between their four links, one 8-wavefront workgroup per CU, su3_force_plaq.hip:
+    # taken where the (y, z) plane is the 64-site tile -- (3,8,8,8), (2,2,8,8), (1,2,8,8) with one / both x neighbours
+    # being the site itself or its only other plane, (4,3,8,8) with an odd x extent; elsewhere the variant falls back
+    # to the thread-per-link kernel;
     # force_tile 5 = thread per link with streamed factors, su3_force_link.hip; plaq_sweep 3 = planes
     # over wavefronts, su3_plaq_nu.hip;
     # force_tile 3 = rows split over wavefronts, su3_force_rows.hip: the lattices above cover its
     # four tile-residency specialisations -- Z | 64, Y Z | 64, X Y Z | 64, none -- and T = 1)
     for occ in (2, 3, 4):
-        for variant in (0, 1, 2, 3, 4, 5, 6):
+        for variant in (0, 1, 2, 3, 4, 5, 6, 7):
             for swz in (0, 1):
                 native.set_tuning('force_occ', occ); native.set_tuning('plaq_occ', occ)
                 native.set_tuning('plaq_sweep', min(variant, 3)); native.set_tuning('force_tile', variant)

@@ -187,7 +187,7 @@ def test_cfg4_trajectory_8x4_units256():
     f_ref = osu3.grad_action(x, beta)
     from l2hmc import native
     try:
-        for ft in (6, 5, 4, 3, 2, 1, 0):
+        for ft in (7, 6, 5, 4, 3, 2, 1, 0):
             native.set_tuning('force_tile', ft)
             f = ops.su3_unpack(ops.su3_force_n(xn, beta, L), L)
             assert np.abs(host(f) - f_ref).max() < 1e-12, ft

@@ -18,9 +18,9 @@ def run(nb, L, reps=20):
     vn = ops.su3_assemble_tah_n(torch.randn(8, nb, 4, V, dtype=torch.float64, device='cuda'))
     f = torch.empty_like(xn)
     ref = None
-    for tile in (2, 6, 5, 4, 3, 1, 0):
+    for tile in ((2, 7, 5) if '--plaq' in sys.argv else (2, 7, 6, 5, 4, 3, 1, 0)):
         native.set_tuning('force_tile', tile)
-        for kick in (False, True):
+        for kick in ((False,) if tile == 7 else (False, True)):
             name = native.kernel_name('l2q_su3_force_kick' if kick else 'l2q_su3_force', L)
 
             def go():

@@ -17,6 +17,7 @@ ENTRY = {   # kernel-name fragment -> C-ABI entry point whose roofline it feeds
     'su3_plaq_slice_kernel': 'l2q_su3_plaq_reduce', 'su3_plaq_kernel': None, 'su3_plaq_sweep_kernel': None,
     'su3_force_slice_kernel<false': 'l2q_su3_force', 'su3_force_tile_kernel<false': None,
     'su3_force_kernel<false': None, 'su3_force_rows_kernel<0': None, 'su3_force_nu_kernel<0': None, 'su3_force_nu_kernel<1': None,
+    'su3_force_plaq_kernel': 'l2q_su3_force',
     'su3_force_link_kernel<0': 'l2q_su3_force', 'su3_force_link_kernel<1': 'l2q_su3_force_kick',
     'su3_force_brick_kernel<0': 'l2q_su3_force', 'su3_force_brick_kernel<1': 'l2q_su3_force_kick',
     'su3_force_rows_kernel<1': None,
