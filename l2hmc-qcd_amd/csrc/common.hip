@@ -232,6 +232,7 @@ int l2q_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "conv_stream")) { slot = &t.conv_stream; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "conv_patch")) { slot = &t.conv_patch; ok = value >= 0 && value <= 2; }
   else if (!strcmp(key, "gemm_h_dma")) { slot = &t.gemm_h_dma; ok = value == 0 || value == 1; }
+  else if (!strcmp(key, "gemm_h_lt")) { slot = &t.gemm_h_lt; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "gemm_h_skinny")) { slot = &t.gemm_h_skinny; ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 8; }
   else if (!strcmp(key, "gemm_h_small")) { slot = &t.gemm_h_small; ok = value == 0 || value == 1; }
   else if (!strcmp(key, "gemm_h_patch")) { slot = &t.gemm_h_patch; ok = value == 0 || value == 1; }

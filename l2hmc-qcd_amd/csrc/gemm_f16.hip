@@ -1163,6 +1163,12 @@ __global__ __launch_bounds__(kBlock) void nchw_to_nhwc_pad_h_kernel(const float*
 template <typename HT>
 bool gemm_h_small_launch(const void* A, const void* W, int M, int N, long K, const EpiH& epi, void* C, int c_is_f32,
                          hipStream_t st);
+// gemm_lt.hip: hipBLASLt for plain layers with M, N, K in the thousands; false -> not taken
+bool gemm_h_lt_shape(int M, int N, long K);
+size_t gemm_h_lt_ws_bytes(int M, int N, long K);
+template <typename HT>
+bool gemm_h_lt_launch(const void* A, const void* W, int M, int N, long K, const EpiH& epi, void* C, int c_is_f32,
+                      void* ws, size_t ws_bytes, hipStream_t st);
 // gemm_f16_dma.hip: 256 x 256 LDS-DMA kernel when the shape fits it; false -> the kernels here
 template <typename HT>
 bool gemm_h_dma_launch(const void* A, const void* W, int M, int N, long K, const EpiH& epi, void* C,
@@ -1317,6 +1323,7 @@ size_t l2q_gemm_h_ws_bytes(int M, int N, long K, long K2) {
     const size_t sk = gemm_h_skinny_ws_bytes(M, N, K, K2);     // partial sums + the slab-major copy of W
     if (sk > need) need = sk;
   }
+  if (K2 == 0 && gemm_h_lt_shape(M, N, K) && gemm_h_lt_ws_bytes(M, N, K) > need) need = gemm_h_lt_ws_bytes(M, N, K);
   return need;
 }
 
@@ -1343,6 +1350,13 @@ int l2q_gemm_h(int half_type, const void* A, int a_is_f32, const void* W, int M,
     const bool done = half_type == L2Q_HALF_F16
                           ? gemm_h_small_launch<_Float16>(A, W, M, N, K, epi, C, c_is_f32, st)
                           : gemm_h_small_launch<__bf16>(A, W, M, N, K, epi, C, c_is_f32, st);
+    if (done) return check_launch("l2q_gemm_h");
+  }
+  // plain layers with every dimension in the thousands: hipBLASLt (gemm_lt.hip), when it is there and takes the shape
+  if (!a_is_f32 && K2 == 0 && gemm_h_lt_shape(M, N, K)) {
+    const bool done = half_type == L2Q_HALF_F16
+                          ? gemm_h_lt_launch<_Float16>(A, W, M, N, K, epi, C, c_is_f32, ws, ws_bytes, st)
+                          : gemm_h_lt_launch<__bf16>(A, W, M, N, K, epi, C, c_is_f32, ws, ws_bytes, st);
     if (done) return check_launch("l2q_gemm_h");
   }
   // big 16-bit x 16-bit layers: 256 x 256 tiles on LDS-DMA staging (gemm_f16_dma.hip)

@@ -34,6 +34,7 @@ struct Tuning {
                               // <= 16 output channels (2: every layer it fits, 0: gather kernel only)
   int conv_stream = 0;        // half conv: 1 = persistent whole-K kernel (conv_stream_f16.hip; measured slower at cfg-3:
                               // 3.7 / 1.8 ms against the gather kernel's 2.6 / 1.2 ms), 0 = gather kernel
+  int gemm_h_lt = 1;          // plain 16-bit layers with M, N, K >= 2048: hipBLASLt (gemm_lt.hip; 0: own kernels only)
   int gemm_h_dma = 1;         // big half GEMMs (M, N % 256 == 0, K % 64 == 0): LDS-DMA 256 x 256 kernel (0: off)
   int gemm_h_skinny = 1;      // wide-K fp32-operand input layer, N <= 256: streaming kernel (gemm_f16_skinny.hip);
                               // 0 off, 1 on (split count chosen), 2 / 4 / 8: that split count (A/B)

@@ -749,6 +749,50 @@ N_ACT = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'leaky_relu': 3, 'elu': 4, 's
 
 
 @pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
+def test_gemm_h_library_route(hd):
+    """Plain 16-bit layers with M, N, K >= 2048 go through hipBLASLt (gemm_lt.hip, tuning gemm_h_lt): the same
+    rounding points as the own kernels -- r16(A W^T + bias), then r16(act(.)) -- so the two routes agree to an ulp of
+    the 16-bit type on a small fraction of the entries (different summation order of the fp32 accumulation); outputs
+    in a 16-bit and in an fp32 container; a shape the route does not take stays on the own kernels."""
+    import emu_native
+    from l2hmc import _ops as ops, native
+    m, n, k = 2048, 2304, 2048
+    g = torch.Generator().manual_seed(23)
+    a = torch.randn(m, k, generator=g).to(hd)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd)
+    b = torch.randn(n, generator=g).to(hd).float()
+    ulp = 2.0 ** -10 if hd == torch.float16 else 2.0 ** -7
+    try:
+        for act, odt in ((None, hd), ('leaky_relu', torch.float32), ('tanh', hd), (None, torch.float32)):
+            native.set_tuning('gemm_h_lt', 1)
+            got = ops.gemm_h(a.cuda(), w.cuda(), b.cuda(), act=act, out_dtype=odt)
+            native.set_tuning('gemm_h_lt', 0)
+            own = ops.gemm_h(a.cuda(), w.cuda(), b.cuda(), act=act, out_dtype=odt)
+            want = torch.empty(m, n, dtype=odt)
+            emu_native.l2q_gemm_h(ops.HALF_TYPES[hd], a, 0, w, m, n, k, None, None, 0, b, None, None,
+                                  1.0, N_ACT[act], want, int(odt == torch.float32), None, 0)
+            assert got.dtype == odt
+            for other in (want, own.cpu()):
+                d = (got.cpu().float() - other.float()).abs()
+                tol = 2.5 * ulp * other.float().abs().clamp(min=1.0)
+                assert bool((d <= tol).all()), (act, odt, float((d / tol).max()))
+                assert float((d > 0).float().mean()) < 0.2, (act, odt)
+        # without a bias, and a shape below the route's threshold
+        native.set_tuning('gemm_h_lt', 1)
+        got = ops.gemm_h(a.cuda(), w.cuda(), None, act=None)
+        native.set_tuning('gemm_h_lt', 0)
+        own = ops.gemm_h(a.cuda(), w.cuda(), None, act=None)
+        d = (got.float() - own.float()).abs()
+        assert bool((d <= 2.5 * ulp * own.float().abs().clamp(min=1.0)).all())
+        native.set_tuning('gemm_h_lt', 1)
+        small = ops.gemm_h(a[:512].cuda(), w.cuda(), b.cuda(), act='relu')
+        native.set_tuning('gemm_h_lt', 0)
+        assert torch.equal(small, ops.gemm_h(a[:512].cuda(), w.cuda(), b.cuda(), act='relu'))
+    finally:
+        native.set_tuning('gemm_h_lt', 1)
+
+
+@pytest.mark.parametrize('hd', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(1024, 1024, 320), (2048, 1024, 256), (1024, 1280, 832)])
 def test_gemm_h_dma(hd, shape):
     """The 256 x 256 LDS-DMA kernel of the big half-precision layers (gemm_f16_dma.hip; M, N % 256 == 0,
