@@ -69,7 +69,8 @@ int l2q_set_tuning(const char* key, int value);
  * kernel that `entry` ("l2q_su3_force", "l2q_su3_force_kick", "l2q_su3_plaq_reduce",
  * "l2q_vnet_heads_vupdate[_pair]_f64", "l2q_gemm_f64": kernel family only) dispatches
  * for a T x X x Y x Z lattice under the current tuning; "" for entry points with a single
- * kernel.  Lets a profile (rocprofv3 --pmc) be matched to the build that is running. */
+ * kernel.  entry "l2q_gemm_h" with (T, X, Y) = (M, N, K): "hipblaslt" when that plain 16-bit layer goes to the
+ * vendor library (gemm_lt.hip: library present, shape taken), "" when it runs on this build's kernels.  Lets a profile (rocprofv3 --pmc) be matched to the build that is running. */
 int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, size_t buf_bytes);
 /* Select and check the device this process drives (one process per GPU): hipSetDevice(device),
  * refuses anything that is not gfx950, touches the device's knob table.  Returns `device` or a

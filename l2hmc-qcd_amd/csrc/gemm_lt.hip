@@ -134,6 +134,8 @@ bool gemm_h_lt_shape(int M, int N, long K) {
          N % 8 == 0 && K % 8 == 0;
 }
 
+bool gemm_h_lt_available() { return lt_api().ok; }
+
 size_t gemm_h_lt_ws_bytes(int M, int N, long K) {
   if (!gemm_h_lt_shape(M, N, K)) return 0;
   return kLtWorkspace + (size_t)M * N * 2 + 256;

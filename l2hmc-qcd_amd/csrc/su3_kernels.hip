@@ -1029,6 +1029,9 @@ bool force_link_applicable(const Dims& d);
 int force_link_inmask(const Dims& d);
 void launch_force_link(bool kick, const double2* xn, Dims d, int nb, double coef, double2* out,
                        hipStream_t st, const double2* vin = nullptr);
+// gemm_lt.hip
+bool gemm_h_lt_shape(int M, int N, long K);
+bool gemm_h_lt_available();
 // su3_force_plaq.hip
 bool force_plaq_applicable(const Dims& d);
 void launch_force_plaq(const double2* xn, Dims d, int nb, double coef, double2* out, hipStream_t st);
@@ -1160,6 +1163,9 @@ int l2q_kernel_name(const char* entry, int T, int X, int Y, int Z, char* buf, si
   } else if (!strncmp(entry, "l2q_vnet_heads_vupdate", 22)) {
     // (for shapes with whole 16-wide K-slabs, which every SU(3) vnet has)
     snprintf(buf, buf_bytes, "%s", t.heads_dma ? "fused_heads_dma_kernel" : "fused_heads_vupdate_kernel");
+  } else if (!strcmp(entry, "l2q_gemm_h")) {
+    // (T, X, Y) carry (M, N, K) here: "hipblaslt" when the plain-layer route of gemm_lt.hip takes the shape
+    if (gemm_h_lt_shape(T, X, (long)Y) && gemm_h_lt_available()) snprintf(buf, buf_bytes, "hipblaslt");
   } else if (!strcmp(entry, "l2q_gemm_sliced_f64")) {
     snprintf(buf, buf_bytes, "gemm_sliced_kernel");
   } else if (!strcmp(entry, "l2q_gemm_f64")) {

@@ -757,6 +757,9 @@ def test_gemm_h_library_route(hd):
     import emu_native
     from l2hmc import _ops as ops, native
     m, n, k = 2048, 2304, 2048
+    # the route IS taken on this box (the library ships with the ROCm image), not silently skipped
+    assert native.kernel_name('l2q_gemm_h', (m, n, k, 0)) == 'hipblaslt'
+    assert native.kernel_name('l2q_gemm_h', (512, n, k, 0)) == ''
     g = torch.Generator().manual_seed(23)
     a = torch.randn(m, k, generator=g).to(hd)
     w = (torch.randn(n, k, generator=g) / k ** 0.5).to(hd)
