@@ -48,7 +48,7 @@ namespace l2q {
 
 // Timing experiments (tools/ab_build.sh ... -DL2Q_PQ_EXP=bits; results WRONG, only the clock is read):
 //   1 no output stores   2 helpers form no neighbour terms   4 the planes' chain operands are requested once, not
-//   per slice   8 no slice refresh loads
+//   per slice   8 no slice refresh loads   16 write-back instead of streaming (nt) stores
 #ifndef L2Q_PQ_EXP
 #define L2Q_PQ_EXP 0
 #endif
@@ -165,21 +165,26 @@ __device__ __forceinline__ PqfOut pqf_sum(const PqfCtx& c, int dir, int half, in
   }
   return PqfOut{f0 * c.coef, f1 * c.coef, f2 * c.coef, f3 * c.coef};
 }
+#if L2Q_PQ_EXP & 16
+#define PQF_ST buf_st
+#else
+#define PQF_ST buf_st_nt
+#endif
 __device__ __forceinline__ void pqf_store(const PqfCtx& c, int dir, int half, int q_sp, int gslice, const PqfOut& o) {
   if (L2Q_PQ_EXP & 1) return;
   const int so = dir * 9 * c.V16 + gslice;
   const __amdgpu_buffer_rsrc_t ro = c.ro;
   if (half == 0) {
-    buf_st_nt(ro, q_sp, so + 1 * c.V16, make_double2(o.f0, o.f1));
-    buf_st_nt(ro, q_sp, so + 2 * c.V16, make_double2(o.f2, o.f3));
-    buf_st_nt(ro, q_sp, so + 3 * c.V16, make_double2(-o.f0, o.f1));
-    buf_st_nt(ro, q_sp, so + 6 * c.V16, make_double2(-o.f2, o.f3));
+    PQF_ST(ro, q_sp, so + 1 * c.V16, make_double2(o.f0, o.f1));
+    PQF_ST(ro, q_sp, so + 2 * c.V16, make_double2(o.f2, o.f3));
+    PQF_ST(ro, q_sp, so + 3 * c.V16, make_double2(-o.f0, o.f1));
+    PQF_ST(ro, q_sp, so + 6 * c.V16, make_double2(-o.f2, o.f3));
   } else {
-    buf_st_nt(ro, q_sp, so + 5 * c.V16, make_double2(o.f0, o.f1));
-    buf_st_nt(ro, q_sp, so + 7 * c.V16, make_double2(-o.f0, o.f1));
-    buf_st_nt(ro, q_sp, so + 0 * c.V16, make_double2(0.0, o.f2));
-    buf_st_nt(ro, q_sp, so + 4 * c.V16, make_double2(0.0, o.f3));
-    buf_st_nt(ro, q_sp, so + 8 * c.V16, make_double2(0.0, -(o.f2 + o.f3)));
+    PQF_ST(ro, q_sp, so + 5 * c.V16, make_double2(o.f0, o.f1));
+    PQF_ST(ro, q_sp, so + 7 * c.V16, make_double2(-o.f0, o.f1));
+    PQF_ST(ro, q_sp, so + 0 * c.V16, make_double2(0.0, o.f2));
+    PQF_ST(ro, q_sp, so + 4 * c.V16, make_double2(0.0, o.f3));
+    PQF_ST(ro, q_sp, so + 8 * c.V16, make_double2(0.0, -(o.f2 + o.f3)));
   }
 }
 
