@@ -32,7 +32,7 @@
 // against 0.39 ms for su3_force_link_kernel, 0.438 against 0.389 ms inside the trajectory -- NOT faster, so it is the
 // opt-in tuning force_tile = 7, not the default.  What it does achieve is the traffic: 1.42 GB of HBM traffic per
 // launch = 1.17 x algorithmic (link kernel 2.02 GB = 1.68 x), L2 hit rate 0.62 (0.46), VALU instructions -5 %.  The
-// removal experiments (-DL2Q_PQ_EXP): no output stores 0.33 ms, no neighbour terms 0.39, chain operands requested
+// removal experiments (-DL2Q_PQ_EXP): no output stores (and, dead code then, no gather of the slots) 0.33 ms, no neighbour terms 0.39, chain operands requested
 // once 0.38, nothing from memory after the first slice 0.26 -- the memory time adds to the arithmetic instead of
 // hiding behind it, whatever the order in which requests and stores are issued (requests one slice ahead, stores
 // deferred into the next slice's products, LDS-only barriers, scheduling fences on / off: all 0.405-0.415 ms).
@@ -47,7 +47,7 @@ namespace l2q {
 #endif
 
 // Timing experiments (tools/ab_build.sh ... -DL2Q_PQ_EXP=bits; results WRONG, only the clock is read):
-//   1 no output stores   2 helpers form no neighbour terms   4 the planes' chain operands are requested once, not
+//   1 no output stores (the gather's slot reads become dead code too)   2 helpers form no neighbour terms   4 the planes' chain operands are requested once, not
 //   per slice   8 no slice refresh loads   16 write-back instead of streaming (nt) stores
 #ifndef L2Q_PQ_EXP
 #define L2Q_PQ_EXP 0
@@ -151,8 +151,9 @@ __host__ __device__ constexpr int pqf_rank(int c, int b) { return b < c ? b : b 
 
 // Gather of one group: 64 half-links (direction dir; half 0: entries (0,1), (0,2) and their mirror images, half 1:
 // entry (1,2), its mirror image and the diagonal): the six slots summed in a fixed order and scaled (pqf_sum), then
-// stored (pqf_store).  (Measured: the stores cost 20 % of the kernel's time wherever they are issued -- right here,
-// after the next slice's operand requests, or deferred into the next slice's products.)
+// stored (pqf_store).  (Measured: gather + stores cost 20 % of the kernel's time wherever the stores are issued -- right
+// here, after the next slice's operand requests, or deferred into the next slice's products; the slot traffic --
+// 72 ds_write_b128 + 96 ds_read_b128 per site next to ~200 operand reads -- is the likelier half of that.)
 struct PqfOut { double f0, f1, f2, f3; };
 __device__ __forceinline__ PqfOut pqf_sum(const PqfCtx& c, int dir, int half, int ltb) {
   const int a0 = kPqfOffSlot + dir * 6 * kPqfSlotB + (2 * half) * kEnt + ltb;
