@@ -21,21 +21,23 @@
 // the sum is order-fixed (bit-reproducible) without atomics and without ordering barriers: compute -> barrier ->
 // all eight wavefronts gather (6 slots -> F, 9 stores per link) and the helpers write the next slice's links ->
 // barrier.  Wavefronts (SIMD = index % 4, so that each SIMD carries ~12 products per slice):
-//     0 (t,y)  1 (t,z)  2 (y,z)  3 helper A: the x-neighbour terms of links t and y + the t-links of the refresh
-//     4 (t,x)  5 (x,y)  6 (x,z)  7 helper B: the x-neighbour term of link z + the spatial links of the refresh
+//     0 (t,y)  1 (t,z)  2 (y,z)  3 helper A: the x-neighbour term of link t + the spatial links of the refresh
+//     4 (t,x)  5 (x,y)  6 (x,z)  7 helper B: the x-neighbour terms of links y and z
 // LDS: links of ONE slice 36 KiB + 4 x 6 slots x 4 KiB = 132 KiB; 256 registers per thread (hipcc needs 172-202
 // for a sweep: the two-workgroup variant of this design spilled, tools/experiments/README.md).
 //
 // Results agree with the thread-per-link kernels to rounding (sum of TAHs instead of TAH of the sum).
 //
-// MEASURED (MI355X, 8^4 x 256 chains; tools/force_bench.py, profiles/r06_force_plaq_ab.txt): 0.405 ms stand-alone
-// against 0.39 ms for su3_force_link_kernel, 0.438 against 0.389 ms inside the trajectory -- NOT faster, so it is the
-// opt-in tuning force_tile = 7, not the default.  What it does achieve is the traffic: 1.42 GB of HBM traffic per
-// launch = 1.17 x algorithmic (link kernel 2.02 GB = 1.68 x), L2 hit rate 0.62 (0.46), VALU instructions -5 %.  The
-// removal experiments (-DL2Q_PQ_EXP): no output stores (and, dead code then, no gather of the slots) 0.33 ms, no neighbour terms 0.39, chain operands requested
-// once 0.38, nothing from memory after the first slice 0.26 -- the memory time adds to the arithmetic instead of
-// hiding behind it, whatever the order in which requests and stores are issued (requests one slice ahead, stores
-// deferred into the next slice's products, LDS-only barriers, scheduling fences on / off: all 0.405-0.415 ms).
+// MEASURED (MI355X, 8^4 x 256 chains; tools/force_bench.py, profiles/r06_force_plaq_ab.txt): 0.391 ms stand-alone
+// against 0.395 ms for su3_force_link_kernel on the same box; inside the trajectory 0.407 against 0.393 ms with the
+// TRAJECTORY 0.3 % shorter (21.30 vs 21.38 ms: less power and HBM traffic left for the neighbours).  Equal within
+// the noise, so it is the opt-in tuning force_tile = 7, not the default.  What it does achieve is the traffic: 1.42 GB
+// of HBM traffic per launch = 1.17 x algorithmic (link kernel 2.02 GB = 1.68 x), L2 hit rate 0.62 (0.46).  In-kernel
+// cycle counters (-DL2Q_PQ_PROF, tools/force_plaq_prof.py): the product phase of a SIMD is 11-13 products of 108
+// four-cycle fp64 FMA instructions = 5600-7100 cycles of VALU issue, the gather ~1500, barrier slack ~600; with the
+// stalls of the first versions gone (chain operands a whole iteration ahead, one gather group per wavefront, LDS-DMA
+// refresh) the kernel draws enough for the socket's 1400 W cap to set the clock, which is what bounds the
+// thread-per-link kernel as well (profiles/r06_force_clock_power.txt).
 #include "su3_force_tile.hpp"
 
 namespace l2q {
@@ -61,10 +63,35 @@ __device__ __forceinline__ void pqf_barrier() { __syncthreads(); }
 #else
 __device__ __forceinline__ void pqf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
+// -DL2Q_PQ_PROF: per-wavefront cycle totals (products, wait at the first barrier, gather / refresh, wait at the second
+// barrier) of workgroup 0, written over the first entries of its output (a timing build: F is wrong there)
+#ifndef L2Q_PQ_PROF
+#define L2Q_PQ_PROF 0
+#endif
+struct PqfProf {
+  long long t[4] = {0, 0, 0, 0};
+  long long last = 0;
+  __device__ __forceinline__ void start() { if (L2Q_PQ_PROF) last = clock64(); }
+  __device__ __forceinline__ void mark(int k) {
+    if (L2Q_PQ_PROF) { const long long now = clock64(); t[k] += now - last; last = now; }
+  }
+  __device__ __forceinline__ void dump(double2* out, int wv, int lane) const {
+    if (L2Q_PQ_PROF && blockIdx.x == 0 && lane == 0) {
+      out[2 * wv] = make_double2((double)t[0], (double)t[1]);
+      out[2 * wv + 1] = make_double2((double)t[2], (double)t[3]);
+    }
+  }
+};
 constexpr int kPqfThreads = kRS * 8;
-constexpr int kPqfOffSlot = 4 * kPlaneB;                 // after the links [dir][entry][site]
+// LDS: t-links of the current slice [9][site], then TWO buffers of spatial links [3 dirs][9][site] (the next slice's
+// arrive by LDS-DMA in the buffer the current one does not use), then the slots
+constexpr int kPqfOffSlot = 7 * kPlaneB;
 constexpr int kPqfSlotB = 4 * kEnt;                      // one slot: [4 component pairs][site] double2 = 4 KiB
-constexpr int kPqfLds = kPqfOffSlot + 4 * 6 * kPqfSlotB; // 36 + 96 KiB
+constexpr int kPqfLds = kPqfOffSlot + 4 * 6 * kPqfSlotB; // 63 + 96 KiB = 162 816 B of the CU's 163 840
+// byte offset of link direction rho in the buffer pair (cur: which spatial buffer holds the current slice)
+__device__ __forceinline__ int pqf_link_base(int rho, int cur) {
+  return rho == 0 ? 0 : (1 + 3 * cur + (rho - 1)) * kPlaneB;
+}
 
 struct T8 {
   double v[8];       // (re, im) of entries (0,1), (0,2), (1,2); Im of entries (0,0), (1,1) (traceless)
@@ -136,6 +163,8 @@ struct PqfCtx {
   int sp, px, py, pz;
   double coef;
   int wv;
+  void* outp;      // (the chain's output: only the L2Q_PQ_PROF dump uses the raw pointer)
+  const char* chain;   // the chain's links (LDS-DMA takes a flat address)
 };
 
 // slot j of link (site byte offset ltb, direction dir): j = r (own-site term of plane {dir, r-th other direction})
@@ -190,15 +219,16 @@ __device__ __forceinline__ void pqf_store(const PqfCtx& c, int dir, int half, in
 }
 
 // Plane wavefront {A, B}, A < B.  Direction 1 (x) leaves the tile, 2 and 3 stay inside, 0 (t) is the sweep.
-// G0, G1 (G1 < 0: none): the gather groups (dir = g & 3, half = g >> 2) this wavefront stores.  A wavefront's
+// G0: the gather group (dir = g & 3, half = g >> 2) this wavefront sums and stores.  A wavefront's
 // operands that come from L2 / HBM are requested one iteration AHEAD (before its gather stores).
-template <int A, int B, int G0, int G1, int RE0 = 0, int RNE = 0>
+template <int A, int B, int G0, int RE0 = 0, int RNE = 0>
 __device__ __forceinline__ void pqf_plane(const PqfCtx& c) {
   constexpr bool TP = A == 0;
   constexpr bool IN_A = A != 1;                                // (t counts as inside: carried)
   constexpr bool IN_B = B != 1;
   constexpr bool PRE_A = TP || !IN_A;                          // U_b(s+a) comes from the chain
   constexpr bool PRE_B = !IN_B;                                // U_a(s+b) comes from the chain: plane (t, x)
+  constexpr bool EARLY = !IN_A || !IN_B;                       // an operand crosses the tile in x
   constexpr int R_AB = pqf_rank(A, B), R_BA = pqf_rank(B, A);
   const Dims& d = c.d;
   const int T = d.T, V16 = c.V16, Vs16 = c.Vs16;
@@ -217,6 +247,8 @@ __device__ __forceinline__ void pqf_plane(const PqfCtx& c) {
     if (PRE_A) ld_m(ubpa_pre, Opnd<false>{0, q_pa, B * 9 * V16 + ts * Vs16}, rs, V16);
     if (PRE_B) ld_m(uapb_pre, Opnd<false>{0, q_pb, A * 9 * V16 + tc0 * Vs16}, rs, V16);
   }
+  PqfProf prof;
+  prof.start();
   const int niter = (c.t1 - c.t0) + 1;
 #pragma unroll 1
   for (int it = 0; it < niter; ++it) {
@@ -226,7 +258,14 @@ __device__ __forceinline__ void pqf_plane(const PqfCtx& c) {
     const int gcur = tcur * Vs16;
     const bool more = it + 1 < niter;
     const bool full = it >= 1;
-    auto lo_ = [&](int rho, int qb) { return Opnd<true>{rho * kPlaneB + lb + qb, qb, rho * 9 * V16 + gcur}; };
+    const int cur = it & 1;
+    auto lo_ = [&](int rho, int qb) { return Opnd<true>{pqf_link_base(rho, cur) + lb + qb, qb, rho * 9 * V16 + gcur}; };
+    auto prefetch_next = [&]() {
+      if (L2Q_PQ_EXP & 4) return;
+      const int ts = TP ? tnext2 : tnext;      // (the last iteration re-requests a valid slice: harmless)
+      if (PRE_A) ld_m(ubpa_pre, Opnd<false>{0, q_pa, B * 9 * V16 + ts * Vs16}, rs, V16);
+      if (PRE_B) ld_m(uapb_pre, Opnd<false>{0, q_pb, A * 9 * V16 + tnext * Vs16}, rs, V16);
+    };
     // this wavefront's share of the slice refresh (RNE entries from entry RE0 of the next slice's 36)
     double2 pt[RNE > 0 ? RNE : 1];
     if (RNE > 0 && more) {
@@ -239,18 +278,29 @@ __device__ __forceinline__ void pqf_plane(const PqfCtx& c) {
     if (TP ? (more || full) : full) {
       // all four operands of the plaquette are requested up front (each is read ONCE: 4 instead of 6 matrix reads) and
       // every product below runs on registers: no LDS latency inside the chain of products
-      M3 ub, uapb, ua, ubpa;
+      M3 ub, ua;
+      M3& uapb = uapb_pre;                                                  // (chain operand, or filled from LDS here)
+      M3& ubpa = ubpa_pre;
       ld_m(ub, lo_(B, q_sp), rs, V16);
-      if (PRE_B) uapb = uapb_pre;
-      else ld_m(uapb, lo_(A, q_pb), rs, V16);
+      if (!PRE_B) ld_m(uapb, lo_(A, q_pb), rs, V16);
       ld_m(ua, lo_(A, q_sp), rs, V16);
-      if (PRE_A) ubpa = ubpa_pre;
-      else ld_m(ubpa, lo_(B, q_pa), rs, V16);
-      M3 lba, t;
+      if (!PRE_A) ld_m(ubpa, lo_(B, q_pa), rs, V16);
+      M3 lba, t, lab;
       m3_mul_nn(lba, ub, uapb);                                             // L_ba = U_b(s) U_a(s+b)
       L2Q_PQ_FENCE();
       m3_mul_na(t, ubpa, lba);                                              // U_b(s+a) L_ba^H
       L2Q_PQ_FENCE();
+      // Wavefronts whose operands cross the tile in x ((t,x), (x,y), (x,z)): the chain operands have their last use
+      // here -- request the NEXT slice's now, a whole iteration ahead (they take ~6000 cycles to arrive under this
+      // kernel's own traffic: in-kernel counters, tools/force_plaq_prof.py).  The temporal planes (t,y), (t,z) read
+      // U_b(s + t), which the refresh requests have already pulled into L2: their request goes out after the first
+      // barrier (EARLY = false; requesting it here costs them 34 spilled registers).
+      if (EARLY) {
+        if (full && IN_B) m3_mul_nn(lab, ua, ubpa);                         // L_ab = U_a(s) U_b(s+a)
+        L2Q_PQ_FENCE();
+        prefetch_next();
+        L2Q_PQ_FENCE();
+      }
       if (full) {
         T8 p;
         tah_prod<false>(p, ua, t);                                          // TAH(P), P = U_a(s) U_b(s+a) L_ba^H
@@ -266,10 +316,10 @@ __device__ __forceinline__ void pqf_plane(const PqfCtx& c) {
       }
       L2Q_PQ_FENCE();
       if (full && IN_B) {
-        // -> link (s+b, a): TAH( U_a(s+b) L_ab^H U_b(s) ),  L_ab = U_a(s) U_b(s+a)
-        M3 lab, t1;
-        m3_mul_nn(lab, ua, ubpa);
+        // -> link (s+b, a): TAH( U_a(s+b) L_ab^H U_b(s) )
+        if (!EARLY) m3_mul_nn(lab, ua, ubpa);                               // L_ab = U_a(s) U_b(s+a)
         L2Q_PQ_FENCE();
+        M3 t1;
         m3_mul_na(t1, uapb, lab);
         L2Q_PQ_FENCE();
         T8 d1;
@@ -277,34 +327,31 @@ __device__ __forceinline__ void pqf_plane(const PqfCtx& c) {
         slot_put(A, 3 + R_AB, lb + q_pb, d1, 1.0);
       }
       L2Q_PQ_FENCE();
+    } else if (EARLY) {
+      prefetch_next();                                                      // (prologue of a spatial plane)
     }
+    prof.mark(0);
     pqf_barrier();                                           // every contribution of this slice is in its slot
-    // next iteration's chain operands FIRST (the last iteration re-requests a valid slice: harmless), then the stores
-    if (!(L2Q_PQ_EXP & 4)) {
-      const int ts = TP ? tnext2 : tnext;
-      if (PRE_A) ld_m(ubpa_pre, Opnd<false>{0, q_pa, B * 9 * V16 + ts * Vs16}, rs, V16);
-      if (PRE_B) ld_m(uapb_pre, Opnd<false>{0, q_pb, A * 9 * V16 + tnext * Vs16}, rs, V16);
-    }
+    prof.mark(1);
+    if (!EARLY) prefetch_next();
     if (RNE > 0 && more) {
 #pragma unroll
       for (int k = 0; k < RNE; ++k)
-        *reinterpret_cast<double2*>(fr_lds + (RE0 + k) * kEnt + ltb) = pt[k];
+        *reinterpret_cast<double2*>(fr_lds + (RE0 + k) * kEnt + ltb) = pt[k];       // (t-links: entries 0..8)
     }
-    if (full) {
-      pqf_store(c, G0 & 3, G0 >> 2, q_sp, gcur, pqf_sum(c, G0 & 3, G0 >> 2, ltb));
-      if (G1 >= 0) {
-        constexpr int G = G1 >= 0 ? G1 : 0;
-        pqf_store(c, G & 3, G >> 2, q_sp, gcur, pqf_sum(c, G & 3, G >> 2, ltb));
-      }
-    }
+    if (full) pqf_store(c, G0 & 3, G0 >> 2, q_sp, gcur, pqf_sum(c, G0 & 3, G0 >> 2, ltb));
+    prof.mark(2);
     pqf_barrier();                                           // slots free, next slice's links in place
+    prof.mark(3);
   }
+  __syncthreads();                                           // (every store of the workgroup is out)
+  prof.dump(reinterpret_cast<double2*>(c.outp), c.wv, c.lt);
 }
 
 // Helper wavefront: the x-neighbour terms of links c in {C0, C1} (C1 < 0: one term), and NE entries starting at
 // entry E0 of the 36 of the next slice's links.
 //   link (s, c) receives  TAH( U_c(s) (U_c(s') U_x(s'+c))^H U_x(s') ),  s' = s - x   (slot 3 + rank_c(x))
-template <int C0, int C1, int E0, int NE>
+template <int C0, int C1, int E0, int NE, int G0>
 __device__ __forceinline__ void pqf_helper(const PqfCtx& c) {
   const Dims& d = c.d;
   const int T = d.T, V16 = c.V16, Vs16 = c.Vs16;
@@ -319,6 +366,10 @@ __device__ __forceinline__ void pqf_helper(const PqfCtx& c) {
     if (C0 > 0) q_mx_pc[0] = hop(q_mx / 16, q, y, z, C0, +1, d) * 16;
     if (C1 > 0) q_mx_pc[1] = hop(q_mx / 16, q, y, z, C1 > 0 ? C1 : 2, +1, d) * 16;
   }
+  PqfProf prof;
+  prof.start();
+  M3 ux, x0, y0, x1, y1;                 // chain operands of the coming slice (requested at the end of the previous one)
+  m3_zero(ux); m3_zero(x0); m3_zero(y0); m3_zero(x1); m3_zero(y1);
   const int niter = (c.t1 - c.t0) + 1;
 #pragma unroll 1
   for (int it = 0; it < niter; ++it) {
@@ -327,31 +378,25 @@ __device__ __forceinline__ void pqf_helper(const PqfCtx& c) {
     const int gcur = tcur * Vs16, gnxt = tnext * Vs16;
     const bool more = it + 1 < niter;
     const bool full = it >= 1;
-    auto lo_ = [&](int rho, int qb) { return Opnd<true>{rho * kPlaneB + lb + qb, qb, rho * 9 * V16 + gcur}; };
-    auto go_ = [&](int rho, int qb) { return Opnd<false>{0, qb, rho * 9 * V16 + gcur}; };
-    auto gn_ = [&](int rho, int qb) { return Opnd<false>{0, qb, rho * 9 * V16 + gnxt}; };
-    double2 pt[NE];
-    if (more && !(L2Q_PQ_EXP & 8)) {
+    const int cur = it & 1;
+    auto lo_ = [&](int rho, int qb) { return Opnd<true>{pqf_link_base(rho, cur) + lb + qb, qb, rho * 9 * V16 + gcur}; };
+    // slice refresh: the next slice's spatial links (entries 9..35) go straight from the chain into the spatial
+    // buffer the current slice does not use -- LDS-DMA, no registers, the whole iteration to arrive
+    if (NE > 0 && more && !(L2Q_PQ_EXP & 8)) {
+      const char* src = c.chain + (long)gnxt + q_sp;
+      char* dst = fr_lds + (1 + 3 * (cur ^ 1)) * kPlaneB;
 #pragma unroll
-      for (int k = 0; k < NE; ++k) pt[k] = buf_ld(rs, q_sp, (E0 + k) * V16 + gnxt);
+      for (int k = 0; k < NE; ++k)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(E0 + k) * V16),
+                                         (__attribute__((address_space(3))) void*)(dst + (E0 - 9 + k) * kEnt), 16, 0, 0);
     }
     if (full && !(L2Q_PQ_EXP & 2)) {
-      // every chain operand of both terms is requested at once (one L2 / HBM latency per slice instead of a chain of
-      // them: with the operands streamed row by row behind each other this wavefront was the slowest of the eight)
-      M3 ux, x0, y0, x1, y1;
-      ld_m(ux, go_(1, q_mx), rs, V16);                                     // U_x(s'), shared by the terms
-      ld_m(x0, go_(C0, q_mx), rs, V16);                                    // U_c(s')
-      if (C0 == 0) ld_m(y0, gn_(1, q_mx), rs, V16);                        // U_x(s' + t)
-      else ld_m(y0, go_(1, q_mx_pc[0]), rs, V16);                          // U_x(s' + c)
+      // the chain operands of both terms were requested a whole iteration ago (below)
       {
         M3 lh, t, uc;
         ld_m(uc, lo_(C0, q_sp), rs, V16);
         m3_mul_nn(lh, x0, y0);
         L2Q_PQ_FENCE();
-        if (C1 >= 0) {                                                     // (x0, y0 are dead: the second term's operands)
-          ld_m(x1, go_(C1 >= 0 ? C1 : 0, q_mx), rs, V16);
-          ld_m(y1, go_(1, q_mx_pc[1]), rs, V16);
-        }
         m3_mul_na(t, uc, lh);
         L2Q_PQ_FENCE();
         T8 h;
@@ -373,17 +418,40 @@ __device__ __forceinline__ void pqf_helper(const PqfCtx& c) {
         L2Q_PQ_FENCE();
       }
     }
-    pqf_barrier();
-    {
-      // slice refresh (single buffer: every plane has passed the barrier above, nobody reads links before the next)
-      if (more && !(L2Q_PQ_EXP & 8)) {
-#pragma unroll
-        for (int k = 0; k < NE; ++k)
-          *reinterpret_cast<double2*>(fr_lds + (E0 + k) * kEnt + ltb) = pt[k];
+    // the NEXT slice's chain operands, a whole iteration ahead (s' = s - x; the last iteration re-requests a valid slice)
+    if (!(L2Q_PQ_EXP & 2)) {
+      const int gn2 = ((tnext + 1 == T) ? 0 : tnext + 1) * Vs16;
+      ld_m(ux, Opnd<false>{0, q_mx, 1 * 9 * V16 + gnxt}, rs, V16);                       // U_x(s')
+      ld_m(x0, Opnd<false>{0, q_mx, C0 * 9 * V16 + gnxt}, rs, V16);                      // U_c(s')
+      if (C0 == 0) ld_m(y0, Opnd<false>{0, q_mx, 1 * 9 * V16 + gn2}, rs, V16);           // U_x(s' + t)
+      else ld_m(y0, Opnd<false>{0, q_mx_pc[0], 1 * 9 * V16 + gnxt}, rs, V16);            // U_x(s' + c)
+      if (C1 >= 0) {
+        ld_m(x1, Opnd<false>{0, q_mx, (C1 >= 0 ? C1 : 0) * 9 * V16 + gnxt}, rs, V16);
+        ld_m(y1, Opnd<false>{0, q_mx_pc[1], 1 * 9 * V16 + gnxt}, rs, V16);
       }
     }
+    prof.mark(0);
     pqf_barrier();
+    prof.mark(1);
+    if (full) pqf_store(c, G0 & 3, G0 >> 2, q_sp, gcur, pqf_sum(c, G0 & 3, G0 >> 2, ltb));
+    {
+      // slice refresh (single buffer: every plane has passed the barrier above, nobody reads links before the next)
+      // the LDS-DMA of the refresh must have landed before the barrier; vmcnt retires in order, and AFTER the DMA this
+      // wavefront has issued the next slice's chain operands (9 requests per matrix) and, in a full iteration, its
+      // gather stores: those may stay in flight
+      if (NE > 0) {
+        constexpr int kAfter = ((C1 >= 0) ? 5 : 3) * 9;
+        constexpr int kStores = (G0 >> 2) == 0 ? 4 : 5;
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAfter + kStores) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAfter) : "memory");
+      }
+    }
+    prof.mark(2);
+    pqf_barrier();
+    prof.mark(3);
   }
+  __syncthreads();
+  prof.dump(reinterpret_cast<double2*>(c.outp), c.wv, c.lt);
 }
 
 __global__ __launch_bounds__(kPqfThreads, 2) void su3_force_plaq_kernel(
@@ -415,11 +483,13 @@ __global__ __launch_bounds__(kPqfThreads, 2) void su3_force_plaq_kernel(
     k.px = q;
   }
   k.coef = coef;
+  k.outp = (void*)(out + c * 36L * V);
+  k.chain = reinterpret_cast<const char*>(xn + c * 36L * V);
   // first slice (t0 - 1) into LDS: 36 entries per site over the 512 threads; wavefront w takes 4 or 5 of them
   {
     const int ta = (k.t0 - 1 + T) % T;
     const int q_sp = k.sp * 16;
-    for (int e = k.wv; e < 36; e += 8) {
+    for (int e = k.wv; e < 36; e += 8) {                         // (iteration 0 reads spatial buffer 0)
       const double2 va = buf_ld(k.rs, q_sp, e * k.V16 + ta * k.Vs16);
       *reinterpret_cast<double2*>(fr_lds + e * kEnt + k.lt * 16) = va;
     }
@@ -427,14 +497,15 @@ __global__ __launch_bounds__(kPqfThreads, 2) void su3_force_plaq_kernel(
   __syncthreads();
   // identical barrier sequence in all eight wavefronts
   switch (k.wv) {
-    case 0: pqf_plane<0, 2, 0, -1>(k); break;
-    case 1: pqf_plane<0, 3, 1, -1>(k); break;
-    case 2: pqf_plane<2, 3, 2, -1>(k); break;
-    case 3: pqf_helper<0, 2, 0, 9>(k); break;                  // x-terms of links t and y; t-links of the refresh
-    case 4: pqf_plane<0, 1, 3, 4, 9, 9>(k); break;                // (+ the x-links of the refresh)
-    case 5: pqf_plane<1, 2, 5, 6>(k); break;
-    case 6: pqf_plane<1, 3, 7, -1>(k); break;
-    default: pqf_helper<3, -1, 18, 18>(k); break;              // x-term of link z; y- and z-links of the refresh
+    // (gather group g = wavefront index: direction g & 3, half g >> 2)
+    case 0: pqf_plane<0, 2, 0>(k); break;
+    case 1: pqf_plane<0, 3, 1>(k); break;
+    case 2: pqf_plane<2, 3, 2>(k); break;
+    case 3: pqf_helper<0, -1, 9, 27, 3>(k); break;             // x-term of link t; the spatial links of the refresh (LDS-DMA)
+    case 4: pqf_plane<0, 1, 4, 0, 9>(k); break;                // (+ the t-links of the refresh)
+    case 5: pqf_plane<1, 2, 5>(k); break;
+    case 6: pqf_plane<1, 3, 6>(k); break;
+    default: pqf_helper<2, 3, 0, 0, 7>(k); break;              // x-terms of links y and z
   }
 }
 
