@@ -94,7 +94,7 @@ __device__ __forceinline__ int pqf_link_base(int rho, int cur) {
 }
 
 struct T8 {
-  double v[8];       // (re, im) of entries (0,1), (0,2), (1,2); Im of entries (0,0), (1,1) (traceless)
+  double v[8];       // TWICE: (re, im) of entries (0,1), (0,2), (1,2); Im of entries (0,0), (1,1) (traceless)
 };
 
 // TAH(X Y) (ADJ_Y = false) or TAH(X Y^H): only the entries the projection keeps are formed (90 of 108 FMAs)
@@ -116,11 +116,13 @@ __device__ __forceinline__ void tah_prod(T8& r, const M3& x, const M3& y) {
       }
       wr[3 * i + j] = sr; wi[3 * i + j] = si;
     }
-  const double tri = (wi[0] + wi[4] + wi[8]) / 3.0;
-  r.v[0] = 0.5 * (wr[1] - wr[3]); r.v[1] = 0.5 * (wi[1] + wi[3]);
-  r.v[2] = 0.5 * (wr[2] - wr[6]); r.v[3] = 0.5 * (wi[2] + wi[6]);
-  r.v[4] = 0.5 * (wr[5] - wr[7]); r.v[5] = 0.5 * (wi[5] + wi[7]);
-  r.v[6] = wi[0] - tri; r.v[7] = wi[4] - tri;
+  // TWICE the projection's components: the 1/2 of (W - W^H)/2 is folded into the gather's coefficient; the trace
+  // term by a multiplication (an fp64 division is ~14 instructions, and there is one per contribution)
+  const double tri2 = (wi[0] + wi[4] + wi[8]) * (2.0 / 3.0);
+  r.v[0] = wr[1] - wr[3]; r.v[1] = wi[1] + wi[3];
+  r.v[2] = wr[2] - wr[6]; r.v[3] = wi[2] + wi[6];
+  r.v[4] = wr[5] - wr[7]; r.v[5] = wi[5] + wi[7];
+  r.v[6] = fma(2.0, wi[0], -tri2); r.v[7] = fma(2.0, wi[4], -tri2);
 }
 
 // TAH(X C) with the right factor C streamed by rows from LDS / the chain (row k of C meets column k of X)
@@ -148,11 +150,13 @@ __device__ __forceinline__ void tah_rstream(T8& r, const M3& x, const Opnd<IN>& 
         wi[3 * i + j] = fma(ar, cr.im[j], wi[3 * i + j]); wi[3 * i + j] = fma(ai, cr.re[j], wi[3 * i + j]);
       }
   }
-  const double tri = (wi[0] + wi[4] + wi[8]) / 3.0;
-  r.v[0] = 0.5 * (wr[1] - wr[3]); r.v[1] = 0.5 * (wi[1] + wi[3]);
-  r.v[2] = 0.5 * (wr[2] - wr[6]); r.v[3] = 0.5 * (wi[2] + wi[6]);
-  r.v[4] = 0.5 * (wr[5] - wr[7]); r.v[5] = 0.5 * (wi[5] + wi[7]);
-  r.v[6] = wi[0] - tri; r.v[7] = wi[4] - tri;
+  // TWICE the projection's components: the 1/2 of (W - W^H)/2 is folded into the gather's coefficient; the trace
+  // term by a multiplication (an fp64 division is ~14 instructions, and there is one per contribution)
+  const double tri2 = (wi[0] + wi[4] + wi[8]) * (2.0 / 3.0);
+  r.v[0] = wr[1] - wr[3]; r.v[1] = wi[1] + wi[3];
+  r.v[2] = wr[2] - wr[6]; r.v[3] = wi[2] + wi[6];
+  r.v[4] = wr[5] - wr[7]; r.v[5] = wi[5] + wi[7];
+  r.v[6] = fma(2.0, wi[0], -tri2); r.v[7] = fma(2.0, wi[4], -tri2);
 }
 
 
@@ -173,7 +177,8 @@ __device__ __forceinline__ void slot_put(int dir, int j, int ltb, const T8& c, d
   const int a = kPqfOffSlot + (dir * 6 + j) * kPqfSlotB + ltb;
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    *reinterpret_cast<double2*>(fr_lds + a + k * kEnt) = make_double2(sgn * c.v[2 * k], sgn * c.v[2 * k + 1]);
+    *reinterpret_cast<double2*>(fr_lds + a + k * kEnt) =
+        sgn < 0.0 ? make_double2(-c.v[2 * k], -c.v[2 * k + 1]) : make_double2(c.v[2 * k], c.v[2 * k + 1]);
 }
 
 __host__ __device__ constexpr int pqf_rank(int c, int b) { return b < c ? b : b - 1; }   // b among the others of c
@@ -193,7 +198,8 @@ __device__ __forceinline__ PqfOut pqf_sum(const PqfCtx& c, int dir, int half, in
     const double2 w = lds_ld(a0 + j * kPqfSlotB + kEnt);
     f0 += u.x; f1 += u.y; f2 += w.x; f3 += w.y;
   }
-  return PqfOut{f0 * c.coef, f1 * c.coef, f2 * c.coef, f3 * c.coef};
+  const double hc = 0.5 * c.coef;                           // (the contributions carry twice the TAH components)
+  return PqfOut{f0 * hc, f1 * hc, f2 * hc, f3 * hc};
 }
 #if L2Q_PQ_EXP & 16
 #define PQF_ST buf_st
