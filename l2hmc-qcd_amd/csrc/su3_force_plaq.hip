@@ -28,10 +28,10 @@
 //
 // Results agree with the thread-per-link kernels to rounding (sum of TAHs instead of TAH of the sum).
 //
-// MEASURED (MI355X, 8^4 x 256 chains; tools/force_bench.py, profiles/r06_force_plaq_ab.txt): 0.391 ms stand-alone
-// against 0.395 ms for su3_force_link_kernel on the same box; inside the trajectory 0.407 against 0.393 ms with the
-// TRAJECTORY 0.3 % shorter (21.30 vs 21.38 ms: less power and HBM traffic left for the neighbours).  Equal within
-// the noise, so it is the opt-in tuning force_tile = 7, not the default.  What it does achieve is the traffic: 1.42 GB
+// MEASURED (MI355X, 8^4 x 256 chains; tools/force_bench.py, profiles/r06_force_plaq_ab.txt): 0.372 ms stand-alone
+// (0.405 of the 8 TB/s roofline) against 0.397 ms for su3_force_link_kernel on the same box; inside the trajectory
+// 0.389 against 0.385 ms with the TRAJECTORY 0.5 % shorter (20.79 vs 20.90 ms: less power and HBM traffic left for
+// the neighbours).  That is inside the box-to-box spread, so it is the opt-in tuning force_tile = 7, not the default.  What it does achieve is the traffic: 1.42 GB
 // of HBM traffic per launch = 1.17 x algorithmic (link kernel 2.02 GB = 1.68 x), L2 hit rate 0.62 (0.46).  In-kernel
 // cycle counters (-DL2Q_PQ_PROF, tools/force_plaq_prof.py): the product phase of a SIMD is 11-13 products of 108
 // four-cycle fp64 FMA instructions = 5600-7100 cycles of VALU issue, the gather ~1500, barrier slack ~600; with the
