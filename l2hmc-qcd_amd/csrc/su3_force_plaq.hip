@@ -442,14 +442,14 @@ __device__ __forceinline__ void pqf_helper(const PqfCtx& c) {
     if (full) pqf_store(c, G0 & 3, G0 >> 2, q_sp, gcur, pqf_sum(c, G0 & 3, G0 >> 2, ltb));
     {
       // slice refresh (single buffer: every plane has passed the barrier above, nobody reads links before the next)
-      // the LDS-DMA of the refresh must have landed before the barrier; vmcnt retires in order, and AFTER the DMA this
-      // wavefront has issued the next slice's chain operands (9 requests per matrix) and, in a full iteration, its
-      // gather stores: those may stay in flight
+      // The LDS-DMA of the refresh must have landed before the barrier.  vmcnt retires in order: AFTER the DMA this
+      // wavefront has issued the next slice's chain operands (9 requests per matrix, behind scheduling fences, so
+      // they cannot move above the DMA) and, in a full iteration, 4-5 gather stores.  Waiting until at most the
+      // operand requests are outstanding is exact without the stores and waits for the oldest few operand
+      // requests (issued thousands of cycles ago) with them -- never for fewer than all of the DMA.
       if (NE > 0) {
         constexpr int kAfter = ((C1 >= 0) ? 5 : 3) * 9;
-        constexpr int kStores = (G0 >> 2) == 0 ? 4 : 5;
-        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAfter + kStores) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAfter) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAfter) : "memory");
       }
     }
     prof.mark(2);
