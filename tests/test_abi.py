@@ -222,3 +222,32 @@ def test_gemm_sliced_isa_discipline():
     spec.loader.exec_module(mod)
     bad, report = mod.check(mod.isa())
     assert bad == 0, report
+
+
+def test_force_plaq_dma_wait_is_sound():
+    """csrc/su3_force_plaq.hip publishes its LDS-DMA slice refresh with a hand-counted `s_waitcnt vmcnt(27)`: vmcnt
+    retires in order, so the wait is sound only if at least 27 vector-memory instructions are issued between the last
+    `global_load_lds_dwordx4` of an iteration and the wait (then "at most 27 outstanding" implies every DMA has
+    landed).  Checked in the ISA of the shipped source (hipcc cross-compiles without a GPU)."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, 'l2hmc-qcd_amd', 'csrc', 'su3_force_plaq.hip')
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+                        '-Wno-unused-function', '-save-temps=obj', '-c', src, '-o', os.path.join(tmp, 'k.o')],
+                       check=True, cwd=os.path.dirname(src), capture_output=True)
+        isa = [f for f in os.listdir(tmp) if f.endswith('gfx950.s')]
+        assert isa, os.listdir(tmp)
+        lines = open(os.path.join(tmp, isa[0])).read().split('\n')
+    code = [l.strip() for l in lines]
+    waits = [i for i, l in enumerate(code) if l.startswith('s_waitcnt vmcnt(27)')]
+    dmas = [i for i, l in enumerate(code) if l.startswith('global_load_lds_dwordx4')]
+    assert len(waits) == 1 and len(dmas) == 27, (len(waits), len(dmas))
+    # the block that holds the wait (the loop is rotated: it sits above the loop head and is entered by a branch)
+    label = next(code[j].split(':')[0] for j in range(waits[0], 0, -1) if code[j].startswith('.LBB'))
+    assert re.match(r'\.LBB\d+_\d+$', label), label
+    after = next(j for j in range(dmas[-1], len(code)) if re.match(r's_c?branch\w*\s+' + re.escape(label) + r'$', code[j]))
+    vmem = [l for l in code[dmas[-1] + 1:after] if re.match(r'(buffer|global|scratch)_(load|store)', l)]
+    assert len(vmem) >= 27, len(vmem)
+    assert code[waits[0] + 1].startswith('s_barrier') or any(c.startswith('s_barrier') for c in code[waits[0]:waits[0] + 6])
