@@ -47,7 +47,8 @@ beta = torch.tensor(a.beta)
 runs = [('Dynamics.forward (L2HMC)', lambda x: dyn((x, beta)), 2 * a.nlf),
         ('apply_transition_hmc', lambda x: dyn.apply_transition_hmc((x, beta), eps=0.1, nleapfrog=2 * a.nlf), 2 * a.nlf)]
 for name, fn, nlf in runs[:1] if a.no_hmc else runs:
-    for _ in range(2):
+    # (the default Dynamics captures its HIP graph the `auto_graph_after`-th time it sees a shape: warm up past that)
+    for _ in range(max(2, int(getattr(dyn, 'auto_graph_after', 1)) + 1)):
         xo, m = fn(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(a.steps):
